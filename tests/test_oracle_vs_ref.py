@@ -1,0 +1,102 @@
+"""Wider differential check of the oracle against the compiled reference.
+
+Only runs where oracle/_ref/libseqalign_ref.so exists (it is built in the
+authoring container from /root/reference and travels to the GPU box as a
+prebuilt, git-ignored file).  Nothing here reads /root/reference.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import orclib as O
+from seqalign_amd import workloads as W
+
+pytestmark = pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built")
+
+
+def in_domain(sc, is_sw):
+    return bool(is_sw) or min(sc.gap_open + sc.gap_extend, sc.gap_extend) >= -abs(sc.min_penalty)
+
+
+def test_builders_match_reference_bytes():
+    for flags in itertools.product([0, 1], repeat=6):
+        spec = {"init": [2, -3, -5, -2, *flags], "wildcards": [["N", 0], ["x", -1]],
+                "mutations": [["a", "c", -3], ["c", "a", -1], ["G", "T", 4]]}
+        assert O.scoring_defined_bytes(O.build_scoring(spec, "oracle")) == \
+            O.scoring_defined_bytes(O.build_scoring(spec, "ref"))
+
+
+def test_lookup_matches_reference():
+    spec = {"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0], "wildcards": [["N", 0], ["R", -1]],
+            "mutations": [["a", "c", -3], ["c", "a", 2], ["n", "a", 7]]}
+    for nomm, cs in itertools.product([0, 1], repeat=2):
+        spec["init"][8], spec["init"][9] = nomm, cs
+        so, sr = O.build_scoring(spec, "oracle"), O.build_scoring(spec, "ref")
+        import ctypes as C
+        for x in b"ACGTNRacgtnr-*":
+            for y in b"ACGTNRacgtnr-*":
+                s, m = C.c_int(0), C.c_int(0)
+                rc = O.oracle().orc_scoring_lookup(C.byref(so), C.c_char(bytes([x])), C.c_char(bytes([y])), C.byref(s), C.byref(m))
+                assert rc == 0 and (s.value, m.value) == O.ref_lookup(sr, x, y)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fill_and_nw_random_scorings(seed):
+    rng = W.Rng(900 + seed)
+    for trial in range(24):
+        v = rng.below(1 << 16, 8).astype(int)
+        flags = [int(v[0] >> k) & 1 for k in range(5)]
+        match, mismatch = 1 + int(v[1] % 4), -int(v[2] % 5)
+        go, ge = -int(v[3] % 9), -int(v[4] % 3)
+        if flags[2] and flags[3]:
+            mismatch = min(mismatch, go + ge)
+        spec = {"init": [match, mismatch, go, ge, *flags, int(v[5] & 1)],
+                "wildcards": [["N", int(v[6] % 3) - 1]] if v[6] & 4 else []}
+        so, sr = O.build_scoring(spec, "oracle"), O.build_scoring(spec, "ref")
+        batch = W.ragged(6, seed=int(v[7]), max_len=40, lower_frac=0.2,
+                         extra=b"N" if spec["wildcards"] else b"")
+        for p in range(batch.n_pairs):
+            a, b = batch.seq_a(p), batch.seq_b(p)
+            for is_sw in (0, 1):
+                if not in_domain(so, is_sw):
+                    continue
+                rc, M, A, B = O.oracle_fill(so, a, b, is_sw)
+                Mr, Ar, Br = O.ref_fill(sr, a, b, is_sw)
+                assert rc == 0 and np.array_equal(M, Mr) and np.array_equal(A, Ar) and np.array_equal(B, Br)
+            if in_domain(so, 0):
+                assert O.oracle_nw(so, a, b)[1:] == tuple(
+                    x if isinstance(x, int) else x for x in O.ref_nw(sr, a, b))
+
+
+def test_sw_walk_uses_reference_reverse_move():
+    """orc_sw_hits' walk == the real alignment_reverse_move chain on the real SW fill."""
+    import ctypes as C
+    lib = O.ref()
+    spec = {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}
+    so, sr = O.build_scoring(spec, "oracle"), O.build_scoring(spec, "ref")
+    batch = W.dna_sw_read_vs_ref(6, seed=5, read_len=40, ref_len=120)
+    for p in range(batch.n_pairs):
+        a, b = batch.seq_a(p), batch.seq_b(p)
+        rc, hits = O.oracle_sw(so, a, b, min_score=8, max_hits=3)
+        assert rc == 0 and hits
+        al = O.Aligner()
+        C.memset(C.byref(al), 0, C.sizeof(al))
+        ba, bb = C.create_string_buffer(a, len(a) + 1), C.create_string_buffer(b, len(b) + 1)
+        lib.aligner_align(C.byref(al), ba, bb, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sr), C.c_char(b"\1"))
+        W_ = len(a) + 1
+        M = np.ctypeslib.as_array(al.match_scores, (W_ * (len(b) + 1),))
+        h = hits[0]
+        assert h["score"] == int(M.max())
+        # replay the best hit with the reference's traceback primitive
+        x, y = h["pos_a"] + h["len_a"], h["pos_b"] + h["len_b"]
+        mat, score = C.c_int(0), C.c_int(int(M[y * W_ + x]))
+        cx, cy, idx = C.c_size_t(x), C.c_size_t(y), C.c_size_t(y * W_ + x)
+        ra, rb = [], []
+        while score.value > 0:
+            ra.append("-" if mat.value == 1 else chr(a[cx.value - 1]))
+            rb.append("-" if mat.value == 2 else chr(b[cy.value - 1]))
+            lib.alignment_reverse_move(C.byref(mat), C.byref(score), C.byref(cx), C.byref(cy), C.byref(idx), C.byref(al))
+        assert ("".join(reversed(ra)), "".join(reversed(rb))) == (h["a"], h["b"])
+        assert (cx.value, cy.value) == (h["pos_a"], h["pos_b"])
+        lib.aligner_destroy(C.byref(al))
