@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the DP-fill hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (seqalign_fill_batch_device: the fill of the
+match / gap_a / gap_b matrices, reference src/alignment.c:28-168) over one
+synthetic batch that is already resident in HBM.  Workload at N=1: BASELINE
+configs[1] -- 10 000 NW pairs, DNA 150x150, default scoring 1/-2/-4/-1.
+For N>1 (launched by torch.distributed.run, one rank per GPU) every rank fills
+its own 10 000-pair shard of a 10 000*N-pair batch: weak scaling, independent
+pairs, NO collective on the data path (the only collectives are the barrier and
+the MAX over ranks of the elapsed time).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+
+Prints ONE JSON line (rank 0).  `value` = all ranks' cells / max-rank seconds.
+`roofline`  : algorithmic bytes per launch / mean kernel duration (HIP events on
+              the launch stream, recorded inside the timed region) vs 8 TB/s.
+`cpu_baseline`: the reference itself (oracle/_ref, built from /root/reference in
+              the authoring container) or, if absent, our C restatement
+              (oracle/), timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT / "seq-align_amd" / "python", ROOT / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import seqalign_amd as S                     # noqa: E402
+from seqalign_amd import workloads as W      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (generator, kwargs, pairs per GPU, is_sw, scoring spec)
+    "C2": ("dna_nw_150", dict(seed=1), 10000, 0, {"preset": "default"},
+           "10k NW pairs, DNA 150x150, default scoring 1/-2/-4/-1 (BASELINE configs[1])"),
+    "C3": ("dna_sw_read_vs_ref", dict(seed=2), 10000, 1, {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]},
+           "10k SW pairs, DNA 150x1000 read-vs-ref, 2/-2/-2/-1 (BASELINE configs[2])"),
+    "C4": ("protein_sw_300", dict(seed=3), 4000, 1, {"preset": "BLOSUM62"},
+           "4k SW pairs, protein 300x300, BLOSUM62 (BASELINE configs[3])"),
+}
+
+
+def cpu_baseline(batch, spec, is_sw, budget_s=20.0):
+    """Reference CPU path on THIS host, bounded sample.  checker code: allowed here."""
+    import orclib as O
+    n = batch.n_pairs
+    ref = O.ref()
+    if ref is not None:
+        sc = O.build_scoring(spec, "ref")
+        al = O.Aligner()
+        C.memset(C.byref(al), 0, C.sizeof(al))
+        bufs = [(batch.seq_a(p), batch.seq_b(p)) for p in range(n)]
+        isw = C.c_char(bytes([is_sw]))
+        cells = 0
+        done = 0
+        t0 = time.perf_counter()
+        while True:
+            for a, b in bufs:
+                ref.aligner_align(C.byref(al), a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), isw)
+                cells += len(a) * len(b)
+                done += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * 0.5:
+                break
+        ref.aligner_destroy(C.byref(al))
+        return dict(value=cells / dt / 1e9, unit="GCUPS", cores=1, kind="reference",
+                    sample=f"{done} pairs ({cells} cells) through aligner_align of the compiled reference "
+                           f"(oracle/_ref), 1 thread, {dt:.1f} s")
+    import seqalign_amd
+    sc = O.Scoring.from_buffer_copy(bytes(seqalign_amd.make_scoring(spec)))
+    cells, secs, reps = 0, 0.0, 0
+    while secs < budget_s * 0.5:
+        chk = C.c_uint64(0)
+        secs += O.oracle().orc_time_fill_batch(C.byref(sc), batch.arena.ctypes.data_as(C.c_char_p),
+                                               batch.off_a.ctypes.data_as(C.c_void_p), batch.len_a.ctypes.data_as(C.c_void_p),
+                                               batch.off_b.ctypes.data_as(C.c_void_p), batch.len_b.ctypes.data_as(C.c_void_p),
+                                               C.c_size_t(n), C.c_int(is_sw), C.byref(chk))
+        cells += batch.cells()
+        reps += 1
+    return dict(value=cells / secs / 1e9, unit="GCUPS", cores=1, kind="port",
+                sample=f"{reps}x{n} pairs ({cells} cells) through orc_fill (oracle/, C restatement), 1 thread, {secs:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    gen, kwargs, per_gpu, is_sw, spec, desc = WORKLOADS[args.workload]
+    per_gpu = args.pairs or per_gpu
+    # one global batch, sharded by contiguous pair index: rank g owns [g*n/G, (g+1)*n/G)
+    batch = getattr(W, gen)(per_gpu * world, **kwargs).shard(rank, world)
+
+    lib = S.lib()
+    ctx = S.Context(local)
+    sc = S.make_scoring(spec)
+    h = ctx.upload_scoring(sc, is_sw)
+    db = S.DeviceBatch(batch, local)
+
+    # kernel choice: measured, not guessed
+    if args.kernel == "auto":
+        best = None
+        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN):
+            ms = db.time_fill_ms(ctx, h, k, 6)[1:]
+            m = float(np.median(ms))
+            if best is None or m < best[1]:
+                best = (k, m)
+        kernel = best[0]
+        if world > 1:   # all ranks run the same kernel
+            t = torch.tensor([kernel], device="cuda")
+            dist.broadcast(t, 0)
+            kernel = int(t.item())
+    else:
+        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN}[args.kernel]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        db.fill(ctx, h, kernel)
+    torch.cuda.synchronize()
+    barrier()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()           # same stream the kernel is launched on
+        db.fill(ctx, h, kernel)
+        ends[i].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([batch.cells()], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells = int(c.item())
+    else:
+        total_cells = batch.cells()
+
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+
+    # parity spot check outside the timed region (checker = oracle): bit-exact int32
+    bit_exact = None
+    if rank == 0:
+        import orclib as O
+        osc = O.Scoring.from_buffer_copy(bytes(sc))
+        bit_exact = True
+        for p in range(0, batch.n_pairs, max(1, batch.n_pairs // 16)):
+            rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
+            gM, gA, gB = db.pair_matrices(p)
+            bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
+
+    if rank == 0:
+        alg_bytes = db.algorithmic_bytes()
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        prof = ROOT / "profiles" / "pmc_traffic.json"
+        if prof.exists():
+            try:
+                t = json.loads(prof.read_text())
+                key = f"{args.workload}:{S.KERNEL_NAMES[kernel]}:{batch.n_pairs}"
+                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "dp_cell_updates_per_sec", "value": total_cells * args.steps / elapsed / 1e9, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": batch.n_pairs,
+                       "global_pairs": batch.n_pairs * world, "kernel": S.KERNEL_NAMES[kernel],
+                       "parallelism": f"pair-sharded x{world}, no collective",
+                       "cells_per_step_per_gpu": batch.cells()},
+            "bit_exact_vs_oracle": bool(bit_exact),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw)
+        print(json.dumps(out), flush=True)
+
+    ctx.release_scoring(h)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

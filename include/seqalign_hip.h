@@ -1,0 +1,200 @@
+/*
+ * seqalign_hip.h -- C ABI of the MI355X (gfx950) DP-fill engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of noporpoise/seq-align:
+ * the O(n*m) affine-gap fill of the match / gap_a / gap_b score matrices
+ * (reference: static alignment_fill_matrices, src/alignment.c:28-168, reached
+ * only through aligner_align, src/alignment.c:170-193).  Plain pointers and
+ * sizes only; no C++ or torch types.  Built by seq-align_amd/Makefile into
+ * seq-align_amd/lib/libseqalign_hip.so together with the host-side mirror of the
+ * reference API (alignment.h, alignment_scoring.h, needleman_wunsch.h,
+ * smith_waterman.h in this directory).
+ *
+ * The reference aligns one pair per call (callback per pair,
+ * src/alignment_cmdline.c:611-622); a 150x150 fill is ~23 k cells, far below one
+ * kernel launch, so the new surface here is a BATCH of independent pairs.
+ * aligner_align() itself is kept (alignment.h) and is a batch of one.
+ *
+ * There is NO CPU fallback: every entry point that needs the device fails with
+ * SEQALIGN_E_NO_DEVICE / SEQALIGN_E_HIP when the HIP runtime or a gfx950 device
+ * is missing.
+ *
+ * Output contract (bit-exact with the reference): for pair p the three matrices
+ * hold (len_a+1)*(len_b+1) int32 each, dense pitch W=len_a+1, cell (i,j) at
+ * j*W+i (ARR_2D_INDEX, src/alignment_macros.h:11), starting mat_off[p] cells
+ * into each of the three arenas.
+ */
+#ifndef SEQALIGN_HIP_H
+#define SEQALIGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "alignment_scoring.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------- */
+enum {
+  SEQALIGN_OK = 0,
+  SEQALIGN_E_NO_DEVICE = 1,   /* no HIP runtime / no gfx950 device            */
+  SEQALIGN_E_HIP = 2,         /* a HIP call failed (see seqalign_last_error)  */
+  SEQALIGN_E_ARG = 3,         /* bad argument                                 */
+  SEQALIGN_E_NOMEM = 4,
+  SEQALIGN_E_UNKNOWN_PAIR = 5,/* character pair without a score and
+                                 use_match_mismatch==0; the reference exit()s
+                                 here (src/alignment_scoring.c:178-181)       */
+  SEQALIGN_E_DOMAIN = 6,      /* NW scoring whose gap penalties are below
+                                 -|min_penalty|: signed overflow (UB) in the
+                                 reference fill                */
+  SEQALIGN_E_TRACEBACK = 7,   /* src/alignment.c:328-349 would exit()         */
+  SEQALIGN_E_TOO_LARGE = 8    /* one pair needs >= 2^31 cells                 */
+};
+
+const char *seqalign_strerror(int code);
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char *seqalign_last_error(void);
+
+/* ---- device context --------------------------------------------------------- */
+typedef struct seqalign_ctx seqalign_ctx_t;
+
+/* Number of visible gfx950 devices (0 when there is no GPU / no runtime). */
+int seqalign_device_count(void);
+
+/* One context per device (one per process in the multi-GPU layout: the batch is
+ * sharded by pair index, no collective -- SURVEY 8e). */
+int seqalign_ctx_create(int device, seqalign_ctx_t **out);
+void seqalign_ctx_destroy(seqalign_ctx_t *ctx);
+int seqalign_ctx_device(const seqalign_ctx_t *ctx);
+
+/* ---- scoring, flattened for the device ------------------------------------- */
+/* scoring_lookup (src/alignment_scoring.c:133-182) is a pure function of
+ * (scoring, a, b); it is flattened ONCE per scoring into a 256-entry
+ * char -> (folded char, class) map plus a dense class x class int32 table and
+ * uploaded.  The handle stays valid until released or the context dies. */
+typedef struct seqalign_dev_scoring seqalign_dev_scoring_t;
+
+int seqalign_scoring_upload(seqalign_ctx_t *ctx, const scoring_t *scoring,
+                            int is_sw, seqalign_dev_scoring_t **out);
+void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scoring_t *h);
+
+/* ---- batch descriptors -------------------------------------------------------- */
+/* Host-side batch: one byte arena + per-pair offsets/lengths (raw chars, not
+ * NUL-dependent, exactly what aligner_align takes per pair). */
+typedef struct {
+  uint64_t n_pairs;
+  const char *arena;       /* all sequence bytes                               */
+  uint64_t arena_bytes;
+  const uint64_t *off_a;   /* [n_pairs] byte offset of seq_a in arena          */
+  const uint32_t *len_a;   /* [n_pairs]                                        */
+  const uint64_t *off_b;
+  const uint32_t *len_b;
+} seqalign_batch_t;
+
+/* Device-resident batch + outputs: every pointer is a DEVICE pointer. */
+typedef struct {
+  uint64_t n_pairs;
+  const uint8_t *arena;
+  const uint64_t *off_a;
+  const uint32_t *len_a;
+  const uint64_t *off_b;
+  const uint32_t *len_b;
+  const uint64_t *mat_off; /* [n_pairs] first cell of pair p in each arena      */
+  int32_t *match_scores;   /* three arenas, same per-pair offsets               */
+  int32_t *gap_a_scores;
+  int32_t *gap_b_scores;
+  uint64_t *status;        /* [n_pairs] ~0 = ok, else row-major index of the
+                              first cell whose character pair has no score     */
+  uint32_t max_len_a;      /* max over the batch (selects columns-per-lane)     */
+  uint32_t max_len_b;
+} seqalign_dev_batch_t;
+
+/* Which fill kernel family to launch. */
+enum {
+  SEQALIGN_KERNEL_AUTO = 0,
+  SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair  */
+  SEQALIGN_KERNEL_ROWSCAN = 2    /* row sweep + max-plus prefix scan for gap_b   */
+};
+
+/* THE HOT PATH.  Replaces alignment_fill_matrices (src/alignment.c:28-168) for a
+ * whole batch: enqueues the fill on `stream` (a hipStream_t passed as void*,
+ * NULL = the context's own stream) and returns without synchronising. */
+int seqalign_fill_batch_device(seqalign_ctx_t *ctx,
+                               const seqalign_dev_scoring_t *scoring,
+                               const seqalign_dev_batch_t *batch, int kernel,
+                               void *stream);
+
+/* SW local maxima (replaces the scan of src/smith_waterman.c:152-156 on the
+ * device): per pair, the best match_scores cell in reference hit order (score
+ * desc, column asc, index asc) and every cell with score >= min_score compacted
+ * into cand[cand_off[p] .. +cand_cap[p]) (unsorted; cand_count[p] may exceed the
+ * capacity, in which case only the first cand_cap[p] were stored).
+ * All pointers are DEVICE pointers. */
+typedef struct {
+  uint64_t n_pairs;
+  const uint32_t *len_a, *len_b;
+  const uint64_t *mat_off;
+  const int32_t *match_scores;
+  int32_t min_score;
+  int32_t *best_score;      /* [n_pairs]                                        */
+  uint64_t *best_index;     /* [n_pairs] row-major cell index                   */
+  uint32_t *cand_count;     /* [n_pairs]                                        */
+  const uint64_t *cand_off; /* [n_pairs]                                        */
+  const uint32_t *cand_cap; /* [n_pairs]                                        */
+  uint32_t *cand_index;     /* compacted cell indices                           */
+  int32_t *cand_score;      /* and their scores                                 */
+} seqalign_sw_reduce_t;
+
+int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r,
+                              void *stream);
+
+/* ---- host-level convenience (H2D -> fill -> D2H) ---------------------------- */
+/* Fills every pair of a HOST batch and copies the matrices back into the three
+ * host arenas (cell offsets mat_off[p], host pointer).  Streams the batch in
+ * chunks that fit the context's device buffers.  status may be NULL. */
+int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
+                        const scoring_t *scoring, int is_sw,
+                        const uint64_t *mat_off, int32_t *match_scores,
+                        int32_t *gap_a_scores, int32_t *gap_b_scores,
+                        uint64_t *status);
+
+/* Global NW over a host batch: GPU fill + host traceback (the traceback is the
+ * reference's consumer, src/needleman_wunsch.c:53-145, fresh code).  Results:
+ * score[p], and the two alignment strings of pair p written NUL-terminated at
+ * out_a + str_off[p], out_b + str_off[p] (capacity len_a+len_b+1 each). */
+int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
+                      const scoring_t *scoring, const uint64_t *str_off,
+                      char *out_a, char *out_b, uint32_t *out_len,
+                      int32_t *out_score);
+
+/* Local SW over a host batch: GPU fill + GPU candidate compaction + host hit
+ * enumeration (src/smith_waterman.c:165-277 semantics, fresh visited mask per
+ * pair).  Emits, per pair, successive hits with score >= min_score[p], at most
+ * max_hits per pair, into the caller's hit array (hit_cap entries total). */
+typedef struct {
+  uint64_t pair;
+  int32_t score;
+  uint32_t pos_a, pos_b, len_a, len_b; /* smith_waterman.c:249-255 */
+  uint32_t length;                     /* alignment columns */
+  uint64_t str_off;                    /* into out_a / out_b */
+} seqalign_sw_hit_t;
+
+int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
+                      const scoring_t *scoring, const int32_t *min_score,
+                      uint32_t max_hits, seqalign_sw_hit_t *hits,
+                      uint64_t hit_cap, uint64_t *n_hits, char *out_a,
+                      char *out_b, uint64_t str_cap);
+
+/* ---- misc ---------------------------------------------------------------------- */
+/* Event pair on a stream for kernel timing (HIP events; bench.py). */
+int seqalign_time_fill_ms(seqalign_ctx_t *ctx,
+                          const seqalign_dev_scoring_t *scoring,
+                          const seqalign_dev_batch_t *batch, int kernel,
+                          void *stream, int repeats, float *ms_each);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQALIGN_HIP_H */

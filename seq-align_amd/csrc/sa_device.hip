@@ -1,0 +1,642 @@
+// sa_device.hip -- the C-ABI shim (include/seqalign_hip.h) over the HIP kernels.
+//
+// Host code above this file is C; this file is the only place that talks to the
+// HIP runtime.  No torch / C++ types cross the boundary.  No CPU fallback: when
+// the runtime or a device is missing every entry point reports it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sa_kernels.h"
+
+extern "C" {
+#include "sa_internal.h"
+}
+
+// ------------------------------------------------------------------ errors ---
+static thread_local std::string g_last_error;
+
+static int fail_hip(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? SEQALIGN_E_NO_DEVICE
+                                                               : SEQALIGN_E_HIP;
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) return fail_hip(_e, #expr);   \
+  } while (0)
+
+extern "C" const char *seqalign_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *seqalign_strerror(int code) {
+  switch (code) {
+    case SEQALIGN_OK: return "ok";
+    case SEQALIGN_E_NO_DEVICE: return "no HIP device (gfx950) available";
+    case SEQALIGN_E_HIP: return "HIP runtime error";
+    case SEQALIGN_E_ARG: return "invalid argument";
+    case SEQALIGN_E_NOMEM: return "out of memory";
+    case SEQALIGN_E_UNKNOWN_PAIR: return "unknown character pair and match/mismatch not set";
+    case SEQALIGN_E_DOMAIN: return "scoring outside the defined domain (penalty below -|min_penalty|)";
+    case SEQALIGN_E_TRACEBACK: return "traceback failed";
+    case SEQALIGN_E_TOO_LARGE: return "pair too large (>= 2^31 cells)";
+  }
+  return "unknown error";
+}
+
+// ----------------------------------------------------------------- context ---
+namespace {
+
+struct DevBuf {   // grow-only device scratch
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return SEQALIGN_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipMalloc"); }
+    cap = want;
+    return SEQALIGN_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct HostBuf {  // grow-only pinned staging
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return SEQALIGN_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipHostMalloc"); }
+    cap = want;
+    return SEQALIGN_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct seqalign_dev_scoring {
+  sa_flat_scoring_t flat;   // host copy (table pointer owned)
+  uint16_t *d_code = nullptr;
+  int32_t *d_table = nullptr;
+};
+
+struct seqalign_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
+  // device scratch for the host-level entry points
+  DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
+  DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
+  HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc;
+  // cached flattened scoring for the legacy single-pair path
+  seqalign_dev_scoring *cached = nullptr;
+  std::vector<unsigned char> cached_key;
+  int cached_is_sw = -1;
+};
+
+extern "C" int seqalign_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
+  if (!out) return SEQALIGN_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    g_last_error = "hipGetDeviceCount: no device";
+    return SEQALIGN_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) return SEQALIGN_E_ARG;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_last_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+    return SEQALIGN_E_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  seqalign_ctx *ctx = new (std::nothrow) seqalign_ctx();
+  if (!ctx) return SEQALIGN_E_NOMEM;
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete ctx; return fail_hip(e, "hipStreamCreate"); }
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  // one chunk of a host-level batch may use up to 40 % of what is free now
+  // (288 GB HBM3E: ~100 GB per chunk on an empty MI355X), overridable
+  ctx->chunk_budget = free_b ? (free_b / 10) * 4 : (size_t)8 << 30;
+  if (const char *env = getenv("SEQALIGN_CHUNK_BYTES")) {
+    size_t v = strtoull(env, nullptr, 10);
+    if (v >= (1u << 20)) ctx->chunk_budget = v;
+  }
+  *out = ctx;
+  return SEQALIGN_OK;
+}
+
+extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
+  for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
+                    &ctx->M, &ctx->A, &ctx->B, &ctx->status, &ctx->best_score, &ctx->best_index,
+                    &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score})
+    b->release();
+  for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc}) b->release();
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int seqalign_ctx_device(const seqalign_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
+// ----------------------------------------------------------------- scoring ---
+extern "C" int seqalign_scoring_upload(seqalign_ctx_t *ctx, const scoring_t *scoring, int is_sw,
+                                       seqalign_dev_scoring_t **out) {
+  if (!ctx || !scoring || !out) return SEQALIGN_E_ARG;
+  *out = nullptr;
+  seqalign_dev_scoring *h = new (std::nothrow) seqalign_dev_scoring();
+  if (!h) return SEQALIGN_E_NOMEM;
+  int rc = sa_flatten_scoring(scoring, is_sw, &h->flat);
+  if (rc != SEQALIGN_OK) { delete h; return rc; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t tb = sizeof(int32_t) * h->flat.n_classes * h->flat.n_classes;
+  hipError_t e = hipMalloc((void **)&h->d_code, sizeof(h->flat.code));
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_table, tb);
+  if (e == hipSuccess) e = hipMemcpy(h->d_code, h->flat.code, sizeof(h->flat.code), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_table, h->flat.table, tb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    seqalign_scoring_release(ctx, h);
+    return fail_hip(e, "scoring upload");
+  }
+  *out = h;
+  return SEQALIGN_OK;
+}
+
+extern "C" void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scoring_t *h) {
+  if (!h) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (h->d_code) (void)hipFree(h->d_code);
+  if (h->d_table) (void)hipFree(h->d_table);
+  sa_flat_scoring_free(&h->flat);
+  if (ctx && ctx->cached == h) { ctx->cached = nullptr; ctx->cached_is_sw = -1; }
+  delete h;
+}
+
+// --------------------------------------------------------------- hot path ---
+static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_dev_batch_t *b) {
+  SaFillParams p;
+  p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
+  p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
+  p.status = b->status; p.code = s->d_code; p.table = s->d_table;
+  p.n_pairs = (uint32_t)b->n_pairs; p.K = s->flat.n_classes;
+  p.gap_open = s->flat.gap_open; p.open1 = s->flat.open1; p.ext = s->flat.ext; p.floor = s->flat.floor;
+  p.gen_eq = s->flat.gen_eq; p.gen_ne = s->flat.gen_ne; p.flags = s->flat.flags;
+  return p;
+}
+
+static int pick_kernel(int kernel) {
+  if (kernel != SEQALIGN_KERNEL_AUTO) return kernel;
+  if (const char *env = getenv("SEQALIGN_KERNEL")) {
+    if (!strcmp(env, "wavefront")) return SEQALIGN_KERNEL_WAVEFRONT;
+    if (!strcmp(env, "rowscan")) return SEQALIGN_KERNEL_ROWSCAN;
+  }
+  return SEQALIGN_KERNEL_ROWSCAN;
+}
+
+extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
+                                          const seqalign_dev_batch_t *batch, int kernel, void *stream) {
+  if (!ctx || !scoring || !batch) return SEQALIGN_E_ARG;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  if (batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_E_ARG;
+  if ((uint64_t)(batch->max_len_a + 1ull) * (batch->max_len_b + 1ull) >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const SaFillParams p = make_params(scoring, batch);
+  hipError_t e;
+  switch (pick_kernel(kernel)) {
+    case SEQALIGN_KERNEL_WAVEFRONT: e = sa_launch_fill_wavefront(p, batch->max_len_a, st); break;
+    case SEQALIGN_KERNEL_ROWSCAN:
+      // the row scan's saturating-add identity assumes gap_extend <= 0; a positive
+      // gap_extend (legal, absurd) takes the wavefront kernel, exact for any sign
+      e = (p.ext > 0) ? sa_launch_fill_wavefront(p, batch->max_len_a, st)
+                      : sa_launch_fill_rowscan(p, batch->max_len_a, st);
+      break;
+    default: return SEQALIGN_E_ARG;
+  }
+  if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
+                                     const seqalign_dev_batch_t *batch, int kernel, void *stream,
+                                     int repeats, float *ms_each) {
+  if (!ctx || repeats <= 0 || !ms_each) return SEQALIGN_E_ARG;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)repeats);
+  for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
+  int rc = SEQALIGN_OK;
+  for (int r = 0; r < repeats && rc == SEQALIGN_OK; ++r) {
+    HIP_TRY(hipEventRecord(ev[2 * r], st));
+    rc = seqalign_fill_batch_device(ctx, scoring, batch, kernel, st);
+    HIP_TRY(hipEventRecord(ev[2 * r + 1], st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int r = 0; r < repeats && rc == SEQALIGN_OK; ++r) HIP_TRY(hipEventElapsedTime(&ms_each[r], ev[2 * r], ev[2 * r + 1]));
+  for (auto &x : ev) (void)hipEventDestroy(x);
+  return rc;
+}
+
+extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r, void *stream) {
+  if (!ctx || !r) return SEQALIGN_E_ARG;
+  if (r->n_pairs == 0) return SEQALIGN_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SaReduceParams p;
+  p.len_a = r->len_a; p.len_b = r->len_b; p.mat_off = r->mat_off; p.M = r->match_scores;
+  p.min_score = r->min_score; p.best_score = r->best_score; p.best_index = r->best_index;
+  p.cand_count = r->cand_count; p.cand_off = r->cand_off; p.cand_cap = r->cand_cap;
+  p.cand_index = r->cand_index; p.cand_score = r->cand_score; p.n_pairs = (uint32_t)r->n_pairs;
+  hipError_t e = sa_launch_sw_reduce(p, st);
+  if (e != hipSuccess) return fail_hip(e, "sw reduce launch");
+  return SEQALIGN_OK;
+}
+
+// ------------------------------------------------- host-level: chunked fill ---
+namespace {
+
+struct Chunk {
+  uint64_t first = 0, count = 0;   // pairs [first, first+count)
+  uint64_t cells = 0, seq_bytes = 0;
+  uint32_t max_a = 0, max_b = 0;
+};
+
+// split the batch into chunks whose matrices (12 B/cell) fit the budget
+static std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget) {
+  std::vector<Chunk> out;
+  Chunk c;
+  const uint64_t max_cells = std::max<uint64_t>(budget / 12, 1);
+  for (uint64_t p = 0; p < b->n_pairs; ++p) {
+    const uint64_t cells = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    if (c.count && c.cells + cells > max_cells) { out.push_back(c); c = Chunk(); c.first = p; }
+    c.count++; c.cells += cells; c.seq_bytes += (uint64_t)b->len_a[p] + b->len_b[p];
+    c.max_a = std::max(c.max_a, b->len_a[p]); c.max_b = std::max(c.max_b, b->len_b[p]);
+  }
+  if (c.count) out.push_back(c);
+  return out;
+}
+
+// Upload one chunk (sequences packed back to back, matrices packed in pair
+// order) and run the fill.  On return the device buffers of ctx hold the
+// results; the stream is NOT synchronised.
+static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
+                     const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out) {
+  const uint64_t n = c.count;
+  int rc;
+  // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
+  const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t));
+  if ((rc = ctx->h_desc.reserve(desc_bytes))) return rc;
+  if ((rc = ctx->h_arena.reserve(c.seq_bytes + 16))) return rc;
+  uint64_t *h_off_a = ctx->h_desc.as<uint64_t>(), *h_off_b = h_off_a + n, *h_mat = h_off_b + n;
+  uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_mat + n), *h_len_b = h_len_a + n;
+  uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
+  uint64_t pos = 0, cell = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k;
+    h_off_a[k] = pos; memcpy(h_seq + pos, b->arena + b->off_a[p], b->len_a[p]); pos += b->len_a[p];
+    h_off_b[k] = pos; memcpy(h_seq + pos, b->arena + b->off_b[p], b->len_b[p]); pos += b->len_b[p];
+    h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
+    h_mat[k] = cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+  }
+  if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
+  if ((rc = ctx->off_a.reserve(n * 8)) || (rc = ctx->off_b.reserve(n * 8)) || (rc = ctx->mat_off.reserve(n * 8)) ||
+      (rc = ctx->len_a.reserve(n * 4)) || (rc = ctx->len_b.reserve(n * 4)) || (rc = ctx->status.reserve(n * 8)))
+    return rc;
+  if ((rc = ctx->M.reserve(c.cells * 4)) || (rc = ctx->A.reserve(c.cells * 4)) || (rc = ctx->B.reserve(c.cells * 4)))
+    return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->arena.p, h_seq, c.seq_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->off_b.p, h_off_b, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->mat_off.p, h_mat, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->len_a.p, h_len_a, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->len_b.p, h_len_b, n * 4, hipMemcpyHostToDevice, st));
+  seqalign_dev_batch_t d;
+  d.n_pairs = n; d.arena = ctx->arena.as<uint8_t>();
+  d.off_a = ctx->off_a.as<uint64_t>(); d.len_a = ctx->len_a.as<uint32_t>();
+  d.off_b = ctx->off_b.as<uint64_t>(); d.len_b = ctx->len_b.as<uint32_t>();
+  d.mat_off = ctx->mat_off.as<uint64_t>();
+  d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+  d.status = ctx->status.as<uint64_t>(); d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+  if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st))) return rc;
+  if (dev_out) *dev_out = d;
+  return SEQALIGN_OK;
+}
+
+// fetch the per-pair status words; returns UNKNOWN_PAIR if any pair flagged
+static int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out) {
+  int rc;
+  if ((rc = ctx->h_misc.reserve(c.count * 8))) return rc;
+  uint64_t *h = ctx->h_misc.as<uint64_t>();
+  HIP_TRY(hipMemcpyAsync(h, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  rc = SEQALIGN_OK;
+  for (uint64_t k = 0; k < c.count; ++k) {
+    if (status_out) status_out[c.first + k] = h[k];
+    if (h[k] != ~0ull) rc = SEQALIGN_E_UNKNOWN_PAIR;
+  }
+  return rc;
+}
+
+static int check_batch(const seqalign_batch_t *b) {
+  if (!b || (b->n_pairs && (!b->arena || !b->off_a || !b->off_b || !b->len_a || !b->len_b))) return SEQALIGN_E_ARG;
+  for (uint64_t p = 0; p < b->n_pairs; ++p)
+    if ((uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull) >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+  return SEQALIGN_OK;
+}
+
+}  // namespace
+
+extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                   int is_sw, const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B,
+                                   uint64_t *status) {
+  if (!ctx || !scoring || !mat_off || !M || !A || !B) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &sc))) return rc;
+  int worst = SEQALIGN_OK;
+  for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
+    if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
+    // copy back: runs of pairs that are contiguous in the caller's arenas go in one piece
+    uint64_t k = 0, dev_cell = 0;
+    while (k < c.count) {
+      uint64_t run_cells = 0, j = k;
+      const uint64_t host0 = mat_off[c.first + k];
+      while (j < c.count && mat_off[c.first + j] == host0 + run_cells) {
+        run_cells += (uint64_t)(batch->len_a[c.first + j] + 1ull) * (batch->len_b[c.first + j] + 1ull);
+        ++j;
+      }
+      const size_t bytes = run_cells * 4;
+      hipError_t e = hipMemcpyAsync(M + host0, ctx->M.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(A + host0, ctx->A.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(B + host0, ctx->B.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
+      if (e != hipSuccess) { rc = fail_hip(e, "D2H matrices"); break; }
+      dev_cell += run_cells;
+      k = j;
+    }
+    if (rc) break;
+    int src = fetch_status(ctx, c, status);   // also synchronises the stream
+    if (src == SEQALIGN_E_UNKNOWN_PAIR) worst = src;
+    else if (src) { rc = src; break; }
+  }
+  seqalign_scoring_release(ctx, sc);
+  return rc ? rc : worst;
+}
+
+// ------------------------------------------- legacy single-pair entry point ---
+static std::once_flag g_default_once;
+static seqalign_ctx *g_default_ctx = nullptr;
+static std::mutex g_default_mu;
+
+extern "C" seqalign_ctx_t *sa_default_ctx_or_die(void) {
+  std::call_once(g_default_once, [] {
+    int dev = 0;
+    if (const char *env = getenv("SEQALIGN_DEVICE")) dev = atoi(env);
+    int rc = seqalign_ctx_create(dev, &g_default_ctx);
+    if (rc != SEQALIGN_OK) {
+      fprintf(stderr, "seqalign: cannot open GPU %d: %s (%s)\n"
+                      "seqalign: this library has no CPU path; an MI355X (gfx950) is required\n",
+              dev, seqalign_strerror(rc), seqalign_last_error());
+      exit(EXIT_FAILURE);
+    }
+  });
+  return g_default_ctx;
+}
+
+extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is_sw, const char *a, size_t len_a,
+                                const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
+  if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
+  std::lock_guard<std::mutex> lock(g_default_mu);   // the default context is shared
+  // one arena: a then b
+  std::vector<char> arena(len_a + len_b + 1);
+  if (len_a) memcpy(arena.data(), a, len_a);
+  if (len_b) memcpy(arena.data() + len_a, b, len_b);
+  const uint64_t off_a = 0, off_b = len_a, mat_off = 0;
+  const uint32_t la = (uint32_t)len_a, lb = (uint32_t)len_b;
+  seqalign_batch_t batch;
+  batch.n_pairs = 1; batch.arena = arena.data(); batch.arena_bytes = arena.size();
+  batch.off_a = &off_a; batch.len_a = &la; batch.off_b = &off_b; batch.len_b = &lb;
+  return seqalign_fill_batch(ctx, &batch, sc, is_sw, &mat_off, M, A, B, status);
+}
+
+// ----------------------------------------------- host-level: NW over a batch ---
+extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                                 int32_t *out_score) {
+  if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &sc))) return rc;
+  // matrices come back through pinned staging, so chunks are also bounded by host memory
+  const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
+  for (const Chunk &c : plan_chunks(batch, budget)) {
+    if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
+    const size_t bytes = c.cells * 4;
+    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) break;
+    hipError_t e = hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) { rc = fail_hip(e, "D2H matrices"); break; }
+    if ((rc = fetch_status(ctx, c, nullptr))) break;   // syncs; unknown pair is fatal for NW
+    uint64_t cell = 0;
+    for (uint64_t k = 0; k < c.count && rc == SEQALIGN_OK; ++k) {
+      const uint64_t p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = ctx->h_M.as<int32_t>() + cell; v.A = ctx->h_A.as<int32_t>() + cell; v.B = ctx->h_B.as<int32_t>() + cell;
+      size_t n = 0;
+      rc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]);
+      out_len[p] = (uint32_t)n;
+      cell += (uint64_t)(v.len_a + 1) * (v.len_b + 1);
+    }
+    if (rc) break;
+  }
+  seqalign_scoring_release(ctx, sc);
+  return rc;
+}
+
+// ----------------------------------------------- host-level: SW over a batch ---
+namespace {
+
+struct Cand { uint32_t idx; int32_t score; };
+
+}  // namespace
+
+extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
+  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+  *n_hits = 0;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &sc))) return rc;
+  uint64_t used_str = 0, found = 0;
+  const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
+
+  // the reduction kernel takes one threshold per launch: group by threshold
+  // inside a chunk (the CLI default depends only on the lengths, so batches of
+  // equal-length pairs need a single launch)
+  for (const Chunk &c : plan_chunks(batch, budget)) {
+    seqalign_dev_batch_t d;
+    if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
+    const uint64_t n = c.count;
+    int32_t thr = min_score[c.first];
+    for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
+
+    // pass 1: counts (capacity 0), pass 2: compaction
+    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
+        (rc = ctx->cand_count.reserve(n * 4)) || (rc = ctx->cand_off.reserve(n * 8)) ||
+        (rc = ctx->cand_cap.reserve(n * 4)))
+      break;
+    seqalign_sw_reduce_t r;
+    memset(&r, 0, sizeof(r));
+    r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+    r.min_score = thr; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+    r.cand_count = ctx->cand_count.as<uint32_t>();
+    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) break;
+    if ((rc = ctx->h_misc.reserve(n * (4 + 8 + 4)))) break;
+    uint32_t *h_count = ctx->h_misc.as<uint32_t>();
+    HIP_TRY(hipMemcpyAsync(h_count, ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> c_off(n);
+    std::vector<uint32_t> c_cap(h_count, h_count + n);
+    uint64_t total = 0;
+    for (uint64_t k = 0; k < n; ++k) { c_off[k] = total; total += c_cap[k]; }
+    if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = ctx->cand_score.reserve(total * 4 + 4))) break;
+    HIP_TRY(hipMemcpyAsync(ctx->cand_off.p, c_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->cand_cap.p, c_cap.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    r.cand_off = ctx->cand_off.as<uint64_t>(); r.cand_cap = ctx->cand_cap.as<uint32_t>();
+    r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_score = ctx->cand_score.as<int32_t>();
+    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) break;
+
+    const size_t bytes = c.cells * 4;
+    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) break;
+    std::vector<uint32_t> h_cidx(total + 1);
+    std::vector<int32_t> h_cscore(total + 1);
+    hipError_t e = hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(h_cidx.data(), ctx->cand_index.p, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(h_cscore.data(), ctx->cand_score.p, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) { rc = fail_hip(e, "D2H SW results"); break; }
+    if ((rc = fetch_status(ctx, c, nullptr))) break;
+
+    // host: hit enumeration with a fresh visited mask per pair
+    // (reference smith_waterman.c:165-277 semantics)
+    uint64_t cell = 0;
+    std::vector<Cand> cand;
+    std::vector<uint32_t> seen;
+    for (uint64_t k = 0; k < n && rc == SEQALIGN_OK; ++k) {
+      const uint64_t p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = ctx->h_M.as<int32_t>() + cell; v.A = ctx->h_A.as<int32_t>() + cell; v.B = ctx->h_B.as<int32_t>() + cell;
+      const size_t W = v.len_a + 1, cells = W * (v.len_b + 1);
+      cell += cells;
+      cand.clear();
+      for (uint32_t q = 0; q < c_cap[k]; ++q) {
+        const Cand cd{h_cidx[c_off[k] + q], h_cscore[c_off[k] + q]};
+        if (cd.score >= min_score[p]) cand.push_back(cd);
+      }
+      // device order is ascending index; stable sort = (score desc, column asc, index asc)
+      std::stable_sort(cand.begin(), cand.end(), [W](const Cand &x, const Cand &y) {
+        if (x.score != y.score) return x.score > y.score;
+        return x.idx % W < y.idx % W;
+      });
+      seen.assign((cells + 31) / 32, 0u);
+      uint32_t emitted = 0;
+      for (const Cand &cd : cand) {
+        if (emitted >= max_hits) break;
+        if ((seen[cd.idx >> 5] >> (cd.idx & 31)) & 1u) continue;
+        size_t x = cd.idx % W, y = cd.idx / W, steps = 0;
+        int matrix = MATCH;
+        int32_t score = cd.score;
+        bool clash = false;
+        for (;; ++steps) {
+          const size_t at = y * W + x;
+          if ((seen[at >> 5] >> (at & 31)) & 1u) { clash = true; break; }
+          seen[at >> 5] |= 1u << (at & 31);
+          if (score == 0) break;
+          if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) break;
+        }
+        if (rc) break;
+        if (clash) continue;
+        if (found >= hit_cap || used_str + steps + 1 > str_cap) { rc = SEQALIGN_E_NOMEM; break; }
+        char *ra = out_a + used_str, *rb = out_b + used_str;
+        x = cd.idx % W; y = cd.idx / W; matrix = MATCH; score = cd.score;
+        for (size_t w = steps; score > 0;) {
+          --w;
+          ra[w] = (matrix == GAP_A) ? '-' : v.a[x - 1];
+          rb[w] = (matrix == GAP_B) ? '-' : v.b[y - 1];
+          if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) break;
+        }
+        if (rc) break;
+        ra[steps] = rb[steps] = '\0';
+        seqalign_sw_hit_t &h = hits[found++];
+        h.pair = p; h.score = cd.score;
+        h.pos_a = (uint32_t)x; h.pos_b = (uint32_t)y;
+        h.len_a = (uint32_t)(cd.idx % W - x); h.len_b = (uint32_t)(cd.idx / W - y);
+        h.length = (uint32_t)steps; h.str_off = used_str;
+        used_str += steps + 1;
+        ++emitted;
+      }
+    }
+    if (rc) break;
+  }
+  *n_hits = found;
+  seqalign_scoring_release(ctx, sc);
+  return rc;
+}
+
+// ------------------------------------------------------------------- probes ---
+extern "C" int sa_dpp_probe(seqalign_ctx_t *ctx, int32_t fill, int32_t *out64) {
+  if (!ctx || !out64) return SEQALIGN_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ctx->status.reserve(64 * 8);
+  if (rc) return rc;
+  hipError_t e = sa_launch_dpp_probe(ctx->status.as<int32_t>(), fill, ctx->stream);
+  if (e != hipSuccess) return fail_hip(e, "dpp probe");
+  HIP_TRY(hipMemcpyAsync(out64, ctx->status.p, 64 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SEQALIGN_OK;
+}

@@ -1,0 +1,54 @@
+/* sa_kernels.h -- launch interface between sa_device.hip and the kernels. */
+#ifndef SA_KERNELS_H
+#define SA_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* Everything one fill launch needs; passed by value as the kernarg. */
+struct SaFillParams {
+  const uint8_t *arena;
+  const uint64_t *off_a;
+  const uint32_t *len_a;
+  const uint64_t *off_b;
+  const uint32_t *len_b;
+  const uint64_t *mat_off;
+  int32_t *M, *A, *B;
+  uint64_t *status;
+  const uint16_t *code;   /* [256] raw char -> folded char | class << 8 */
+  const int32_t *table;   /* [K*K] */
+  uint32_t n_pairs;
+  uint32_t K;
+  int32_t gap_open, open1, ext, floor, gen_eq, gen_ne;
+  uint32_t flags;         /* SA_F_* (sa_internal.h) */
+};
+
+struct SaReduceParams {
+  const uint32_t *len_a, *len_b;
+  const uint64_t *mat_off;
+  const int32_t *M;
+  int32_t min_score;
+  int32_t *best_score;
+  uint64_t *best_index;
+  uint32_t *cand_count;
+  const uint64_t *cand_off;
+  const uint32_t *cand_cap;
+  uint32_t *cand_index;
+  int32_t *cand_score;
+  uint32_t n_pairs;
+};
+
+/* substitution lookup flavour */
+enum { SA_SUBST_SIMPLE = 0, SA_SUBST_LDS = 1, SA_SUBST_GLOBAL = 2 };
+#define SA_LDS_TABLE_MAX_K 64
+
+/* returns hipSuccess or the launch error; never synchronises */
+hipError_t sa_launch_fill_wavefront(const SaFillParams &p, uint32_t max_len_a,
+                                    hipStream_t stream);
+hipError_t sa_launch_fill_rowscan(const SaFillParams &p, uint32_t max_len_a,
+                                  hipStream_t stream);
+hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
+/* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
+hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);
+
+#endif

@@ -1,0 +1,341 @@
+"""ctypes driver for seq-align_amd/lib/libseqalign_hip.so (tests + bench only).
+
+The product is the C-ABI shared library (include/seqalign_hip.h and the mirrored
+reference headers next to it).  Python is not on the hot path: this module only
+loads the .so, mirrors the C structs and moves pointers around.  torch is used
+by DeviceBatch for device memory and streams (plumbing).
+
+There is no fallback of any kind: if the library is missing, `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import workloads  # noqa: F401
+
+PKG_ROOT = Path(__file__).resolve().parents[2]          # seq-align_amd/
+REPO_ROOT = PKG_ROOT.parent
+LIB_PATH = PKG_ROOT / "lib" / "libseqalign_hip.so"
+
+OK, E_NO_DEVICE, E_HIP, E_ARG, E_NOMEM, E_UNKNOWN_PAIR, E_DOMAIN, E_TRACEBACK, E_TOO_LARGE = range(9)
+KERNEL_AUTO, KERNEL_WAVEFRONT, KERNEL_ROWSCAN = 0, 1, 2
+KERNEL_NAMES = {KERNEL_AUTO: "auto", KERNEL_WAVEFRONT: "wavefront", KERNEL_ROWSCAN: "rowscan"}
+STATUS_OK = 0xFFFFFFFFFFFFFFFF
+
+
+class Scoring(C.Structure):
+    """scoring_t -- include/alignment_scoring.h (reference alignment_scoring.h:19-40)."""
+    _fields_ = [
+        ("gap_open", C.c_int), ("gap_extend", C.c_int),
+        ("no_start_gap_penalty", C.c_bool), ("no_end_gap_penalty", C.c_bool),
+        ("no_gaps_in_a", C.c_bool), ("no_gaps_in_b", C.c_bool),
+        ("no_mismatches", C.c_bool), ("use_match_mismatch", C.c_bool),
+        ("match", C.c_int), ("mismatch", C.c_int),
+        ("case_sensitive", C.c_bool),
+        ("wildcards", C.c_uint32 * 8), ("swap_set", (C.c_uint32 * 8) * 256),
+        ("wildscores", C.c_int * 256), ("swap_scores", (C.c_int * 256) * 256),
+        ("min_penalty", C.c_int), ("max_penalty", C.c_int),
+    ]
+
+
+class BatchDesc(C.Structure):
+    """seqalign_batch_t"""
+    _fields_ = [("n_pairs", C.c_uint64), ("arena", C.c_void_p), ("arena_bytes", C.c_uint64),
+                ("off_a", C.c_void_p), ("len_a", C.c_void_p), ("off_b", C.c_void_p), ("len_b", C.c_void_p)]
+
+
+class DevBatchDesc(C.Structure):
+    """seqalign_dev_batch_t"""
+    _fields_ = [("n_pairs", C.c_uint64), ("arena", C.c_void_p), ("off_a", C.c_void_p),
+                ("len_a", C.c_void_p), ("off_b", C.c_void_p), ("len_b", C.c_void_p),
+                ("mat_off", C.c_void_p), ("match_scores", C.c_void_p), ("gap_a_scores", C.c_void_p),
+                ("gap_b_scores", C.c_void_p), ("status", C.c_void_p),
+                ("max_len_a", C.c_uint32), ("max_len_b", C.c_uint32)]
+
+
+class SwReduceDesc(C.Structure):
+    """seqalign_sw_reduce_t"""
+    _fields_ = [("n_pairs", C.c_uint64), ("len_a", C.c_void_p), ("len_b", C.c_void_p),
+                ("mat_off", C.c_void_p), ("match_scores", C.c_void_p), ("min_score", C.c_int32),
+                ("best_score", C.c_void_p), ("best_index", C.c_void_p), ("cand_count", C.c_void_p),
+                ("cand_off", C.c_void_p), ("cand_cap", C.c_void_p), ("cand_index", C.c_void_p),
+                ("cand_score", C.c_void_p)]
+
+
+class SwHit(C.Structure):
+    """seqalign_sw_hit_t"""
+    _fields_ = [("pair", C.c_uint64), ("score", C.c_int32), ("pos_a", C.c_uint32), ("pos_b", C.c_uint32),
+                ("len_a", C.c_uint32), ("len_b", C.c_uint32), ("length", C.c_uint32), ("str_off", C.c_uint64)]
+
+
+class SeqAlignError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        l = lib()
+        super().__init__(f"{where}: {l.seqalign_strerror(code).decode()} [{code}] {l.seqalign_last_error().decode()}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The product library.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} missing: build it with `make -C {PKG_ROOT}` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU path")
+        l = C.CDLL(str(LIB_PATH))
+        l.seqalign_strerror.restype = C.c_char_p
+        l.seqalign_last_error.restype = C.c_char_p
+        l.needleman_wunsch_new.restype = C.c_void_p
+        l.smith_waterman_new.restype = C.c_void_p
+        l.alignment_create.restype = C.c_void_p
+        l.smith_waterman_get_aligner.restype = C.c_void_p
+        _lib = l
+    return _lib
+
+
+def _check(code: int, where: str):
+    if code != OK:
+        raise SeqAlignError(code, where)
+
+
+def _ptr(arr) -> C.c_void_p:
+    return C.c_void_p(arr.ctypes.data) if arr is not None else C.c_void_p(0)
+
+
+def make_scoring(spec: dict) -> Scoring:
+    """Build a scoring_t through OUR host library (scoring_init & friends).
+    Same JSON-able spec as tests/orclib.build_scoring."""
+    l = lib()
+    sc = Scoring()
+    C.memset(C.byref(sc), 0, C.sizeof(sc))
+    if "preset" in spec:
+        getattr(l, "scoring_system_" + spec["preset"])(C.byref(sc))
+    else:
+        l.scoring_init(C.byref(sc), *[C.c_int(int(v)) for v in spec["init"][:4]],
+                       *[C.c_bool(bool(v)) for v in spec["init"][4:]])
+    for ch, s in spec.get("wildcards", []):
+        l.scoring_add_wildcard(C.byref(sc), C.c_char(ch.encode()), C.c_int(s))
+    for a, b, s in spec.get("mutations", []):
+        l.scoring_add_mutation(C.byref(sc), C.c_char(a.encode()), C.c_char(b.encode()), C.c_int(s))
+    if "use_match_mismatch" in spec:
+        sc.use_match_mismatch = bool(spec["use_match_mismatch"])
+    for k, v in spec.get("flags", {}).items():
+        setattr(sc, k, bool(v))
+    return sc
+
+
+def batch_desc(batch: "workloads.Batch") -> BatchDesc:
+    return BatchDesc(batch.n_pairs, batch.arena.ctypes.data, batch.arena.nbytes,
+                     batch.off_a.ctypes.data, batch.len_a.ctypes.data,
+                     batch.off_b.ctypes.data, batch.len_b.ctypes.data)
+
+
+class Context:
+    """seqalign_ctx_t* for one device."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p(0)
+        _check(lib().seqalign_ctx_create(C.c_int(device), C.byref(self._h)), "seqalign_ctx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().seqalign_ctx_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- scoring -----------------------------------------------------------
+    def upload_scoring(self, scoring: Scoring, is_sw: int) -> C.c_void_p:
+        h = C.c_void_p(0)
+        _check(lib().seqalign_scoring_upload(self._h, C.byref(scoring), C.c_int(is_sw), C.byref(h)),
+               "seqalign_scoring_upload")
+        return h
+
+    def release_scoring(self, h):
+        lib().seqalign_scoring_release(self._h, h)
+
+    # ---- host-level --------------------------------------------------------
+    def fill_batch(self, batch, scoring: Scoring, is_sw: int, check: bool = True):
+        """H2D -> GPU fill -> D2H.  Returns (M, A, B, mat_off, status) numpy."""
+        cells = batch.matrix_cells()
+        mat_off = np.zeros(batch.n_pairs, np.uint64)
+        if batch.n_pairs:
+            mat_off[1:] = np.cumsum(cells)[:-1]
+        total = int(cells.sum())
+        M = np.empty(total, np.int32); A = np.empty(total, np.int32); B = np.empty(total, np.int32)
+        status = np.zeros(batch.n_pairs, np.uint64)
+        d = batch_desc(batch)
+        rc = lib().seqalign_fill_batch(self._h, C.byref(d), C.byref(scoring), C.c_int(is_sw), _ptr(mat_off),
+                                       _ptr(M), _ptr(A), _ptr(B), _ptr(status))
+        if check:
+            _check(rc, "seqalign_fill_batch")
+        return (M, A, B, mat_off, status) if check else (rc, M, A, B, mat_off, status)
+
+    def nw_batch(self, batch, scoring: Scoring):
+        n = batch.n_pairs
+        caps = batch.len_a.astype(np.uint64) + batch.len_b.astype(np.uint64) + np.uint64(1)
+        str_off = np.zeros(n, np.uint64)
+        if n:
+            str_off[1:] = np.cumsum(caps)[:-1]
+        total = int(caps.sum()) + 1
+        out_a, out_b = np.zeros(total, np.uint8), np.zeros(total, np.uint8)
+        out_len, out_score = np.zeros(n, np.uint32), np.zeros(n, np.int32)
+        d = batch_desc(batch)
+        _check(lib().seqalign_nw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(str_off), _ptr(out_a),
+                                       _ptr(out_b), _ptr(out_len), _ptr(out_score)), "seqalign_nw_batch")
+        res = []
+        for p in range(n):
+            o, ln = int(str_off[p]), int(out_len[p])
+            res.append((int(out_score[p]), out_a[o:o + ln].tobytes(), out_b[o:o + ln].tobytes()))
+        return res
+
+    def sw_batch(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, hit_cap: int | None = None):
+        n = batch.n_pairs
+        ms = np.full(n, min_score, np.int32) if np.isscalar(min_score) else np.asarray(min_score, np.int32)
+        hit_cap = hit_cap or max(1024, 64 * n)
+        hits = (SwHit * hit_cap)()
+        str_cap = int(hit_cap * (int(batch.len_a.max(initial=0)) + int(batch.len_b.max(initial=0)) + 2))
+        str_cap = min(str_cap, 1 << 30)
+        out_a, out_b = np.zeros(str_cap, np.uint8), np.zeros(str_cap, np.uint8)
+        n_hits = C.c_uint64(0)
+        d = batch_desc(batch)
+        _check(lib().seqalign_sw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
+                                       hits, C.c_uint64(hit_cap), C.byref(n_hits), _ptr(out_a), _ptr(out_b),
+                                       C.c_uint64(str_cap)), "seqalign_sw_batch")
+        per_pair = [[] for _ in range(n)]
+        for k in range(n_hits.value):
+            h = hits[k]
+            per_pair[h.pair].append(dict(score=h.score, pos_a=h.pos_a, pos_b=h.pos_b, len_a=h.len_a, len_b=h.len_b,
+                                         a=out_a[h.str_off:h.str_off + h.length].tobytes().decode(),
+                                         b=out_b[h.str_off:h.str_off + h.length].tobytes().decode()))
+        return per_pair
+
+    def dpp_probe(self, fill: int = -7):
+        out = np.zeros(64, np.int32)
+        _check(lib().sa_dpp_probe(self._h, C.c_int32(fill), _ptr(out)), "sa_dpp_probe")
+        return out
+
+
+class DeviceBatch:
+    """A batch resident in HBM (torch tensors own the memory) + its three output
+    arenas.  `pad_cells` aligns each pair's first cell (32 cells = 128 B)."""
+
+    def __init__(self, batch, device: int = 0, pad_cells: int = 32):
+        import torch
+        self.torch = torch
+        self.host = batch
+        dev = torch.device("cuda", device)
+        self.device = device
+        cells = batch.matrix_cells()
+        padded = (cells + pad_cells - 1) // pad_cells * pad_cells
+        mat_off = np.zeros(batch.n_pairs, np.int64)
+        if batch.n_pairs:
+            mat_off[1:] = np.cumsum(padded)[:-1]
+        self.mat_off_host = mat_off.astype(np.uint64)
+        self.cells_host = cells
+        self.total_cells = int(padded.sum())
+        t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else
+                                       (a.view(np.int32) if a.dtype == np.uint32 else a)).to(dev)
+        self.arena = t(batch.arena)
+        self.off_a, self.len_a = t(batch.off_a), t(batch.len_a)
+        self.off_b, self.len_b = t(batch.off_b), t(batch.len_b)
+        self.mat_off = t(self.mat_off_host)
+        self.M = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
+        self.A = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
+        self.B = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(batch.n_pairs, dtype=torch.int64, device=dev)
+        self.desc = DevBatchDesc(batch.n_pairs, self.arena.data_ptr(), self.off_a.data_ptr(),
+                                 self.len_a.data_ptr(), self.off_b.data_ptr(), self.len_b.data_ptr(),
+                                 self.mat_off.data_ptr(), self.M.data_ptr(), self.A.data_ptr(),
+                                 self.B.data_ptr(), self.status.data_ptr(),
+                                 int(batch.len_a.max(initial=0)), int(batch.len_b.max(initial=0)))
+
+    def fill(self, ctx: Context, dev_scoring, kernel: int = KERNEL_AUTO, stream=None):
+        """Enqueue THE HOT PATH on torch's current stream (no sync)."""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().seqalign_fill_batch_device(ctx._h, dev_scoring, C.byref(self.desc), C.c_int(kernel),
+                                                C.c_void_p(st)), "seqalign_fill_batch_device")
+
+    def time_fill_ms(self, ctx: Context, dev_scoring, kernel: int, repeats: int, stream=None):
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device).cuda_stream
+        ms = (C.c_float * repeats)()
+        _check(lib().seqalign_time_fill_ms(ctx._h, dev_scoring, C.byref(self.desc), C.c_int(kernel),
+                                           C.c_void_p(st), C.c_int(repeats), ms), "seqalign_time_fill_ms")
+        return list(ms)
+
+    def algorithmic_bytes(self) -> int:
+        """3*4*(len_a+1)*(len_b+1) written + (len_a+len_b) read per pair."""
+        return int(12 * self.cells_host.sum() + self.host.len_a.astype(np.int64).sum()
+                   + self.host.len_b.astype(np.int64).sum())
+
+    def pair_matrices(self, p: int):
+        o, n = int(self.mat_off_host[p]), int(self.cells_host[p])
+        return tuple(x[o:o + n].cpu().numpy() for x in (self.M, self.A, self.B))
+
+    def sw_reduce(self, ctx: Context, min_score: int, with_candidates: bool = True):
+        """Device SW reduction; returns (best_score, best_index, counts, cand lists)."""
+        torch = self.torch
+        n = self.host.n_pairs
+        dev = self.M.device
+        best_s = torch.zeros(n, dtype=torch.int32, device=dev)
+        best_i = torch.zeros(n, dtype=torch.int64, device=dev)
+        count = torch.zeros(n, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        r = SwReduceDesc(n, self.len_a.data_ptr(), self.len_b.data_ptr(), self.mat_off.data_ptr(),
+                         self.M.data_ptr(), min_score, best_s.data_ptr(), best_i.data_ptr(),
+                         count.data_ptr(), 0, 0, 0, 0)
+        _check(lib().seqalign_sw_reduce_device(ctx._h, C.byref(r), C.c_void_p(st)), "seqalign_sw_reduce_device")
+        torch.cuda.synchronize(self.device)
+        cands = None
+        if with_candidates:
+            cap = count.cpu().numpy().astype(np.uint32)
+            off = np.zeros(n, np.uint64)
+            if n:
+                off[1:] = np.cumsum(cap.astype(np.uint64))[:-1]
+            total = int(cap.sum())
+            d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+            d_cap = torch.from_numpy(cap.view(np.int32)).to(dev)
+            c_idx = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+            c_sc = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+            r.cand_off, r.cand_cap = d_off.data_ptr(), d_cap.data_ptr()
+            r.cand_index, r.cand_score = c_idx.data_ptr(), c_sc.data_ptr()
+            _check(lib().seqalign_sw_reduce_device(ctx._h, C.byref(r), C.c_void_p(st)), "seqalign_sw_reduce_device")
+            torch.cuda.synchronize(self.device)
+            ci, cs = c_idx.cpu().numpy().view(np.uint32), c_sc.cpu().numpy()
+            cands = [(ci[int(off[p]):int(off[p]) + int(cap[p])], cs[int(off[p]):int(off[p]) + int(cap[p])])
+                     for p in range(n)]
+        return best_s.cpu().numpy(), best_i.cpu().numpy(), count.cpu().numpy(), cands
+
+
+EXPORTED_SYMBOLS = [
+    # include/seqalign_hip.h
+    "seqalign_strerror", "seqalign_last_error", "seqalign_device_count", "seqalign_ctx_create",
+    "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
+    "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_fill_batch", "seqalign_nw_batch",
+    "seqalign_sw_batch", "seqalign_time_fill_ms",
+    # include/alignment_scoring.h
+    "scoring_init", "scoring_add_wildcard", "scoring_add_mutation", "scoring_add_mutations", "scoring_print",
+    "scoring_lookup", "scoring_system_PAM30", "scoring_system_PAM70", "scoring_system_BLOSUM80",
+    "scoring_system_BLOSUM62", "scoring_system_DNA_hybridization", "scoring_system_default", "blosum62",
+    # include/alignment.h
+    "align_col_mismatch", "align_col_indel", "align_col_context", "align_col_stop", "aligner_align",
+    "aligner_destroy", "alignment_create", "alignment_ensure_capacity", "alignment_free",
+    "alignment_reverse_move", "alignment_print_matrices", "alignment_colour_print_against",
+    "alignment_print_spacer",
+    # include/needleman_wunsch.h, include/smith_waterman.h
+    "needleman_wunsch_new", "needleman_wunsch_free", "needleman_wunsch_align", "needleman_wunsch_align2",
+    "smith_waterman_new", "smith_waterman_free", "smith_waterman_get_aligner", "smith_waterman_align",
+    "smith_waterman_align2", "smith_waterman_fetch", "sort_match_indices",
+]

@@ -1,0 +1,376 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle
+and the committed golden vectors.  Bit-exact int32 everywhere (integer work).
+
+Run on an MI355X:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import itertools
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import orclib as O
+import seqalign_amd as S
+from seqalign_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+KERNELS = [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN]
+KID = lambda k: S.KERNEL_NAMES[k]
+
+
+def load(name):
+    return json.loads((GOLD / name).read_text())
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a device; there is no CPU fallback"
+    with S.Context(0) as c:
+        yield c
+
+
+def oracle_scoring_of(sc: S.Scoring) -> O.Scoring:
+    return O.Scoring.from_buffer_copy(bytes(sc))
+
+
+def device_fill(ctx, batch, sc, is_sw, kernel, poison=True):
+    import torch
+    h = ctx.upload_scoring(sc, is_sw)
+    db = S.DeviceBatch(batch, 0)
+    if poison:
+        for t in (db.M, db.A, db.B):
+            t.fill_(0x5A5A5A5A)
+    db.fill(ctx, h, kernel)
+    torch.cuda.synchronize()
+    ctx.release_scoring(h)
+    return db
+
+
+def assert_pairs_match_oracle(db, batch, osc, is_sw, pairs, tag=""):
+    for p in pairs:
+        rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
+        assert rc == 0
+        gM, gA, gB = db.pair_matrices(p)
+        for name, g, w in (("M", gM, M), ("A", gA, A), ("B", gB, B)):
+            if not np.array_equal(g, w):
+                bad = int(np.nonzero(g != w)[0][0])
+                Wd = len(batch.seq_a(p)) + 1
+                raise AssertionError(f"{tag} pair {p} matrix {name} first diff at cell {bad} "
+                                     f"(i={bad % Wd}, j={bad // Wd}): gpu {g[bad]} oracle {w[bad]}; "
+                                     f"a={batch.seq_a(p)!r} b={batch.seq_b(p)!r}")
+
+
+# ------------------------------------------------------------------ hardware --
+def test_dpp_wave_shr1_is_a_full_wave_shift(ctx):
+    """The kernels rely on v_mov_b32_dpp wave_shr:1 shifting across all 64 lanes."""
+    out = ctx.dpp_probe(fill=-7)
+    want = np.concatenate([[-7], np.arange(63) * 3 + 1]).astype(np.int32)
+    assert np.array_equal(out, want), out
+
+
+# -------------------------------------------------------------- golden vectors --
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_reference_known_answer_matrices(ctx, kernel):
+    """README.md:118-145: every cell of the three matrices, incl. the NW floor."""
+    v = [x for x in load("kat.json")["nw"] if "match_scores" in x][0]
+    sc = S.make_scoring(v["scoring"])
+    batch = W.from_pairs([(v["a"].encode(), v["b"].encode())])
+    db = device_fill(ctx, batch, sc, 0, kernel)
+    M, A, B = db.pair_matrices(0)
+    assert M.tolist() == sum(v["match_scores"], [])
+    assert A.tolist() == sum(v["gap_a_scores"], [])
+    assert B.tolist() == sum(v["gap_b_scores"], [])
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_fill_small_golden_all_flag_combinations(ctx, kernel):
+    """Matrices produced by the compiled reference for all 32 flag combinations."""
+    n = 0
+    for case in load("fill_small.json")["cases"]:
+        sc = S.make_scoring(case["scoring"])
+        for key, is_sw in (("nw", 0), ("sw", 1)):
+            pairs = [p for p in case["pairs"] if key in p]
+            if not pairs:
+                continue
+            batch = W.from_pairs([(p["a"].encode(), p["b"].encode()) for p in pairs])
+            db = device_fill(ctx, batch, sc, is_sw, kernel)
+            for k, p in enumerate(pairs):
+                M, A, B = db.pair_matrices(k)
+                assert (M.tolist(), A.tolist(), B.tolist()) == (p[key]["M"], p[key]["A"], p[key]["B"]), \
+                    (case["scoring"], p["a"], p["b"], key)
+                n += 1
+            assert (db.status.cpu().numpy() == -1).all()
+    assert n > 250
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+@pytest.mark.parametrize("name", ["C2", "C2_related", "C3", "C4"])
+def test_config_golden_digests(ctx, kernel, name):
+    """64 seeded pairs per BASELINE config: FNV digests from the compiled reference."""
+    cfg = load("configs.json")[name]
+    sc = S.make_scoring(cfg["scoring"])
+    batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
+    db = device_fill(ctx, batch, sc, cfg["is_sw"], kernel)
+    for p, g in enumerate(cfg["pairs"]):
+        M, A, B = db.pair_matrices(p)
+        assert (f"{O.fnv(M):016x}", f"{O.fnv(A):016x}", f"{O.fnv(B):016x}") == (g["M"], g["A"], g["B"]), (name, p)
+
+
+# ------------------------------------------------------- differential vs oracle --
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+@pytest.mark.parametrize("is_sw", [0, 1])
+def test_all_flag_combinations_vs_oracle(ctx, kernel, is_sw):
+    for idx, flags in enumerate(itertools.product([0, 1], repeat=5)):
+        mismatch = -6 if (flags[2] and flags[3]) else -2
+        spec = {"init": [1, mismatch, -4, -1, *flags, idx & 1],
+                "wildcards": [["N", -1]] if idx % 3 == 0 else [],
+                "mutations": [["a", "c", -3], ["c", "a", 2]] if idx % 4 == 1 else []}
+        sc = S.make_scoring(spec)
+        batch = W.ragged(24, seed=300 + idx, max_len=90, lower_frac=0.2,
+                         extra=b"N" if spec["wildcards"] else b"")
+        db = device_fill(ctx, batch, sc, is_sw, kernel)
+        assert_pairs_match_oracle(db, batch, oracle_scoring_of(sc), is_sw, range(batch.n_pairs),
+                                  tag=f"{KID(kernel)} flags={flags}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+@pytest.mark.parametrize("max_len,n", [(1, 16), (64, 32), (65, 32), (200, 24), (330, 12), (700, 8), (1300, 4)])
+def test_ragged_lengths_and_column_strips(ctx, kernel, max_len, n):
+    """Empty sequences, every columns-per-lane instantiation, and (len_a > 512)
+    the multi-strip path whose left boundary is read back from the matrices."""
+    for is_sw, spec in ((0, {"preset": "default"}), (1, {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}),
+                        (0, {"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0]})):
+        sc = S.make_scoring(spec)
+        batch = W.ragged(n, seed=max_len * 7 + is_sw, max_len=max_len, lower_frac=0.1)
+        # force the extremes into the batch
+        fixed = [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"ACGT" * (max_len // 4), b"ACGT" * (max_len // 4))]
+        pairs = [(batch.seq_a(p), batch.seq_b(p)) for p in range(batch.n_pairs)] + fixed
+        batch = W.from_pairs(pairs)
+        db = device_fill(ctx, batch, sc, is_sw, kernel)
+        assert_pairs_match_oracle(db, batch, oracle_scoring_of(sc), is_sw, range(batch.n_pairs),
+                                  tag=f"{KID(kernel)} max_len={max_len} sw={is_sw}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_protein_presets_vs_oracle(ctx, kernel):
+    for preset, is_sw in (("BLOSUM62", 1), ("BLOSUM62", 0), ("PAM30", 1), ("BLOSUM80", 0), ("PAM70", 1)):
+        sc = S.make_scoring({"preset": preset})
+        batch = W.ragged(12, seed=len(preset) + is_sw, max_len=320, alphabet=b"ARNDCQEGHILKMFPSTWYVBZX",
+                         lower_frac=0.2, extra=b"J*")
+        db = device_fill(ctx, batch, sc, is_sw, kernel)
+        assert_pairs_match_oracle(db, batch, oracle_scoring_of(sc), is_sw, range(batch.n_pairs),
+                                  tag=f"{KID(kernel)} {preset}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_unknown_pair_is_reported_per_pair(ctx, kernel):
+    """use_match_mismatch off + a pair missing from the table: the reference exit()s
+    at the first such cell in row-major order; we report that cell index."""
+    sc = S.make_scoring({"preset": "DNA_hybridization"})
+    pairs = [(b"ACGT", b"ACGT"), (b"ACGTN", b"ACGT"), (b"ACGT", b"AXGT"), (b"AC", b"GT")]
+    batch = W.from_pairs(pairs)
+    db = device_fill(ctx, batch, sc, 0, kernel)
+    st = db.status.cpu().numpy().view(np.uint64)
+    assert st[0] == S.STATUS_OK and st[3] == S.STATUS_OK
+    assert st[1] == 1 * 6 + 5          # row 1, column 5 ('N' is a[4])
+    assert st[2] == 2 * 5 + 1          # row 2 ('X' is b[1]), column 1
+    osc = oracle_scoring_of(sc)
+    assert_pairs_match_oracle(db, batch, osc, 0, [0, 3])
+
+
+def test_wide_alphabet_uses_the_global_table(ctx):
+    """> 64 classes: substitution table stays in global memory (SA_SUBST_GLOBAL)."""
+    letters = [chr(c) for c in range(33, 33 + 70)]
+    muts = [[x, y, ((ord(x) * 7 + ord(y) * 3) % 11) - 5] for x in letters for y in letters]
+    spec = {"init": [1, -6, -4, -1, 0, 0, 0, 0, 0, 1], "mutations": muts}
+    sc = S.make_scoring(spec)
+    batch = W.ragged(10, seed=5, max_len=100, alphabet="".join(letters).encode() + b"~")
+    for kernel in KERNELS:
+        for is_sw in (0, 1):
+            db = device_fill(ctx, batch, sc, is_sw, kernel)
+            assert_pairs_match_oracle(db, batch, oracle_scoring_of(sc), is_sw, range(batch.n_pairs))
+
+
+# ------------------------------------------------------------ full-size configs --
+FULL = {
+    "C2": dict(gen=W.dna_nw_150, n=10000, kwargs=dict(seed=1), is_sw=0, scoring={"preset": "default"}),
+    "C3": dict(gen=W.dna_sw_read_vs_ref, n=10000, kwargs=dict(seed=2), is_sw=1,
+               scoring={"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}),
+    "C4": dict(gen=W.protein_sw_300, n=4000, kwargs=dict(seed=3), is_sw=1, scoring={"preset": "BLOSUM62"}),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_config_properties(ctx, name):
+    """BASELINE sizes: (1) the two independently scheduled kernels agree on every
+    byte, (2) a strided sample equals the oracle, (3) SW: the reduction kernel's
+    best cell equals max(M) in reference hit order, (4) NW: last-cell scores equal
+    the host traceback's, (5) duplicated pairs give identical matrices."""
+    import torch
+    cfg = FULL[name]
+    sc = S.make_scoring(cfg["scoring"])
+    osc = oracle_scoring_of(sc)
+    batch = cfg["gen"](cfg["n"], **cfg["kwargs"])
+    # property 5: make the last 8 pairs copies of the first 8
+    for k in range(8):
+        batch.off_a[-1 - k], batch.off_b[-1 - k] = batch.off_a[k], batch.off_b[k]
+    db1 = device_fill(ctx, batch, sc, cfg["is_sw"], S.KERNEL_WAVEFRONT)
+    sums1 = [int(t.to(torch.int64).sum().item()) for t in (db1.M, db1.A, db1.B)]
+    M1 = db1.M.clone(); A1 = db1.A.clone(); B1 = db1.B.clone()
+    del db1
+    db2 = device_fill(ctx, batch, sc, cfg["is_sw"], S.KERNEL_ROWSCAN)
+    # padding cells between pairs keep the poison in both runs, so whole arenas compare
+    assert torch.equal(M1, db2.M) and torch.equal(A1, db2.A) and torch.equal(B1, db2.B)
+    assert sums1 == [int(t.to(torch.int64).sum().item()) for t in (db2.M, db2.A, db2.B)]
+    del M1, A1, B1
+    sample = list(range(0, batch.n_pairs, max(1, batch.n_pairs // 48)))
+    assert_pairs_match_oracle(db2, batch, osc, cfg["is_sw"], sample, tag=name)
+    for k in range(8):
+        for x, y in zip(db2.pair_matrices(k), db2.pair_matrices(batch.n_pairs - 1 - k)):
+            assert np.array_equal(x, y)
+    assert (db2.status.cpu().numpy() == -1).all()
+    if cfg["is_sw"]:
+        best_s, best_i, count, _ = db2.sw_reduce(ctx, min_score=60, with_candidates=False)
+        for p in sample:
+            M, _, _ = db2.pair_matrices(p)
+            Wd = int(batch.len_a[p]) + 1
+            assert best_s[p] == M.max()
+            idx = np.nonzero(M == M.max())[0]
+            cols = idx % Wd
+            want = idx[np.lexsort((idx, cols))][0] if M.max() > 0 else 0
+            assert best_i[p] == want
+            assert count[p] == int((M >= 60).sum())
+    else:
+        last = torch.from_numpy((db2.mat_off_host + db2.cells_host.astype(np.uint64) - 1).astype(np.int64)).cuda()
+        end = torch.maximum(torch.maximum(db2.M[last], db2.A[last]), db2.B[last]).cpu().numpy()
+        for p in sample:
+            rc, s, _, _ = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and s == end[p]
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_transpose_symmetry(ctx, kernel):
+    """Symmetric scoring: swapping a and b transposes the matrices and swaps
+    gap_a <-> gap_b (a size-independent property of the recurrence)."""
+    sc = S.make_scoring({"preset": "default"})
+    batch = W.ragged(16, seed=99, max_len=180)
+    swapped = W.Batch(batch.arena, batch.off_b, batch.len_b, batch.off_a, batch.len_a)
+    for is_sw in (0, 1):
+        d1, d2 = device_fill(ctx, batch, sc, is_sw, kernel), device_fill(ctx, swapped, sc, is_sw, kernel)
+        for p in range(batch.n_pairs):
+            la, lb = int(batch.len_a[p]), int(batch.len_b[p])
+            M1, A1, B1 = (x.reshape(lb + 1, la + 1) for x in d1.pair_matrices(p))
+            M2, A2, B2 = (x.reshape(la + 1, lb + 1) for x in d2.pair_matrices(p))
+            assert np.array_equal(M1, M2.T) and np.array_equal(A1, B2.T) and np.array_equal(B1, A2.T)
+
+
+# --------------------------------------------------- host-level + legacy surface --
+def test_host_level_fill_batch_and_chunking(ctx):
+    import os
+    sc = S.make_scoring({"preset": "default"})
+    batch = W.ragged(300, seed=4, max_len=120)
+    M, A, B, off, status = ctx.fill_batch(batch, sc, 0)
+    osc = oracle_scoring_of(sc)
+    for p in range(0, 300, 7):
+        rc, oM, oA, oB = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), 0)
+        o, n = int(off[p]), oM.size
+        assert np.array_equal(M[o:o + n], oM) and np.array_equal(A[o:o + n], oA) and np.array_equal(B[o:o + n], oB)
+    # tiny chunk budget -> many chunks, same bytes
+    os.environ["SEQALIGN_CHUNK_BYTES"] = str(1 << 20)
+    try:
+        with S.Context(0) as small:
+            M2, A2, B2, _, _ = small.fill_batch(batch, sc, 0)
+    finally:
+        del os.environ["SEQALIGN_CHUNK_BYTES"]
+    assert np.array_equal(M, M2) and np.array_equal(A, A2) and np.array_equal(B, B2)
+
+
+def test_nw_batch_strings_match_oracle_and_golden(ctx):
+    cfg = load("configs.json")["C2_related"]
+    sc = S.make_scoring(cfg["scoring"])
+    batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
+    res = ctx.nw_batch(batch, sc)
+    for p, g in enumerate(cfg["pairs"]):
+        assert res[p] == (g["score"], g["result_a"].encode(), g["result_b"].encode())
+    # flags + ragged vs oracle
+    for flags in ((1, 1, 0, 0, 0), (0, 0, 1, 0, 0), (0, 0, 0, 0, 1), (1, 0, 0, 1, 0)):
+        spec = {"init": [1, -2, -4, -1, *flags, 0]}
+        sc = S.make_scoring(spec)
+        batch = W.ragged(40, seed=sum(flags) + 10, max_len=70)
+        res = ctx.nw_batch(batch, sc)
+        osc = oracle_scoring_of(sc)
+        for p in range(batch.n_pairs):
+            rc, s, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and res[p] == (s, ra, rb)
+
+
+def test_sw_batch_hits_match_oracle(ctx):
+    for spec, gen, kw, thr in (
+            ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, W.dna_sw_read_vs_ref, dict(seed=21, read_len=60, ref_len=300), 24),
+            ({"preset": "BLOSUM62"}, W.protein_sw_300, dict(seed=22, length=120), 24),
+            ({"init": [1, -2, -4, -1, 0, 0, 1, 1, 0, 1]}, W.dna_nw_150, dict(seed=23, length=40, related=True), 3)):
+        sc = S.make_scoring(spec)
+        batch = gen(24, **kw)
+        got = ctx.sw_batch(batch, sc, thr, max_hits=5)
+        osc = oracle_scoring_of(sc)
+        for p in range(batch.n_pairs):
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, 5)
+            assert rc == 0 and got[p] == want, (spec, p)
+
+
+def test_legacy_api_known_answers(ctx):
+    """The reference's own tests (tests.c) replayed against OUR library through the
+    reference-shaped API: needleman_wunsch_align / smith_waterman_fetch."""
+    lib = S.lib()
+    kat = load("kat.json")
+    nw = C.c_void_p(lib.needleman_wunsch_new())
+    res = C.c_void_p(lib.alignment_create(C.c_size_t(256)))
+    for v in kat["nw"]:                      # same aligner re-used, like tests.c:133-163
+        sc = S.make_scoring(v["scoring"])
+        lib.needleman_wunsch_align(v["a"].encode(), v["b"].encode(), C.byref(sc), nw, res)
+        r = O.Alignment.from_address(res.value)
+        assert (C.string_at(r.result_a).decode(), C.string_at(r.result_b).decode()) == (v["result_a"], v["result_b"])
+        if "score" in v:
+            assert r.score == v["score"]
+    lib.needleman_wunsch_free(nw)
+    for v in kat["sw"]:
+        sc = S.make_scoring(v["scoring"])
+        sw = C.c_void_p(lib.smith_waterman_new())
+        a, b = v["a"].encode(), v["b"].encode()
+        lib.smith_waterman_align(a, b, C.byref(sc), sw)
+        for want in v["hits"]:
+            assert lib.smith_waterman_fetch(sw, res) == 1
+            r = O.Alignment.from_address(res.value)
+            assert [C.string_at(r.result_a).decode(), C.string_at(r.result_b).decode()] == want
+        # a re-used sw_aligner_t gives the hits of a fresh one
+        lib.smith_waterman_align(a, b, C.byref(sc), sw)
+        assert lib.smith_waterman_fetch(sw, res) == 1
+        r = O.Alignment.from_address(res.value)
+        assert [C.string_at(r.result_a).decode(), C.string_at(r.result_b).decode()] == v["hits"][0]
+        lib.smith_waterman_free(sw)
+    lib.alignment_free(res)
+
+
+def test_legacy_sw_fetch_matches_oracle_hit_lists(ctx):
+    lib = S.lib()
+    spec = {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}
+    sc, osc = S.make_scoring(spec), O.build_scoring(spec, "oracle")
+    batch = W.dna_sw_read_vs_ref(6, seed=31, read_len=50, ref_len=200)
+    sw = C.c_void_p(lib.smith_waterman_new())
+    res = C.c_void_p(lib.alignment_create(C.c_size_t(16)))
+    for p in range(batch.n_pairs):
+        a, b = batch.seq_a(p), batch.seq_b(p)
+        lib.smith_waterman_align2(a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), sw)
+        rc, want = O.oracle_sw(osc, a, b, 0, 12)
+        for h in want:
+            assert lib.smith_waterman_fetch(sw, res) == 1
+            r = O.Alignment.from_address(res.value)
+            assert (r.score, r.pos_a, r.pos_b, r.len_a, r.len_b, C.string_at(r.result_a).decode(),
+                    C.string_at(r.result_b).decode()) == (h["score"], h["pos_a"], h["pos_b"], h["len_a"],
+                                                         h["len_b"], h["a"], h["b"])
+    lib.smith_waterman_free(sw)
+    lib.alignment_free(res)
