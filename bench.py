@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -135,7 +135,7 @@ def main():
     # kernel choice: measured, not guessed
     if args.kernel == "auto":
         best = None
-        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN):
+        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM):
             ms = db.time_fill_ms(ctx, h, k, 6)[1:]
             m = float(np.median(ms))
             if best is None or m < best[1]:
@@ -146,14 +146,15 @@ def main():
             dist.broadcast(t, 0)
             kernel = int(t.item())
     else:
-        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN}[args.kernel]
+        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM}[args.kernel]
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
-        db.fill(ctx, h, kernel)
+        db.fill(ctx, h, kernel, order_after_current=False)
     torch.cuda.synchronize()
     barrier()
 
@@ -162,9 +163,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record()           # same stream the kernel is launched on
-        db.fill(ctx, h, kernel)
-        ends[i].record()
+        starts[i].record(db.stream)  # the stream the kernel is launched on
+        db.fill(ctx, h, kernel, order_after_current=False)
+        ends[i].record(db.stream)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

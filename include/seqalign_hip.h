@@ -115,7 +115,12 @@ typedef struct {
 enum {
   SEQALIGN_KERNEL_AUTO = 0,
   SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair  */
-  SEQALIGN_KERNEL_ROWSCAN = 2    /* row sweep + max-plus prefix scan for gap_b   */
+  SEQALIGN_KERNEL_ROWSCAN = 2,   /* row sweep + max-plus prefix scan for gap_b,
+                                    rows stored straight from registers        */
+  SEQALIGN_KERNEL_STREAM = 3     /* same sweep, output through an LDS ring as
+                                    aligned 1 KiB blocks (len_a <= 511 and the
+                                    three arenas congruent mod 1 KiB; otherwise
+                                    the call falls back to ROWSCAN)            */
 };
 
 /* THE HOT PATH.  Replaces alignment_fill_matrices (src/alignment.c:28-168) for a

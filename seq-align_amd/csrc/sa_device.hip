@@ -221,8 +221,9 @@ static int pick_kernel(int kernel) {
   if (const char *env = getenv("SEQALIGN_KERNEL")) {
     if (!strcmp(env, "wavefront")) return SEQALIGN_KERNEL_WAVEFRONT;
     if (!strcmp(env, "rowscan")) return SEQALIGN_KERNEL_ROWSCAN;
+    if (!strcmp(env, "stream")) return SEQALIGN_KERNEL_STREAM;
   }
-  return SEQALIGN_KERNEL_ROWSCAN;
+  return SEQALIGN_KERNEL_STREAM;   // measured fastest (profiles/); falls back when not applicable
 }
 
 extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
@@ -234,13 +235,17 @@ extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_de
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const SaFillParams p = make_params(scoring, batch);
   hipError_t e;
-  switch (pick_kernel(kernel)) {
+  int which = pick_kernel(kernel);
+  // a positive gap_extend (legal, absurd) breaks the row scan's saturating-add
+  // identity; the wavefront kernel is exact for any sign
+  if (p.ext > 0) which = SEQALIGN_KERNEL_WAVEFRONT;
+  if (which == SEQALIGN_KERNEL_STREAM && !sa_stream_kernel_applicable(p, batch->max_len_a))
+    which = SEQALIGN_KERNEL_ROWSCAN;
+  switch (which) {
     case SEQALIGN_KERNEL_WAVEFRONT: e = sa_launch_fill_wavefront(p, batch->max_len_a, st); break;
+    case SEQALIGN_KERNEL_STREAM: e = sa_launch_fill_stream(p, batch->max_len_a, st); break;
     case SEQALIGN_KERNEL_ROWSCAN:
-      // the row scan's saturating-add identity assumes gap_extend <= 0; a positive
-      // gap_extend (legal, absurd) takes the wavefront kernel, exact for any sign
-      e = (p.ext > 0) ? sa_launch_fill_wavefront(p, batch->max_len_a, st)
-                      : sa_launch_fill_rowscan(p, batch->max_len_a, st);
+      e = sa_launch_fill_rowscan(p, batch->max_len_a, st);
       break;
     default: return SEQALIGN_E_ARG;
   }

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sa_kernels.h"
 
@@ -79,18 +80,25 @@ typedef int v2i_u __attribute__((ext_vector_type(2), aligned(4)));
 typedef int v3i_u __attribute__((ext_vector_type(3), aligned(4)));
 typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 
+// SA_STORE_NT (experiment builds only): mark the matrix stores non-temporal
+#ifdef SA_STORE_NT
+#define SA_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define SA_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 template <int N>
 __device__ __forceinline__ void store_run(int32_t *dst, const int (&v)[N]) {
   if constexpr (N == 1) {
-    dst[0] = v[0];
+    SA_STORE(dst, v[0]);
   } else if constexpr (N == 2) {
-    *reinterpret_cast<v2i_u *>(dst) = v2i_u{v[0], v[1]};
+    SA_STORE(reinterpret_cast<v2i_u *>(dst), (v2i_u{v[0], v[1]}));
   } else if constexpr (N == 3) {
-    *reinterpret_cast<v3i_u *>(dst) = v3i_u{v[0], v[1], v[2]};
+    SA_STORE(reinterpret_cast<v3i_u *>(dst), (v3i_u{v[0], v[1], v[2]}));
   } else if constexpr (N == 4) {
-    *reinterpret_cast<v4i_u *>(dst) = v4i_u{v[0], v[1], v[2], v[3]};
+    SA_STORE(reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
   } else {
-    *reinterpret_cast<v4i_u *>(dst) = v4i_u{v[0], v[1], v[2], v[3]};
+    SA_STORE(reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
     int rest[N - 4];
 #pragma unroll
     for (int k = 0; k < N - 4; ++k) rest[k] = v[4 + k];
@@ -103,6 +111,17 @@ __device__ __forceinline__ void store_partial(int32_t *dst, const int (&v)[N], i
 #pragma unroll
   for (int k = 0; k < N; ++k)
     if (k < n) dst[k] = v[k];
+}
+
+// columns per lane for a batch whose longest seq_a is max_len_a; SEQALIGN_CPL
+// (tuning experiments) may raise it
+inline uint32_t columns_per_lane(uint32_t max_len_a) {
+  uint32_t need = (max_len_a + kWave - 1) / kWave;
+  if (const char *env = getenv("SEQALIGN_CPL")) {
+    const uint32_t v = (uint32_t)atoi(env);
+    if (v > need && v <= 8) need = v;
+  }
+  return need;
 }
 
 // border values (reference alignment.c:46-81)

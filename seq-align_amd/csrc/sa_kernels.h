@@ -47,6 +47,10 @@ hipError_t sa_launch_fill_wavefront(const SaFillParams &p, uint32_t max_len_a,
                                     hipStream_t stream);
 hipError_t sa_launch_fill_rowscan(const SaFillParams &p, uint32_t max_len_a,
                                   hipStream_t stream);
+/* LDS-ring stream writer; only when sa_stream_kernel_applicable() */
+bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
+hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
+                                 hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
 hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);

@@ -18,11 +18,14 @@ from . import workloads  # noqa: F401
 
 PKG_ROOT = Path(__file__).resolve().parents[2]          # seq-align_amd/
 REPO_ROOT = PKG_ROOT.parent
-LIB_PATH = PKG_ROOT / "lib" / "libseqalign_hip.so"
+import os as _os
+# SEQALIGN_LIB: tuning experiments point this at an alternative build of the same library
+LIB_PATH = Path(_os.environ.get("SEQALIGN_LIB") or (PKG_ROOT / "lib" / "libseqalign_hip.so"))
 
 OK, E_NO_DEVICE, E_HIP, E_ARG, E_NOMEM, E_UNKNOWN_PAIR, E_DOMAIN, E_TRACEBACK, E_TOO_LARGE = range(9)
-KERNEL_AUTO, KERNEL_WAVEFRONT, KERNEL_ROWSCAN = 0, 1, 2
-KERNEL_NAMES = {KERNEL_AUTO: "auto", KERNEL_WAVEFRONT: "wavefront", KERNEL_ROWSCAN: "rowscan"}
+KERNEL_AUTO, KERNEL_WAVEFRONT, KERNEL_ROWSCAN, KERNEL_STREAM = 0, 1, 2, 3
+KERNEL_NAMES = {KERNEL_AUTO: "auto", KERNEL_WAVEFRONT: "wavefront", KERNEL_ROWSCAN: "rowscan",
+                KERNEL_STREAM: "stream"}
 STATUS_OK = 0xFFFFFFFFFFFFFFFF
 
 
@@ -252,24 +255,36 @@ class DeviceBatch:
         self.off_a, self.len_a = t(batch.off_a), t(batch.len_a)
         self.off_b, self.len_b = t(batch.off_b), t(batch.len_b)
         self.mat_off = t(self.mat_off_host)
-        self.M = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
-        self.A = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
-        self.B = torch.empty(self.total_cells, dtype=torch.int32, device=dev)
+        # one allocation, three 4 KiB-aligned arenas: the stream kernel wants the
+        # arenas congruent mod 1 KiB (torch's allocator only promises 512 B)
+        stride = (self.total_cells + 1023) // 1024 * 1024
+        self._arena3 = torch.empty(3 * stride + 1024, dtype=torch.int32, device=dev)
+        skew = (-(self._arena3.data_ptr() // 4)) % 1024
+        self.M = self._arena3[skew:skew + self.total_cells]
+        self.A = self._arena3[skew + stride:skew + stride + self.total_cells]
+        self.B = self._arena3[skew + 2 * stride:skew + 2 * stride + self.total_cells]
         self.status = torch.zeros(batch.n_pairs, dtype=torch.int64, device=dev)
+        # launches go to a real (non-null) torch stream: a NULL stream handle means
+        # "the context's own stream" in the C ABI, and torch events only see torch streams
+        self.stream = torch.cuda.Stream(dev)
         self.desc = DevBatchDesc(batch.n_pairs, self.arena.data_ptr(), self.off_a.data_ptr(),
                                  self.len_a.data_ptr(), self.off_b.data_ptr(), self.len_b.data_ptr(),
                                  self.mat_off.data_ptr(), self.M.data_ptr(), self.A.data_ptr(),
                                  self.B.data_ptr(), self.status.data_ptr(),
                                  int(batch.len_a.max(initial=0)), int(batch.len_b.max(initial=0)))
 
-    def fill(self, ctx: Context, dev_scoring, kernel: int = KERNEL_AUTO, stream=None):
-        """Enqueue THE HOT PATH on torch's current stream (no sync)."""
-        st = stream if stream is not None else self.torch.cuda.current_stream(self.device).cuda_stream
+    def fill(self, ctx: Context, dev_scoring, kernel: int = KERNEL_AUTO, order_after_current: bool = True):
+        """Enqueue THE HOT PATH on self.stream (no host sync).  By default the launch
+        is ordered after work already queued on torch's current stream (e.g. the
+        tests' poison fill)."""
+        if order_after_current:
+            self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
         _check(lib().seqalign_fill_batch_device(ctx._h, dev_scoring, C.byref(self.desc), C.c_int(kernel),
-                                                C.c_void_p(st)), "seqalign_fill_batch_device")
+                                                C.c_void_p(self.stream.cuda_stream)), "seqalign_fill_batch_device")
 
-    def time_fill_ms(self, ctx: Context, dev_scoring, kernel: int, repeats: int, stream=None):
-        st = stream if stream is not None else self.torch.cuda.current_stream(self.device).cuda_stream
+    def time_fill_ms(self, ctx: Context, dev_scoring, kernel: int, repeats: int):
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        st = self.stream.cuda_stream
         ms = (C.c_float * repeats)()
         _check(lib().seqalign_time_fill_ms(ctx._h, dev_scoring, C.byref(self.desc), C.c_int(kernel),
                                            C.c_void_p(st), C.c_int(repeats), ms), "seqalign_time_fill_ms")
@@ -292,7 +307,8 @@ class DeviceBatch:
         best_s = torch.zeros(n, dtype=torch.int32, device=dev)
         best_i = torch.zeros(n, dtype=torch.int64, device=dev)
         count = torch.zeros(n, dtype=torch.int32, device=dev)
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        st = self.stream.cuda_stream
         r = SwReduceDesc(n, self.len_a.data_ptr(), self.len_b.data_ptr(), self.mat_off.data_ptr(),
                          self.M.data_ptr(), min_score, best_s.data_ptr(), best_i.data_ptr(),
                          count.data_ptr(), 0, 0, 0, 0)
@@ -311,6 +327,7 @@ class DeviceBatch:
             c_sc = torch.zeros(total + 1, dtype=torch.int32, device=dev)
             r.cand_off, r.cand_cap = d_off.data_ptr(), d_cap.data_ptr()
             r.cand_index, r.cand_score = c_idx.data_ptr(), c_sc.data_ptr()
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _check(lib().seqalign_sw_reduce_device(ctx._h, C.byref(r), C.c_void_p(st)), "seqalign_sw_reduce_device")
             torch.cuda.synchronize(self.device)
             ci, cs = c_idx.cpu().numpy().view(np.uint32), c_sc.cpu().numpy()

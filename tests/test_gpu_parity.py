@@ -17,7 +17,7 @@ from seqalign_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
-KERNELS = [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN]
+KERNELS = [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM]
 KID = lambda k: S.KERNEL_NAMES[k]
 
 
@@ -206,8 +206,8 @@ FULL = {
 
 @pytest.mark.parametrize("name", list(FULL))
 def test_full_size_config_properties(ctx, name):
-    """BASELINE sizes: (1) the two independently scheduled kernels agree on every
-    byte, (2) a strided sample equals the oracle, (3) SW: the reduction kernel's
+    """BASELINE sizes: (1) the three independently scheduled kernels agree on every
+    byte (incl. the untouched padding between pairs), (2) a strided sample equals the oracle, (3) SW: the reduction kernel's
     best cell equals max(M) in reference hit order, (4) NW: last-cell scores equal
     the host traceback's, (5) duplicated pairs give identical matrices."""
     import torch
@@ -222,10 +222,13 @@ def test_full_size_config_properties(ctx, name):
     sums1 = [int(t.to(torch.int64).sum().item()) for t in (db1.M, db1.A, db1.B)]
     M1 = db1.M.clone(); A1 = db1.A.clone(); B1 = db1.B.clone()
     del db1
-    db2 = device_fill(ctx, batch, sc, cfg["is_sw"], S.KERNEL_ROWSCAN)
-    # padding cells between pairs keep the poison in both runs, so whole arenas compare
-    assert torch.equal(M1, db2.M) and torch.equal(A1, db2.A) and torch.equal(B1, db2.B)
-    assert sums1 == [int(t.to(torch.int64).sum().item()) for t in (db2.M, db2.A, db2.B)]
+    for other in (S.KERNEL_ROWSCAN, S.KERNEL_STREAM):
+        db2 = device_fill(ctx, batch, sc, cfg["is_sw"], other)
+        # padding cells between pairs keep the poison in every run, so whole arenas compare
+        assert torch.equal(M1, db2.M) and torch.equal(A1, db2.A) and torch.equal(B1, db2.B), KID(other)
+        assert sums1 == [int(t.to(torch.int64).sum().item()) for t in (db2.M, db2.A, db2.B)]
+        if other != S.KERNEL_STREAM:
+            del db2
     del M1, A1, B1
     sample = list(range(0, batch.n_pairs, max(1, batch.n_pairs // 48)))
     assert_pairs_match_oracle(db2, batch, osc, cfg["is_sw"], sample, tag=name)
