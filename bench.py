@@ -105,11 +105,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
+    from seqalign_amd.dist import Group, env_world
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local, world = env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -117,9 +115,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    grp = Group("nccl", torch.device("cuda", local))   # "nccl" is RCCL on ROCm; no-op at world 1
 
     gen, kwargs, per_gpu, is_sw, spec, desc = WORKLOADS[args.workload]
     per_gpu = args.pairs or per_gpu
@@ -140,17 +136,11 @@ def main():
             m = float(np.median(ms))
             if best is None or m < best[1]:
                 best = (k, m)
-        kernel = best[0]
-        if world > 1:   # all ranks run the same kernel
-            t = torch.tensor([kernel], device="cuda")
-            dist.broadcast(t, 0)
-            kernel = int(t.item())
+        kernel = grp.broadcast_int(best[0], 0)   # all ranks run the same kernel
     else:
         kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM}[args.kernel]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = grp.barrier
 
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -170,15 +160,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([batch.cells()], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = int(c.item())
-    else:
-        total_cells = batch.cells()
+    elapsed = grp.max_float(elapsed)               # MAX over ranks
+    total_cells = grp.sum_int(batch.cells())       # whole-job cells per step
 
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
 
@@ -225,8 +208,7 @@ def main():
 
     ctx.release_scoring(h)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

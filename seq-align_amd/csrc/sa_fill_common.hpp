@@ -80,29 +80,33 @@ typedef int v2i_u __attribute__((ext_vector_type(2), aligned(4)));
 typedef int v3i_u __attribute__((ext_vector_type(3), aligned(4)));
 typedef int v4i_u __attribute__((ext_vector_type(4), aligned(4)));
 
-// SA_STORE_NT (experiment builds only): mark the matrix stores non-temporal
-#ifdef SA_STORE_NT
-#define SA_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define SA_STORE(ptr, val) (*(ptr) = (val))
-#endif
+// NT = non-temporal hint (global_store ... nt).  Measured on C2 (10k 150x150,
+// same box, profiles/r01_variants.txt): row-sweep kernels gain 10-20 % with it
+// (the matrices are write-once streams, nothing re-reads them from L2), the
+// wavefront kernel loses 4x (its 12-B per-row pieces NEED to merge in L2).
+// (a macro, not a template: the pointer must keep its aligned(4) typedef)
+#define SA_STORE_VEC(NT, ptr, val)                                   \
+  do {                                                               \
+    if constexpr (NT) __builtin_nontemporal_store((val), (ptr));     \
+    else *(ptr) = (val);                                             \
+  } while (0)
 
-template <int N>
+template <int N, bool NT = false>
 __device__ __forceinline__ void store_run(int32_t *dst, const int (&v)[N]) {
   if constexpr (N == 1) {
-    SA_STORE(dst, v[0]);
+    SA_STORE_VEC(NT, dst, (int32_t)v[0]);
   } else if constexpr (N == 2) {
-    SA_STORE(reinterpret_cast<v2i_u *>(dst), (v2i_u{v[0], v[1]}));
+    SA_STORE_VEC(NT, reinterpret_cast<v2i_u *>(dst), (v2i_u{v[0], v[1]}));
   } else if constexpr (N == 3) {
-    SA_STORE(reinterpret_cast<v3i_u *>(dst), (v3i_u{v[0], v[1], v[2]}));
+    SA_STORE_VEC(NT, reinterpret_cast<v3i_u *>(dst), (v3i_u{v[0], v[1], v[2]}));
   } else if constexpr (N == 4) {
-    SA_STORE(reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
+    SA_STORE_VEC(NT, reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
   } else {
-    SA_STORE(reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
+    SA_STORE_VEC(NT, reinterpret_cast<v4i_u *>(dst), (v4i_u{v[0], v[1], v[2], v[3]}));
     int rest[N - 4];
 #pragma unroll
     for (int k = 0; k < N - 4; ++k) rest[k] = v[4 + k];
-    store_run<N - 4>(dst + 4, rest);
+    store_run<N - 4, NT>(dst + 4, rest);
   }
 }
 

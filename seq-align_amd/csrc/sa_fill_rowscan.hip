@@ -81,9 +81,9 @@ fill_rowscan_kernel(const SaFillParams p) {
       sw.row(k, j, lb, la, W, lane, col0, ncol, read_lane(feed.code, q), read_lane(feed.Z, q),
              read_lane(feed.B, q), mv, av, bv);
       if (ncol == CPL) {
-        store_run<CPL>(Mg + off, mv);
-        store_run<CPL>(Ag + off, av);
-        store_run<CPL>(Bg + off, bv);
+        store_run<CPL, true>(Mg + off, mv);
+        store_run<CPL, true>(Ag + off, av);
+        store_run<CPL, true>(Bg + off, bv);
       } else if (ncol > 0) {
         store_partial<CPL>(Mg + off, mv, ncol);
         store_partial<CPL>(Ag + off, av, ncol);

@@ -45,7 +45,8 @@ struct StreamOut {
       int32_t *dst = g0[m] + rv + 4 * lane;
       if (inside) {
         typedef int v4i_a __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<v4i_a *>(dst) = v4i_a{q.x, q.y, q.z, q.w};                     // aligned dwordx4
+        // aligned global_store_dwordx4 ... nt: write-once stream (see store_vec)
+        __builtin_nontemporal_store(v4i_a{q.x, q.y, q.z, q.w}, reinterpret_cast<v4i_a *>(dst));
       } else {
         const uint32_t e = rv + 4 * lane;
         if (e + 0 >= a0 && e + 0 < vend) dst[0] = q.x;
@@ -165,7 +166,8 @@ static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
   const bool general =
       p.flags & (SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_HAS_SENTINEL);
   const dim3 grid((p.n_pairs + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-  const size_t rings = (size_t)kWavesPerBlock * 3 * R * sizeof(int32_t);
+  size_t rings = (size_t)kWavesPerBlock * 3 * R * sizeof(int32_t);
+  if (const char *env = getenv("SEQALIGN_LDS_PAD")) rings += (size_t)atoi(env);   // occupancy experiments
   if (p.K <= 1) {
     if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R>), grid, block, rings, stream, p, 0u);
     else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R>), grid, block, rings, stream, p, 0u);

@@ -258,6 +258,7 @@ class DeviceBatch:
         # one allocation, three 4 KiB-aligned arenas: the stream kernel wants the
         # arenas congruent mod 1 KiB (torch's allocator only promises 512 B)
         stride = (self.total_cells + 1023) // 1024 * 1024
+        stride += int(_os.environ.get("SEQALIGN_ARENA_SKEW", "0")) // 256 * 256   # layout experiments
         self._arena3 = torch.empty(3 * stride + 1024, dtype=torch.int32, device=dev)
         skew = (-(self._arena3.data_ptr() // 4)) % 1024
         self.M = self._arena3[skew:skew + self.total_cells]
