@@ -10,14 +10,15 @@
 //        B(i) = max(B(i-1) + ext, cin(i)),  cin(i) = max(max(M,A)(i-1) + open1, floor)
 //     i.e. B(i) = max_k (cin(k) + (i-k)*ext): a prefix scan in the (max,+)
 //     semiring.  Each lane scans its CPL columns serially, the 64 lane totals are
-//     scanned with 6 DPP steps (row_shr 1,2,4,8, row_bcast 15, 31), and the carry
-//     is applied on the way out.
-// Exactness: the wave scan adds up to 63*CPL*ext to cells that may hold the NW
-// floor INT_MIN+|min_penalty| (reference alignment.c:41); those adds SATURATE
-// (v_add_i32 clamp).  A saturated term is below the floor, every true gap_b is
-// >= floor, so it can never be the maximum: results are bit-identical to the
-// serial recurrence.  Every other add is one the reference performs itself
-// (value >= floor plus one penalty >= -|min_penalty|).
+//     scanned across the wave (wave_scan_maxplus: de-trended, 6 DPP max steps),
+//     and the carry is applied on the way out.
+// Exactness: cells may hold the NW floor INT_MIN+|min_penalty| (reference
+// alignment.c:41), so no step may add a multiple of ext to an arbitrary cell.
+// The wave scan never does (see wave_scan_maxplus); the carry into a lane's
+// first column is one saturating add (v_add_i32 clamp) whose only saturating
+// input is the "no carry" identity INT_MIN of lane 0.  Every other add is one the
+// reference performs itself (value >= floor plus one penalty >= -|min_penalty|,
+// SURVEY A.3-3).  Results are bit-identical to the serial recurrence.
 #pragma once
 
 #include "sa_fill_common.hpp"
@@ -34,19 +35,25 @@ __device__ __forceinline__ int dpp_mov(int old, int src) {
   return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
 }
 
-// Inclusive (max,+) scan over the 64 lanes: I_l = max_{m<=l} (g_m + (l-m)*d).
-// d1..d8 = 1,2,4,8 * d; kb15 = ((lane&15)+1)*d; kb31 = ((lane&31)+1)*d.
-__device__ __forceinline__ int wave_scan_maxplus(int g, int d1, int d2, int d4, int d8,
-                                                 int kb15, int kb31) {
+// Inclusive (max,+) scan over the 64 lanes: I_l = max_{m<=l} (g_m + (l-m)*d),
+// d <= 0.  De-trended: with u_m = g_m - m*d the decay disappears,
+//     I_l = l*d + max_{m<=l} u_m,
+// so the wave part is a PLAIN max scan -- 6 v_max_i32 with a DPP source
+// (row_shr 1,2,4,8, row_bcast 15/31; INT_MIN is max's identity, so lanes without
+// a source are untouched) -- instead of 6 x (shift, saturating add, max).
+// Exact without saturation: u_m = g_m + m*|d| cannot underflow, and
+// I_l >= g_l >= floor because the maximum includes m = l.
+// lane_d = lane * d.
+__device__ __forceinline__ int wave_scan_maxplus(int g, int lane_d) {
   constexpr int NEG = INT32_MIN;
-  int v = g;
-  v = max(v, add_sat(dpp_mov<0x111, 0xf>(NEG, v), d1));   // row_shr:1
-  v = max(v, add_sat(dpp_mov<0x112, 0xf>(NEG, v), d2));   // row_shr:2
-  v = max(v, add_sat(dpp_mov<0x114, 0xf>(NEG, v), d4));   // row_shr:4
-  v = max(v, add_sat(dpp_mov<0x118, 0xf>(NEG, v), d8));   // row_shr:8
-  v = max(v, add_sat(dpp_mov<0x142, 0xa>(NEG, v), kb15)); // row_bcast:15 -> rows 1,3
-  v = max(v, add_sat(dpp_mov<0x143, 0xc>(NEG, v), kb31)); // row_bcast:31 -> rows 2,3
-  return v;
+  int u = (int)((unsigned)g - (unsigned)lane_d);
+  u = max(u, dpp_mov<0x111, 0xf>(NEG, u));   // row_shr:1
+  u = max(u, dpp_mov<0x112, 0xf>(NEG, u));   // row_shr:2
+  u = max(u, dpp_mov<0x114, 0xf>(NEG, u));   // row_shr:4
+  u = max(u, dpp_mov<0x118, 0xf>(NEG, u));   // row_shr:8
+  u = max(u, dpp_mov<0x142, 0xa>(NEG, u));   // row_bcast:15 -> rows 1,3
+  u = max(u, dpp_mov<0x143, 0xc>(NEG, u));   // row_bcast:31 -> rows 2,3
+  return addw(u, lane_d);
 }
 
 // wave-uniform scoring constants
@@ -97,8 +104,13 @@ struct RowSweep {
                                       int lane, uint32_t col0, int ncol, int code_b, int feedZ, int feedB,
                                       int (&mv)[CPL], int (&av)[CPL], int (&bv)[CPL], int edge_a = 0) {
     // edge_a (COL0 only): gap_a of the border cell (0, j)
-    int xd = wave_shr1(X[CPL - 1], boundX);        // max3 of (i-1, j-1)
-    boundX = max(feedZ, feedB);
+    int xd;                                        // max3 of (i-1, j-1)
+    if constexpr (COL0) {
+      xd = wave_shr1(X[CPL - 1], X[CPL - 1]);      // lane 0's value is overridden below
+    } else {
+      xd = wave_shr1(X[CPL - 1], boundX);
+      boundX = max(feedZ, feedB);
+    }
     int z[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -141,7 +153,8 @@ struct RowSweep {
 #pragma unroll
       for (int c = 0; c < CPL; ++c) bv[c] = k.floor_;
     } else {
-      const int zin = wave_shr1(z[CPL - 1], feedZ);   // max(M,A) of (i-1, j)
+      const int zin = COL0 ? wave_shr1(z[CPL - 1], z[CPL - 1])   // lane 0: overridden below
+                           : wave_shr1(z[CPL - 1], feedZ);       // max(M,A) of (i-1, j)
       int L[CPL];
       {
         const int cin0 = max(addw(zin, r_open), r_floor);
@@ -158,9 +171,7 @@ struct RowSweep {
         const int cin = max(addw(z[c - 1], r_open), r_floor);
         L[c] = max(addw(L[c - 1], r_ext), cin);
       }
-      const int d = CPL * r_ext;
-      const int incl = wave_scan_maxplus(L[CPL - 1], d, 2 * d, 4 * d, 8 * d,
-                                         ((lane & 15) + 1) * d, ((lane & 31) + 1) * d);
+      const int incl = wave_scan_maxplus(L[CPL - 1], lane * (CPL * r_ext));
       const int e = wave_shr1(incl, INT32_MIN);       // gap_b of (col0, j), lanes >= 1
       bv[0] = max(L[0], add_sat(e, r_ext));
 #pragma unroll

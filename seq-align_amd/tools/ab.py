@@ -7,7 +7,8 @@ the distribution).
         "stream" "stream:SEQALIGN_LDS_PAD=16384" "rowscan"
 
 A variant is  kernel[:ENV=VALUE[,ENV=VALUE...]]; the env vars are set around the
-launches (the launchers read them at launch time)."""
+launches (the launchers read them at launch time).  To compare two BUILDS run
+the tool once per build with SEQALIGN_LIB set and alternate the invocations."""
 import argparse
 import json
 import os
