@@ -10,7 +10,7 @@ its own 10 000-pair shard of a 10 000*N-pair batch: weak scaling, independent
 pairs, NO collective on the data path (the only collectives are the barrier and
 the MAX over ranks of the elapsed time).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 10
 
 Prints ONE JSON line (rank 0).  `value` = all ranks' cells / max-rank seconds.
 `roofline`  : algorithmic bytes per launch / mean kernel duration (HIP events on
@@ -96,8 +96,8 @@ def cpu_baseline(batch, spec, is_sw, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
@@ -202,6 +202,21 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if is_sw:
+            # the SW local-maxima reduction, a separate kernel (4 B/cell read)
+            thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+            for i in range(11):
+                ev[i].record(db.stream)
+                db.sw_reduce_launch(ctx, thr)
+            ev[11].record(db.stream)
+            torch.cuda.synchronize()
+            rms = float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(1, 11)]))
+            rbytes = int(4 * db.cells_host.sum())
+            out["sw_reduce"] = {"min_score": thr, "kernel_ms": rms, "bound": "hbm",
+                                "achieved": rbytes / (rms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": rbytes / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": rbytes}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw)
         print(json.dumps(out), flush=True)

@@ -155,6 +155,25 @@ typedef struct {
 int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r,
                               void *stream);
 
+/* NW traceback on the device: consumes the matrices a fill left in
+ * HBM and applies needleman_wunsch.c:53-132 / alignment.c:244-350 per pair.
+ * Pair p's two alignment strings are written RIGHT-ALIGNED into
+ * out_a/out_b[str_off[p] .. str_off[p]+len_a+len_b): they start at
+ * str_off[p]+out_head[p] and are out_len[p] long (no NUL).  status[p] is 0 or a
+ * SEQALIGN_E_* code.  All pointers are DEVICE pointers. */
+typedef struct {
+  const uint64_t *str_off;
+  char *out_a, *out_b;
+  uint32_t *out_head, *out_len;
+  int32_t *out_score;
+  uint32_t *status;
+} seqalign_nw_trace_t;
+
+int seqalign_nw_traceback_device(seqalign_ctx_t *ctx,
+                                 const seqalign_dev_scoring_t *scoring,
+                                 const seqalign_dev_batch_t *batch,
+                                 const seqalign_nw_trace_t *trace, void *stream);
+
 /* ---- host-level convenience (H2D -> fill -> D2H) ---------------------------- */
 /* Fills every pair of a HOST batch and copies the matrices back into the three
  * host arenas (cell offsets mat_off[p], host pointer).  Streams the batch in
@@ -165,8 +184,11 @@ int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                         int32_t *gap_a_scores, int32_t *gap_b_scores,
                         uint64_t *status);
 
-/* Global NW over a host batch: GPU fill + host traceback (the traceback is the
- * reference's consumer, src/needleman_wunsch.c:53-145, fresh code).  Results:
+/* Global NW over a host batch: GPU fill + traceback (the reference's consumer,
+ * src/needleman_wunsch.c:53-145, fresh code).  By default the traceback also runs
+ * on the device and only the strings cross PCIe; SEQALIGN_TRACEBACK=host copies
+ * the matrices back and walks them on the host (north_star's literal split --
+ * identical results, PCIe-bound).  Results:
  * score[p], and the two alignment strings of pair p written NUL-terminated at
  * out_a + str_off[p], out_b + str_off[p] (capacity len_a+len_b+1 each). */
 int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,

@@ -102,7 +102,8 @@ struct seqalign_ctx {
   // device scratch for the host-level entry points
   DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
   DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
-  HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc;
+  DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
+  HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // cached flattened scoring for the legacy single-pair path
   seqalign_dev_scoring *cached = nullptr;
   std::vector<unsigned char> cached_key;
@@ -162,9 +163,12 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
   for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
                     &ctx->M, &ctx->A, &ctx->B, &ctx->status, &ctx->best_score, &ctx->best_index,
-                    &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score})
+                    &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score,
+                    &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
     b->release();
-  for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc}) b->release();
+  for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
+                     &ctx->h_tb, &ctx->h_tmeta})
+    b->release();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -203,6 +207,18 @@ extern "C" void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scori
   if (ctx && ctx->cached == h) { ctx->cached = nullptr; ctx->cached_is_sw = -1; }
   delete h;
 }
+
+namespace {
+// releases an uploaded scoring on every exit path of the host-level entry points
+struct ScoringGuard {
+  seqalign_ctx *ctx;
+  seqalign_dev_scoring *h = nullptr;
+  explicit ScoringGuard(seqalign_ctx *c) : ctx(c) {}
+  ~ScoringGuard() { if (h) seqalign_scoring_release(ctx, h); }
+  ScoringGuard(const ScoringGuard &) = delete;
+  ScoringGuard &operator=(const ScoringGuard &) = delete;
+};
+}  // namespace
 
 // --------------------------------------------------------------- hot path ---
 static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_dev_batch_t *b) {
@@ -270,6 +286,24 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
   for (int r = 0; r < repeats && rc == SEQALIGN_OK; ++r) HIP_TRY(hipEventElapsedTime(&ms_each[r], ev[2 * r], ev[2 * r + 1]));
   for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;
+}
+
+extern "C" int seqalign_nw_traceback_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc,
+                                            const seqalign_dev_batch_t *b, const seqalign_nw_trace_t *t,
+                                            void *stream) {
+  if (!ctx || !sc || !b || !t) return SEQALIGN_E_ARG;
+  if (b->n_pairs == 0) return SEQALIGN_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SaTraceParams p;
+  p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
+  p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
+  p.code = sc->d_code; p.table = sc->d_table; p.str_off = t->str_off; p.out_a = t->out_a; p.out_b = t->out_b;
+  p.out_head = t->out_head; p.out_len = t->out_len; p.out_score = t->out_score; p.trace_status = t->status;
+  p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
+  p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
+  hipError_t e = sa_launch_nw_traceback(p, st);
+  if (e != hipSuccess) return fail_hip(e, "nw traceback launch");
+  return SEQALIGN_OK;
 }
 
 extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r, void *stream) {
@@ -389,8 +423,9 @@ extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  seqalign_dev_scoring *sc = nullptr;
-  if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &sc))) return rc;
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
   int worst = SEQALIGN_OK;
   for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
     if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
@@ -416,7 +451,6 @@ extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *
     if (src == SEQALIGN_E_UNKNOWN_PAIR) worst = src;
     else if (src) { rc = src; break; }
   }
-  seqalign_scoring_release(ctx, sc);
   return rc ? rc : worst;
 }
 
@@ -457,6 +491,57 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
 }
 
 // ----------------------------------------------- host-level: NW over a batch ---
+static bool traceback_on_host() {
+  const char *env = getenv("SEQALIGN_TRACEBACK");
+  return env && !strcmp(env, "host");
+}
+
+// device traceback of one already-filled chunk; strings land in the caller's buffers
+static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
+                                     const seqalign_dev_scoring *sc, const seqalign_dev_batch_t &d,
+                                     const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                                     int32_t *out_score) {
+  const uint64_t n = c.count;
+  int rc;
+  // per-pair slots of len_a+len_b chars in a compact device arena
+  if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 16))) return rc;
+  uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
+  uint64_t total = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    h_off[k] = total;
+    total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
+  }
+  if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
+      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
+      (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
+    return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
+  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status, n each
+  seqalign_nw_trace_t t;
+  t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+  t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
+  t.status = d_meta + 3 * n;
+  if ((rc = seqalign_nw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+  uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 16, hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k;
+    const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
+    if (status) return (int)status;
+    memcpy(out_a + str_off[p], ha + h_off[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
+    memcpy(out_b + str_off[p], hb + h_off[k] + head, len);
+    out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
+    out_len[p] = len;
+    out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+  }
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                  const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
                                  int32_t *out_score) {
@@ -465,35 +550,39 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  seqalign_dev_scoring *sc = nullptr;
-  if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &sc))) return rc;
-  // matrices come back through pinned staging, so chunks are also bounded by host memory
-  const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
+  const bool on_host = traceback_on_host();
+  // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
+  const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;
   for (const Chunk &c : plan_chunks(batch, budget)) {
-    if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
+    seqalign_dev_batch_t d;
+    if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
+    if (!on_host) {
+      if ((rc = nw_chunk_device_traceback(ctx, batch, c, sc, d, str_off, out_a, out_b, out_len, out_score))) return rc;
+      continue;
+    }
     const size_t bytes = c.cells * 4;
-    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) break;
-    hipError_t e = hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) { rc = fail_hip(e, "D2H matrices"); break; }
-    if ((rc = fetch_status(ctx, c, nullptr))) break;   // syncs; unknown pair is fatal for NW
+    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs; unknown pair is fatal for NW
     uint64_t cell = 0;
-    for (uint64_t k = 0; k < c.count && rc == SEQALIGN_OK; ++k) {
+    for (uint64_t k = 0; k < c.count; ++k) {
       const uint64_t p = c.first + k;
       sa_view_t v;
       v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
       v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
       v.M = ctx->h_M.as<int32_t>() + cell; v.A = ctx->h_A.as<int32_t>() + cell; v.B = ctx->h_B.as<int32_t>() + cell;
       size_t n = 0;
-      rc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]);
+      if ((rc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]))) return rc;
       out_len[p] = (uint32_t)n;
       cell += (uint64_t)(v.len_a + 1) * (v.len_b + 1);
     }
-    if (rc) break;
   }
-  seqalign_scoring_release(ctx, sc);
-  return rc;
+  return SEQALIGN_OK;
 }
 
 // ----------------------------------------------- host-level: SW over a batch ---
@@ -512,8 +601,9 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  seqalign_dev_scoring *sc = nullptr;
-  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &sc))) return rc;
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
   uint64_t used_str = 0, found = 0;
   const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
 
@@ -583,15 +673,24 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
         const Cand cd{h_cidx[c_off[k] + q], h_cscore[c_off[k] + q]};
         if (cd.score >= min_score[p]) cand.push_back(cd);
       }
-      // device order is ascending index; stable sort = (score desc, column asc, index asc)
-      std::stable_sort(cand.begin(), cand.end(), [W](const Cand &x, const Cand &y) {
-        if (x.score != y.score) return x.score > y.score;
-        return x.idx % W < y.idx % W;
-      });
+      // hit order = (score desc, column asc, index asc).  A high-scoring pair can have
+      // tens of thousands of cells above min_score and the enumeration usually stops
+      // after a few hits, so the candidates are heaped (O(n)) and popped on demand
+      // instead of sorted (the reference sorts ~80 % of ALL cells, smith_waterman.c:159-161).
+      auto later = [W](const Cand &x, const Cand &y) {   // true if x comes AFTER y
+        if (x.score != y.score) return x.score < y.score;
+        const uint32_t cx = x.idx % W, cy = y.idx % W;
+        if (cx != cy) return cx > cy;
+        return x.idx > y.idx;
+      };
+      std::make_heap(cand.begin(), cand.end(), later);
       seen.assign((cells + 31) / 32, 0u);
       uint32_t emitted = 0;
-      for (const Cand &cd : cand) {
+      while (!cand.empty()) {
         if (emitted >= max_hits) break;
+        std::pop_heap(cand.begin(), cand.end(), later);
+        const Cand cd = cand.back();
+        cand.pop_back();
         if ((seen[cd.idx >> 5] >> (cd.idx & 31)) & 1u) continue;
         size_t x = cd.idx % W, y = cd.idx / W, steps = 0;
         int matrix = MATCH;
@@ -629,7 +728,6 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     if (rc) break;
   }
   *n_hits = found;
-  seqalign_scoring_release(ctx, sc);
   return rc;
 }
 

@@ -38,6 +38,26 @@ struct SaReduceParams {
   uint32_t n_pairs;
 };
 
+struct SaTraceParams {
+  const uint8_t *arena;
+  const uint64_t *off_a;
+  const uint32_t *len_a;
+  const uint64_t *off_b;
+  const uint32_t *len_b;
+  const uint64_t *mat_off;
+  const int32_t *M, *A, *B;
+  const uint16_t *code;
+  const int32_t *table;
+  const uint64_t *str_off;
+  char *out_a, *out_b;
+  uint32_t *out_head, *out_len;
+  int32_t *out_score;
+  uint32_t *trace_status;
+  uint32_t n_pairs, K;
+  int32_t open1, ext, gen_eq, gen_ne;
+  uint32_t flags;
+};
+
 /* substitution lookup flavour */
 enum { SA_SUBST_SIMPLE = 0, SA_SUBST_LDS = 1, SA_SUBST_GLOBAL = 2 };
 #define SA_LDS_TABLE_MAX_K 64
@@ -52,6 +72,7 @@ bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
                                  hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
+hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
 hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);
 

@@ -44,36 +44,48 @@ sw_reduce_kernel(const SaReduceParams p) {
   Best best{0, 0, 0};                                   // cell 0 holds score 0
   uint32_t count = 0;                                   // wave-uniform
 
-  for (uint32_t base = 0; base < cells; base += kWave * 4) {
-    const uint32_t i0 = base + lane * 4;
-    int v[4];
-    if (i0 + 4 <= cells) {
-      const v4i_u q = *reinterpret_cast<const v4i_u *>(M + i0);
-      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
+  // 4 independent 1 KiB loads per wave in flight per step: with one wave per pair
+  // (4 k - 10 k waves) a single load per step leaves HBM latency exposed
+  constexpr int kUnroll = 4;
+  constexpr uint32_t kStep = kWave * 4 * kUnroll;
+  for (uint32_t base = 0; base < cells; base += kStep) {
+    int v[kUnroll][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = (i0 + k < cells) ? M[i0 + k] : 0;
-    }
-    uint32_t mine = 0;
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
+      if (i0 + 4 <= cells) {
+        const v4i_u q = __builtin_nontemporal_load(reinterpret_cast<const v4i_u *>(M + i0));
+        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+      } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (v[k] >= best.score && v[k] > 0) {
-        const unsigned idx = i0 + k, col = idx % W;
-        if (better(v[k], col, idx, best)) best = Best{v[k], col, idx};
+        for (int k = 0; k < 4; ++k) v[u][k] = (i0 + k < cells) ? M[i0 + k] : 0;
       }
-      mine += (v[k] >= min_score);
     }
-    // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
-    const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t pos = count + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-    count += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-    if (mine) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
+      uint32_t mine = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (v[k] >= min_score) {
-          if (pos < cap) { cidx[pos] = i0 + k; cscore[pos] = v[k]; }
-          ++pos;
+        if (v[u][k] >= best.score && v[u][k] > 0) {
+          const unsigned idx = i0 + k, col = idx % W;
+          if (better(v[u][k], col, idx, best)) best = Best{v[u][k], col, idx};
+        }
+        mine += (v[u][k] >= min_score);
+      }
+      // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
+      const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
+      if ((b0 | b1 | b2) == 0) continue;                // wave-uniform: no candidate in this KiB
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t pos = count + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+      count += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      if (mine) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (v[u][k] >= min_score) {
+            if (pos < cap) { cidx[pos] = i0 + k; cscore[pos] = v[u][k]; }
+            ++pos;
+          }
         }
       }
     }

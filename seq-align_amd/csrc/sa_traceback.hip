@@ -1,0 +1,103 @@
+// sa_traceback.hip -- Needleman-Wunsch traceback on the device.
+//
+// The reference re-derives each predecessor from the three score matrices with
+// equality tests, priority GAP_A, GAP_B, MATCH (src/alignment.c:244-350), after
+// choosing the end matrix at the bottom-right cell (src/needleman_wunsch.c:53-66).
+// This kernel does exactly that on the matrices the fill kernel left in HBM, so
+// an end-to-end batch returns O(len_a+len_b) characters per pair over PCIe
+// instead of 12 B per DP cell (273 KB per 150x150 pair).
+//
+// One LANE per pair (64 pairs per wave): the walk is a chain of dependent loads
+// (~len_a+len_b steps), so the only parallelism is across pairs.  Each lane
+// writes its alignment right-to-left into its slot and reports where it starts;
+// the host left-aligns while copying out of the staging buffer.
+#include "sa_fill_common.hpp"
+
+namespace sa {
+
+enum { MAT_MATCH = 0, MAT_GAP_A = 1, MAT_GAP_B = 2 };
+
+__global__ void __launch_bounds__(64) nw_traceback_kernel(const SaTraceParams p) {
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= p.n_pairs) return;
+
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair];
+  const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
+  const uint8_t *__restrict__ sb_ = p.arena + p.off_b[pair];
+  const uint64_t mo = p.mat_off[pair];
+  const int32_t *__restrict__ Mg = p.M + mo;
+  const int32_t *__restrict__ Ag = p.A + mo;
+  const int32_t *__restrict__ Bg = p.B + mo;
+  const uint32_t W = la + 1;
+  char *oa = p.out_a + p.str_off[pair];
+  char *ob = p.out_b + p.str_off[pair];
+
+  const bool no_start = p.flags & SA_F_NO_START_GAP, no_end = p.flags & SA_F_NO_END_GAP;
+  const bool no_gaps_a = p.flags & SA_F_NO_GAPS_A, no_gaps_b = p.flags & SA_F_NO_GAPS_B;
+  const int K = (int)p.K;
+
+  // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
+  const uint32_t corner = W * (lb + 1) - 1;
+  int matrix = MAT_MATCH;
+  int score = Mg[corner];
+  { const int b = Bg[corner]; if (b >= score) { matrix = MAT_GAP_B; score = b; } }
+  { const int a = Ag[corner]; if (a >= score) { matrix = MAT_GAP_A; score = a; } }
+  p.out_score[pair] = score;
+
+  uint32_t x = la, y = lb, head = la + lb, err = 0;
+  while (x > 0 && y > 0) {
+    const uint8_t ca = sa_[x - 1], cb = sb_[y - 1];
+    --head;
+    oa[head] = (matrix == MAT_GAP_A) ? '-' : (char)ca;
+    ob[head] = (matrix == MAT_GAP_B) ? '-' : (char)cb;
+
+    // gap costs for leaving (x,y) (alignment.c:261-272)
+    long long open_a = p.open1, ext_a = p.ext, open_b = p.open1, ext_b = p.ext;
+    if (no_end) {
+      if (x == la) open_a = ext_a = 0;
+      if (y == lb) open_b = ext_b = 0;
+    }
+    if (no_start) {   // x, y >= 1 here; kept for symmetry with the reference
+      if (x == 0) open_a = ext_a = 0;
+      if (y == 0) open_b = ext_b = 0;
+    }
+    long long via_m, via_a, via_b;
+    if (matrix == MAT_MATCH) {
+      const int code_a = p.code[ca], code_b = p.code[cb];
+      int s = (K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? p.gen_eq : p.gen_ne)
+                       : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * K, code_b, p.table,
+                                                      p.gen_eq, p.gen_ne);
+      if (s == SA_S_UNKNOWN) { err = 5 /* SEQALIGN_E_UNKNOWN_PAIR */; break; }
+      // a blocked pair (no_mismatches, not a match) looks up as score 0 upstream
+      // (alignment_scoring.c:148-153 with no wildcard involved)
+      if (s == SA_S_BLOCKED) s = 0;
+      via_m = via_a = via_b = s; --x; --y;
+    } else if (matrix == MAT_GAP_A) {
+      via_m = via_b = open_a; via_a = ext_a; --y;
+    } else {
+      via_m = via_a = open_b; via_b = ext_b; --x;
+    }
+    const uint32_t at = y * W + x;
+    const long long av = Ag[at], bv = Bg[at], mv = Mg[at], cur = score;
+    if ((!no_gaps_a || x == 0 || x == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
+    else if ((!no_gaps_b || y == 0 || y == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
+    else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
+    else { err = 7 /* SEQALIGN_E_TRACEBACK */; break; }
+  }
+  if (!err) {
+    for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)sb_[y - 1]; }   // needleman_wunsch.c:117-123
+    for (; x > 0; --x) { --head; oa[head] = (char)sa_[x - 1]; ob[head] = '-'; }   // :126-132
+  }
+  p.out_head[pair] = head;
+  p.out_len[pair] = la + lb - head;
+  p.trace_status[pair] = err;
+}
+
+}  // namespace sa
+
+hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
+  if (p.n_pairs == 0) return hipSuccess;
+  const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
+  hipLaunchKernelGGL(sa::nw_traceback_kernel, grid, block, 0, stream, p);
+  return hipGetLastError();
+}

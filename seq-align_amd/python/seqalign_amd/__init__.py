@@ -300,6 +300,19 @@ class DeviceBatch:
         o, n = int(self.mat_off_host[p]), int(self.cells_host[p])
         return tuple(x[o:o + n].cpu().numpy() for x in (self.M, self.A, self.B))
 
+    def sw_reduce_launch(self, ctx: Context, min_score: int):
+        """Enqueue the SW reduction (best cell + count, no compaction) on self.stream."""
+        torch = self.torch
+        if not hasattr(self, "_red"):
+            n, dev = self.host.n_pairs, self.M.device
+            self._red = (torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int64, device=dev),
+                         torch.zeros(n, dtype=torch.int32, device=dev))
+        bs, bi, cnt = self._red
+        r = SwReduceDesc(self.host.n_pairs, self.len_a.data_ptr(), self.len_b.data_ptr(), self.mat_off.data_ptr(),
+                         self.M.data_ptr(), min_score, bs.data_ptr(), bi.data_ptr(), cnt.data_ptr(), 0, 0, 0, 0)
+        _check(lib().seqalign_sw_reduce_device(ctx._h, C.byref(r), C.c_void_p(self.stream.cuda_stream)),
+               "seqalign_sw_reduce_device")
+
     def sw_reduce(self, ctx: Context, min_score: int, with_candidates: bool = True):
         """Device SW reduction; returns (best_score, best_index, counts, cand lists)."""
         torch = self.torch
@@ -341,7 +354,7 @@ EXPORTED_SYMBOLS = [
     # include/seqalign_hip.h
     "seqalign_strerror", "seqalign_last_error", "seqalign_device_count", "seqalign_ctx_create",
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
-    "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_fill_batch", "seqalign_nw_batch",
+    "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms",
     # include/alignment_scoring.h
     "scoring_init", "scoring_add_wildcard", "scoring_add_mutation", "scoring_add_mutations", "scoring_print",

@@ -292,18 +292,23 @@ def test_host_level_fill_batch_and_chunking(ctx):
     assert np.array_equal(M, M2) and np.array_equal(A, A2) and np.array_equal(B, B2)
 
 
-def test_nw_batch_strings_match_oracle_and_golden(ctx):
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
+    """End-to-end NW: GPU fill + traceback on the device (default) or on the host
+    from the copied-back matrices (SEQALIGN_TRACEBACK=host); identical strings."""
+    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
     cfg = load("configs.json")["C2_related"]
     sc = S.make_scoring(cfg["scoring"])
     batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
     res = ctx.nw_batch(batch, sc)
     for p, g in enumerate(cfg["pairs"]):
         assert res[p] == (g["score"], g["result_a"].encode(), g["result_b"].encode())
-    # flags + ragged vs oracle
-    for flags in ((1, 1, 0, 0, 0), (0, 0, 1, 0, 0), (0, 0, 0, 0, 1), (1, 0, 0, 1, 0)):
-        spec = {"init": [1, -2, -4, -1, *flags, 0]}
+    # every flag combination (inside the parity domain) + ragged incl. empty sequences, vs oracle
+    for idx, flags in enumerate(itertools.product([0, 1], repeat=5)):
+        spec = {"init": [1, -6 if (flags[2] and flags[3]) else -2, -4, -1, *flags, idx & 1],
+                "wildcards": [["N", -1]] if idx % 3 == 0 else []}
         sc = S.make_scoring(spec)
-        batch = W.ragged(40, seed=sum(flags) + 10, max_len=70)
+        batch = W.ragged(24, seed=idx + 10, max_len=70, lower_frac=0.2, extra=b"N" if spec["wildcards"] else b"")
         res = ctx.nw_batch(batch, sc)
         osc = oracle_scoring_of(sc)
         for p in range(batch.n_pairs):
