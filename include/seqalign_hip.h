@@ -155,9 +155,16 @@ typedef struct {
 int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r,
                               void *stream);
 
-/* NW traceback on the device: consumes the matrices a fill left in
- * HBM and applies needleman_wunsch.c:53-132 / alignment.c:244-350 per pair.
- * Pair p's two alignment strings are written RIGHT-ALIGNED into
+/* Traceback on the device: consumes the matrices a fill left in HBM
+ * and applies alignment.c:244-350 per pair, one lane per pair.
+ *   NW (seqalign_nw_traceback_device): needleman_wunsch.c:53-132 from the
+ *       bottom-right cell to the border.
+ *   SW (seqalign_sw_traceback_device): the local alignment ending at
+ *       start_index[p] (a match_scores cell, normally best_index from
+ *       seqalign_sw_reduce_device), walked until the score is 0 -- what the first
+ *       smith_waterman_fetch returns (smith_waterman.c:165-258); out_pos gets
+ *       pos_a, pos_b, len_a, len_b (4 per pair).
+ * Pair p's two strings are written RIGHT-ALIGNED into
  * out_a/out_b[str_off[p] .. str_off[p]+len_a+len_b): they start at
  * str_off[p]+out_head[p] and are out_len[p] long (no NUL).  status[p] is 0 or a
  * SEQALIGN_E_* code.  All pointers are DEVICE pointers. */
@@ -167,12 +174,18 @@ typedef struct {
   uint32_t *out_head, *out_len;
   int32_t *out_score;
   uint32_t *status;
-} seqalign_nw_trace_t;
+  const uint64_t *start_index; /* SW only */
+  uint32_t *out_pos;           /* SW only */
+} seqalign_trace_t;
 
 int seqalign_nw_traceback_device(seqalign_ctx_t *ctx,
                                  const seqalign_dev_scoring_t *scoring,
                                  const seqalign_dev_batch_t *batch,
-                                 const seqalign_nw_trace_t *trace, void *stream);
+                                 const seqalign_trace_t *trace, void *stream);
+int seqalign_sw_traceback_device(seqalign_ctx_t *ctx,
+                                 const seqalign_dev_scoring_t *scoring,
+                                 const seqalign_dev_batch_t *batch,
+                                 const seqalign_trace_t *trace, void *stream);
 
 /* ---- host-level convenience (H2D -> fill -> D2H) ---------------------------- */
 /* Fills every pair of a HOST batch and copies the matrices back into the three
@@ -196,10 +209,14 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                       char *out_a, char *out_b, uint32_t *out_len,
                       int32_t *out_score);
 
-/* Local SW over a host batch: GPU fill + GPU candidate compaction + host hit
- * enumeration (src/smith_waterman.c:165-277 semantics, fresh visited mask per
- * pair).  Emits, per pair, successive hits with score >= min_score[p], at most
- * max_hits per pair, into the caller's hit array (hit_cap entries total). */
+/* Local SW over a host batch (src/smith_waterman.c:165-277 semantics, fresh
+ * visited mask per pair).  Emits, per pair, successive hits with
+ * score >= min_score[p], at most max_hits per pair, into the caller's hit array
+ * (hit_cap entries total).
+ *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit; only
+ *       the strings cross PCIe.
+ *   max_hits  > 1 (or SEQALIGN_TRACEBACK=host): GPU fill + GPU candidate
+ *       compaction, matrices copied back, hits enumerated on the host. */
 typedef struct {
   uint64_t pair;
   int32_t score;

@@ -16,6 +16,9 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline $*"
 echo "$CMD" > "$OUT/command.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
+# the same pass once more as CSV: the human-readable --stats table that gets committed
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $CMD > "$OUT/stats.log" 2>&1
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 i=0
 for set in "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "FETCH_SIZE" \

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -288,10 +290,10 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
   return rc;
 }
 
-extern "C" int seqalign_nw_traceback_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc,
-                                            const seqalign_dev_batch_t *b, const seqalign_nw_trace_t *t,
-                                            void *stream) {
+static int launch_traceback(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b,
+                            const seqalign_trace_t *t, void *stream, bool sw) {
   if (!ctx || !sc || !b || !t) return SEQALIGN_E_ARG;
+  if (sw && (!t->start_index || !t->out_pos)) return SEQALIGN_E_ARG;
   if (b->n_pairs == 0) return SEQALIGN_OK;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   SaTraceParams p;
@@ -299,11 +301,24 @@ extern "C" int seqalign_nw_traceback_device(seqalign_ctx_t *ctx, const seqalign_
   p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
   p.code = sc->d_code; p.table = sc->d_table; p.str_off = t->str_off; p.out_a = t->out_a; p.out_b = t->out_b;
   p.out_head = t->out_head; p.out_len = t->out_len; p.out_score = t->out_score; p.trace_status = t->status;
+  p.start_index = sw ? t->start_index : nullptr; p.out_pos = sw ? t->out_pos : nullptr;
   p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
   p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
   hipError_t e = sa_launch_nw_traceback(p, st);
-  if (e != hipSuccess) return fail_hip(e, "nw traceback launch");
+  if (e != hipSuccess) return fail_hip(e, "traceback launch");
   return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_nw_traceback_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc,
+                                            const seqalign_dev_batch_t *b, const seqalign_trace_t *t,
+                                            void *stream) {
+  return launch_traceback(ctx, sc, b, t, stream, false);
+}
+
+extern "C" int seqalign_sw_traceback_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc,
+                                            const seqalign_dev_batch_t *b, const seqalign_trace_t *t,
+                                            void *stream) {
+  return launch_traceback(ctx, sc, b, t, stream, true);
 }
 
 extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r, void *stream) {
@@ -491,6 +506,87 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
 }
 
 // ----------------------------------------------- host-level: NW over a batch ---
+namespace {
+
+struct Cand { uint32_t idx; int32_t score; };
+
+struct PairHits {
+  std::vector<seqalign_sw_hit_t> hits;   // str_off relative to str_a / str_b below
+  std::string str_a, str_b;
+};
+
+// run fn(0..n-1) on host threads (pairs are independent); SEQALIGN_HOST_THREADS overrides
+template <class F>
+static void parallel_for(uint64_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned want = hw ? std::min(hw, 32u) : 4u;
+  if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
+  const unsigned nt = (unsigned)std::min<uint64_t>(want, n);
+  if (nt <= 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
+  std::atomic<uint64_t> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; ++t)
+    pool.emplace_back([&] { for (uint64_t k; (k = next.fetch_add(1)) < n;) fn(k); });
+  for (auto &th : pool) th.join();
+}
+
+// Successive local alignments of one pair in reference order (score desc, column
+// asc, index asc), fresh visited mask, at most max_hits (smith_waterman.c:165-277).
+// A high-scoring pair can have tens of thousands of cells above min_score and the
+// enumeration usually stops after a few hits, so the candidates are heaped (O(n))
+// and popped on demand instead of sorted (upstream sorts ~80 % of ALL cells, :159-161).
+static int enumerate_hits(const sa_view_t &v, std::vector<Cand> &cand, uint32_t max_hits, PairHits &out) {
+  const size_t W = v.len_a + 1, cells = W * (v.len_b + 1);
+  auto later = [W](const Cand &x, const Cand &y) {   // true if x comes AFTER y
+    if (x.score != y.score) return x.score < y.score;
+    const uint32_t cx = x.idx % W, cy = y.idx % W;
+    if (cx != cy) return cx > cy;
+    return x.idx > y.idx;
+  };
+  std::make_heap(cand.begin(), cand.end(), later);
+  std::vector<uint32_t> seen((cells + 31) / 32, 0u);
+  int rc = SEQALIGN_OK;
+  while (!cand.empty() && out.hits.size() < max_hits) {
+    std::pop_heap(cand.begin(), cand.end(), later);
+    const Cand cd = cand.back();
+    cand.pop_back();
+    if ((seen[cd.idx >> 5] >> (cd.idx & 31)) & 1u) continue;
+    size_t x = cd.idx % W, y = cd.idx / W, steps = 0;
+    int matrix = MATCH;
+    int32_t score = cd.score;
+    bool clash = false;
+    for (;; ++steps) {   // pass 1: walk to score 0, marking; abandon on a marked cell
+      const size_t at = y * W + x;
+      if ((seen[at >> 5] >> (at & 31)) & 1u) { clash = true; break; }
+      seen[at >> 5] |= 1u << (at & 31);
+      if (score == 0) break;
+      if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) return rc;
+    }
+    if (clash) continue;
+    const size_t off = out.str_a.size();
+    out.str_a.resize(off + steps + 1);
+    out.str_b.resize(off + steps + 1);
+    char *ra = &out.str_a[off], *rb = &out.str_b[off];
+    x = cd.idx % W; y = cd.idx / W; matrix = MATCH; score = cd.score;
+    for (size_t w = steps; score > 0;) {   // pass 2: replay, writing right to left
+      --w;
+      ra[w] = (matrix == GAP_A) ? '-' : v.a[x - 1];
+      rb[w] = (matrix == GAP_B) ? '-' : v.b[y - 1];
+      if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) return rc;
+    }
+    ra[steps] = rb[steps] = '\0';
+    seqalign_sw_hit_t h;
+    h.pair = 0; h.score = cd.score;
+    h.pos_a = (uint32_t)x; h.pos_b = (uint32_t)y;
+    h.len_a = (uint32_t)(cd.idx % W - x); h.len_b = (uint32_t)(cd.idx / W - y);
+    h.length = (uint32_t)steps; h.str_off = off;
+    out.hits.push_back(h);
+  }
+  return SEQALIGN_OK;
+}
+
+}  // namespace
+
 static bool traceback_on_host() {
   const char *env = getenv("SEQALIGN_TRACEBACK");
   return env && !strcmp(env, "host");
@@ -518,7 +614,8 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
   uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status, n each
-  seqalign_nw_trace_t t;
+  seqalign_trace_t t;
+  memset(&t, 0, sizeof(t));
   t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
   t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
   t.status = d_meta + 3 * n;
@@ -569,28 +666,31 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     HIP_TRY(hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs; unknown pair is fatal for NW
-    uint64_t cell = 0;
-    for (uint64_t k = 0; k < c.count; ++k) {
+    std::vector<uint64_t> cell0(c.count);
+    { uint64_t cell = 0;
+      for (uint64_t k = 0; k < c.count; ++k) {
+        cell0[k] = cell;
+        cell += (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+      } }
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(c.count, [&](uint64_t k) {
       const uint64_t p = c.first + k;
       sa_view_t v;
       v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
       v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
-      v.M = ctx->h_M.as<int32_t>() + cell; v.A = ctx->h_A.as<int32_t>() + cell; v.B = ctx->h_B.as<int32_t>() + cell;
+      v.M = ctx->h_M.as<int32_t>() + cell0[k]; v.A = ctx->h_A.as<int32_t>() + cell0[k];
+      v.B = ctx->h_B.as<int32_t>() + cell0[k];
       size_t n = 0;
-      if ((rc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]))) return rc;
+      int prc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]);
       out_len[p] = (uint32_t)n;
-      cell += (uint64_t)(v.len_a + 1) * (v.len_b + 1);
-    }
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) return rc;
   }
   return SEQALIGN_OK;
 }
 
 // ----------------------------------------------- host-level: SW over a batch ---
-namespace {
-
-struct Cand { uint32_t idx; int32_t score; };
-
-}  // namespace
 
 extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                  const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
@@ -605,6 +705,65 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
   seqalign_dev_scoring *sc = guard.h;
   uint64_t used_str = 0, found = 0;
+  if (max_hits == 0) return SEQALIGN_OK;
+  if (max_hits == 1 && !traceback_on_host()) {
+    // best hit only: nothing but the strings crosses PCIe
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
+      seqalign_dev_batch_t d;
+      if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
+      const uint64_t n = c.count;
+      if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+      seqalign_sw_reduce_t r;
+      memset(&r, 0, sizeof(r));
+      r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+      r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+      if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
+      if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
+      uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
+      uint64_t total = 0;
+      for (uint64_t k = 0; k < n; ++k) {
+        h_off[k] = total;
+        total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
+      }
+      if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
+          (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)) ||
+          (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
+        return rc;
+      hipStream_t st = ctx->stream;
+      HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
+      uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
+      seqalign_trace_t t;
+      memset(&t, 0, sizeof(t));
+      t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+      t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
+      t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
+      if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+      uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
+      HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
+      if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+      const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+      for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t p = c.first + k;
+        const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
+        const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+        if (status) return (int)status;
+        if (score <= 0 || score < min_score[p]) continue;
+        if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
+        memcpy(out_a + used_str, ha + h_off[k] + head, len);
+        memcpy(out_b + used_str, hb + h_off[k] + head, len);
+        out_a[used_str + len] = out_b[used_str + len] = '\0';
+        seqalign_sw_hit_t &h = hits[found++];
+        const uint32_t *pos = h_meta + 4 * n + 4 * k;
+        h.pair = p; h.score = score; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+        h.length = len; h.str_off = used_str;
+        used_str += len + 1;
+      }
+    }
+    *n_hits = found;
+    return SEQALIGN_OK;
+  }
   const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
 
   // the reduction kernel takes one threshold per launch: group by threshold
@@ -655,74 +814,45 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     if (e != hipSuccess) { rc = fail_hip(e, "D2H SW results"); break; }
     if ((rc = fetch_status(ctx, c, nullptr))) break;
 
-    // host: hit enumeration with a fresh visited mask per pair
-    // (reference smith_waterman.c:165-277 semantics)
-    uint64_t cell = 0;
-    std::vector<Cand> cand;
-    std::vector<uint32_t> seen;
-    for (uint64_t k = 0; k < n && rc == SEQALIGN_OK; ++k) {
+    // host: hit enumeration with a fresh visited mask per pair (reference
+    // smith_waterman.c:165-277 semantics).  Pairs are independent -> host threads.
+    std::vector<uint64_t> cell0(n);
+    { uint64_t cell = 0;
+      for (uint64_t k = 0; k < n; ++k) {
+        cell0[k] = cell;
+        cell += (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+      } }
+    std::vector<PairHits> per_pair(n);
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(n, [&](uint64_t k) {
       const uint64_t p = c.first + k;
       sa_view_t v;
       v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
       v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
-      v.M = ctx->h_M.as<int32_t>() + cell; v.A = ctx->h_A.as<int32_t>() + cell; v.B = ctx->h_B.as<int32_t>() + cell;
-      const size_t W = v.len_a + 1, cells = W * (v.len_b + 1);
-      cell += cells;
-      cand.clear();
+      v.M = ctx->h_M.as<int32_t>() + cell0[k]; v.A = ctx->h_A.as<int32_t>() + cell0[k];
+      v.B = ctx->h_B.as<int32_t>() + cell0[k];
+      std::vector<Cand> cand;
+      cand.reserve(c_cap[k]);
       for (uint32_t q = 0; q < c_cap[k]; ++q) {
         const Cand cd{h_cidx[c_off[k] + q], h_cscore[c_off[k] + q]};
         if (cd.score >= min_score[p]) cand.push_back(cd);
       }
-      // hit order = (score desc, column asc, index asc).  A high-scoring pair can have
-      // tens of thousands of cells above min_score and the enumeration usually stops
-      // after a few hits, so the candidates are heaped (O(n)) and popped on demand
-      // instead of sorted (the reference sorts ~80 % of ALL cells, smith_waterman.c:159-161).
-      auto later = [W](const Cand &x, const Cand &y) {   // true if x comes AFTER y
-        if (x.score != y.score) return x.score < y.score;
-        const uint32_t cx = x.idx % W, cy = y.idx % W;
-        if (cx != cy) return cx > cy;
-        return x.idx > y.idx;
-      };
-      std::make_heap(cand.begin(), cand.end(), later);
-      seen.assign((cells + 31) / 32, 0u);
-      uint32_t emitted = 0;
-      while (!cand.empty()) {
-        if (emitted >= max_hits) break;
-        std::pop_heap(cand.begin(), cand.end(), later);
-        const Cand cd = cand.back();
-        cand.pop_back();
-        if ((seen[cd.idx >> 5] >> (cd.idx & 31)) & 1u) continue;
-        size_t x = cd.idx % W, y = cd.idx / W, steps = 0;
-        int matrix = MATCH;
-        int32_t score = cd.score;
-        bool clash = false;
-        for (;; ++steps) {
-          const size_t at = y * W + x;
-          if ((seen[at >> 5] >> (at & 31)) & 1u) { clash = true; break; }
-          seen[at >> 5] |= 1u << (at & 31);
-          if (score == 0) break;
-          if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) break;
-        }
-        if (rc) break;
-        if (clash) continue;
-        if (found >= hit_cap || used_str + steps + 1 > str_cap) { rc = SEQALIGN_E_NOMEM; break; }
-        char *ra = out_a + used_str, *rb = out_b + used_str;
-        x = cd.idx % W; y = cd.idx / W; matrix = MATCH; score = cd.score;
-        for (size_t w = steps; score > 0;) {
-          --w;
-          ra[w] = (matrix == GAP_A) ? '-' : v.a[x - 1];
-          rb[w] = (matrix == GAP_B) ? '-' : v.b[y - 1];
-          if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) break;
-        }
-        if (rc) break;
-        ra[steps] = rb[steps] = '\0';
+      int prc = enumerate_hits(v, cand, max_hits, per_pair[k]);
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) break;
+    for (uint64_t k = 0; k < n && rc == SEQALIGN_OK; ++k) {
+      const PairHits &ph = per_pair[k];
+      for (size_t i = 0; i < ph.hits.size(); ++i) {
+        const seqalign_sw_hit_t &src = ph.hits[i];
+        if (found >= hit_cap || used_str + src.length + 1 > str_cap) { rc = SEQALIGN_E_NOMEM; break; }
+        memcpy(out_a + used_str, ph.str_a.data() + src.str_off, src.length + 1);
+        memcpy(out_b + used_str, ph.str_b.data() + src.str_off, src.length + 1);
         seqalign_sw_hit_t &h = hits[found++];
-        h.pair = p; h.score = cd.score;
-        h.pos_a = (uint32_t)x; h.pos_b = (uint32_t)y;
-        h.len_a = (uint32_t)(cd.idx % W - x); h.len_b = (uint32_t)(cd.idx / W - y);
-        h.length = (uint32_t)steps; h.str_off = used_str;
-        used_str += steps + 1;
-        ++emitted;
+        h = src;
+        h.pair = c.first + k;
+        h.str_off = used_str;
+        used_str += src.length + 1;
       }
     }
     if (rc) break;

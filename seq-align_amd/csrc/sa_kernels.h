@@ -53,6 +53,8 @@ struct SaTraceParams {
   uint32_t *out_head, *out_len;
   int32_t *out_score;
   uint32_t *trace_status;
+  const uint64_t *start_index; /* SW: end cell of the hit per pair; NULL = NW        */
+  uint32_t *out_pos;           /* SW: [4*n] pos_a, pos_b, len_a, len_b               */
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;

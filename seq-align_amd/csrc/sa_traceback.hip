@@ -1,4 +1,5 @@
-// sa_traceback.hip -- Needleman-Wunsch traceback on the device.
+// sa_traceback.hip -- traceback on the device: global NW, and the
+// best local SW hit.
 //
 // The reference re-derives each predecessor from the three score matrices with
 // equality tests, priority GAP_A, GAP_B, MATCH (src/alignment.c:244-350), after
@@ -17,7 +18,11 @@ namespace sa {
 
 enum { MAT_MATCH = 0, MAT_GAP_A = 1, MAT_GAP_B = 2 };
 
-__global__ void __launch_bounds__(64) nw_traceback_kernel(const SaTraceParams p) {
+// SW: start_index != nullptr -> local alignment ending at that match_scores cell
+// (smith_waterman.c:165-258 on a fresh mask: the first fetched hit always
+// succeeds), walked until the score reaches 0.
+template <bool SW>
+__global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= p.n_pairs) return;
 
@@ -36,16 +41,25 @@ __global__ void __launch_bounds__(64) nw_traceback_kernel(const SaTraceParams p)
   const bool no_gaps_a = p.flags & SA_F_NO_GAPS_A, no_gaps_b = p.flags & SA_F_NO_GAPS_B;
   const int K = (int)p.K;
 
-  // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
-  const uint32_t corner = W * (lb + 1) - 1;
   int matrix = MAT_MATCH;
-  int score = Mg[corner];
-  { const int b = Bg[corner]; if (b >= score) { matrix = MAT_GAP_B; score = b; } }
-  { const int a = Ag[corner]; if (a >= score) { matrix = MAT_GAP_A; score = a; } }
+  int score;
+  uint32_t x, y, head = la + lb, err = 0;
+  if constexpr (SW) {
+    const uint32_t end = (uint32_t)p.start_index[pair];
+    x = end % W; y = end / W;
+    score = Mg[end];
+  } else {
+    // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
+    const uint32_t corner = W * (lb + 1) - 1;
+    x = la; y = lb;
+    score = Mg[corner];
+    { const int b = Bg[corner]; if (b >= score) { matrix = MAT_GAP_B; score = b; } }
+    { const int a = Ag[corner]; if (a >= score) { matrix = MAT_GAP_A; score = a; } }
+  }
   p.out_score[pair] = score;
+  const uint32_t end_x = x, end_y = y;
 
-  uint32_t x = la, y = lb, head = la + lb, err = 0;
-  while (x > 0 && y > 0) {
+  while (SW ? (score > 0) : (x > 0 && y > 0)) {
     const uint8_t ca = sa_[x - 1], cb = sb_[y - 1];
     --head;
     oa[head] = (matrix == MAT_GAP_A) ? '-' : (char)ca;
@@ -84,10 +98,19 @@ __global__ void __launch_bounds__(64) nw_traceback_kernel(const SaTraceParams p)
     else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
     else { err = 7 /* SEQALIGN_E_TRACEBACK */; break; }
   }
-  if (!err) {
-    for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)sb_[y - 1]; }   // needleman_wunsch.c:117-123
-    for (; x > 0; --x) { --head; oa[head] = (char)sa_[x - 1]; ob[head] = '-'; }   // :126-132
+  if constexpr (!SW) {
+    if (!err) {
+      for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)sb_[y - 1]; }   // needleman_wunsch.c:117-123
+      for (; x > 0; --x) { --head; oa[head] = (char)sa_[x - 1]; ob[head] = '-'; }   // :126-132
+    }
+  } else {
+    // smith_waterman.c:251-255: start position and consumed lengths
+    p.out_pos[4 * pair + 0] = x;
+    p.out_pos[4 * pair + 1] = y;
+    p.out_pos[4 * pair + 2] = end_x - x;
+    p.out_pos[4 * pair + 3] = end_y - y;
   }
+  (void)end_x; (void)end_y;
   p.out_head[pair] = head;
   p.out_len[pair] = la + lb - head;
   p.trace_status[pair] = err;
@@ -98,6 +121,7 @@ __global__ void __launch_bounds__(64) nw_traceback_kernel(const SaTraceParams p)
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
-  hipLaunchKernelGGL(sa::nw_traceback_kernel, grid, block, 0, stream, p);
+  if (p.start_index) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(sa::traceback_kernel<false>, grid, block, 0, stream, p);
   return hipGetLastError();
 }

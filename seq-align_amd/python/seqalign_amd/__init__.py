@@ -354,7 +354,7 @@ EXPORTED_SYMBOLS = [
     # include/seqalign_hip.h
     "seqalign_strerror", "seqalign_last_error", "seqalign_device_count", "seqalign_ctx_create",
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
-    "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
+    "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms",
     # include/alignment_scoring.h
     "scoring_init", "scoring_add_wildcard", "scoring_add_mutation", "scoring_add_mutations", "scoring_print",

@@ -316,17 +316,24 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
             assert rc == 0 and res[p] == (s, ra, rb)
 
 
-def test_sw_batch_hits_match_oracle(ctx):
+@pytest.mark.parametrize("max_hits,where", [(5, "device"), (1, "device"), (1, "host")])
+def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
+    """max_hits=1 on the device = fill + reduction + traceback of the best hit, all
+    in HBM; otherwise candidates + matrices go back and the host enumerates."""
+    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
     for spec, gen, kw, thr in (
             ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, W.dna_sw_read_vs_ref, dict(seed=21, read_len=60, ref_len=300), 24),
             ({"preset": "BLOSUM62"}, W.protein_sw_300, dict(seed=22, length=120), 24),
-            ({"init": [1, -2, -4, -1, 0, 0, 1, 1, 0, 1]}, W.dna_nw_150, dict(seed=23, length=40, related=True), 3)):
+            ({"init": [1, -2, -4, -1, 0, 0, 1, 1, 0, 1]}, W.dna_nw_150, dict(seed=23, length=40, related=True), 3),
+            # free start/end gaps + asymmetric mutations, as in the reference's examples/sw_example.c:30-46
+            ({"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0], "mutations": [["a", "c", -2], ["c", "a", -1]]},
+             W.dna_nw_150, dict(seed=24, length=70, related=True), 4)):
         sc = S.make_scoring(spec)
         batch = gen(24, **kw)
-        got = ctx.sw_batch(batch, sc, thr, max_hits=5)
+        got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits)
         osc = oracle_scoring_of(sc)
         for p in range(batch.n_pairs):
-            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, 5)
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
             assert rc == 0 and got[p] == want, (spec, p)
 
 
