@@ -114,8 +114,13 @@ def main():
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
+    # SEQALIGN_DIST_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to
+    # exercise the multi-process path on a 1-GPU box; the driver's runs use RCCL.
+    backend = os.environ.get("SEQALIGN_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    grp = Group("nccl", torch.device("cuda", local))   # "nccl" is RCCL on ROCm; no-op at world 1
+    grp = Group(backend, torch.device("cuda", local) if backend == "nccl" else None)   # "nccl" is RCCL on ROCm
 
     gen, kwargs, per_gpu, is_sw, spec, desc = WORKLOADS[args.workload]
     per_gpu = args.pairs or per_gpu
