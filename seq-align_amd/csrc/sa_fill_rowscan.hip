@@ -69,7 +69,7 @@ fill_rowscan_kernel(const SaFillParams p) {
     const uint32_t cols = min(kStrip, la - i0);
     const uint32_t col0 = i0 + lane * CPL;
     const int ncol = max(0, min(CPL, (int)cols - lane * CPL));
-    sw.start_strip(p, k, bd, sa_, la, i0, col0);
+    sw.start_strip(p, k, bd, sa_, la, i0, col0, lane);
     __builtin_amdgcn_s_waitcnt(kWaitVm0);   // seq_a codes landed (see RowFeed::load)
 
     RowFeed feed;
@@ -100,8 +100,7 @@ fill_rowscan_kernel(const SaFillParams p) {
 
 template <int CPL>
 static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
-  const bool general =
-      p.flags & (SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_HAS_SENTINEL);
+  const bool general = needs_general(p);
   const dim3 grid((p.n_pairs + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   if (p.K <= 1) {
     if (general) hipLaunchKernelGGL((fill_rowscan_kernel<CPL, SA_SUBST_SIMPLE, true>), grid, block, 0, stream, p);

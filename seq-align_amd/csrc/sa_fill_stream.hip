@@ -23,63 +23,85 @@
 //
 // LDS per wave: 3 rings x R ints (R = 512 for len_a <= 255, else 1024) = 6 / 12
 // KiB; one wave per pair, 4 pairs per workgroup, no barrier after the table load.
+//
+// Tuning record (C2, in-process A/B with seq-align_amd/tools/ab.py, round 1):
+//   flush unit 1 KiB vs 2 KiB, 1/2/4/8 pairs per workgroup (4 and 8 best), 8-24
+//   resident waves per CU, cache-policy bits (plain / nt / sc1 / sc0 sc1, +-2 %;
+//   nt kept), removing the arithmetic or the LDS ring altogether: none moves the
+//   kernel by more than a few percent.  A store-only kernel with the same write
+//   pattern (tools/probes/scatter_probe.hip) runs 0.445 ms vs 0.466 ms for this
+//   kernel on a fast box: the kernel is within 5 % of what its own write pattern
+//   can do; what is left is the gap between that pattern and a linear memset.
 #include "sa_rowsweep.hpp"
 
 namespace sa {
 
-constexpr int kBlockInts = 256;   // flush unit: 64 lanes x dwordx4 = 1 KiB
+constexpr int kKiBInts = 256;     // one store instruction: 64 lanes x dwordx4 = 1 KiB
 
-template <int R>
+// FB = flush unit in ints (a multiple of 256): FB/256 back-to-back 1 KiB stores
+// per matrix, FB*4-byte aligned
+template <int R, int CPL, int FB>
 struct StreamOut {
+  static constexpr int kBlockInts = FB;
   int32_t *ring;        // this wave's rings: M at 0, A at R, B at 2R (ints)
+  uint32_t slot[CPL];   // ring index of my CPL cells in the row being appended
   int32_t *g0[3];       // matrix base minus a0 ints: g0 + v is 1 KiB aligned when v % 256 == 0
   uint32_t a0, vend;    // virtual range of the pair: [a0, vend)
   uint32_t wv, rv;      // virtual write / flush positions (rv % 256 == 0)
 
   __device__ __forceinline__ void flush_block(int lane) {
-    const uint32_t ro = rv & (R - 1);
-    const bool inside = (rv >= a0) && (rv + kBlockInts <= vend);   // wave-uniform
+    const bool inside = (rv >= a0) && (rv + FB <= vend);   // wave-uniform
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      const v4i_u q = *reinterpret_cast<const v4i_u *>(ring + m * R + ro + 4 * lane);   // ds_read_b128
-      int32_t *dst = g0[m] + rv + 4 * lane;
-      if (inside) {
-        typedef int v4i_a __attribute__((ext_vector_type(4)));
-        // aligned global_store_dwordx4 ... nt: write-once stream (see store_vec)
-        __builtin_nontemporal_store(v4i_a{q.x, q.y, q.z, q.w}, reinterpret_cast<v4i_a *>(dst));
-      } else {
-        const uint32_t e = rv + 4 * lane;
-        if (e + 0 >= a0 && e + 0 < vend) dst[0] = q.x;
-        if (e + 1 >= a0 && e + 1 < vend) dst[1] = q.y;
-        if (e + 2 >= a0 && e + 2 < vend) dst[2] = q.z;
-        if (e + 3 >= a0 && e + 3 < vend) dst[3] = q.w;
+#pragma unroll
+      for (int kb = 0; kb < FB / kKiBInts; ++kb) {
+        const uint32_t v0 = rv + kb * kKiBInts;
+        const uint32_t ro = v0 & (R - 1);
+        const v4i_u q = *reinterpret_cast<const v4i_u *>(ring + m * R + ro + 4 * lane);   // ds_read_b128
+        int32_t *dst = g0[m] + v0 + 4 * lane;
+        if (inside) {
+          typedef int v4i_a __attribute__((ext_vector_type(4)));
+          // aligned global_store_dwordx4 ... nt: write-once stream (see SA_STORE_VEC)
+          __builtin_nontemporal_store(v4i_a{q.x, q.y, q.z, q.w}, reinterpret_cast<v4i_a *>(dst));
+        } else {
+          const uint32_t e = v0 + 4 * lane;
+          if (e + 0 >= a0 && e + 0 < vend) dst[0] = q.x;
+          if (e + 1 >= a0 && e + 1 < vend) dst[1] = q.y;
+          if (e + 2 >= a0 && e + 2 < vend) dst[2] = q.z;
+          if (e + 3 >= a0 && e + 3 < vend) dst[3] = q.w;
+        }
       }
     }
-    rv += kBlockInts;
+    rv += FB;
+  }
+
+  __device__ __forceinline__ void start(int lane) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) slot[c] = (wv + lane * CPL + c) & (R - 1);
   }
 
   // append one row: lane holds CPL consecutive cells starting at row position
   // lane*CPL.  ALL 64 lanes write, also those past the row's end: their cells land
   // at ring positions >= wv+W, which are not valid data yet (never flushed before
   // the next row overwrites them) and cannot reach back to unflushed cells because
-  // 255 + 64*CPL <= R.  No per-lane predicate, no branch.
-  template <int CPL>
+  // 255 + 64*CPL <= R.  No per-lane predicate, no branch; the ring slots advance by
+  // W per row (one add + one and per cell).
   __device__ __forceinline__ void append_row(int lane, uint32_t W, const int (&mv)[CPL],
                                              const int (&av)[CPL], const int (&bv)[CPL]) {
-    static_assert(kBlockInts - 1 + kWave * CPL <= R, "ring too small for unpredicated appends");
-    const uint32_t at = wv + lane * CPL;
+    static_assert(FB - 1 + kWave * CPL <= R, "ring too small for unpredicated appends");
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t i = (at + c) & (R - 1);
+      const uint32_t i = slot[c];
       ring[i] = mv[c];
       ring[R + i] = av[c];
       ring[2 * R + i] = bv[c];
+      slot[c] = (i + W) & (R - 1);
     }
     wv += W;
     // reads below see the writes above: one wave, LDS ops execute in order; the
     // fence only stops the compiler from reordering them
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (wv - rv >= (uint32_t)kBlockInts) flush_block(lane);
+    while (wv - rv >= (uint32_t)FB) flush_block(lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 
@@ -88,8 +110,8 @@ struct StreamOut {
   }
 };
 
-template <int CPL, int SUBST, bool GENERAL, int R>
-__global__ void __launch_bounds__(kWave *kWavesPerBlock)
+template <int CPL, int SUBST, bool GENERAL, int R, int FB>
+__global__ void __launch_bounds__(kWave * 8)
 fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int32_t *table = p.table;
@@ -101,7 +123,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const uint32_t pair = blockIdx.x * kWavesPerBlock + wave;
+  const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + wave;
   if (pair >= p.n_pairs) return;   // wave-uniform, after the only barrier
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair];
@@ -114,22 +136,23 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   const Border bd{p.floor, p.gap_open, p.ext, (p.flags & SA_F_IS_SW) != 0,
                   (p.flags & SA_F_NO_START_GAP) != 0};
 
-  StreamOut<R> out;
+  StreamOut<R, CPL, FB> out;
   out.ring = lds + table_ints + wave * (3 * R);
-  // the three arenas are congruent mod 1 KiB (checked on the host)
-  out.a0 = (uint32_t)(((uintptr_t)(p.M + mo) >> 2) & (kBlockInts - 1));
+  // the three arenas are congruent mod 4 KiB (checked on the host)
+  out.a0 = (uint32_t)(((uintptr_t)(p.M + mo) >> 2) & (FB - 1));
   out.g0[0] = p.M + mo - out.a0;
   out.g0[1] = p.A + mo - out.a0;
   out.g0[2] = p.B + mo - out.a0;
   out.vend = out.a0 + W * (lb + 1);
   out.wv = out.a0;
   out.rv = 0;
+  out.start(lane);
 
   const uint32_t col0 = (uint32_t)(lane * CPL) - 1u;                 // matrix column lane*CPL + c
   const int ncol = max(0, min(CPL, (int)W - lane * CPL));
 
   RowSweep<CPL, SUBST, GENERAL, true> sw;
-  sw.start_strip(p, k, bd, sa_, la, 0, col0);
+  sw.start_strip(p, k, bd, sa_, la, 0, col0, lane);
   __builtin_amdgcn_s_waitcnt(kWaitVm0);   // seq_a codes landed (see RowFeed::load)
 
   {  // row 0 (reference alignment.c:46-69): (0,0) = 0; M = A = floor, B = edge
@@ -140,7 +163,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
       mv[c] = av[c] = (ci == 0) ? 0 : k.floor_;
       bv[c] = (ci == 0) ? 0 : bd.edge_gap(ci);
     }
-    out.template append_row<CPL>(lane, W, mv, av, bv);
+    out.append_row(lane, W, mv, av, bv);
   }
 
   int chunk_code = 0;
@@ -153,7 +176,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
     }
     int mv[CPL], av[CPL], bv[CPL];
     sw.row(k, j, lb, la, W, lane, col0, ncol, read_lane(chunk_code, q), 0, 0, mv, av, bv, bd.edge_gap(j));
-    out.template append_row<CPL>(lane, W, mv, av, bv);
+    out.append_row(lane, W, mv, av, bv);
   }
   out.finish(lane);
 
@@ -161,23 +184,24 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   if (lane == 0) p.status[pair] = err;
 }
 
-template <int CPL, int R>
+template <int CPL, int R, int FB>
 static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
-  const bool general =
-      p.flags & (SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_HAS_SENTINEL);
-  const dim3 grid((p.n_pairs + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-  size_t rings = (size_t)kWavesPerBlock * 3 * R * sizeof(int32_t);
+  const bool general = needs_general(p);
+  int wpb = kWavesPerBlock;   // pairs per workgroup; SEQALIGN_WPB in {1,2,4} (tuning experiments)
+  if (const char *env = getenv("SEQALIGN_WPB")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8) wpb = v; }
+  const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
+  size_t rings = (size_t)wpb * 3 * R * sizeof(int32_t);
   if (const char *env = getenv("SEQALIGN_LDS_PAD")) rings += (size_t)atoi(env);   // occupancy experiments
   if (p.K <= 1) {
-    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R>), grid, block, rings, stream, p, 0u);
-    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R>), grid, block, rings, stream, p, 0u);
+    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R, FB>), grid, block, rings, stream, p, 0u);
+    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R, FB>), grid, block, rings, stream, p, 0u);
   } else if (p.K <= SA_LDS_TABLE_MAX_K) {
     const uint32_t tints = (p.K * p.K + 3u) & ~3u;   // keep the rings 16 B aligned
     const size_t lds = rings + tints * sizeof(int32_t);
-    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, true, R>), grid, block, lds, stream, p, tints);
-    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, false, R>), grid, block, lds, stream, p, tints);
+    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, true, R, FB>), grid, block, lds, stream, p, tints);
+    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, false, R, FB>), grid, block, lds, stream, p, tints);
   } else {
-    hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_GLOBAL, true, R>), grid, block, rings, stream, p, 0u);
+    hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_GLOBAL, true, R, FB>), grid, block, rings, stream, p, 0u);
   }
   return hipGetLastError();
 }
@@ -187,18 +211,25 @@ static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
 bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
   if (max_len_a + 1 > 8 * sa::kWave) return false;                 // a row must fit one wave
   const uintptr_t m = (uintptr_t)p.M, a = (uintptr_t)p.A, b = (uintptr_t)p.B;
-  return ((m ^ a) & 1023) == 0 && ((m ^ b) & 1023) == 0;          // arenas congruent mod 1 KiB
+  return ((m ^ a) & 4095) == 0 && ((m ^ b) & 4095) == 0;          // arenas congruent mod 4 KiB
+}
+
+// flush unit: SEQALIGN_FLUSH_INTS in {256, 512} (tuning experiments)
+static int flush_ints() {
+  if (const char *env = getenv("SEQALIGN_FLUSH_INTS")) return atoi(env);
+  return 256;
 }
 
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   // columns per lane: the border column is a column too
   const uint32_t need = sa::columns_per_lane(max_len_a + 1);
-  if (need <= 1) return sa::launch_cpl<1, 512>(p, stream);
-  if (need <= 2) return sa::launch_cpl<2, 512>(p, stream);
-  if (need <= 3) return sa::launch_cpl<3, 512>(p, stream);
-  if (need <= 4) return sa::launch_cpl<4, 512>(p, stream);
-  if (need <= 5) return sa::launch_cpl<5, 1024>(p, stream);
-  if (need <= 6) return sa::launch_cpl<6, 1024>(p, stream);
-  return sa::launch_cpl<8, 1024>(p, stream);
+  const bool big = flush_ints() == 512;
+  if (need <= 1) return big ? sa::launch_cpl<1, 1024, 512>(p, stream) : sa::launch_cpl<1, 512, 256>(p, stream);
+  if (need <= 2) return big ? sa::launch_cpl<2, 1024, 512>(p, stream) : sa::launch_cpl<2, 512, 256>(p, stream);
+  if (need <= 3) return big ? sa::launch_cpl<3, 1024, 512>(p, stream) : sa::launch_cpl<3, 512, 256>(p, stream);
+  if (need <= 4) return big ? sa::launch_cpl<4, 1024, 512>(p, stream) : sa::launch_cpl<4, 512, 256>(p, stream);
+  if (need <= 5) return sa::launch_cpl<5, 1024, 256>(p, stream);
+  if (need <= 6) return sa::launch_cpl<6, 1024, 256>(p, stream);
+  return sa::launch_cpl<8, 1024, 256>(p, stream);
 }

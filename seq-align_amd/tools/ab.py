@@ -39,7 +39,21 @@ batch = getattr(W, gen)(args.pairs or per_gpu, **kwargs)
 ctx = S.Context(0)
 h = ctx.upload_scoring(S.make_scoring(spec), is_sw)
 db = S.DeviceBatch(batch, 0)
-KID = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM}
+KID = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM,
+       "memset": -1}   # memset = torch fill_ of the same three arenas: this box's write ceiling
+
+
+def time_memset(repeats):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+    with torch.cuda.stream(db.stream):
+        for i in range(repeats):
+            ev[i].record(db.stream)
+            db.M.fill_(7); db.A.fill_(7); db.B.fill_(7)
+        ev[repeats].record(db.stream)
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(repeats)]
+
+
 parsed = []
 for v in args.variants:
     name, _, envs = v.partition(":")
@@ -50,7 +64,7 @@ for r in range(args.rounds + 1):
     for v, kid, env in parsed:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
-        ms = db.time_fill_ms(ctx, h, kid, args.launches)
+        ms = time_memset(args.launches) if kid < 0 else db.time_fill_ms(ctx, h, kid, args.launches)
         for k, o in old.items():
             if o is None:
                 os.environ.pop(k, None)
