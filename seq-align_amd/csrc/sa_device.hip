@@ -108,7 +108,7 @@ struct seqalign_ctx {
   HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // cached flattened scoring for the legacy single-pair path
   seqalign_dev_scoring *cached = nullptr;
-  std::vector<unsigned char> cached_key;
+  uint64_t cached_fp = 0;
   int cached_is_sw = -1;
 };
 
@@ -430,6 +430,9 @@ static int check_batch(const seqalign_batch_t *b) {
 
 }  // namespace
 
+static int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
+                               const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status);
+
 extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                    int is_sw, const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B,
                                    uint64_t *status) {
@@ -440,7 +443,12 @@ extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *
   HIP_TRY(hipSetDevice(ctx->device));
   ScoringGuard guard(ctx);
   if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &guard.h))) return rc;
-  seqalign_dev_scoring *sc = guard.h;
+  return fill_batch_uploaded(ctx, batch, guard.h, mat_off, M, A, B, status);
+}
+
+static int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
+                               const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
+  int rc = SEQALIGN_OK;
   int worst = SEQALIGN_OK;
   for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
     if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
@@ -489,10 +497,49 @@ extern "C" seqalign_ctx_t *sa_default_ctx_or_die(void) {
   return g_default_ctx;
 }
 
+// FNV-1a over everything scoring_lookup can see (header fields, wildcard and swap
+// bitsets, and the scores whose bit is set): the legacy per-pair API re-uses the
+// uploaded scoring while the caller's scoring_t is unchanged.
+static uint64_t scoring_fingerprint(const scoring_t *sc, int is_sw) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  };
+  const int head[] = {sc->gap_open, sc->gap_extend, sc->no_start_gap_penalty, sc->no_end_gap_penalty,
+                      sc->no_gaps_in_a, sc->no_gaps_in_b, sc->no_mismatches, sc->use_match_mismatch,
+                      sc->match, sc->mismatch, sc->case_sensitive, sc->min_penalty, sc->max_penalty, is_sw};
+  mix(head, sizeof(head));
+  mix(sc->wildcards, sizeof(sc->wildcards));
+  mix(sc->swap_set, sizeof(sc->swap_set));
+  for (int a = 0; a < 256; ++a) {
+    if ((sc->wildcards[a >> 5] >> (a & 31)) & 1u) mix(&sc->wildscores[a], sizeof(int));
+    for (int w = 0; w < 8; ++w) {
+      uint32_t bits = sc->swap_set[a][w];
+      while (bits) {
+        const int b = w * 32 + __builtin_ctz(bits);
+        bits &= bits - 1;
+        mix(&sc->swap_scores[a][b], sizeof(int));
+      }
+    }
+  }
+  return h;
+}
+
 extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is_sw, const char *a, size_t len_a,
                                 const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
   if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
   std::lock_guard<std::mutex> lock(g_default_mu);   // the default context is shared
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint64_t fp = scoring_fingerprint(sc, is_sw);
+  if (!ctx->cached || ctx->cached_fp != fp || ctx->cached_is_sw != is_sw) {
+    if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
+    ctx->cached = nullptr;
+    int rc = seqalign_scoring_upload(ctx, sc, is_sw, &ctx->cached);
+    if (rc) return rc;
+    ctx->cached_fp = fp;
+    ctx->cached_is_sw = is_sw;
+  }
   // one arena: a then b
   std::vector<char> arena(len_a + len_b + 1);
   if (len_a) memcpy(arena.data(), a, len_a);
@@ -502,7 +549,9 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
   seqalign_batch_t batch;
   batch.n_pairs = 1; batch.arena = arena.data(); batch.arena_bytes = arena.size();
   batch.off_a = &off_a; batch.len_a = &la; batch.off_b = &off_b; batch.len_b = &lb;
-  return seqalign_fill_batch(ctx, &batch, sc, is_sw, &mat_off, M, A, B, status);
+  int rc = check_batch(&batch);
+  if (rc) return rc;
+  return fill_batch_uploaded(ctx, &batch, ctx->cached, &mat_off, M, A, B, status);
 }
 
 // ----------------------------------------------- host-level: NW over a batch ---

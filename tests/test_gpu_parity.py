@@ -389,3 +389,29 @@ def test_legacy_sw_fetch_matches_oracle_hit_lists(ctx):
                                                          h["len_b"], h["a"], h["b"])
     lib.smith_waterman_free(sw)
     lib.alignment_free(res)
+
+
+def test_legacy_api_sees_scoring_edits_between_calls(ctx):
+    """The per-pair API keeps the flattened scoring on the device while the caller's
+    scoring_t is unchanged; an edit through the same pointer must be picked up."""
+    lib = S.lib()
+    sc = S.make_scoring({"preset": "default"})
+    nw = C.c_void_p(lib.needleman_wunsch_new())
+    res = C.c_void_p(lib.alignment_create(C.c_size_t(64)))
+    a, b = b"ACGTTGCAAC", b"ACGATGCTAC"
+
+    def run():
+        lib.needleman_wunsch_align(a, b, C.byref(sc), nw, res)
+        r = O.Alignment.from_address(res.value)
+        return r.score, C.string_at(r.result_a), C.string_at(r.result_b)
+
+    for step in range(3):
+        rc, s, ra, rb = O.oracle_nw(oracle_scoring_of(sc), a, b)
+        assert rc == 0 and run() == (s, ra, rb) and run() == (s, ra, rb)
+        if step == 0:
+            lib.scoring_add_mutation(C.byref(sc), C.c_char(b"t"), C.c_char(b"a"), C.c_int(3))
+        else:
+            sc.gap_extend = -2
+            sc.min_penalty = min(sc.min_penalty, sc.gap_open + sc.gap_extend)
+    lib.alignment_free(res)
+    lib.needleman_wunsch_free(nw)
