@@ -415,3 +415,67 @@ def test_legacy_api_sees_scoring_edits_between_calls(ctx):
             sc.min_penalty = min(sc.min_penalty, sc.gap_open + sc.gap_extend)
     lib.alignment_free(res)
     lib.needleman_wunsch_free(nw)
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KID)
+def test_dense_packing_and_odd_arena_alignment(ctx, kernel):
+    """Pairs packed back to back (pad_cells=1: every 4-byte alignment of a pair's
+    first cell, neighbours share 1 KiB blocks) -- the stream kernel's partial first /
+    last blocks must not touch a neighbour's cells; and arenas that are NOT congruent
+    mod 4 KiB, where the stream kernel must hand over to the row-store kernel."""
+    import torch
+    sc = S.make_scoring({"preset": "default"})
+    osc = oracle_scoring_of(sc)
+    batch = W.ragged(200, seed=77, max_len=150)
+    h = ctx.upload_scoring(sc, 0)
+    db = S.DeviceBatch(batch, 0, pad_cells=1)
+    for t in (db.M, db.A, db.B):
+        t.fill_(0x5A5A5A5A)
+    db.fill(ctx, h, kernel)
+    torch.cuda.synchronize()
+    assert_pairs_match_oracle(db, batch, osc, 0, range(batch.n_pairs), tag=f"dense {KID(kernel)}")
+    # skewed arenas: rebuild the descriptor with A shifted by 5 ints, B by 300
+    total = db.total_cells
+    raw = torch.full((3 * total + 4096,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    M, A, B = raw[0:total], raw[total + 5:2 * total + 5], raw[2 * total + 300:3 * total + 300]
+    db.M, db.A, db.B = M, A, B
+    db.desc.match_scores, db.desc.gap_a_scores, db.desc.gap_b_scores = M.data_ptr(), A.data_ptr(), B.data_ptr()
+    db.fill(ctx, h, kernel)
+    torch.cuda.synchronize()
+    assert_pairs_match_oracle(db, batch, osc, 0, range(batch.n_pairs), tag=f"skewed {KID(kernel)}")
+    # nothing outside the three arenas was written
+    assert int((raw[total:total + 5] != 0x5A5A5A5A).sum()) == 0
+    assert int((raw[2 * total + 5:2 * total + 300] != 0x5A5A5A5A).sum()) == 0
+    assert int((raw[3 * total + 300:] != 0x5A5A5A5A).sum()) == 0
+    ctx.release_scoring(h)
+
+
+def test_randomised_scorings_differential(ctx):
+    """A few hundred random (scoring, batch) combinations through the default
+    kernel choice, NW and SW: penalties, all five flags, case sensitivity,
+    wildcards and asymmetric mutations drawn from a seeded stream."""
+    rng = W.Rng(20260928)
+    checked = 0
+    for trial in range(60):
+        v = rng.below(1 << 20, 12).astype(int)
+        flags = [int(v[0] >> k) & 1 for k in range(5)]
+        match, mismatch = int(v[1] % 6), -int(v[2] % 7)
+        go, ge = -int(v[3] % 12), -int(v[4] % 4)
+        if flags[2] and flags[3]:
+            mismatch = min(mismatch, go + ge)
+        spec = {"init": [match, mismatch, go, ge, *flags, int(v[5] & 1)], "wildcards": [], "mutations": []}
+        if v[6] & 1:
+            spec["wildcards"].append(["N", int(v[6] % 5) - 2])
+        if v[7] & 1:
+            spec["mutations"] += [["a", "g", int(v[7] % 7) - 3], ["g", "a", int(v[8] % 7) - 3], ["T", "c", 2]]
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        batch = W.ragged(16, seed=int(v[9]), max_len=int(20 + v[10] % 200), lower_frac=0.25,
+                         extra=b"N" if spec["wildcards"] else b"")
+        for is_sw in (0, 1):
+            if not is_sw and min(osc.gap_open + osc.gap_extend, osc.gap_extend) < -abs(osc.min_penalty):
+                continue
+            db = device_fill(ctx, batch, sc, is_sw, S.KERNEL_AUTO)
+            assert_pairs_match_oracle(db, batch, osc, is_sw, range(batch.n_pairs), tag=f"trial {trial} {spec}")
+            checked += batch.n_pairs
+    assert checked > 1500
