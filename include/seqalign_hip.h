@@ -30,7 +30,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "alignment_scoring.h"
+#include "seqalign_compat.h"
 
 #ifdef __cplusplus
 extern "C" {
