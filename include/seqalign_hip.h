@@ -213,10 +213,13 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * visited mask per pair).  Emits, per pair, successive hits with
  * score >= min_score[p], at most max_hits per pair, into the caller's hit array
  * (hit_cap entries total).
- *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit; only
- *       the strings cross PCIe.
- *   max_hits  > 1 (or SEQALIGN_TRACEBACK=host): GPU fill + GPU candidate
- *       compaction, matrices copied back, hits enumerated on the host. */
+ *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit.
+ *   max_hits <= 16: GPU fill + GPU candidate compaction + segmented sort + GPU
+ *       enumeration (one lane per pair, visited bitmap in HBM).
+ *   In both cases only the strings cross PCIe.
+ *   max_hits > 16 (or SEQALIGN_TRACEBACK=host): the matrices and the compacted
+ *       candidates are copied back and the hits are enumerated on the host
+ *       (threaded over pairs). */
 typedef struct {
   uint64_t pair;
   int32_t score;

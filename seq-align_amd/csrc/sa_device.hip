@@ -105,6 +105,7 @@ struct seqalign_ctx {
   DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
   DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
+  DevBuf e[12];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
   HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // cached flattened scoring for the legacy single-pair path
   seqalign_dev_scoring *cached = nullptr;
@@ -168,6 +169,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
                     &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score,
                     &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
     b->release();
+  for (DevBuf &b : ctx->e) b.release();
   for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
                      &ctx->h_tb, &ctx->h_tmeta})
     b->release();
@@ -329,7 +331,8 @@ extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_
   p.len_a = r->len_a; p.len_b = r->len_b; p.mat_off = r->mat_off; p.M = r->match_scores;
   p.min_score = r->min_score; p.best_score = r->best_score; p.best_index = r->best_index;
   p.cand_count = r->cand_count; p.cand_off = r->cand_off; p.cand_cap = r->cand_cap;
-  p.cand_index = r->cand_index; p.cand_score = r->cand_score; p.n_pairs = (uint32_t)r->n_pairs;
+  p.cand_index = r->cand_index; p.cand_score = r->cand_score; p.cand_key = nullptr;
+  p.n_pairs = (uint32_t)r->n_pairs;
   hipError_t e = sa_launch_sw_reduce(p, st);
   if (e != hipSuccess) return fail_hip(e, "sw reduce launch");
   return SEQALIGN_OK;
@@ -741,6 +744,142 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
 
 // ----------------------------------------------- host-level: SW over a batch ---
 
+// up to this many hits per pair the enumeration runs on the device
+static const uint32_t kDeviceEnumMaxHits = 16;
+
+// SW hits of one already-filled chunk, enumerated on the device (sa_sw_enum.hip):
+// reduce (count) -> reduce (compact + keys) -> segmented sort -> enumerate ->
+// gather strings -> D2H.  Appends to the caller's hit array / string buffers.
+static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
+                                     const seqalign_dev_scoring *sc, const seqalign_dev_batch_t &d,
+                                     const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                                     uint64_t hit_cap, uint64_t *found, char *out_a, char *out_b, uint64_t str_cap,
+                                     uint64_t *used_str) {
+  const uint64_t n = c.count;
+  hipStream_t st = ctx->stream;
+  int rc;
+  DevBuf &d_min = ctx->e[0], &d_key_in = ctx->e[1], &d_key_out = ctx->e[2], &d_idx_out = ctx->e[3],
+         &d_tmp = ctx->e[4], &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
+         &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
+
+  int32_t thr = min_score[c.first];
+  for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
+
+  // pass 1: how many cells >= threshold per pair
+  if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
+      (rc = ctx->cand_count.reserve(n * 4)) || (rc = ctx->cand_off.reserve((n + 1) * 8)) ||
+      (rc = ctx->cand_cap.reserve(n * 4)) || (rc = d_min.reserve(n * 4)))
+    return rc;
+  SaReduceParams r;
+  memset(&r, 0, sizeof(r));
+  r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.min_score = thr;
+  r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+  r.cand_count = ctx->cand_count.as<uint32_t>(); r.n_pairs = (uint32_t)n;
+  hipError_t e = sa_launch_sw_reduce(r, st);
+  if (e != hipSuccess) return fail_hip(e, "sw reduce");
+  std::vector<uint32_t> count(n);
+  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  // host prefixes: candidate segments, visited-bitmap words, string slots
+  std::vector<uint64_t> offs(4 * (n + 1));
+  uint64_t *cand_off = offs.data(), *mask_off = cand_off + n + 1, *str_off = mask_off + n + 1,
+           *dst_off = str_off + n + 1;
+  uint64_t total = 0, mask_words = 0, str_total = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k, la = batch->len_a[p], lb = batch->len_b[p];
+    cand_off[k] = total; total += count[k];
+    mask_off[k] = mask_words; mask_words += ((la + 1) * (lb + 1) + 31) / 32;
+    str_off[k] = str_total; str_total += (uint64_t)max_hits * (la + lb);
+  }
+  cand_off[n] = total; mask_off[n] = mask_words; str_off[n] = str_total;
+  if (total >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+
+  if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = d_key_in.reserve(total * 8 + 8)) ||
+      (rc = d_key_out.reserve(total * 8 + 8)) || (rc = d_idx_out.reserve(total * 4 + 4)) ||
+      (rc = d_mask.reserve(mask_words * 4 + 4)) || (rc = d_offs.reserve(offs.size() * 8)) ||
+      (rc = ctx->t_out_a.reserve(str_total + 16)) || (rc = ctx->t_out_b.reserve(str_total + 16)) ||
+      (rc = d_hits.reserve(n * max_hits * sizeof(SaDevHit) + 16)) || (rc = d_meta.reserve(n * 12)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 3 * (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->cand_cap.p, count.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
+  const uint64_t *dv_cand_off = d_offs.as<uint64_t>(), *dv_mask_off = dv_cand_off + n + 1,
+                 *dv_str_off = dv_mask_off + n + 1;
+
+  // pass 2: compaction with sort keys, then the stable segmented sort
+  r.cand_off = dv_cand_off; r.cand_cap = ctx->cand_cap.as<uint32_t>();
+  r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_key = d_key_in.as<uint64_t>();
+  if ((e = sa_launch_sw_reduce(r, st)) != hipSuccess) return fail_hip(e, "sw reduce (compaction)");
+  if (total) {
+    size_t tmp_bytes = 0;
+    e = sa_sort_candidates(nullptr, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off, st);
+    if (e != hipSuccess) return fail_hip(e, "segmented sort (size query)");
+    if ((rc = d_tmp.reserve(tmp_bytes + 16))) return rc;
+    e = sa_sort_candidates(d_tmp.p, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off, st);
+    if (e != hipSuccess) return fail_hip(e, "segmented sort");
+  }
+
+  // enumeration: one lane per pair
+  SaEnumParams q;
+  memset(&q, 0, sizeof(q));
+  q.arena = d.arena; q.off_a = d.off_a; q.len_a = d.len_a; q.off_b = d.off_b; q.len_b = d.len_b;
+  q.mat_off = d.mat_off; q.M = d.match_scores; q.A = d.gap_a_scores; q.B = d.gap_b_scores;
+  q.code = sc->d_code; q.table = sc->d_table; q.cand_off = dv_cand_off; q.cand_count = ctx->cand_count.as<uint32_t>();
+  q.sorted_key = d_key_out.as<uint64_t>(); q.sorted_index = d_idx_out.as<uint32_t>(); q.min_score = d_min.as<int32_t>();
+  q.mask = d_mask.as<uint32_t>(); q.mask_off = dv_mask_off; q.str_off = dv_str_off;
+  q.out_a = ctx->t_out_a.as<char>(); q.out_b = ctx->t_out_b.as<char>(); q.hits = d_hits.as<SaDevHit>();
+  uint32_t *d_m = d_meta.as<uint32_t>();
+  q.hit_count = d_m; q.str_used = d_m + n; q.enum_status = d_m + 2 * n;
+  q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.max_hits = max_hits; q.open1 = sc->flat.open1;
+  q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
+  if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
+
+  std::vector<uint32_t> meta(3 * n);
+  std::vector<SaDevHit> dev_hits(n * max_hits);
+  HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  uint64_t gathered = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint32_t status = meta[2 * n + k] & 0x7fffffffu;
+    if (status) return (int)status;
+    dst_off[k] = gathered;
+    gathered += meta[n + k];
+  }
+  // pack every pair's strings back to back and bring them over in one copy
+  if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
+      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+    return rc;
+  uint64_t *dv_dst_off = d_offs.as<uint64_t>() + 3 * (n + 1);
+  HIP_TRY(hipMemcpyAsync(dv_dst_off, dst_off, n * 8, hipMemcpyHostToDevice, st));
+  if ((e = sa_launch_gather_strings(q.out_a, q.out_b, dv_str_off, q.str_used, dv_dst_off, d_gath_a.as<char>(),
+                                    d_gath_b.as<char>(), (uint32_t)n, st)) != hipSuccess)
+    return fail_hip(e, "gather strings");
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  for (uint64_t k = 0; k < n; ++k) {
+    for (uint32_t i = 0; i < meta[k]; ++i) {
+      const SaDevHit &src = dev_hits[k * max_hits + i];
+      if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
+      memcpy(out_a + *used_str, ha + dst_off[k] + src.str_off, src.length);
+      memcpy(out_b + *used_str, hb + dst_off[k] + src.str_off, src.length);
+      out_a[*used_str + src.length] = out_b[*used_str + src.length] = '\0';
+      seqalign_sw_hit_t &h = hits[(*found)++];
+      h.pair = c.first + k; h.score = src.score; h.pos_a = src.pos_a; h.pos_b = src.pos_b;
+      h.len_a = src.len_a; h.len_b = src.len_b; h.length = src.length; h.str_off = *used_str;
+      *used_str += src.length + 1;
+    }
+  }
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                  const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
                                  uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
@@ -812,6 +951,17 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     }
     *n_hits = found;
     return SEQALIGN_OK;
+  }
+  if (max_hits <= kDeviceEnumMaxHits && !traceback_on_host()) {
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
+      seqalign_dev_batch_t d;
+      if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
+      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, sc, d, min_score, max_hits, hits, hit_cap, &found, out_a,
+                                          out_b, str_cap, &used_str)))
+        break;
+    }
+    *n_hits = found;
+    return rc;
   }
   const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
 

@@ -35,7 +35,41 @@ struct SaReduceParams {
   const uint32_t *cand_cap;
   uint32_t *cand_index;
   int32_t *cand_score;
+  uint64_t *cand_key;     /* optional: (INT32_MAX - score) << 32 | column, for the device sort */
   uint32_t n_pairs;
+};
+
+/* one SW hit as the enumeration kernel reports it (smith_waterman.c:249-255) */
+struct SaDevHit {
+  int32_t score;
+  uint32_t pos_a, pos_b, len_a, len_b, length;
+  uint32_t str_off;       /* into the pair's string slot */
+};
+
+struct SaEnumParams {
+  const uint8_t *arena;
+  const uint64_t *off_a;
+  const uint32_t *len_a;
+  const uint64_t *off_b;
+  const uint32_t *len_b;
+  const uint64_t *mat_off;
+  const int32_t *M, *A, *B;
+  const uint16_t *code;
+  const int32_t *table;
+  const uint64_t *cand_off;      /* [n] start of the pair's sorted candidates       */
+  const uint32_t *cand_count;    /* [n]                                            */
+  const uint64_t *sorted_key;
+  const uint32_t *sorted_index;
+  const int32_t *min_score;      /* [n]                                            */
+  uint32_t *mask;                /* visited bits, zeroed by the caller              */
+  const uint64_t *mask_off;      /* [n] in 32-bit words                            */
+  const uint64_t *str_off;       /* [n] slot of max_hits*(len_a+len_b) chars        */
+  char *out_a, *out_b;
+  SaDevHit *hits;                /* [n * max_hits]                                  */
+  uint32_t *hit_count, *str_used, *enum_status;
+  uint32_t n_pairs, K, max_hits;
+  int32_t open1, ext, gen_eq, gen_ne;
+  uint32_t flags;
 };
 
 struct SaTraceParams {
@@ -74,6 +108,13 @@ bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
                                  hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
+hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
+                              const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,
+                              const uint64_t *seg_off, hipStream_t stream);
+hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
+hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,
+                                    const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,
+                                    uint32_t n_pairs, hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
 hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);

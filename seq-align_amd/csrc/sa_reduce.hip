@@ -40,6 +40,7 @@ sw_reduce_kernel(const SaReduceParams p) {
   const uint32_t cap = p.cand_cap ? p.cand_cap[pair] : 0;
   uint32_t *cidx = p.cand_index ? p.cand_index + p.cand_off[pair] : nullptr;
   int32_t *cscore = p.cand_score ? p.cand_score + p.cand_off[pair] : nullptr;
+  uint64_t *ckey = p.cand_key ? p.cand_key + p.cand_off[pair] : nullptr;
 
   Best best{0, 0, 0};                                   // cell 0 holds score 0
   uint32_t count = 0;                                   // wave-uniform
@@ -83,7 +84,11 @@ sw_reduce_kernel(const SaReduceParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (v[u][k] >= min_score) {
-            if (pos < cap) { cidx[pos] = i0 + k; cscore[pos] = v[u][k]; }
+            if (pos < cap) {
+              cidx[pos] = i0 + k;
+              if (cscore) cscore[pos] = v[u][k];
+              if (ckey) ckey[pos] = ((uint64_t)(uint32_t)(INT32_MAX - v[u][k]) << 32) | ((i0 + k) % W);
+            }
             ++pos;
           }
         }

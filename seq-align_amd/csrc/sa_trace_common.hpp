@@ -1,0 +1,65 @@
+// sa_trace_common.hpp -- one traceback step on the device, shared by
+// sa_traceback.hip (NW / best SW hit) and sa_sw_enum.hip (SW hit enumeration).
+// Decision order of alignment_reverse_move (reference src/alignment.c:244-350).
+#pragma once
+
+#include "sa_fill_common.hpp"
+
+namespace sa {
+
+enum { MAT_MATCH = 0, MAT_GAP_A = 1, MAT_GAP_B = 2 };
+
+// read-only view of one pair for the walkers
+struct PairView {
+  const uint8_t *seq_a, *seq_b;
+  const int32_t *M, *A, *B;
+  uint32_t la, lb, W;
+};
+
+struct TraceConsts {
+  const uint16_t *code;
+  const int32_t *table;
+  int K, open1, ext, gen_eq, gen_ne;
+  bool no_start, no_end, no_gaps_a, no_gaps_b;
+};
+
+// Moves (x,y,matrix,score) to the predecessor.  Returns 0, or SEQALIGN_E_UNKNOWN_PAIR
+// (5) / SEQALIGN_E_TRACEBACK (7).
+__device__ __forceinline__ uint32_t reverse_move(const PairView &v, const TraceConsts &k, uint32_t &x,
+                                                 uint32_t &y, int &matrix, int &score) {
+  // gap costs for leaving (x,y) (alignment.c:261-272)
+  long long open_a = k.open1, ext_a = k.ext, open_b = k.open1, ext_b = k.ext;
+  if (k.no_end) {
+    if (x == v.la) open_a = ext_a = 0;
+    if (y == v.lb) open_b = ext_b = 0;
+  }
+  if (k.no_start) {   // x, y >= 1 for every caller; kept for symmetry with the reference
+    if (x == 0) open_a = ext_a = 0;
+    if (y == 0) open_b = ext_b = 0;
+  }
+  long long via_m, via_a, via_b;
+  if (matrix == MAT_MATCH) {
+    const int code_a = k.code[v.seq_a[x - 1]], code_b = k.code[v.seq_b[y - 1]];
+    int s = (k.K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
+                       : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * k.K, code_b, k.table,
+                                                      k.gen_eq, k.gen_ne);
+    if (s == SA_S_UNKNOWN) return 5;
+    // a blocked pair (no_mismatches, not a match) looks up as score 0 upstream
+    // (alignment_scoring.c:148-153 with no wildcard involved)
+    if (s == SA_S_BLOCKED) s = 0;
+    via_m = via_a = via_b = s; --x; --y;
+  } else if (matrix == MAT_GAP_A) {
+    via_m = via_b = open_a; via_a = ext_a; --y;
+  } else {
+    via_m = via_a = open_b; via_b = ext_b; --x;
+  }
+  const uint32_t at = y * v.W + x;
+  const long long av = v.A[at], bv = v.B[at], mv = v.M[at], cur = score;
+  if ((!k.no_gaps_a || x == 0 || x == v.la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
+  else if ((!k.no_gaps_b || y == 0 || y == v.lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
+  else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
+  else return 7;
+  return 0;
+}
+
+}  // namespace sa

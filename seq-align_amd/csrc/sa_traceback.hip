@@ -12,11 +12,9 @@
 // (~len_a+len_b steps), so the only parallelism is across pairs.  Each lane
 // writes its alignment right-to-left into its slot and reports where it starts;
 // the host left-aligns while copying out of the staging buffer.
-#include "sa_fill_common.hpp"
+#include "sa_trace_common.hpp"
 
 namespace sa {
-
-enum { MAT_MATCH = 0, MAT_GAP_A = 1, MAT_GAP_B = 2 };
 
 // SW: start_index != nullptr -> local alignment ending at that match_scores cell
 // (smith_waterman.c:165-258 on a fresh mask: the first fetched hit always
@@ -37,9 +35,10 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   char *oa = p.out_a + p.str_off[pair];
   char *ob = p.out_b + p.str_off[pair];
 
-  const bool no_start = p.flags & SA_F_NO_START_GAP, no_end = p.flags & SA_F_NO_END_GAP;
-  const bool no_gaps_a = p.flags & SA_F_NO_GAPS_A, no_gaps_b = p.flags & SA_F_NO_GAPS_B;
-  const int K = (int)p.K;
+  const PairView v{sa_, sb_, Mg, Ag, Bg, la, lb, W};
+  const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
+                      (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
+                      (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
 
   int matrix = MAT_MATCH;
   int score;
@@ -64,39 +63,7 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
     --head;
     oa[head] = (matrix == MAT_GAP_A) ? '-' : (char)ca;
     ob[head] = (matrix == MAT_GAP_B) ? '-' : (char)cb;
-
-    // gap costs for leaving (x,y) (alignment.c:261-272)
-    long long open_a = p.open1, ext_a = p.ext, open_b = p.open1, ext_b = p.ext;
-    if (no_end) {
-      if (x == la) open_a = ext_a = 0;
-      if (y == lb) open_b = ext_b = 0;
-    }
-    if (no_start) {   // x, y >= 1 here; kept for symmetry with the reference
-      if (x == 0) open_a = ext_a = 0;
-      if (y == 0) open_b = ext_b = 0;
-    }
-    long long via_m, via_a, via_b;
-    if (matrix == MAT_MATCH) {
-      const int code_a = p.code[ca], code_b = p.code[cb];
-      int s = (K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? p.gen_eq : p.gen_ne)
-                       : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * K, code_b, p.table,
-                                                      p.gen_eq, p.gen_ne);
-      if (s == SA_S_UNKNOWN) { err = 5 /* SEQALIGN_E_UNKNOWN_PAIR */; break; }
-      // a blocked pair (no_mismatches, not a match) looks up as score 0 upstream
-      // (alignment_scoring.c:148-153 with no wildcard involved)
-      if (s == SA_S_BLOCKED) s = 0;
-      via_m = via_a = via_b = s; --x; --y;
-    } else if (matrix == MAT_GAP_A) {
-      via_m = via_b = open_a; via_a = ext_a; --y;
-    } else {
-      via_m = via_a = open_b; via_b = ext_b; --x;
-    }
-    const uint32_t at = y * W + x;
-    const long long av = Ag[at], bv = Bg[at], mv = Mg[at], cur = score;
-    if ((!no_gaps_a || x == 0 || x == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
-    else if ((!no_gaps_b || y == 0 || y == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
-    else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
-    else { err = 7 /* SEQALIGN_E_TRACEBACK */; break; }
+    if ((err = reverse_move(v, k, x, y, matrix, score))) break;
   }
   if constexpr (!SW) {
     if (!err) {

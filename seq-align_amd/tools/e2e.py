@@ -43,10 +43,17 @@ with S.Context(0) as ctx:
         t0 = time.perf_counter(); hits = ctx.sw_batch(batch, sc, thr, max_hits=1, hit_cap=n + 8); t1 = time.perf_counter()
         out[f"sw_batch_{name}_best_hit_device"] = dict(seconds=t1 - t0, gcups=batch.cells() / (t1 - t0) / 1e9,
                                                       hits=sum(len(h) for h in hits))
-        # up to 4 hits: candidates + matrices to the host (a tenth of the config)
+        # up to 4 hits per pair, enumerated on the device (full config)
+        ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * n + 8)
+        t0 = time.perf_counter(); hits = ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * n + 8); t1 = time.perf_counter()
+        out[f"sw_batch_{name}_4hits_device"] = dict(seconds=t1 - t0, gcups=batch.cells() / (t1 - t0) / 1e9,
+                                                   hits=sum(len(h) for h in hits))
+        # the same through the host path (candidates + matrices over PCIe), a tenth of the config
+        os.environ["SEQALIGN_TRACEBACK"] = "host"
         batch = getattr(W, gen)(n // 10, **kwargs)
         ctx.sw_batch(batch, sc, thr, max_hits=4)
         t0 = time.perf_counter(); hits = ctx.sw_batch(batch, sc, thr, max_hits=4); t1 = time.perf_counter()
         out[f"sw_batch_{name}_tenth_4hits_host"] = dict(seconds=t1 - t0, gcups=batch.cells() / (t1 - t0) / 1e9,
                                                        hits=sum(len(h) for h in hits))
+        os.environ["SEQALIGN_TRACEBACK"] = "device"
 print(json.dumps(out, indent=1))

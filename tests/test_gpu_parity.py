@@ -316,10 +316,12 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
             assert rc == 0 and res[p] == (s, ra, rb)
 
 
-@pytest.mark.parametrize("max_hits,where", [(5, "device"), (1, "device"), (1, "host")])
+@pytest.mark.parametrize("max_hits,where", [(5, "device"), (16, "device"), (1, "device"), (1, "host"), (5, "host"),
+                                            (40, "device")])
 def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
-    """max_hits=1 on the device = fill + reduction + traceback of the best hit, all
-    in HBM; otherwise candidates + matrices go back and the host enumerates."""
+    """max_hits=1: fill + reduction + traceback of the best hit on the device;
+    max_hits<=16: candidates sorted and enumerated on the device (one lane per pair);
+    larger / SEQALIGN_TRACEBACK=host: candidates + matrices go back, host enumerates."""
     monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
     for spec, gen, kw, thr in (
             ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, W.dna_sw_read_vs_ref, dict(seed=21, read_len=60, ref_len=300), 24),
