@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -436,6 +438,45 @@ static int check_batch(const seqalign_batch_t *b) {
 static int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
                                const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status);
 
+// Device -> pageable host memory.  A plain hipMemcpy to pageable memory is staged
+// by the runtime at ~12 GB/s; large copies go through our own two pinned buffers
+// instead: the DMA of slice i+1 overlaps a multi-threaded memcpy of slice i into
+// the caller's buffer.  The stream must be idle w.r.t. `src` producers (it is
+// enqueued behind them) and is synchronised on return.
+static void parallel_memcpy(void *dst, const void *src, size_t bytes);
+static int copy_out_pipelined(seqalign_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
+  const size_t kSlice = (size_t)32 << 20;
+  if (bytes < (size_t)4 << 20) {
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SEQALIGN_OK;
+  }
+  int rc;
+  if ((rc = ctx->h_M.reserve(kSlice)) || (rc = ctx->h_A.reserve(kSlice))) return rc;
+  void *pin[2] = {ctx->h_M.p, ctx->h_A.p};
+  hipEvent_t ev[2];
+  HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i <= n_slices && e == hipSuccess; ++i) {
+    if (i < n_slices) {
+      const size_t off = i * kSlice, len = std::min(kSlice, bytes - off);
+      e = hipMemcpyAsync(pin[i & 1], static_cast<const char *>(src_dev) + off, len, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[i & 1], ctx->stream);
+    }
+    if (i > 0 && e == hipSuccess) {
+      const size_t j = i - 1, off = j * kSlice, len = std::min(kSlice, bytes - off);
+      e = hipEventSynchronize(ev[j & 1]);
+      if (e == hipSuccess) parallel_memcpy(static_cast<char *>(dst) + off, pin[j & 1], len);
+    }
+  }
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (e != hipSuccess) return fail_hip(e, "pipelined D2H");
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                    int is_sw, const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B,
                                    uint64_t *status) {
@@ -465,10 +506,10 @@ static int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batc
         ++j;
       }
       const size_t bytes = run_cells * 4;
-      hipError_t e = hipMemcpyAsync(M + host0, ctx->M.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(A + host0, ctx->A.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(B + host0, ctx->B.as<int32_t>() + dev_cell, bytes, hipMemcpyDeviceToHost, ctx->stream);
-      if (e != hipSuccess) { rc = fail_hip(e, "D2H matrices"); break; }
+      if ((rc = copy_out_pipelined(ctx, M + host0, ctx->M.as<int32_t>() + dev_cell, bytes)) ||
+          (rc = copy_out_pipelined(ctx, A + host0, ctx->A.as<int32_t>() + dev_cell, bytes)) ||
+          (rc = copy_out_pipelined(ctx, B + host0, ctx->B.as<int32_t>() + dev_cell, bytes)))
+        break;
       dev_cell += run_cells;
       k = j;
     }
@@ -567,20 +608,81 @@ struct PairHits {
   std::string str_a, str_b;
 };
 
-// run fn(0..n-1) on host threads (pairs are independent); SEQALIGN_HOST_THREADS overrides
+// Persistent host worker pool: run fn(0..n-1) over the workers + the caller.
+// Pairs / memcpy pieces are independent.  SEQALIGN_HOST_THREADS overrides the
+// worker count (default min(hardware threads, 32)).  One job at a time.
+class HostPool {
+ public:
+  static HostPool &get() { static HostPool pool; return pool; }
+  void run(uint64_t n, const std::function<void(uint64_t)> &fn) {
+    if (n == 0) return;
+    if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
+    std::lock_guard<std::mutex> one_job(job_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = (unsigned)workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    for (uint64_t k; (k = next_.fetch_add(1)) < n;) fn(k);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned want = hw ? std::min(hw, 32u) : 4u;
+    if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
+    for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto &th : workers_) th.join();
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return generation_ != seen; });
+      seen = generation_;
+      if (stop_) return;
+      const std::function<void(uint64_t)> *fn = fn_;
+      const uint64_t n = n_;
+      lk.unlock();
+      for (uint64_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
+      lk.lock();
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(uint64_t)> *fn_ = nullptr;
+  uint64_t n_ = 0, generation_ = 0;
+  std::atomic<uint64_t> next_{0};
+  unsigned pending_ = 0;
+  bool stop_ = false;
+};
+
 template <class F>
 static void parallel_for(uint64_t n, F fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  unsigned want = hw ? std::min(hw, 32u) : 4u;
-  if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
-  const unsigned nt = (unsigned)std::min<uint64_t>(want, n);
-  if (nt <= 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
-  std::atomic<uint64_t> next{0};
-  std::vector<std::thread> pool;
-  for (unsigned t = 0; t < nt; ++t)
-    pool.emplace_back([&] { for (uint64_t k; (k = next.fetch_add(1)) < n;) fn(k); });
-  for (auto &th : pool) th.join();
+  HostPool::get().run(n, std::function<void(uint64_t)>(fn));
 }
+
+}  // namespace
+
+static void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+  const size_t kPiece = (size_t)2 << 20;
+  const uint64_t pieces = (bytes + kPiece - 1) / kPiece;
+  parallel_for(pieces, [&](uint64_t i) {
+    const size_t off = i * kPiece;
+    memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(kPiece, bytes - off));
+  });
+}
+
+namespace {
 
 // Successive local alignments of one pair in reference order (score desc, column
 // asc, index asc), fresh visited mask, at most max_hits (smith_waterman.c:165-277).

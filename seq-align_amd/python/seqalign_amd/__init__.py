@@ -170,14 +170,19 @@ class Context:
         lib().seqalign_scoring_release(self._h, h)
 
     # ---- host-level --------------------------------------------------------
-    def fill_batch(self, batch, scoring: Scoring, is_sw: int, check: bool = True):
-        """H2D -> GPU fill -> D2H.  Returns (M, A, B, mat_off, status) numpy."""
+    def fill_batch(self, batch, scoring: Scoring, is_sw: int, check: bool = True, out=None):
+        """H2D -> GPU fill -> D2H.  Returns (M, A, B, mat_off, status) numpy.
+        out=(M, A, B) re-uses caller-owned (already touched) arrays."""
         cells = batch.matrix_cells()
         mat_off = np.zeros(batch.n_pairs, np.uint64)
         if batch.n_pairs:
             mat_off[1:] = np.cumsum(cells)[:-1]
         total = int(cells.sum())
-        M = np.empty(total, np.int32); A = np.empty(total, np.int32); B = np.empty(total, np.int32)
+        if out is not None:
+            M, A, B = out
+            assert M.size >= total and A.size >= total and B.size >= total
+        else:
+            M = np.empty(total, np.int32); A = np.empty(total, np.int32); B = np.empty(total, np.int32)
         status = np.zeros(batch.n_pairs, np.uint64)
         d = batch_desc(batch)
         rc = lib().seqalign_fill_batch(self._h, C.byref(d), C.byref(scoring), C.c_int(is_sw), _ptr(mat_off),
