@@ -47,6 +47,8 @@ WORKLOADS = {
            "10k NW pairs, DNA 150x150, default scoring 1/-2/-4/-1 (BASELINE configs[1])"),
     "C3": ("dna_sw_read_vs_ref", dict(seed=2), 10000, 1, {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]},
            "10k SW pairs, DNA 150x1000 read-vs-ref, 2/-2/-2/-1 (BASELINE configs[2])"),
+    "L1000": ("dna_nw_150", dict(seed=4, length=1000), 1000, 0, {"preset": "default"},
+              "1k NW pairs, DNA 1000x1000 (long-sequence check, not a BASELINE config)"),
     "C4": ("protein_sw_300", dict(seed=3), 4000, 1, {"preset": "BLOSUM62"},
            "4k SW pairs, protein 300x300, BLOSUM62 (BASELINE configs[3])"),
 }

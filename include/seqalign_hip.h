@@ -118,8 +118,8 @@ enum {
   SEQALIGN_KERNEL_ROWSCAN = 2,   /* row sweep + max-plus prefix scan for gap_b,
                                     rows stored straight from registers        */
   SEQALIGN_KERNEL_STREAM = 3     /* same sweep, output through an LDS ring as
-                                    aligned 1 KiB blocks (len_a <= 511 and the
-                                    three arenas congruent mod 1 KiB; otherwise
+                                    aligned 1 KiB blocks (len_a <= 1023 and the
+                                    three arenas congruent mod 4 KiB; otherwise
                                     the call falls back to ROWSCAN)            */
 };
 

@@ -123,7 +123,7 @@ inline uint32_t columns_per_lane(uint32_t max_len_a) {
   uint32_t need = (max_len_a + kWave - 1) / kWave;
   if (const char *env = getenv("SEQALIGN_CPL")) {
     const uint32_t v = (uint32_t)atoi(env);
-    if (v > need && v <= 8) need = v;
+    if (v > need && v <= 16) need = v;
   }
   return need;
 }

@@ -184,10 +184,10 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   if (lane == 0) p.status[pair] = err;
 }
 
-template <int CPL, int R, int FB>
+template <int CPL, int R, int FB, int WPB = kWavesPerBlock>
 static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
   const bool general = needs_general(p);
-  int wpb = kWavesPerBlock;   // pairs per workgroup; SEQALIGN_WPB in {1,2,4} (tuning experiments)
+  int wpb = WPB;   // pairs per workgroup; SEQALIGN_WPB in {1,2,4,8} (tuning experiments)
   if (const char *env = getenv("SEQALIGN_WPB")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8) wpb = v; }
   const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
   size_t rings = (size_t)wpb * 3 * R * sizeof(int32_t);
@@ -209,7 +209,7 @@ static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
 }  // namespace sa
 
 bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
-  if (max_len_a + 1 > 8 * sa::kWave) return false;                 // a row must fit one wave
+  if (max_len_a + 1 > 16 * sa::kWave) return false;                // a row must fit one wave (CPL <= 16)
   const uintptr_t m = (uintptr_t)p.M, a = (uintptr_t)p.A, b = (uintptr_t)p.B;
   return ((m ^ a) & 4095) == 0 && ((m ^ b) & 4095) == 0;          // arenas congruent mod 4 KiB
 }
@@ -231,5 +231,8 @@ hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a, hipS
   if (need <= 4) return big ? sa::launch_cpl<4, 1024, 512>(p, stream) : sa::launch_cpl<4, 512, 256>(p, stream);
   if (need <= 5) return sa::launch_cpl<5, 1024, 256>(p, stream);
   if (need <= 6) return sa::launch_cpl<6, 1024, 256>(p, stream);
-  return sa::launch_cpl<8, 1024, 256>(p, stream);
+  if (need <= 8) return sa::launch_cpl<8, 1024, 256>(p, stream);
+  // 513..1023 columns: 12 / 16 columns per lane, 24 KiB of rings per wave -> 2 pairs per workgroup
+  if (need <= 12) return sa::launch_cpl<12, 2048, 256, 2>(p, stream);
+  return sa::launch_cpl<16, 2048, 256, 2>(p, stream);
 }
