@@ -1,0 +1,463 @@
+/*
+ * seqalign_cli.c -- batch command-line front-end: `seqalign_nw` (global) and
+ * `seqalign_sw` (local), SURVEY 8f-3.
+ *
+ * Same options and the same output text as the reference tools
+ * (src/tools/nw_cmdline.c:78-149, src/tools/sw_cmdline.c:125-314, option set of
+ * src/alignment_cmdline.c:179-532), but pairs are not aligned one at a time:
+ * they are collected and go through seqalign_nw_batch / seqalign_sw_batch in
+ * batches, so the GPU sees thousands of pairs per launch.  Differences, all
+ * deliberate: (1) --match/--mismatch/--gapopen/--gapextend also lower
+ * min_penalty, so the NW floor stays defined (upstream leaves it stale: UB,
+ * SURVEY A.3-3); (2) every pair's local hits come from a fresh visited mask
+ * (SURVEY A.3-2); (3) no gzip input, no interactive stepping; (4) --zam is not
+ * provided.  --printmatrices uses the per-pair API (it needs the matrices on the
+ * host).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "seqalign_hip.h"
+#include "seqalign_io.h"
+
+enum { TOOL_NW, TOOL_SW };
+
+typedef struct {
+  int tool;
+  int case_sensitive, print_scores, print_seq, print_matrices, print_fasta, print_pretty, print_colour;
+  int min_score, min_score_set;
+  unsigned max_hits; int max_hits_set;
+  unsigned context;
+  const char *seq1, *seq2;
+  const char *files1[64], *files2[64];
+  int n_files;
+} opts_t;
+
+typedef struct { char *name, *seq; size_t len; } rec_t;
+typedef struct { rec_t *a, *b; size_t n, cap; } pairs_t;
+
+static scoring_t scoring;   /* 271 KB */
+static opts_t opt;
+
+static void die(const char *msg, const char *arg)
+{
+  fprintf(stderr, "Error: ");
+  fprintf(stderr, msg, arg);
+  fprintf(stderr, "\nusage: %s [OPTIONS] [seq1 seq2]   (options as in seq-align's %s)\n",
+          opt.tool == TOOL_NW ? "seqalign_nw" : "seqalign_sw",
+          opt.tool == TOOL_NW ? "needleman_wunsch" : "smith_waterman");
+  exit(EXIT_FAILURE);
+}
+
+static int parse_int(const char *s, int *out)
+{
+  char *end;
+  long v = strtol(s, &end, 10);
+  if(end == s || *end) return 0;
+  *out = (int)v;
+  return 1;
+}
+
+static char *dup_n(const char *s, size_t n)
+{
+  char *d = malloc(n + 1);
+  if(!d) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
+  memcpy(d, s, n);
+  d[n] = '\0';
+  return d;
+}
+
+static void add_pair(pairs_t *ps, const char *na, const char *sa, size_t la, const char *nb, const char *sb, size_t lb)
+{
+  if(ps->n == ps->cap) {
+    ps->cap = ps->cap ? 2 * ps->cap : 1024;
+    ps->a = realloc(ps->a, ps->cap * sizeof(rec_t));
+    ps->b = realloc(ps->b, ps->cap * sizeof(rec_t));
+    if(!ps->a || !ps->b) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
+  }
+  ps->a[ps->n].name = dup_n(na, strlen(na)); ps->a[ps->n].seq = dup_n(sa, la); ps->a[ps->n].len = la;
+  ps->b[ps->n].name = dup_n(nb, strlen(nb)); ps->b[ps->n].seq = dup_n(sb, lb); ps->b[ps->n].len = lb;
+  ps->n++;
+}
+
+static void free_pairs(pairs_t *ps)
+{
+  size_t i;
+  for(i = 0; i < ps->n; i++) { free(ps->a[i].name); free(ps->a[i].seq); free(ps->b[i].name); free(ps->b[i].seq); }
+  ps->n = 0;
+}
+
+/* ---------------------------------------------------------------- options */
+
+static void parse_args(int argc, char **argv)
+{
+  int i, scoring_set = 0, subst_set = 0, match_set = 0, mismatch_set = 0;
+  if(argc == 1) die("No input specified%s", "");
+
+  /* pass 1: case sensitivity and the scoring system (alignment_cmdline.c:203-250) */
+  for(i = 1; i < argc; i++) {
+    if(!strcasecmp(argv[i], "--case_sensitive")) opt.case_sensitive = 1;
+    else if(!strcasecmp(argv[i], "--scoring") && i + 1 < argc) {
+      const char *n = argv[++i];
+      if(scoring_set) die("More than one scoring system specified - not permitted%s", "");
+      if(!strcasecmp(n, "PAM30")) scoring_system_PAM30(&scoring);
+      else if(!strcasecmp(n, "PAM70")) scoring_system_PAM70(&scoring);
+      else if(!strcasecmp(n, "BLOSUM80")) scoring_system_BLOSUM80(&scoring);
+      else if(!strcasecmp(n, "BLOSUM62")) scoring_system_BLOSUM62(&scoring);
+      else if(!strcasecmp(n, "DNA_HYBRIDIZATION")) scoring_system_DNA_hybridization(&scoring);
+      else die("Unknown --scoring choice '%s'", n);
+      scoring_set = 1;
+    }
+  }
+  /* pass 2 (alignment_cmdline.c:252-485) */
+  for(i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    if(a[0] != '-' || !strcmp(a, "-")) {
+      if(argc - i != 2) die("Unknown options: '%s'", a);
+      opt.seq1 = argv[i]; opt.seq2 = argv[i+1];
+      break;
+    }
+    if(!strcasecmp(a, "--case_sensitive")) continue;
+    else if(!strcasecmp(a, "--scoring")) i++;
+    else if(!strcasecmp(a, "--freestartgap")) { if(opt.tool != TOOL_NW) die("--freestartgap only valid with Needleman-Wunsch%s", ""); scoring.no_start_gap_penalty = 1; }
+    else if(!strcasecmp(a, "--freeendgap")) { if(opt.tool != TOOL_NW) die("--freeendgap only valid with Needleman-Wunsch%s", ""); scoring.no_end_gap_penalty = 1; }
+    else if(!strcasecmp(a, "--nogaps")) scoring.no_gaps_in_a = scoring.no_gaps_in_b = 1;
+    else if(!strcasecmp(a, "--nogapsin1")) scoring.no_gaps_in_a = 1;
+    else if(!strcasecmp(a, "--nogapsin2")) scoring.no_gaps_in_b = 1;
+    else if(!strcasecmp(a, "--nomismatches")) scoring.no_mismatches = 1;
+    else if(!strcasecmp(a, "--printscores")) { if(opt.tool != TOOL_NW) die("--printscores only valid with Needleman-Wunsch%s", ""); opt.print_scores = 1; }
+    else if(!strcasecmp(a, "--printseq")) { if(opt.tool != TOOL_SW) die("--printseq only valid with Smith-Waterman%s", ""); opt.print_seq = 1; }
+    else if(!strcasecmp(a, "--printmatrices")) opt.print_matrices = 1;
+    else if(!strcasecmp(a, "--printfasta")) opt.print_fasta = 1;
+    else if(!strcasecmp(a, "--pretty")) opt.print_pretty = 1;
+    else if(!strcasecmp(a, "--colour")) opt.print_colour = 1;
+    else if(!strcasecmp(a, "--stdin")) { opt.files1[opt.n_files] = "-"; opt.files2[opt.n_files++] = NULL; }
+    else if(i + 1 >= argc) die("%s takes an argument", a);
+    else if(!strcasecmp(a, "--match")) { if(!parse_int(argv[++i], &scoring.match)) die("Invalid --match argument ('%s') must be an int", argv[i]); match_set = 1; }
+    else if(!strcasecmp(a, "--mismatch")) { if(!parse_int(argv[++i], &scoring.mismatch)) die("Invalid --mismatch argument ('%s') must be an int", argv[i]); mismatch_set = 1; }
+    else if(!strcasecmp(a, "--gapopen")) { if(!parse_int(argv[++i], &scoring.gap_open)) die("Invalid --gapopen argument ('%s') must be an int", argv[i]); }
+    else if(!strcasecmp(a, "--gapextend")) { if(!parse_int(argv[++i], &scoring.gap_extend)) die("Invalid --gapextend argument ('%s') must be an int", argv[i]); }
+    else if(!strcasecmp(a, "--minscore")) { if(opt.tool != TOOL_SW) die("--minscore only valid with Smith-Waterman%s", ""); if(!parse_int(argv[++i], &opt.min_score)) die("Invalid --minscore '%s'", argv[i]); opt.min_score_set = 1; }
+    else if(!strcasecmp(a, "--maxhits")) { int v; if(opt.tool != TOOL_SW) die("--maxhits only valid with Smith-Waterman%s", ""); if(!parse_int(argv[++i], &v) || v < 0) die("Invalid --maxhits '%s'", argv[i]); opt.max_hits = (unsigned)v; opt.max_hits_set = 1; }
+    else if(!strcasecmp(a, "--context")) { int v; if(opt.tool != TOOL_SW) die("--context only valid with Smith-Waterman%s", ""); if(!parse_int(argv[++i], &v) || v < 0) die("Invalid --context '%s'", argv[i]); opt.context = (unsigned)v; }
+    else if(!strcasecmp(a, "--file")) { opt.files1[opt.n_files] = argv[++i]; opt.files2[opt.n_files++] = NULL; }
+    else if(!strcasecmp(a, "--files")) {
+      if(i + 2 >= argc) die("--files option takes 2 arguments%s", "");
+      opt.files1[opt.n_files] = argv[i+1];
+      opt.files2[opt.n_files++] = (!strcmp(argv[i+1], "-") && !strcmp(argv[i+2], "-")) ? NULL : argv[i+2];
+      i += 2;
+    }
+    else if(!strcasecmp(a, "--wildcard")) {
+      int w;
+      if(i + 2 >= argc || strlen(argv[i+1]) != 1 || !parse_int(argv[i+2], &w)) die("--wildcard <w> <s> takes a single character and a number%s", "");
+      scoring_add_wildcard(&scoring, argv[i+1][0], w);
+      i += 2;
+    }
+    else if(!strcasecmp(a, "--substitution_matrix") || !strcasecmp(a, "--substitution_pairs")) {
+      char err[256];
+      FILE *f = fopen(argv[++i], "r");
+      int rc;
+      if(!f) die("Couldn't read file: %s", argv[i]);
+      rc = !strcasecmp(a, "--substitution_matrix") ? seqalign_scoring_load_matrix(f, &scoring, opt.case_sensitive, err, sizeof err)
+                                                    : seqalign_scoring_load_pairs(f, &scoring, opt.case_sensitive, err, sizeof err);
+      fclose(f);
+      if(rc) { fprintf(stderr, "Error: %s\nFile: %s\n", err, argv[i]); exit(EXIT_FAILURE); }
+      subst_set = 1;
+    }
+    else die("Unknown argument '%s'", a);
+    if(opt.n_files >= 64) die("too many input files%s", "");
+  }
+  if((match_set && !mismatch_set && !scoring.no_mismatches) || (!match_set && mismatch_set))
+    die("--match --mismatch must both be set or neither set%s", "");
+  if(subst_set && !match_set) scoring.use_match_mismatch = 0;
+  if(scoring.use_match_mismatch && scoring.match < scoring.mismatch) die("Match value should not be less than mismatch penalty%s", "");
+  if(opt.tool == TOOL_NW && scoring.no_mismatches && (scoring.no_gaps_in_a || scoring.no_gaps_in_b))
+    die("--nogaps.. --nomismatches cannot be used at together%s", "");
+  if(!opt.seq1 && !opt.n_files) die("No input specified%s", "");
+
+  /* keep min/max_penalty covering every penalty in use (see file header) */
+  {
+    int vals[4] = { scoring.match, scoring.mismatch, scoring.gap_open + scoring.gap_extend, scoring.gap_extend }, k;
+    for(k = 0; k < 4; k++) {
+      if(vals[k] < scoring.min_penalty) scoring.min_penalty = vals[k];
+      if(vals[k] > scoring.max_penalty) scoring.max_penalty = vals[k];
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- printing */
+
+static void put_line(const char *mine, const char *other)
+{
+  if(opt.print_colour) alignment_colour_print_against(mine, other, scoring.case_sensitive);
+  else fputs(mine, stdout);
+}
+
+/* nw_cmdline.c:78-149 */
+static void print_nw(const rec_t *ra, const rec_t *rb, const char *res_a, const char *res_b, int score)
+{
+  const char *na = ra->name[0] ? ra->name : NULL, *nb = rb->name[0] ? rb->name : NULL;
+  if(opt.print_fasta && na) { fputs(na, stdout); putc('\n', stdout); }
+  if(opt.print_fasta && opt.print_pretty && nb) { fputs(nb, stdout); putc('\n', stdout); }
+  put_line(res_a, res_b); putc('\n', stdout);
+  if(opt.print_pretty) { alignment_print_spacer(res_a, res_b, &scoring); putc('\n', stdout); }
+  else if(opt.print_fasta && nb) { fputs(nb, stdout); putc('\n', stdout); }
+  put_line(res_b, res_a); putc('\n', stdout);
+  if(opt.print_scores) printf("score: %i\n", score);
+  putc('\n', stdout);
+}
+
+/* sw_cmdline.c:60-93 */
+static void print_sw_part(const char *mine, const char *other, size_t pos, size_t len, const char *whole,
+                          size_t spaces_left, size_t spaces_right, size_t ctx_left, size_t ctx_right)
+{
+  size_t i;
+  printf("  ");
+  for(i = 0; i < spaces_left; i++) putc(' ', stdout);
+  if(ctx_left > 0) {
+    if(opt.print_colour) fputs(align_col_context, stdout);
+    printf("%.*s", (int)ctx_left, whole + pos - ctx_left);
+    if(opt.print_colour) fputs(align_col_stop, stdout);
+  }
+  put_line(mine, other);
+  if(ctx_right > 0) {
+    if(opt.print_colour) fputs(align_col_context, stdout);
+    printf("%.*s", (int)ctx_right, whole + pos + len);
+    if(opt.print_colour) fputs(align_col_stop, stdout);
+  }
+  for(i = 0; i < spaces_right; i++) putc(' ', stdout);
+  printf("  [pos: %li; len: %lu]\n", (long)pos, (unsigned long)len);
+}
+
+#define MAX2(x,y) ((x) >= (y) ? (x) : (y))
+#define MIN2(x,y) ((x) <= (y) ? (x) : (y))
+
+/* sw_cmdline.c:152-201 (per-pair heading) */
+static void print_sw_heading(size_t index, const rec_t *ra, const rec_t *rb)
+{
+  printf("== Alignment %zu lengths (%lu, %lu):\n", index, (unsigned long)ra->len, (unsigned long)rb->len);
+  if(opt.print_fasta && ra->name[0]) { fputs(ra->name, stdout); putc('\n', stdout); }
+  if(opt.print_seq) { fputs(ra->seq, stdout); putc('\n', stdout); }
+  if(opt.print_fasta && rb->name[0]) { fputs(rb->name, stdout); putc('\n', stdout); }
+  if(opt.print_seq) { fputs(rb->seq, stdout); putc('\n', stdout); }
+  putc('\n', stdout);
+}
+
+/* sw_cmdline.c:219-305 (one hit) */
+static void print_sw_hit(size_t index, size_t hit_index, const rec_t *ra, const rec_t *rb,
+                         const seqalign_sw_hit_t *h, const char *res_a, const char *res_b)
+{
+  size_t ctx_l = 0, ctx_r = 0, ls_a = 0, ls_b = 0, rs_a = 0, rs_b = 0, k;
+  printf("hit %zu.%zu score: %i\n", index, hit_index, h->score);
+  if(opt.context) {
+    size_t rem_a = ra->len - (h->pos_a + h->len_a), rem_b = rb->len - (h->pos_b + h->len_b);
+    ctx_l = MIN2(MAX2((size_t)h->pos_a, (size_t)h->pos_b), (size_t)opt.context);
+    ctx_r = MIN2(MAX2(rem_a, rem_b), (size_t)opt.context);
+    ls_a = ctx_l > h->pos_a ? ctx_l - h->pos_a : 0;
+    ls_b = ctx_l > h->pos_b ? ctx_l - h->pos_b : 0;
+    rs_a = ctx_r > rem_a ? ctx_r - rem_a : 0;
+    rs_b = ctx_r > rem_b ? ctx_r - rem_b : 0;
+  }
+  print_sw_part(res_a, res_b, h->pos_a, h->len_a, ra->seq, ls_a, rs_a, ctx_l - ls_a, ctx_r - rs_a);
+  if(opt.print_pretty) {
+    size_t max_l = MAX2(ls_a, ls_b), max_r = MAX2(rs_a, rs_b);
+    fputs("  ", stdout);
+    for(k = 0; k < max_l; k++) putc(' ', stdout);
+    for(k = 0; k < ctx_l - max_l; k++) putc('.', stdout);
+    alignment_print_spacer(res_a, res_b, &scoring);
+    for(k = 0; k < ctx_r - max_r; k++) putc('.', stdout);
+    for(k = 0; k < max_r; k++) putc(' ', stdout);
+    putc('\n', stdout);
+  }
+  print_sw_part(res_b, res_a, h->pos_b, h->len_b, rb->seq, ls_b, rs_b, ctx_l - ls_b, ctx_r - rs_b);
+  printf("\n");
+}
+
+/* ---------------------------------------------------------------- batches */
+
+static void build_batch(const pairs_t *ps, size_t first, size_t n, seqalign_batch_t *b, char **arena,
+                        uint64_t **off_a, uint64_t **off_b, uint32_t **len_a, uint32_t **len_b)
+{
+  size_t i, total = 1, pos = 0;
+  for(i = 0; i < n; i++) total += ps->a[first+i].len + ps->b[first+i].len;
+  *arena = malloc(total);
+  *off_a = malloc(n * sizeof(uint64_t)); *off_b = malloc(n * sizeof(uint64_t));
+  *len_a = malloc(n * sizeof(uint32_t)); *len_b = malloc(n * sizeof(uint32_t));
+  for(i = 0; i < n; i++) {
+    const rec_t *ra = &ps->a[first+i], *rb = &ps->b[first+i];
+    (*off_a)[i] = pos; memcpy(*arena + pos, ra->seq, ra->len); pos += ra->len; (*len_a)[i] = (uint32_t)ra->len;
+    (*off_b)[i] = pos; memcpy(*arena + pos, rb->seq, rb->len); pos += rb->len; (*len_b)[i] = (uint32_t)rb->len;
+  }
+  b->n_pairs = n; b->arena = *arena; b->arena_bytes = total;
+  b->off_a = *off_a; b->len_a = *len_a; b->off_b = *off_b; b->len_b = *len_b;
+}
+
+static void check(int rc, const char *what)
+{
+  if(rc != SEQALIGN_OK) {
+    fprintf(stderr, "Error: %s: %s %s\n", what, seqalign_strerror(rc), seqalign_last_error());
+    exit(EXIT_FAILURE);
+  }
+}
+
+static size_t g_alignment_index = 0;
+
+static void run_nw(seqalign_ctx_t *ctx, const pairs_t *ps)
+{
+  seqalign_batch_t b; char *arena; uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
+  size_t n = ps->n, i, total = 0;
+  uint64_t *str_off = malloc(n * sizeof(uint64_t));
+  uint32_t *out_len = malloc(n * sizeof(uint32_t));
+  int32_t *score = malloc(n * sizeof(int32_t));
+  char *out_a, *out_b;
+  if(!n) { free(str_off); free(out_len); free(score); return; }
+  build_batch(ps, 0, n, &b, &arena, &off_a, &off_b, &len_a, &len_b);
+  for(i = 0; i < n; i++) { str_off[i] = total; total += (size_t)len_a[i] + len_b[i] + 1; }
+  out_a = malloc(total + 1); out_b = malloc(total + 1);
+  check(seqalign_nw_batch(ctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch");
+  for(i = 0; i < n; i++) {
+    if(opt.print_matrices) {   /* needs the matrices on the host: per-pair API */
+      nw_aligner_t *nw = needleman_wunsch_new();
+      alignment_t *r = alignment_create(256);
+      needleman_wunsch_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, nw, r);
+      alignment_print_matrices(nw);
+      alignment_free(r); needleman_wunsch_free(nw);
+    }
+    print_nw(&ps->a[i], &ps->b[i], out_a + str_off[i], out_b + str_off[i], score[i]);
+  }
+  fflush(stdout);
+  free(arena); free(off_a); free(off_b); free(len_a); free(len_b);
+  free(str_off); free(out_len); free(score); free(out_a); free(out_b);
+}
+
+static void run_sw(seqalign_ctx_t *ctx, const pairs_t *ps)
+{
+  /* pairs with an empty sequence are reported and skipped upstream (sw_cmdline.c:137-151) */
+  seqalign_batch_t b; char *arena; uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
+  size_t n = ps->n, i, h0;
+  int32_t *min_score = malloc((n + 1) * sizeof(int32_t));
+  const unsigned cap = opt.max_hits_set ? opt.max_hits : 16;   /* device path; see re-run below */
+  uint64_t hit_cap, n_hits = 0, str_cap = 0;
+  seqalign_sw_hit_t *hits;
+  char *out_a, *out_b;
+  if(!n) { free(min_score); return; }
+  build_batch(ps, 0, n, &b, &arena, &off_a, &off_b, &len_a, &len_b);
+  for(i = 0; i < n; i++) {
+    /* sw_cmdline.c:192-197 */
+    min_score[i] = opt.min_score_set ? opt.min_score
+                                     : (int)(scoring.match * MAX2(0.2 * MIN2(len_a[i], len_b[i]), 2));
+    str_cap += (uint64_t)(cap ? cap : 1) * ((uint64_t)len_a[i] + len_b[i] + 1);
+  }
+  hit_cap = (uint64_t)n * (cap ? cap : 1) + 16;
+  hits = malloc(hit_cap * sizeof(*hits));
+  out_a = malloc(str_cap + 16); out_b = malloc(str_cap + 16);
+  if(cap) check(seqalign_sw_batch(ctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch");
+
+  for(i = 0, h0 = 0; i < n; i++) {
+    size_t h1 = h0, k;
+    while(h1 < n_hits && hits[h1].pair == i) h1++;
+    if(ps->a[i].len == 0 || ps->b[i].len == 0) {
+      fprintf(stderr, "Error: Sequences must have length > 0\n");
+      if(opt.print_fasta && ps->a[i].name[0] && ps->b[i].name[0]) fprintf(stderr, "%s\n%s\n", ps->a[i].name, ps->b[i].name);
+      h0 = h1;
+      continue;
+    }
+    print_sw_heading(g_alignment_index, &ps->a[i], &ps->b[i]);
+    if(opt.print_matrices) {
+      sw_aligner_t *sw = smith_waterman_new();
+      smith_waterman_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, sw);
+      alignment_print_matrices(smith_waterman_get_aligner(sw));
+      smith_waterman_free(sw);
+    }
+    if(!opt.max_hits_set && h1 - h0 == cap) {
+      /* the device path stopped at its cap but the user asked for "no limit":
+       * re-run this one pair through the per-pair API, which has none */
+      sw_aligner_t *sw = smith_waterman_new();
+      alignment_t *r = alignment_create(256);
+      size_t hit_index = 0;
+      smith_waterman_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, sw);
+      while(smith_waterman_fetch(sw, r) && r->score >= min_score[i]) {
+        seqalign_sw_hit_t h;
+        h.pair = i; h.score = r->score; h.pos_a = (uint32_t)r->pos_a; h.pos_b = (uint32_t)r->pos_b;
+        h.len_a = (uint32_t)r->len_a; h.len_b = (uint32_t)r->len_b; h.length = (uint32_t)r->length; h.str_off = 0;
+        print_sw_hit(g_alignment_index, hit_index++, &ps->a[i], &ps->b[i], &h, r->result_a, r->result_b);
+      }
+      alignment_free(r); smith_waterman_free(sw);
+    } else {
+      for(k = h0; k < h1; k++)
+        print_sw_hit(g_alignment_index, k - h0, &ps->a[i], &ps->b[i], &hits[k], out_a + hits[k].str_off, out_b + hits[k].str_off);
+    }
+    fputs("==\n", stdout);
+    g_alignment_index++;
+    h0 = h1;
+  }
+  fflush(stdout);
+  free(arena); free(off_a); free(off_b); free(len_a); free(len_b);
+  free(min_score); free(hits); free(out_a); free(out_b);
+}
+
+/* ------------------------------------------------------------------- main */
+
+#define BATCH_PAIRS 65536
+
+static void flush(seqalign_ctx_t *ctx, pairs_t *ps)
+{
+  if(opt.tool == TOOL_NW) run_nw(ctx, ps); else run_sw(ctx, ps);
+  free_pairs(ps);
+}
+
+int main(int argc, char **argv)
+{
+  const char *base = strrchr(argv[0], '/');
+  seqalign_ctx_t *ctx = NULL;
+  pairs_t ps = {0};
+  int f, rc;
+  base = base ? base + 1 : argv[0];
+  memset(&opt, 0, sizeof opt);
+  opt.tool = strstr(base, "sw") ? TOOL_SW : TOOL_NW;
+
+  scoring_system_default(&scoring);
+  if(opt.tool == TOOL_SW) {   /* sw_cmdline.c:37-46 */
+    scoring.match = 2; scoring.mismatch = -2; scoring.gap_open = -2; scoring.gap_extend = -1;
+  }
+  parse_args(argc, argv);
+
+  rc = seqalign_ctx_create(getenv("SEQALIGN_DEVICE") ? atoi(getenv("SEQALIGN_DEVICE")) : 0, &ctx);
+  if(rc != SEQALIGN_OK) {
+    fprintf(stderr, "seqalign: cannot open the GPU: %s (%s)\nseqalign: there is no CPU path; an MI355X (gfx950) is required\n",
+            seqalign_strerror(rc), seqalign_last_error());
+    return EXIT_FAILURE;
+  }
+
+  if(opt.seq1) add_pair(&ps, "", opt.seq1, strlen(opt.seq1), "", opt.seq2, strlen(opt.seq2));
+  for(f = 0; f < opt.n_files; f++) {
+    seqalign_reader_t *r1 = seqalign_reader_open(opt.files1[f]), *r2 = NULL;
+    const char *n1, *s1, *n2, *s2;
+    size_t l1, l2;
+    if(!r1) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files1[f]); return EXIT_FAILURE; }
+    if(opt.files2[f] && !(r2 = seqalign_reader_open(opt.files2[f]))) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files2[f]); return EXIT_FAILURE; }
+    for(;;) {   /* two records at a time (alignment_cmdline.c:611-622) */
+      char *n1c, *s1c;
+      if(!seqalign_reader_next(r1, &n1, &s1, &l1)) break;
+      n1c = dup_n(n1, strlen(n1)); s1c = dup_n(s1, l1);
+      if(!seqalign_reader_next(r2 ? r2 : r1, &n2, &s2, &l2)) {
+        fprintf(stderr, "Odd number of sequences - I read in pairs!\n");
+        free(n1c); free(s1c);
+        break;
+      }
+      add_pair(&ps, n1c, s1c, l1, n2, s2, l2);
+      free(n1c); free(s1c);
+      if(ps.n >= BATCH_PAIRS) flush(ctx, &ps);
+    }
+    seqalign_reader_close(r1);
+    if(r2) seqalign_reader_close(r2);
+  }
+  flush(ctx, &ps);
+  free(ps.a); free(ps.b);
+  seqalign_ctx_destroy(ctx);
+  return EXIT_SUCCESS;
+}

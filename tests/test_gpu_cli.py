@@ -1,0 +1,186 @@
+"""GPU tier: the batch command-line front-end (seq-align_amd/bin/seqalign_nw,
+seqalign_sw) against the reference's documented output text (README.md) and the
+oracle.  The Perl wrappers' regular expressions (perl/SmithWaterman.pm:239-275,
+perl/NeedlemanWunsch.pm) define what the text must look like to a consumer."""
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+import orclib as O
+from seqalign_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+NW = ROOT / "seq-align_amd" / "bin" / "seqalign_nw"
+SW = ROOT / "seq-align_amd" / "bin" / "seqalign_sw"
+
+
+def run(exe, *args, stdin=None):
+    assert exe.exists(), f"{exe} missing: run make -C seq-align_amd"
+    p = subprocess.run([str(exe), *args], input=stdin, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+def spacer(a, b):
+    return "".join(" " if "-" in (x, y) else "|" if x.lower() == y.lower() else "*" for x, y in zip(a, b))
+
+
+def test_readme_basic_examples():
+    # README.md:65-74
+    assert run(NW, "CAGACGT", "CGATA") == "C-AGACGT\nCGATA---\n\n"
+    assert run(NW, "--printscores", "CAGACGT", "CGATA") == "C-AGACGT\nCGATA---\nscore: -11\n\n"
+
+
+def test_readme_printmatrices_text():
+    """README.md:118-145: the three matrices, the parameter line, then the alignment."""
+    out = run(NW, "--printmatrices", "ACAGGT", "AAGGT")
+    want = """seq_a: ACAGGT
+seq_b: AAGGT
+match_scores:
+  0:    0 -2147483643 -2147483643 -2147483643 -2147483643 -2147483643 -2147483643
+  1:  -2147483643   1  -7  -5  -9 -10 -11
+  2:  -2147483643  -4  -1  -3  -7  -8  -9
+  3:  -2147483643  -8  -6  -3  -2  -6 -10
+  4:  -2147483643  -9  -7  -8  -2  -1  -8
+  5:  -2147483643 -10  -8  -9 -10  -4   0
+gap_a_scores:
+  0:    0 -2147483643 -2147483643 -2147483643 -2147483643 -2147483643 -2147483643
+  1:   -5 -10 -11 -12 -13 -14 -15
+  2:   -6  -4  -9 -10 -11 -12 -13
+  3:   -7  -5  -6  -8 -12 -13 -14
+  4:   -8  -6  -7  -8  -7 -11 -13
+  5:   -9  -7  -8  -9  -7  -6 -11
+gap_b_scores:
+  0:    0  -5  -6  -7  -8  -9 -10
+  1:  -2147483643 -10  -4  -5  -6  -7  -8
+  2:  -2147483643 -11  -9  -6  -7  -8  -9
+  3:  -2147483643 -12 -10 -11  -8  -7  -8
+  4:  -2147483643 -13 -11 -12 -13  -7  -6
+  5:  -2147483643 -14 -12 -13 -14 -12  -9
+match: 1 mismatch: -2 gapopen: -4 gapexend: -1
+
+ACAGGT
+A-AGGT
+"""
+    assert out.split() == want.split()                    # README flattens the tabs
+    assert "  1:\t-2147483643\t  1\t -7" in out           # the real separators are tabs (alignment.c:368-373)
+    assert out.endswith("\nACAGGT\nA-AGGT\n\n")
+
+
+def test_fasta_file_stdin_and_formats(tmp_path):
+    fa = tmp_path / "dna.fa"       # README.md:79-88
+    fa.write_text(">seqA\nACAATAGAC\n>seqB\nACGAATAGAT\n>seqC\nACGTGA\nCAGAT\n>seqD\nGTGGACG\nAGTA\n")
+    want = "AC-AATAGAC\nACGAATAGAT\nscore: 1\n\nACGTGAC-AGAT\nGTG-GACGAGTA\nscore: -12\n\n"   # scores: SURVEY A.3-1
+    assert run(NW, "--printscores", "--file", str(fa)) == want
+    assert run(NW, "--printscores", "--stdin", stdin=fa.read_text()) == want
+    assert run(NW, "--printscores", "--file", "-", stdin=fa.read_text()) == want
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    a.write_text("ACAATAGAC\nACGTGACAGAT\n"); b.write_text("ACGAATAGAT\nGTGGACGAGTA\n")
+    assert run(NW, "--printscores", "--files", str(a), str(b)) == want
+    out = run(NW, "--pretty", "--printfasta", "--file", str(fa))
+    assert out == (">seqA\n>seqB\nAC-AATAGAC\n|| ||||||*\nACGAATAGAT\n\n"
+                   ">seqC\n>seqD\nACGTGAC-AGAT\n" + spacer("ACGTGAC-AGAT", "GTG-GACGAGTA") + "\nGTG-GACGAGTA\n\n")
+    out = run(NW, "--printfasta", "--file", str(fa))
+    assert out.startswith(">seqA\nAC-AATAGAC\n>seqB\nACGAATAGAT\n\n")
+    col = run(NW, "--colour", "ACGT", "AGT")
+    assert "\033[91m" in col and "\033[0m" in col
+
+
+def test_nw_options_match_oracle(tmp_path):
+    batch = W.ragged(300, seed=5, max_len=80, lower_frac=0.2, extra=b"N")
+    f = tmp_path / "pairs.txt"
+    f.write_text("".join(f"{batch.seq_a(p).decode() or 'A'}\n{batch.seq_b(p).decode() or 'C'}\n" for p in range(300)))
+    pairs = [((batch.seq_a(p) or b"A"), (batch.seq_b(p) or b"C")) for p in range(300)]
+    for args, spec in (
+            ([], {"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}),
+            (["--freestartgap", "--freeendgap", "--wildcard", "N", "0"],
+             {"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0], "wildcards": [["N", 0]]}),
+            (["--match", "2", "--mismatch", "-3", "--gapopen", "-5", "--gapextend", "-2", "--nogapsin1"],
+             {"init": [2, -3, -5, -2, 0, 0, 1, 0, 0, 0]}),
+            (["--scoring", "BLOSUM62", "--case_sensitive"], None)):
+        out = run(NW, "--printscores", *args, "--file", str(f))
+        blocks = out.strip("\n").split("\n\n")
+        assert len(blocks) == 300
+        if spec is None:
+            import seqalign_amd as S
+            sc = O.Scoring.from_buffer_copy(bytes(S.make_scoring({"preset": "BLOSUM62"})))
+        else:
+            sc = O.build_scoring(spec, "oracle")
+            sc.min_penalty = min(sc.min_penalty, -5)      # the CLI starts from the default scoring's range
+        for (a, b), blk in zip(pairs, blocks):
+            rc, score, ra, rb = O.oracle_nw(sc, a, b)
+            assert rc == 0 and blk == f"{ra.decode()}\n{rb.decode()}\nscore: {score}", (args, a, b)
+
+
+def expected_sw_text(index, a, b, hits, context=0, pretty=False):
+    out = [f"== Alignment {index} lengths ({len(a)}, {len(b)}):", ""]
+    for k, h in enumerate(hits):
+        out.append(f"hit {index}.{k} score: {h['score']}")
+        rem_a, rem_b = len(a) - (h["pos_a"] + h["len_a"]), len(b) - (h["pos_b"] + h["len_b"])
+        cl = min(max(h["pos_a"], h["pos_b"]), context)
+        cr = min(max(rem_a, rem_b), context)
+        ls_a, ls_b = max(cl - h["pos_a"], 0), max(cl - h["pos_b"], 0)
+        rs_a, rs_b = max(cr - rem_a, 0), max(cr - rem_b, 0)
+
+        def part(s, pos, ln, whole, ls, rs):
+            return ("  " + " " * ls + whole[pos - (cl - ls):pos] + s + whole[pos + ln:pos + ln + (cr - rs)]
+                    + " " * rs + f"  [pos: {pos}; len: {ln}]")
+        out.append(part(h["a"], h["pos_a"], h["len_a"], a, ls_a, rs_a))
+        if pretty:
+            ml, mr = max(ls_a, ls_b), max(rs_a, rs_b)
+            out.append("  " + " " * ml + "." * (cl - ml) + spacer(h["a"], h["b"]) + "." * (cr - mr) + " " * mr)
+        out.append(part(h["b"], h["pos_b"], h["len_b"], b, ls_b, rs_b))
+        out.append("")
+    out.append("==")
+    return "\n".join(out) + "\n"
+
+
+def test_sw_cli_text_and_perl_wrapper_grammar(tmp_path):
+    sc = O.build_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, "oracle")   # sw_cmdline.c:37-46
+    batch = W.dna_sw_read_vs_ref(40, seed=8, read_len=60, ref_len=200)
+    f = tmp_path / "reads.fa"
+    f.write_text("".join(f">r{p}\n{batch.seq_a(p).decode()}\n>ref{p}\n{batch.seq_b(p).decode()}\n" for p in range(40)))
+    for extra, ctx, pretty in (([], 0, False), (["--pretty"], 0, True), (["--context", "5", "--pretty"], 5, True),
+                               (["--maxhits", "2", "--context", "300"], 300, False)):
+        out = run(SW, *extra, "--file", str(f))
+        want = ""
+        for p in range(40):
+            a, b = batch.seq_a(p), batch.seq_b(p)
+            thr = W.default_minscore(2, len(a), len(b))
+            rc, hits = O.oracle_sw(sc, a, b, thr, 2 if "--maxhits" in extra else 1 << 30)
+            want += expected_sw_text(p, a.decode(), b.decode(), hits, ctx, pretty)
+        assert out == want, extra
+    # what perl/SmithWaterman.pm:239-275 expects to parse from `--pretty`
+    out = run(SW, "--pretty", "--minscore", "20", batch.seq_a(0).decode(), batch.seq_b(0).decode()).split("\n")
+    assert out[0].startswith("== Alignment 0 lengths (60, 200):")
+    i = 2
+    n_hits = 0
+    while not out[i].startswith("=="):
+        assert re.match(r"^hit \d+\.(\d+) score: (\d+)$", out[i])
+        assert re.match(r"^  (.*)  \[pos: (\d+); len: (\d+)\]$", out[i + 1])
+        assert re.match(r"^  ([\|\* ]+)$", out[i + 2])
+        assert re.match(r"^  (.*)  \[pos: (\d+); len: (\d+)\]$", out[i + 3])
+        assert out[i + 4] == ""
+        i += 5
+        n_hits += 1
+    assert n_hits >= 1
+
+
+def test_sw_cli_protein_matrix_file(tmp_path):
+    """--substitution_matrix with a file rendered from the BLOSUM62 preset gives
+    the hits of --scoring BLOSUM62 when match/mismatch are supplied too."""
+    import seqalign_amd as S
+    preset = S.make_scoring({"preset": "BLOSUM62"})
+    letters = "ARNDCQEGHILKMFPSTWYVBZX*"
+    m = tmp_path / "b62.txt"
+    m.write_text("   " + "  ".join(letters) + "\n" + "".join(
+        a + " " + " ".join(str(preset.swap_scores[ord(a.lower())][ord(b.lower())]) for b in letters) + "\n" for a in letters))
+    batch = W.protein_sw_300(6, seed=4, length=80)
+    f = tmp_path / "prot.txt"
+    f.write_text("".join(f"{batch.seq_a(p).decode()}\n{batch.seq_b(p).decode()}\n" for p in range(6)))
+    common = ["--gapopen", "-10", "--gapextend", "-1", "--minscore", "15", "--maxhits", "3", "--file", str(f)]
+    assert run(SW, "--scoring", "BLOSUM62", *common) == \
+        run(SW, "--substitution_matrix", str(m), "--match", "1", "--mismatch", "-4", *common)
