@@ -92,6 +92,15 @@ def lib():
             raise FileNotFoundError(
                 f"{LIB_PATH} missing: build it with `make -C {PKG_ROOT}` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU path")
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64, and a
+        # process that loads /opt/rocm's copy first (through our DT_NEEDED) and torch's
+        # second ends up with two runtimes, the second of which sees no device.  When
+        # torch is installed, let it load first; our library then binds to the same
+        # runtime by SONAME.  (The C tools and non-Python callers use /opt/rocm's.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(str(LIB_PATH))
         l.seqalign_strerror.restype = C.c_char_p
         l.seqalign_last_error.restype = C.c_char_p
@@ -361,7 +370,10 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms",
-    # include/alignment_scoring.h
+    # include/seqalign_io.h
+    "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
+    "seqalign_reader_next",
+    # include/seqalign_compat.h (scoring)
     "scoring_init", "scoring_add_wildcard", "scoring_add_mutation", "scoring_add_mutations", "scoring_print",
     "scoring_lookup", "scoring_system_PAM30", "scoring_system_PAM70", "scoring_system_BLOSUM80",
     "scoring_system_BLOSUM62", "scoring_system_DNA_hybridization", "scoring_system_default", "blosum62",
