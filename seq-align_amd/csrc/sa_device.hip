@@ -23,6 +23,73 @@ extern "C" {
 #include "sa_internal.h"
 }
 
+namespace {
+
+// Persistent host worker pool: run fn(0..n-1) over the workers + the caller.
+// Pairs / memcpy pieces are independent.  SEQALIGN_HOST_THREADS overrides the
+// worker count (default min(hardware threads, 32)).  One job at a time.
+class HostPool {
+ public:
+  static HostPool &get() { static HostPool pool; return pool; }
+  void run(uint64_t n, const std::function<void(uint64_t)> &fn) {
+    if (n == 0) return;
+    if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
+    std::lock_guard<std::mutex> one_job(job_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = (unsigned)workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    for (uint64_t k; (k = next_.fetch_add(1)) < n;) fn(k);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned want = hw ? std::min(hw, 32u) : 4u;
+    if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
+    for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto &th : workers_) th.join();
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return generation_ != seen; });
+      seen = generation_;
+      if (stop_) return;
+      const std::function<void(uint64_t)> *fn = fn_;
+      const uint64_t n = n_;
+      lk.unlock();
+      for (uint64_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
+      lk.lock();
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(uint64_t)> *fn_ = nullptr;
+  uint64_t n_ = 0, generation_ = 0;
+  std::atomic<uint64_t> next_{0};
+  unsigned pending_ = 0;
+  bool stop_ = false;
+};
+
+template <class F>
+static void parallel_for(uint64_t n, F fn) {
+  HostPool::get().run(n, std::function<void(uint64_t)>(fn));
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------ errors ---
 static thread_local std::string g_last_error;
 
@@ -153,6 +220,9 @@ extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
   // one chunk of a host-level batch may use up to 40 % of what is free now
   // (288 GB HBM3E: ~100 GB per chunk on an empty MI355X), overridable
   ctx->chunk_budget = free_b ? (free_b / 10) * 4 : (size_t)8 << 30;
+  // ...but not more than 48 GB: beyond that a chunk only adds allocation time (page
+  // tables for tens of GB) and delays the first results; SEQALIGN_CHUNK_BYTES overrides
+  ctx->chunk_budget = std::min<size_t>(ctx->chunk_budget, (size_t)48 << 30);
   if (const char *env = getenv("SEQALIGN_CHUNK_BYTES")) {
     size_t v = strtoull(env, nullptr, 10);
     if (v >= (1u << 20)) ctx->chunk_budget = v;
@@ -379,13 +449,21 @@ static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &
   uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_mat + n), *h_len_b = h_len_a + n;
   uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
   uint64_t pos = 0, cell = 0;
-  for (uint64_t k = 0; k < n; ++k) {
+  for (uint64_t k = 0; k < n; ++k) {   // offsets: a sequential prefix
     const uint64_t p = c.first + k;
-    h_off_a[k] = pos; memcpy(h_seq + pos, b->arena + b->off_a[p], b->len_a[p]); pos += b->len_a[p];
-    h_off_b[k] = pos; memcpy(h_seq + pos, b->arena + b->off_b[p], b->len_b[p]); pos += b->len_b[p];
+    h_off_a[k] = pos; pos += b->len_a[p];
+    h_off_b[k] = pos; pos += b->len_b[p];
     h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
     h_mat[k] = cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
   }
+  constexpr uint64_t kPack = 2048;     // bytes: in parallel, 2048 pairs per task
+  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
+    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
+      const uint64_t p = c.first + k;
+      memcpy(h_seq + h_off_a[k], b->arena + b->off_a[p], b->len_a[p]);
+      memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
+    }
+  });
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   if ((rc = ctx->off_a.reserve(n * 8)) || (rc = ctx->off_b.reserve(n * 8)) || (rc = ctx->mat_off.reserve(n * 8)) ||
       (rc = ctx->len_a.reserve(n * 4)) || (rc = ctx->len_b.reserve(n * 4)) || (rc = ctx->status.reserve(n * 8)))
@@ -608,68 +686,6 @@ struct PairHits {
   std::string str_a, str_b;
 };
 
-// Persistent host worker pool: run fn(0..n-1) over the workers + the caller.
-// Pairs / memcpy pieces are independent.  SEQALIGN_HOST_THREADS overrides the
-// worker count (default min(hardware threads, 32)).  One job at a time.
-class HostPool {
- public:
-  static HostPool &get() { static HostPool pool; return pool; }
-  void run(uint64_t n, const std::function<void(uint64_t)> &fn) {
-    if (n == 0) return;
-    if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
-    std::lock_guard<std::mutex> one_job(job_mu_);
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; next_.store(0); pending_ = (unsigned)workers_.size(); ++generation_;
-    }
-    cv_.notify_all();
-    for (uint64_t k; (k = next_.fetch_add(1)) < n;) fn(k);
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-  }
-
- private:
-  HostPool() {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned want = hw ? std::min(hw, 32u) : 4u;
-    if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
-    for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
-    cv_.notify_all();
-    for (auto &th : workers_) th.join();
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return generation_ != seen; });
-      seen = generation_;
-      if (stop_) return;
-      const std::function<void(uint64_t)> *fn = fn_;
-      const uint64_t n = n_;
-      lk.unlock();
-      for (uint64_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
-      lk.lock();
-      if (--pending_ == 0) done_cv_.notify_one();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_, job_mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(uint64_t)> *fn_ = nullptr;
-  uint64_t n_ = 0, generation_ = 0;
-  std::atomic<uint64_t> next_{0};
-  unsigned pending_ = 0;
-  bool stop_ = false;
-};
-
-template <class F>
-static void parallel_for(uint64_t n, F fn) {
-  HostPool::get().run(n, std::function<void(uint64_t)>(fn));
-}
 
 }  // namespace
 
@@ -780,16 +796,20 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
   HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 16, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
-  for (uint64_t k = 0; k < n; ++k) {
-    const uint64_t p = c.first + k;
-    const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
-    if (status) return (int)status;
-    memcpy(out_a + str_off[p], ha + h_off[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
-    memcpy(out_b + str_off[p], hb + h_off[k] + head, len);
-    out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
-    out_len[p] = len;
-    out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
-  }
+  for (uint64_t k = 0; k < n; ++k)
+    if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
+  constexpr uint64_t kPack = 2048;
+  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
+    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
+      const uint64_t p = c.first + k;
+      const uint32_t head = h_meta[k], len = h_meta[n + k];
+      memcpy(out_a + str_off[p], ha + h_off[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
+      memcpy(out_b + str_off[p], hb + h_off[k] + head, len);
+      out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
+      out_len[p] = len;
+      out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+    }
+  });
   return SEQALIGN_OK;
 }
 

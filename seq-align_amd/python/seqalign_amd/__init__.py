@@ -200,7 +200,9 @@ class Context:
             _check(rc, "seqalign_fill_batch")
         return (M, A, B, mat_off, status) if check else (rc, M, A, B, mat_off, status)
 
-    def nw_batch(self, batch, scoring: Scoring):
+    def nw_batch(self, batch, scoring: Scoring, raw: bool = False):
+        """seqalign_nw_batch.  raw=True returns the C-side arrays (str_off, out_a,
+        out_b, out_len, out_score) without building Python tuples per pair."""
         n = batch.n_pairs
         caps = batch.len_a.astype(np.uint64) + batch.len_b.astype(np.uint64) + np.uint64(1)
         str_off = np.zeros(n, np.uint64)
@@ -212,13 +214,18 @@ class Context:
         d = batch_desc(batch)
         _check(lib().seqalign_nw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(str_off), _ptr(out_a),
                                        _ptr(out_b), _ptr(out_len), _ptr(out_score)), "seqalign_nw_batch")
+        if raw:
+            return str_off, out_a, out_b, out_len, out_score
         res = []
         for p in range(n):
             o, ln = int(str_off[p]), int(out_len[p])
             res.append((int(out_score[p]), out_a[o:o + ln].tobytes(), out_b[o:o + ln].tobytes()))
         return res
 
-    def sw_batch(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, hit_cap: int | None = None):
+    def sw_batch(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, hit_cap: int | None = None,
+                 raw: bool = False):
+        """seqalign_sw_batch.  raw=True returns (n_hits, hits array, out_a, out_b)
+        without building Python dicts per hit."""
         n = batch.n_pairs
         ms = np.full(n, min_score, np.int32) if np.isscalar(min_score) else np.asarray(min_score, np.int32)
         hit_cap = hit_cap or max(1024, 64 * n)
@@ -231,6 +238,8 @@ class Context:
         _check(lib().seqalign_sw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
                                        hits, C.c_uint64(hit_cap), C.byref(n_hits), _ptr(out_a), _ptr(out_b),
                                        C.c_uint64(str_cap)), "seqalign_sw_batch")
+        if raw:
+            return n_hits.value, hits, out_a, out_b
         per_pair = [[] for _ in range(n)]
         for k in range(n_hits.value):
             h = hits[k]
