@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
+                    help="output arenas: the library's spread allocator (seqalign_arenas_alloc) or one packed allocation")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +154,7 @@ def main():
     ctx = S.Context(local)
     sc = S.make_scoring(spec)
     h = ctx.upload_scoring(sc, is_sw)
-    db = S.DeviceBatch(batch, local)
+    db = S.DeviceBatch(batch, local, placement=args.placement, ctx=ctx)   # arenas from seqalign_arenas_alloc
 
     # kernel choice: measured, not guessed
     if args.kernel == "auto":
@@ -222,6 +224,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": batch.n_pairs,
                        "global_pairs": batch.n_pairs * world, "kernel": S.KERNEL_NAMES[kernel],
                        "parallelism": f"pair-sharded x{world}, no collective",
+                       "arena_placement": args.placement, "arena_placement_quality": round(db.placement_quality, 3),
                        "cells_per_step_per_gpu": batch.cells()},
             "bit_exact_vs_oracle": bool(bit_exact),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -234,6 +234,22 @@ int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                       uint64_t hit_cap, uint64_t *n_hits, char *out_a,
                       char *out_b, uint64_t str_cap);
 
+/* ---- arena placement ----------------------------------------------------------- */
+/* Three device buffers of bytes_each for seqalign_dev_batch_t's match_scores /
+ * gap_a_scores / gap_b_scores (the reference's three malloc'd matrices,
+ * src/alignment.c:183-190, for a whole batch), placed far apart in HBM: on MI355X
+ * concurrent write streams within the same ~16 GiB of physical address space slow
+ * each other down by ~25 %; hipMalloc'ing the three back to back is
+ * the worst case.  Any 4 KiB-aligned device memory is accepted by the fill -- this
+ * is only the fast way to get it.  The context's own scratch (host-level entry
+ * points) is allocated the same way.  The placement is checked with a write
+ * probe and re-tried a few times (up to a few seconds the first time; arenas are
+ * meant to be kept and reused); *quality, if not NULL, receives the probe's
+ * 3-stream / 1-stream bandwidth ratio (~0.95 good, ~0.75 arenas disturb each other,
+ * < 0 not probed: arenas under 64 MiB or over 12 GiB).  Free with seqalign_arenas_free. */
+int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);
+int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]);
+
 /* ---- misc ---------------------------------------------------------------------- */
 /* Event pair on a stream for kernel timing (HIP events; bench.py). */
 int seqalign_time_fill_ms(seqalign_ctx_t *ctx,

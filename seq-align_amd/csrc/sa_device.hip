@@ -182,6 +182,39 @@ struct seqalign_ctx {
   int cached_is_sw = -1;
 };
 
+// grow the context's three matrix arenas together (spread placement, sa_placement.hip)
+static int reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->M.cap && bytes <= ctx->A.cap && bytes <= ctx->B.cap) return SEQALIGN_OK;
+  ctx->M.release(); ctx->A.release(); ctx->B.release();
+  const size_t want = bytes + bytes / 8 + 4096;
+  void *a[3];
+  hipError_t e = sa_alloc_arenas_spread(want, a, ctx->stream, nullptr);
+  if (e != hipSuccess) return fail_hip(e, "hipMalloc (matrix arenas)");
+  ctx->M.p = a[0]; ctx->A.p = a[1]; ctx->B.p = a[2];
+  ctx->M.cap = ctx->A.cap = ctx->B.cap = want;
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality) {
+  if (!ctx || !arenas || !bytes_each) return SEQALIGN_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  float q = -1.f;
+  hipError_t e = sa_alloc_arenas_spread((size_t)bytes_each, arenas, ctx->stream, &q);
+  if (e != hipSuccess) return fail_hip(e, "hipMalloc (matrix arenas)");
+  if (quality) *quality = q;
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]) {
+  if (!ctx || !arenas) return SEQALIGN_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int k = 0; k < 3; ++k) {
+    if (arenas[k]) (void)hipFree(arenas[k]);
+    arenas[k] = nullptr;
+  }
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -468,8 +501,7 @@ static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &
   if ((rc = ctx->off_a.reserve(n * 8)) || (rc = ctx->off_b.reserve(n * 8)) || (rc = ctx->mat_off.reserve(n * 8)) ||
       (rc = ctx->len_a.reserve(n * 4)) || (rc = ctx->len_b.reserve(n * 4)) || (rc = ctx->status.reserve(n * 8)))
     return rc;
-  if ((rc = ctx->M.reserve(c.cells * 4)) || (rc = ctx->A.reserve(c.cells * 4)) || (rc = ctx->B.reserve(c.cells * 4)))
-    return rc;
+  if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->arena.p, h_seq, c.seq_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, n * 8, hipMemcpyHostToDevice, st));

@@ -39,92 +39,132 @@ namespace sa {
 constexpr int kKiBInts = 256;     // one store instruction: 64 lanes x dwordx4 = 1 KiB
 
 // FB = flush unit in ints (a multiple of 256): FB/256 back-to-back 1 KiB stores
-// per matrix, FB*4-byte aligned
+// per matrix, FB*4-byte aligned.
+//
+// Everything that is the same for the 64 lanes (the pair's extent, the stream
+// positions, the flush decision, the store base addresses) lives in SGPRs: the
+// pair index is made wave-uniform with v_readfirstlane, so the flush test is an
+// s_cmp, a full block is three ds_read_b128 + three global_store_dwordx4 with an
+// SGPR base (one VALU op for the LDS address), and only the ring write addresses
+// are per-lane state.  The kernel is bound by instruction issue as much as by
+// HBM (SQ_ACTIVE_INST_ANY ~80 % of the issue slots), so every
+// instruction taken out of the row loop is time.
+typedef int v4i_a __attribute__((ext_vector_type(4)));   // 16 B aligned
+
 template <int R, int CPL, int FB>
 struct StreamOut {
   static constexpr int kBlockInts = FB;
-  int32_t *ring;        // this wave's rings: M at 0, A at R, B at 2R (ints)
-  uint32_t slot[CPL];   // ring index of my CPL cells in the row being appended
-  int32_t *g0[3];       // matrix base minus a0 ints: g0 + v is 1 KiB aligned when v % 256 == 0
-  uint32_t a0, vend;    // virtual range of the pair: [a0, vend)
-  uint32_t wv, rv;      // virtual write / flush positions (rv % 256 == 0)
+  static constexpr uint32_t kRingBytes = 4u * R;
+  char *lds;            // workgroup LDS base
+  uint32_t ring_b;      // SGPR: byte offset of this wave's M ring, a multiple of 4R; A at +4R, B at +8R
+  uint32_t ring_v;      // the same in a VGPR (v_and_or_b32 takes one SGPR operand only)
+  uint32_t wr[CPL];     // VGPR: byte offset (M ring) of my CPL cells in the row being appended
+  uint32_t rd_lane;     // VGPR: ring_b + 16*lane
+  uint32_t st_lane;     // VGPR: 16*lane
+  int32_t *g0[3];       // SGPR: matrix base minus a0 ints: g0 + v is 1 KiB aligned when v % 256 == 0
+  uint32_t a0, vend;    // SGPR: virtual range of the pair: [a0, vend)
+  uint32_t wv, rv;      // SGPR: virtual write / flush positions (rv % 256 == 0)
 
-  __device__ __forceinline__ void flush_block(int lane) {
-    const bool inside = (rv >= a0) && (rv + FB <= vend);   // wave-uniform
+  __device__ __forceinline__ void flush_block() {
+    const bool inside = (rv >= a0) && (rv + FB <= vend);   // s_cmp
+    const uint32_t rd = rd_lane + ((rv & (R - 1)) << 2);
+    v4i_a q[3][FB / kKiBInts];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-      for (int kb = 0; kb < FB / kKiBInts; ++kb) {
-        const uint32_t v0 = rv + kb * kKiBInts;
-        const uint32_t ro = v0 & (R - 1);
-        const v4i_u q = *reinterpret_cast<const v4i_u *>(ring + m * R + ro + 4 * lane);   // ds_read_b128
-        int32_t *dst = g0[m] + v0 + 4 * lane;
-        if (inside) {
-          typedef int v4i_a __attribute__((ext_vector_type(4)));
-          // aligned global_store_dwordx4 ... nt: write-once stream (see SA_STORE_VEC)
-          __builtin_nontemporal_store(v4i_a{q.x, q.y, q.z, q.w}, reinterpret_cast<v4i_a *>(dst));
-        } else {
-          const uint32_t e = v0 + 4 * lane;
-          if (e + 0 >= a0 && e + 0 < vend) dst[0] = q.x;
-          if (e + 1 >= a0 && e + 1 < vend) dst[1] = q.y;
-          if (e + 2 >= a0 && e + 2 < vend) dst[2] = q.z;
-          if (e + 3 >= a0 && e + 3 < vend) dst[3] = q.w;
+      for (int kb = 0; kb < FB / kKiBInts; ++kb)   // ds_read_b128, immediate offsets
+        q[m][kb] = *reinterpret_cast<const v4i_a *>(lds + rd + m * kRingBytes + kb * 1024);
+    if (inside) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int kb = 0; kb < FB / kKiBInts; ++kb) {
+#ifdef SA_EXP_STORE_MASK   // experiment build: which of the three streams are written at all
+          if (!((SA_EXP_STORE_MASK >> m) & 1)) continue;
+#endif
+          // aligned global_store_dwordx4 ... nt (write-once stream, see SA_STORE_VEC), SGPR base + lane offset
+          char *blk = reinterpret_cast<char *>(g0[m] + rv + kb * kKiBInts);
+          __builtin_nontemporal_store(q[m][kb], reinterpret_cast<v4i_a *>(blk + st_lane));
         }
-      }
+    } else {   // first / last block of the pair: dword predicates
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int kb = 0; kb < FB / kKiBInts; ++kb) {
+          const uint32_t e = rv + kb * kKiBInts + (st_lane >> 2);
+          int32_t *dst = g0[m] + e;
+          if (e + 0 >= a0 && e + 0 < vend) dst[0] = q[m][kb].x;
+          if (e + 1 >= a0 && e + 1 < vend) dst[1] = q[m][kb].y;
+          if (e + 2 >= a0 && e + 2 < vend) dst[2] = q[m][kb].z;
+          if (e + 3 >= a0 && e + 3 < vend) dst[3] = q[m][kb].w;
+        }
     }
     rv += FB;
   }
 
   __device__ __forceinline__ void start(int lane) {
+    rd_lane = ring_b + 16u * lane;
+    st_lane = 16u * lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ring_v) : "s"(ring_b));
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) slot[c] = (wv + lane * CPL + c) & (R - 1);
+    for (int c = 0; c < CPL; ++c) wr[c] = (((wv + lane * CPL + c) & (R - 1)) << 2) | ring_b;
   }
 
   // append one row: lane holds CPL consecutive cells starting at row position
   // lane*CPL.  ALL 64 lanes write, also those past the row's end: their cells land
   // at ring positions >= wv+W, which are not valid data yet (never flushed before
   // the next row overwrites them) and cannot reach back to unflushed cells because
-  // 255 + 64*CPL <= R.  No per-lane predicate, no branch; the ring slots advance by
-  // W per row (one add + one and per cell).
-  __device__ __forceinline__ void append_row(int lane, uint32_t W, const int (&mv)[CPL],
-                                             const int (&av)[CPL], const int (&bv)[CPL]) {
+  // 255 + 64*CPL <= R.  No per-lane predicate, no branch; a write address advances
+  // by W ints per row and wraps inside the 4R-byte aligned ring (v_add + v_and_or).
+  __device__ __forceinline__ void append_row(uint32_t W, const int (&mv)[CPL], const int (&av)[CPL],
+                                             const int (&bv)[CPL]) {
     static_assert(FB - 1 + kWave * CPL <= R, "ring too small for unpredicated appends");
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t i = slot[c];
-      ring[i] = mv[c];
-      ring[R + i] = av[c];
-      ring[2 * R + i] = bv[c];
-      slot[c] = (i + W) & (R - 1);
+      char *cell = lds + wr[c];
+      *reinterpret_cast<int32_t *>(cell) = mv[c];
+      *reinterpret_cast<int32_t *>(cell + kRingBytes) = av[c];
+      *reinterpret_cast<int32_t *>(cell + 2 * kRingBytes) = bv[c];
+      // wr = ((wr + 4W) & (4R-1)) | ring_b; spelled out, or the compiler splits the OR off
+      // into a third op per cell
+      const uint32_t t = wr[c] + 4u * W;
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wr[c]) : "v"(t), "s"(kRingBytes - 1), "v"(ring_v));
     }
     wv += W;
     // reads below see the writes above: one wave, LDS ops execute in order; the
     // fence only stops the compiler from reordering them
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (wv - rv >= (uint32_t)FB) flush_block(lane);
+    while (wv - rv >= (uint32_t)FB) flush_block();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 
-  __device__ __forceinline__ void finish(int lane) {
-    while (rv < wv) flush_block(lane);
+  __device__ __forceinline__ void finish() {
+    while (rv < wv) flush_block();
   }
 };
 
+// LDS: the rings first (ring bases must be 4R-byte aligned), the substitution
+// table behind them
 template <int CPL, int SUBST, bool GENERAL, int R, int FB>
 __global__ void __launch_bounds__(kWave * 8)
 fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t waves = blockDim.x >> 6;
   const int32_t *table = p.table;
   if constexpr (SUBST == SA_SUBST_LDS) {
-    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) lds[k] = p.table[k];
+    int32_t *tbl = lds + waves * (3 * R);
+    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) tbl[k] = p.table[k];
     __syncthreads();
-    table = lds;
+    table = tbl;
   }
 
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR: so is all per-pair state below
+  const uint32_t pair = blockIdx.x * waves + wave;
   if (pair >= p.n_pairs) return;   // wave-uniform, after the only barrier
+#ifdef SA_EXP_TRACE   // experiment build (make exp): where and when did this wave run?
+  const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair];
   const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
@@ -137,7 +177,8 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
                   (p.flags & SA_F_NO_START_GAP) != 0};
 
   StreamOut<R, CPL, FB> out;
-  out.ring = lds + table_ints + wave * (3 * R);
+  out.lds = reinterpret_cast<char *>(lds);
+  out.ring_b = wave * (3u * 4u * R);
   // the three arenas are congruent mod 4 KiB (checked on the host)
   out.a0 = (uint32_t)(((uintptr_t)(p.M + mo) >> 2) & (FB - 1));
   out.g0[0] = p.M + mo - out.a0;
@@ -163,7 +204,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
       mv[c] = av[c] = (ci == 0) ? 0 : k.floor_;
       bv[c] = (ci == 0) ? 0 : bd.edge_gap(ci);
     }
-    out.append_row(lane, W, mv, av, bv);
+    out.append_row(W, mv, av, bv);
   }
 
   int chunk_code = 0;
@@ -176,12 +217,22 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
     }
     int mv[CPL], av[CPL], bv[CPL];
     sw.row(k, j, lb, la, W, lane, col0, ncol, read_lane(chunk_code, q), 0, 0, mv, av, bv, bd.edge_gap(j));
-    out.append_row(lane, W, mv, av, bv);
+    out.append_row(W, mv, av, bv);
   }
-  out.finish(lane);
+  out.finish();
 
+#ifdef SA_EXP_TRACE
+  // status <- xcc(4) | HW_ID[15:0] (wave, simd, pipe, cu, sh, se) | t0 (22 bits) | t1 (22 bits), 10 ns ticks
+  const uint64_t trace_t1 = __builtin_amdgcn_s_memrealtime();
+  const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+  if (lane == 0)
+    p.status[pair] = ((uint64_t)(xcc & 15) << 60) | ((uint64_t)(hw & 0xffff) << 44) |
+                     ((trace_t0 & 0x3fffff) << 22) | (trace_t1 & 0x3fffff);
+  (void)sw;
+#else
   const unsigned long long err = sw.reduce_err();
   if (lane == 0) p.status[pair] = err;
+#endif
 }
 
 template <int CPL, int R, int FB, int WPB = kWavesPerBlock>

@@ -116,6 +116,9 @@ hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const 
                                     const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,
                                     uint32_t n_pairs, hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
+/* three device allocations of `bytes`, spread over HBM and checked (sa_placement.hip);
+ * *quality (may be NULL): 3-stream / 1-stream write bandwidth ratio of the result, < 0 if not probed */
+hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream, float *quality);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
 hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);
 

@@ -254,11 +254,30 @@ class Context:
         return out
 
 
+_ARENA_CTX = {}
+
+
+def _arena_context(device: int) -> "Context":
+    """One long-lived context per device for arena allocations of DeviceBatches
+    created without one."""
+    if device not in _ARENA_CTX:
+        _ARENA_CTX[device] = Context(device)
+    return _ARENA_CTX[device]
+
+
+class _RawDeviceInts:
+    """int32 device memory owned by the library, exposed to torch (zero copy)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
 class DeviceBatch:
     """A batch resident in HBM (torch tensors own the memory) + its three output
     arenas.  `pad_cells` aligns each pair's first cell (32 cells = 128 B)."""
 
-    def __init__(self, batch, device: int = 0, pad_cells: int = 32):
+    def __init__(self, batch, device: int = 0, pad_cells: int = 32, placement: str = "spread", ctx=None):
         import torch
         self.torch = torch
         self.host = batch
@@ -278,15 +297,28 @@ class DeviceBatch:
         self.off_a, self.len_a = t(batch.off_a), t(batch.len_a)
         self.off_b, self.len_b = t(batch.off_b), t(batch.len_b)
         self.mat_off = t(self.mat_off_host)
-        # one allocation, three 4 KiB-aligned arenas: the stream kernel wants the
-        # arenas congruent mod 1 KiB (torch's allocator only promises 512 B)
         stride = (self.total_cells + 1023) // 1024 * 1024
-        stride += int(_os.environ.get("SEQALIGN_ARENA_SKEW", "0")) // 256 * 256   # layout experiments
-        self._arena3 = torch.empty(3 * stride + 1024, dtype=torch.int32, device=dev)
-        skew = (-(self._arena3.data_ptr() // 4)) % 1024
-        self.M = self._arena3[skew:skew + self.total_cells]
-        self.A = self._arena3[skew + stride:skew + stride + self.total_cells]
-        self.B = self._arena3[skew + 2 * stride:skew + 2 * stride + self.total_cells]
+        self.placement_quality = -1.0
+        if placement == "packed":
+            # one allocation, three 4 KiB-aligned arenas back to back (the stream kernel
+            # wants the arenas congruent mod 4 KiB; torch's allocator only promises 512 B)
+            stride += int(_os.environ.get("SEQALIGN_ARENA_SKEW", "0")) // 256 * 256   # layout experiments
+            self._arena3 = torch.empty(3 * stride + 1024, dtype=torch.int32, device=dev)
+            skew = (-(self._arena3.data_ptr() // 4)) % 1024
+            self.M = self._arena3[skew:skew + self.total_cells]
+            self.A = self._arena3[skew + stride:skew + stride + self.total_cells]
+            self.B = self._arena3[skew + 2 * stride:skew + 2 * stride + self.total_cells]
+        else:
+            # the library's allocator: arenas spread over HBM (seqalign_arenas_alloc)
+            self._ctx = ctx if ctx is not None else _arena_context(device)
+            ptrs = (C.c_void_p * 3)()
+            q = C.c_float(-1.0)
+            _check(lib().seqalign_arenas_alloc(self._ctx._h, C.c_uint64(4 * stride), ptrs, C.byref(q)),
+                   "seqalign_arenas_alloc")
+            self._arena_ptrs = ptrs
+            self.placement_quality = float(q.value)
+            self.M, self.A, self.B = (torch.as_tensor(_RawDeviceInts(ptrs[k], self.total_cells), device=dev)
+                                      for k in range(3))
         self.status = torch.zeros(batch.n_pairs, dtype=torch.int64, device=dev)
         # launches go to a real (non-null) torch stream: a NULL stream handle means
         # "the context's own stream" in the C ABI, and torch events only see torch streams
@@ -296,6 +328,17 @@ class DeviceBatch:
                                  self.mat_off.data_ptr(), self.M.data_ptr(), self.A.data_ptr(),
                                  self.B.data_ptr(), self.status.data_ptr(),
                                  int(batch.len_a.max(initial=0)), int(batch.len_b.max(initial=0)))
+
+    def __del__(self):
+        ptrs = getattr(self, "_arena_ptrs", None)
+        if ptrs is not None and getattr(self._ctx, "_h", None):
+            self.M = self.A = self.B = None
+            try:
+                self.torch.cuda.synchronize(self.device)
+                lib().seqalign_arenas_free(self._ctx._h, ptrs)
+            except Exception:
+                pass
+            self._arena_ptrs = None
 
     def fill(self, ctx: Context, dev_scoring, kernel: int = KERNEL_AUTO, order_after_current: bool = True):
         """Enqueue THE HOT PATH on self.stream (no host sync).  By default the launch
@@ -378,7 +421,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_strerror", "seqalign_last_error", "seqalign_device_count", "seqalign_ctx_create",
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
-    "seqalign_sw_batch", "seqalign_time_fill_ms",
+    "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
     "seqalign_reader_next",

@@ -32,7 +32,8 @@ ap.add_argument("--workload", default="C2")
 ap.add_argument("--pairs", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--launches", type=int, default=10)
-ap.add_argument("--skew", type=int, default=0, help="extra ints between the three arenas (layout experiments)")
+ap.add_argument("--skew", type=int, default=0, help="extra ints between the three arenas (layout experiments; packed only)")
+ap.add_argument("--placement", default="spread", choices=["spread", "packed"])
 args = ap.parse_args()
 
 gen, kwargs, per_gpu, is_sw, spec, _ = WORKLOADS[args.workload]
@@ -40,7 +41,7 @@ batch = getattr(W, gen)(args.pairs or per_gpu, **kwargs)
 os.environ["SEQALIGN_ARENA_SKEW"] = str(args.skew)
 ctx = S.Context(0)
 h = ctx.upload_scoring(S.make_scoring(spec), is_sw)
-db = S.DeviceBatch(batch, 0)
+db = S.DeviceBatch(batch, 0, placement="packed" if args.skew else args.placement, ctx=ctx)
 KID = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM,
        "memset": -1}   # memset = torch fill_ of the same three arenas: this box's write ceiling
 
