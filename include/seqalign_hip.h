@@ -246,7 +246,7 @@ int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * probe and re-tried a few times (up to a few seconds the first time; arenas are
  * meant to be kept and reused); *quality, if not NULL, receives the probe's
  * 3-stream / 1-stream bandwidth ratio (~0.95 good, ~0.75 arenas disturb each other,
- * < 0 not probed: arenas under 64 MiB or over 12 GiB).  Free with seqalign_arenas_free. */
+ * < 0 not probed: arenas under 256 MiB or over 12 GiB).  Free with seqalign_arenas_free. */
 int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);
 int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]);
 

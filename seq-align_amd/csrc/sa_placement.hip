@@ -17,7 +17,7 @@
 // Physical addresses are not visible from user space, but the driver hands out
 // VRAM roughly in address order, so: allocate arena, spacer, arena, spacer,
 // arena, then free the spacers (the arenas keep their placement, the spacers
-// cost nothing afterwards).  Because that is a heuristic, the result is CHECKED
+// cost nothing afterwards; a spacer is a run of arena-sized allocations, see alloc3).  Because that is a heuristic, the result is CHECKED
 // with a 3-stream write probe against a 1-stream baseline on the same memory and
 // re-tried with a different spacing, keeping the best.
 #include <hip/hip_runtime.h>
@@ -105,19 +105,27 @@ void free3(void *a[3]) {
   }
 }
 
+// arena, spacer, arena, spacer, arena; the spacers are freed again.  A spacer is made of allocations of the
+// ARENA's size: the driver's buddy allocator serves a request from the free lists of the block sizes it decomposes
+// into, so one big spacer allocation would leave the fragments next to the previous arena for the next arena
+// to land in; same-sized fillers use exactly those fragments up first.
 hipError_t alloc3(size_t bytes, size_t spacer, void *out[3]) {
   out[0] = out[1] = out[2] = nullptr;
-  void *gap[2] = {nullptr, nullptr};
+  std::vector<void *> fill;
+  const size_t n_fill = spacer ? (spacer + bytes - 1) / bytes : 0;
   hipError_t e = hipSuccess;
   for (int k = 0; k < 3 && e == hipSuccess; ++k) {
-    if (k && spacer && hipMalloc(&gap[k - 1], spacer) != hipSuccess) {   // no room for the spacer: carry on without
-      gap[k - 1] = nullptr;
-      (void)hipGetLastError();
+    for (size_t f = 0; k && f < n_fill; ++f) {
+      void *p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess) {   // no room: carry on with what we have
+        (void)hipGetLastError();
+        break;
+      }
+      fill.push_back(p);
     }
     e = hipMalloc(&out[k], bytes);
   }
-  for (void *g : gap)
-    if (g) (void)hipFree(g);
+  for (void *p : fill) (void)hipFree(p);
   if (e != hipSuccess) free3(out);
   return e;
 }
@@ -134,7 +142,7 @@ hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream
   if (quality) *quality = -1.f;
   size_t spacer = gib << 30, free_b = 0, total_b = 0;
   // arenas as large as the granule span several of them anyway; small ones are not bandwidth-bound
-  if (bytes >= spacer / 2 || bytes < ((size_t)64 << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+  if (bytes >= spacer / 2 || bytes < ((size_t)256 << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess)
     spacer = 0;
   if (!spacer) return alloc3(bytes, 0, out);
 
