@@ -940,11 +940,12 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint64_t> offs(4 * (n + 1));
   uint64_t *cand_off = offs.data(), *mask_off = cand_off + n + 1, *str_off = mask_off + n + 1,
            *dst_off = str_off + n + 1;
-  uint64_t total = 0, mask_words = 0, str_total = 0;
+  uint64_t total = 0, mask_words = 0, str_total = 0, max_mask_words = 0;
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k, la = batch->len_a[p], lb = batch->len_b[p];
     cand_off[k] = total; total += count[k];
     mask_off[k] = mask_words; mask_words += ((la + 1) * (lb + 1) + 31) / 32;
+    max_mask_words = std::max(max_mask_words, ((la + 1) * (lb + 1) + 31) / 32);
     str_off[k] = str_total; str_total += (uint64_t)max_hits * (la + lb);
   }
   cand_off[n] = total; mask_off[n] = mask_words; str_off[n] = str_total;
@@ -990,6 +991,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.hit_count = d_m; q.str_used = d_m + n; q.enum_status = d_m + 2 * n;
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.max_hits = max_hits; q.open1 = sc->flat.open1;
   q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
+  q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
   if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
 
   std::vector<uint32_t> meta(3 * n);

@@ -70,6 +70,7 @@ struct SaEnumParams {
   uint32_t n_pairs, K, max_hits;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
+  uint32_t max_mask_words;       /* largest per-pair bitmap, 32-bit words            */
 };
 
 struct SaTraceParams {

@@ -11,11 +11,12 @@
 //
 // Here: sa_reduce.hip compacts the cells >= min_score (ascending index) together
 // with the sort key (INT_MAX - score) << 32 | column; a stable segmented radix sort
-// (hipCUB -- not the hot path) orders each pair's candidates; then ONE LANE per
-// pair runs the sequential enumeration against a per-pair visited bitmap in HBM
-// (fresh = zeroed per call) and writes its hits' strings
-// left-aligned into the pair's slot.  Latency-bound by construction (the reference
-// algorithm is sequential per pair); the parallelism is across pairs.
+// (hipCUB -- not the hot path) orders each pair's candidates; then the sequential
+// enumeration runs per pair against a visited bitmap (fresh per call, SURVEY
+// A.3-2) and writes its hits' strings left-aligned into the pair's slot: one WAVE
+// per pair with the bitmap in LDS and 64 speculative walks per round
+// (sw_enumerate_wave_kernel, below), or -- for pairs too large for that -- one
+// LANE per pair with the bitmap in HBM (sw_enumerate_kernel, the literal procedure).
 #include <hipcub/hipcub.hpp>
 
 #include "sa_trace_common.hpp"
@@ -85,6 +86,167 @@ __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) 
   p.enum_status[pair] = err ? err : (exhausted ? 0u : 0x80000000u);   // top bit: stopped at max_hits
 }
 
+// ---------------------------------------------------------------------------
+// One WAVE per pair, visited bitmap in LDS, 64 candidates at a time.
+//
+// Numbers that shaped it (C3, 150x1000, min_score 60; oracle statistics): a pair has
+// ~15 000 candidates, ~8 000 of them already marked when their turn comes, ~7 000
+// walks of which all but ~1 end after 1-2 steps on a marked cell.  With one lane per
+// pair that is ~30 000 dependent HBM round trips per pair on 157 waves (141 ms).
+//
+// The path a candidate would walk does not depend on the marks -- only where it
+// stops does.  So per batch of 64 consecutive candidates:
+//   speculate  every lane walks ITS candidate against the bitmap as it is now, records
+//              the first kPath cells and why it stopped (start marked / met a marked cell /
+//              reached score 0 / path longer than kPath).  The loads of the 64 walks
+//              overlap.
+//   apply      in candidate order (ballot + ctz), wave-uniformly: replay the recorded
+//              cells against the CURRENT bitmap -- marks made by earlier candidates of
+//              the same batch can only stop a walk earlier, exactly as in the sequential
+//              procedure -- marking as the reference does.  A walk that outlives its
+//              recording is continued for real (uniform serial walk); a walk that
+//              reaches score 0 is a hit and is replayed once more to write its strings
+//              (smith_waterman.c:217-244).
+// The bitmap (one bit per cell) lives in LDS; pairs whose bitmap exceeds 64 KiB take
+// the one-lane kernel above.
+constexpr int kPath = 4;
+enum { R_NONE = 0, R_SKIP, R_CLASH, R_ZERO, R_CAP, R_ERR };
+
+__device__ __forceinline__ bool seen_bit(const uint32_t *seen, uint32_t at) { return (seen[at >> 5] >> (at & 31)) & 1u; }
+
+__global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParams p) {
+  extern __shared__ uint32_t seen[];
+  const uint32_t pair = blockIdx.x;
+  const int lane = threadIdx.x;
+
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint64_t mo = p.mat_off[pair];
+  const PairView v{p.arena + p.off_a[pair], p.arena + p.off_b[pair], p.M + mo, p.A + mo, p.B + mo, la, lb, W};
+  const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
+                      (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
+                      (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
+  const uint32_t words = (W * (lb + 1) + 31) / 32;
+  for (uint32_t i = lane; i < words; i += 64) seen[i] = 0;   // fresh mask per call
+  __syncthreads();
+
+  const uint64_t *keys = p.sorted_key + p.cand_off[pair];
+  const uint32_t *cells = p.sorted_index + p.cand_off[pair];
+  const uint32_t n_cand = p.cand_count[pair];
+  const int min_score = p.min_score[pair];
+  char *oa = p.out_a + p.str_off[pair];
+  char *ob = p.out_b + p.str_off[pair];
+  SaDevHit *hits = p.hits + (uint64_t)pair * p.max_hits;
+
+  uint32_t emitted = 0, used = 0, err = 0;   // wave-uniform
+  bool exhausted = true, done = false;
+  for (uint32_t base = 0; base < n_cand && !done; base += 64) {
+    const uint32_t idx = base + lane;
+    bool valid = idx < n_cand;
+    const int cscore = valid ? INT32_MAX - (int)(keys[idx] >> 32) : INT32_MIN;
+    const uint32_t cell = valid ? cells[idx] : 0u;
+    valid = valid && cscore >= min_score;              // sorted: the valid lanes are a prefix
+    const uint32_t nvalid = __popcll(__ballot(valid));
+    if (nvalid == 0) break;                            // nothing later qualifies
+
+    // ---- speculate
+    uint32_t path[kPath];
+    int plen = 0, reason = R_NONE, matrix = MAT_MATCH, score = cscore;
+    uint32_t x = cell % W, y = cell / W, lerr = 0;
+    if (valid) {
+      if (seen_bit(seen, cell)) reason = R_SKIP;       // smith_waterman.c:269
+#pragma unroll
+      for (int s = 0; s < kPath; ++s) {
+        if (reason == R_NONE) {
+          const uint32_t at = y * W + x;
+          if (s > 0 && seen_bit(seen, at)) {
+            reason = R_CLASH;
+          } else {
+            path[s] = at; plen = s + 1;
+            if (score == 0) reason = R_ZERO;
+            else if ((lerr = reverse_move(v, k, x, y, matrix, score))) reason = R_ERR;
+          }
+        }
+      }
+      if (reason == R_NONE) reason = R_CAP;            // kPath cells recorded, kPath moves made
+    }
+    __syncthreads();
+
+    // ---- apply, in candidate order
+    uint32_t cur = 0;
+    while (cur < nvalid) {
+      const bool want = valid && (uint32_t)lane >= cur && reason != R_SKIP && !seen_bit(seen, cell);
+      const unsigned long long m = __ballot(want);
+      if (m == 0) break;
+      const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+      const int r_i = __builtin_amdgcn_readlane(reason, i), plen_i = __builtin_amdgcn_readlane(plen, i);
+      bool clash = false;
+#pragma unroll
+      for (int s = 0; s < kPath; ++s) {
+        if (s < plen_i && !clash) {
+          const uint32_t at = __builtin_amdgcn_readlane(path[s], i);
+          if (s > 0 && seen_bit(seen, at)) clash = true;
+          else seen[at >> 5] |= 1u << (at & 31);       // every lane writes the same word: same value
+        }
+      }
+      cur = i + 1;
+      if (clash || r_i == R_CLASH) continue;
+      if (r_i == R_ERR) { err = __builtin_amdgcn_readlane(lerr, i); done = true; break; }
+
+      // the walk is still alive: score 0 reached (R_ZERO) or recording ran out (R_CAP)
+      const int end_score = __builtin_amdgcn_readlane(cscore, i);
+      const uint32_t end = __builtin_amdgcn_readlane(cell, i);
+      uint32_t steps = plen_i - 1;
+      bool zero = (r_i == R_ZERO);
+      if (r_i == R_CAP) {                              // continue for real, wave-uniformly
+        uint32_t cx = __builtin_amdgcn_readlane(x, i), cy = __builtin_amdgcn_readlane(y, i);
+        int cm = __builtin_amdgcn_readlane(matrix, i), cs = __builtin_amdgcn_readlane(score, i);
+        for (steps = kPath;; ++steps) {
+          const uint32_t at = cy * W + cx;
+          if (seen_bit(seen, at)) { clash = true; break; }
+          seen[at >> 5] |= 1u << (at & 31);
+          if (cs == 0) { zero = true; break; }
+          if ((err = reverse_move(v, k, cx, cy, cm, cs))) break;
+        }
+        if (err) { done = true; break; }
+        if (clash) continue;
+      }
+      if (!zero) continue;
+
+      // a hit (smith_waterman.c:217-255): replay, writing the columns right to left
+      uint32_t hx = end % W, hy = end / W;
+      int hm = MAT_MATCH, hs = end_score;
+      for (uint32_t w = steps; hs > 0;) {
+        --w;
+        if (lane == 0) {
+          oa[used + w] = (hm == MAT_GAP_A) ? '-' : (char)v.seq_a[hx - 1];
+          ob[used + w] = (hm == MAT_GAP_B) ? '-' : (char)v.seq_b[hy - 1];
+        }
+        if ((err = reverse_move(v, k, hx, hy, hm, hs))) break;
+      }
+      if (err) { done = true; break; }
+      if (lane == 0) {
+        SaDevHit h;
+        h.score = end_score; h.pos_a = hx; h.pos_b = hy;
+        h.len_a = end % W - hx; h.len_b = end / W - hy; h.length = steps; h.str_off = used;
+        hits[emitted] = h;
+      }
+      ++emitted;
+      used += steps;
+      if (emitted >= p.max_hits) {
+        exhausted = (base + (uint32_t)i + 1 >= n_cand);
+        done = true;
+        break;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    p.hit_count[pair] = emitted;
+    p.str_used[pair] = used;
+    p.enum_status[pair] = err ? err : (exhausted ? 0u : 0x80000000u);   // top bit: stopped at max_hits
+  }
+}
+
 // strings of all pairs packed back to back for one D2H: one wave per pair
 __global__ void __launch_bounds__(256) gather_strings_kernel(const char *src_a, const char *src_b,
                                                              const uint64_t *str_off, const uint32_t *used,
@@ -111,7 +273,12 @@ hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_
 
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(sa::sw_enumerate_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+  const size_t lds = (size_t)p.max_mask_words * 4;
+  const char *force = getenv("SEQALIGN_SW_ENUM");   // "lane": the one-lane-per-pair kernel (experiments)
+  if (lds <= 65536 && !(force && force[0] == 'l'))
+    hipLaunchKernelGGL(sa::sw_enumerate_wave_kernel, dim3(p.n_pairs), dim3(64), lds, stream, p);
+  else
+    hipLaunchKernelGGL(sa::sw_enumerate_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 

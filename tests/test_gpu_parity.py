@@ -339,6 +339,39 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
             assert rc == 0 and got[p] == want, (spec, p)
 
 
+@pytest.mark.parametrize("enum_kernel", ["wave", "lane"])
+def test_sw_enumeration_repeats_and_ties(ctx, enum_kernel, monkeypatch):
+    """Device multi-hit enumeration on inputs built to stress its order rules: tandem
+    repeats (many equal-score candidates: column-ascending, then index-ascending ties),
+    long walks (longer than the wave kernel's recorded path), many hits per pair and
+    the max_hits cut -- the wave-per-pair kernel (batches of 64 speculative walks) and
+    the lane-per-pair kernel must both reproduce the sequential reference procedure."""
+    monkeypatch.setenv("SEQALIGN_SW_ENUM", enum_kernel)
+    rng = W.Rng(77)
+
+    def rand(n):
+        return bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+
+    pairs = []
+    for k in range(40):
+        unit = rand(3 + k % 7)
+        a = unit * (4 + k % 9) + rand(k % 13)
+        b = rand(k % 11) + unit * (6 + k % 17) + unit[::-1] * (k % 5)
+        pairs.append((a, b))
+    pairs += [(b"ACGT" * 30, b"ACGT" * 80), (b"A" * 90, b"A" * 200), (b"", b"ACGT"), (b"ACGTTGCA" * 12, b"TGCAACGT" * 30)]
+    batch = W.from_pairs(pairs)
+    for spec, thr in (({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 8), ({"init": [1, -1, -3, -1, 0, 0, 0, 0, 0, 0]}, 3),
+                      ({"init": [3, -3, -4, -2, 0, 0, 0, 0, 1, 0]}, 12)):
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        for max_hits in (3, 16):
+            got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits)
+            for p in range(batch.n_pairs):
+                rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
+                assert rc == 0 and got[p] == want, (enum_kernel, spec, max_hits, p)
+            assert max(len(h) for h in got) == max_hits   # the cut is exercised
+
+
 def test_legacy_api_known_answers(ctx):
     """The reference's own tests (tests.c) replayed against OUR library through the
     reference-shaped API: needleman_wunsch_align / smith_waterman_fetch."""
