@@ -214,12 +214,15 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * score >= min_score[p], at most max_hits per pair, into the caller's hit array
  * (hit_cap entries total).
  *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit.
- *   max_hits <= 16: GPU fill + GPU candidate compaction + segmented sort + GPU
- *       enumeration (one lane per pair, visited bitmap in HBM).
- *   In both cases only the strings cross PCIe.
- *   max_hits > 16 (or SEQALIGN_TRACEBACK=host): the matrices and the compacted
- *       candidates are copied back and the hits are enumerated on the host
- *       (threaded over pairs). */
+ *   max_hits >= 2: GPU fill + GPU candidate compaction + segmented sort + GPU
+ *       enumeration with 16 hit slots per pair (one wave per pair, visited bitmap
+ *       in LDS; one lane per pair with the bitmap in HBM for pairs over 524 k
+ *       cells).  Only the strings cross PCIe.  A pair that fills all 16 slots
+ *       while max_hits asks for more is finished on the host from its matrices
+ *       and candidates (rare: that pair's data only).
+ *   SEQALIGN_TRACEBACK=host: the matrices and the compacted candidates of every
+ *       pair are copied back and the hits are enumerated on the host (threaded
+ *       over pairs). */
 typedef struct {
   uint64_t pair;
   int32_t score;

@@ -904,11 +904,15 @@ static const uint32_t kDeviceEnumMaxHits = 16;
 // SW hits of one already-filled chunk, enumerated on the device (sa_sw_enum.hip):
 // reduce (count) -> reduce (compact + keys) -> segmented sort -> enumerate ->
 // gather strings -> D2H.  Appends to the caller's hit array / string buffers.
+//
+// want_hits > max_hits (the caller asked for more hits than the device slots hold): pairs that fill all
+// max_hits slots with candidates still left are finished on the host -- their matrices and candidates are
+// still in the context's scratch -- with the full limit; the others (nearly all, in practice) are done.
 static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
-                                     const seqalign_dev_scoring *sc, const seqalign_dev_batch_t &d,
-                                     const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
-                                     uint64_t hit_cap, uint64_t *found, char *out_a, char *out_b, uint64_t str_cap,
-                                     uint64_t *used_str) {
+                                     const scoring_t *scoring, const seqalign_dev_scoring *sc,
+                                     const seqalign_dev_batch_t &d, const int32_t *min_score, uint32_t max_hits,
+                                     uint32_t want_hits, seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *found,
+                                     char *out_a, char *out_b, uint64_t str_cap, uint64_t *used_str) {
   const uint64_t n = c.count;
   hipStream_t st = ctx->stream;
   int rc;
@@ -1006,6 +1010,59 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     dst_off[k] = gathered;
     gathered += meta[n + k];
   }
+  // pairs that ran into the slot limit while the caller wants more: host enumeration with the full limit
+  std::vector<uint64_t> capped;
+  if (want_hits > max_hits)
+    for (uint64_t k = 0; k < n; ++k)
+      if ((meta[2 * n + k] & 0x80000000u) && meta[k] >= max_hits) capped.push_back(k);
+  std::vector<PairHits> redo(capped.size());
+  std::vector<int64_t> redo_of(capped.empty() ? 0 : n, -1);
+  if (!capped.empty()) {
+    std::vector<uint64_t> cell0(n + 1, 0);
+    for (uint64_t k = 0; k < n; ++k)
+      cell0[k + 1] = cell0[k] + (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+    std::vector<uint64_t> m_off(capped.size() + 1, 0), c_off(capped.size() + 1, 0);
+    for (size_t j = 0; j < capped.size(); ++j) {
+      const uint64_t k = capped[j];
+      redo_of[k] = (int64_t)j;
+      m_off[j + 1] = m_off[j] + (cell0[k + 1] - cell0[k]);
+      c_off[j + 1] = c_off[j] + count[k];
+    }
+    std::vector<int32_t> hM(m_off.back() + 1), hA(m_off.back() + 1), hB(m_off.back() + 1);
+    std::vector<uint32_t> h_idx(c_off.back() + 1);
+    std::vector<uint64_t> h_key(c_off.back() + 1);
+    for (size_t j = 0; j < capped.size(); ++j) {
+      const uint64_t k = capped[j], cells = cell0[k + 1] - cell0[k];
+      HIP_TRY(hipMemcpyAsync(hM.data() + m_off[j], ctx->M.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hA.data() + m_off[j], ctx->A.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hB.data() + m_off[j], ctx->B.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      if (count[k]) {
+        HIP_TRY(hipMemcpyAsync(h_idx.data() + c_off[j], ctx->cand_index.as<uint32_t>() + cand_off[k], count[k] * 4ull,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_key.data() + c_off[j], d_key_in.as<uint64_t>() + cand_off[k], count[k] * 8ull,
+                               hipMemcpyDeviceToHost, st));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(capped.size(), [&](uint64_t j) {
+      const uint64_t k = capped[j], p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = hM.data() + m_off[j]; v.A = hA.data() + m_off[j]; v.B = hB.data() + m_off[j];
+      std::vector<Cand> cand;
+      cand.reserve(count[k]);
+      for (uint64_t q = 0; q < count[k]; ++q) {
+        const Cand cd{h_idx[c_off[j] + q], INT32_MAX - (int32_t)(h_key[c_off[j] + q] >> 32)};
+        if (cd.score >= min_score[p]) cand.push_back(cd);
+      }
+      const int prc = enumerate_hits(v, cand, want_hits, redo[j]);
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) return rc;
+  }
+
   // pack every pair's strings back to back and bring them over in one copy
   if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
       (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
@@ -1021,6 +1078,18 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
 
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
   for (uint64_t k = 0; k < n; ++k) {
+    if (!capped.empty() && redo_of[k] >= 0) {   // finished on the host
+      const PairHits &ph = redo[(size_t)redo_of[k]];
+      for (const seqalign_sw_hit_t &src : ph.hits) {
+        if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
+        memcpy(out_a + *used_str, ph.str_a.data() + src.str_off, src.length + 1);
+        memcpy(out_b + *used_str, ph.str_b.data() + src.str_off, src.length + 1);
+        seqalign_sw_hit_t &h = hits[(*found)++];
+        h = src; h.pair = c.first + k; h.str_off = *used_str;
+        *used_str += src.length + 1;
+      }
+      continue;
+    }
     for (uint32_t i = 0; i < meta[k]; ++i) {
       const SaDevHit &src = dev_hits[k * max_hits + i];
       if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
@@ -1108,12 +1177,14 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     *n_hits = found;
     return SEQALIGN_OK;
   }
-  if (max_hits <= kDeviceEnumMaxHits && !traceback_on_host()) {
+  if (!traceback_on_host()) {
+    // up to kDeviceEnumMaxHits hits per pair on the device; a pair that needs more is finished on the host
+    const uint32_t slots = std::min(max_hits, kDeviceEnumMaxHits);
     for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
       seqalign_dev_batch_t d;
       if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
-      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, sc, d, min_score, max_hits, hits, hit_cap, &found, out_a,
-                                          out_b, str_cap, &used_str)))
+      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, d, min_score, slots, max_hits, hits, hit_cap,
+                                          &found, out_a, out_b, str_cap, &used_str)))
         break;
     }
     *n_hits = found;

@@ -25,5 +25,5 @@ thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
 ctx = S.Context(0)
 for it in range(3):
     t0 = time.perf_counter()
-    nh = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=max_hits * n + 8, raw=True)[0]
+    nh = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=min(max_hits, 20) * n + 8, raw=True)[0]
     print(name, "max_hits", max_hits, "hits", nh, "%.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
