@@ -85,7 +85,7 @@ float placement_quality(void *const a[3], size_t bytes, hipStream_t st) {
   const uint32_t region_kib = 88;
   const size_t use = std::min(bytes, (size_t)1 << 30) / 1024;            // KiB per arena
   const uint32_t n_regions = (uint32_t)(use / region_kib);
-  if (n_regions < 4096) return -1.f;
+  if (n_regions < 2048) return -1.f;
   const uint64_t kib = (uint64_t)n_regions * region_kib;
   const float t3 = median_ms(st, [&] {
     hipLaunchKernelGGL(probe_three_streams, dim3((n_regions + 3) / 4), dim3(256), 24576, st, (char *)a[0], (char *)a[1],

@@ -339,6 +339,33 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
             assert rc == 0 and got[p] == want, (spec, p)
 
 
+def test_arena_allocator(ctx):
+    """seqalign_arenas_alloc: three 4 KiB-aligned device buffers the fill accepts; small
+    requests are not probed (quality < 0), large ones report the write-probe ratio."""
+    import torch
+    lib = S.lib()
+    for nbytes, probed in ((1 << 20, False), (300 << 20, True)):
+        ptrs = (C.c_void_p * 3)()
+        q = C.c_float(0.0)
+        assert lib.seqalign_arenas_alloc(ctx._h, C.c_uint64(nbytes), ptrs, C.byref(q)) == 0
+        assert all(p and p % 4096 == 0 for p in ptrs) and len({int(p) for p in ptrs}) == 3
+        assert (q.value > 0.3) if probed else (q.value < 0)
+        assert lib.seqalign_arenas_free(ctx._h, ptrs) == 0
+        assert not any(ptrs)
+    # a batch on library-placed arenas and one on a packed allocation give the same bytes
+    sc = S.make_scoring({"preset": "default"})
+    batch = W.dna_nw_150(3000, seed=5)
+    h = ctx.upload_scoring(sc, 0)
+    a = S.DeviceBatch(batch, 0, placement="spread", ctx=ctx)
+    b = S.DeviceBatch(batch, 0, placement="packed")
+    for db in (a, b):
+        db.M.fill_(-7); db.A.fill_(-7); db.B.fill_(-7)
+        db.fill(ctx, h, S.KERNEL_AUTO)
+    torch.cuda.synchronize()
+    assert torch.equal(a.M, b.M) and torch.equal(a.A, b.A) and torch.equal(a.B, b.B)
+    ctx.release_scoring(h)
+
+
 @pytest.mark.parametrize("enum_kernel", ["wave", "lane"])
 def test_sw_enumeration_repeats_and_ties(ctx, enum_kernel, monkeypatch):
     """Device multi-hit enumeration on inputs built to stress its order rules: tandem
