@@ -936,9 +936,21 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   hipError_t e = sa_launch_sw_reduce(r, st);
   if (e != hipSuccess) return fail_hip(e, "sw reduce");
   std::vector<uint32_t> count(n);
+  std::vector<int32_t> best(n);
   HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(best.data(), ctx->best_score.p, n * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
+  // sort key = (cap - score) << column_bits | column: only its used bits are sorted
+  int32_t key_cap = thr;
+  uint32_t max_la = 1;
+  for (uint64_t k = 0; k < n; ++k) {
+    key_cap = std::max(key_cap, best[k]);
+    max_la = std::max(max_la, batch->len_a[c.first + k]);
+  }
+  uint32_t key_shift = 1, span_bits = 1;
+  while ((max_la >> key_shift) != 0) ++key_shift;                                   // column <= len_a
+  while (span_bits < 32 && (((uint64_t)key_cap - (uint64_t)(int64_t)thr) >> span_bits) != 0) ++span_bits;
 
   // host prefixes: candidate segments, visited-bitmap words, string slots
   std::vector<uint64_t> offs(4 * (n + 1));
@@ -970,15 +982,18 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   // pass 2: compaction with sort keys, then the stable segmented sort
   r.cand_off = dv_cand_off; r.cand_cap = ctx->cand_cap.as<uint32_t>();
   r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_key = d_key_in.as<uint64_t>();
+  r.key_cap = key_cap; r.key_shift = key_shift;
   if ((e = sa_launch_sw_reduce(r, st)) != hipSuccess) return fail_hip(e, "sw reduce (compaction)");
   if (total) {
     size_t tmp_bytes = 0;
     e = sa_sort_candidates(nullptr, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
-                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off, st);
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
+                           (int)(key_shift + span_bits), st);
     if (e != hipSuccess) return fail_hip(e, "segmented sort (size query)");
     if ((rc = d_tmp.reserve(tmp_bytes + 16))) return rc;
     e = sa_sort_candidates(d_tmp.p, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
-                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off, st);
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
+                           (int)(key_shift + span_bits), st);
     if (e != hipSuccess) return fail_hip(e, "segmented sort");
   }
 
@@ -996,6 +1011,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.max_hits = max_hits; q.open1 = sc->flat.open1;
   q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
+  q.key_cap = key_cap; q.key_shift = key_shift;
   if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
 
   std::vector<uint32_t> meta(3 * n);
@@ -1054,7 +1070,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       std::vector<Cand> cand;
       cand.reserve(count[k]);
       for (uint64_t q = 0; q < count[k]; ++q) {
-        const Cand cd{h_idx[c_off[j] + q], INT32_MAX - (int32_t)(h_key[c_off[j] + q] >> 32)};
+        const Cand cd{h_idx[c_off[j] + q], key_cap - (int32_t)(h_key[c_off[j] + q] >> key_shift)};
         if (cd.score >= min_score[p]) cand.push_back(cd);
       }
       const int prc = enumerate_hits(v, cand, want_hits, redo[j]);

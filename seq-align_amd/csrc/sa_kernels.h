@@ -35,8 +35,10 @@ struct SaReduceParams {
   const uint32_t *cand_cap;
   uint32_t *cand_index;
   int32_t *cand_score;
-  uint64_t *cand_key;     /* optional: (INT32_MAX - score) << 32 | column, for the device sort */
+  uint64_t *cand_key;     /* optional: (key_cap - score) << key_shift | column, for the device sort */
   uint32_t n_pairs;
+  int32_t key_cap;        /* >= every score in the batch: keys ascend as scores descend      */
+  uint32_t key_shift;     /* bits of the column field                                        */
 };
 
 /* one SW hit as the enumeration kernel reports it (smith_waterman.c:249-255) */
@@ -71,6 +73,8 @@ struct SaEnumParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t max_mask_words;       /* largest per-pair bitmap, 32-bit words            */
+  int32_t key_cap;               /* sorted_key = (key_cap - score) << key_shift | column */
+  uint32_t key_shift;
 };
 
 struct SaTraceParams {
@@ -111,7 +115,7 @@ hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
                               const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,
-                              const uint64_t *seg_off, hipStream_t stream);
+                              const uint64_t *seg_off, int key_bits, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,
                                     const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,

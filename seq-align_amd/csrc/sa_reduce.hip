@@ -87,7 +87,7 @@ sw_reduce_kernel(const SaReduceParams p) {
             if (pos < cap) {
               cidx[pos] = i0 + k;
               if (cscore) cscore[pos] = v[u][k];
-              if (ckey) ckey[pos] = ((uint64_t)(uint32_t)(INT32_MAX - v[u][k]) << 32) | ((i0 + k) % W);
+              if (ckey) ckey[pos] = ((uint64_t)(uint32_t)(p.key_cap - v[u][k]) << p.key_shift) | ((i0 + k) % W);
             }
             ++pos;
           }

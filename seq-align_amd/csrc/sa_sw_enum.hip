@@ -10,7 +10,7 @@
 // after max_hits (sw_cmdline.c:214-217).
 //
 // Here: sa_reduce.hip compacts the cells >= min_score (ascending index) together
-// with the sort key (INT_MAX - score) << 32 | column; a stable segmented radix sort
+// with the sort key (cap - score) << column_bits | column; a stable segmented radix sort
 // (hipCUB -- not the hot path) orders each pair's candidates; then the sequential
 // enumeration runs per pair against a visited bitmap (fresh per call, SURVEY
 // A.3-2) and writes its hits' strings left-aligned into the pair's slot: one WAVE
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) 
   bool exhausted = true;
   for (; kpos < n_cand; ++kpos) {
     if (emitted >= p.max_hits) { exhausted = false; break; }
-    const int cscore = INT32_MAX - (int)(keys[kpos] >> 32);
+    const int cscore = p.key_cap - (int)(keys[kpos] >> p.key_shift);
     if (cscore < min_score) break;                     // sorted: nothing later qualifies
     const uint32_t end = cells[kpos];
     if ((seen[end >> 5] >> (end & 31)) & 1u) continue; // smith_waterman.c:269
@@ -121,11 +121,11 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
+  const uint32_t words = (W * (lb + 1) + 31) / 32;
   const PairView v{p.arena + p.off_a[pair], p.arena + p.off_b[pair], p.M + mo, p.A + mo, p.B + mo, la, lb, W};
   const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
-  const uint32_t words = (W * (lb + 1) + 31) / 32;
   for (uint32_t i = lane; i < words; i += 64) seen[i] = 0;   // fresh mask per call
   __syncthreads();
 
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   for (uint32_t base = 0; base < n_cand && !done; base += 64) {
     const uint32_t idx = base + lane;
     bool valid = idx < n_cand;
-    const int cscore = valid ? INT32_MAX - (int)(keys[idx] >> 32) : INT32_MIN;
+    const int cscore = valid ? p.key_cap - (int)(keys[idx] >> p.key_shift) : INT32_MIN;
     const uint32_t cell = valid ? cells[idx] : 0u;
     valid = valid && cscore >= min_score;              // sorted: the valid lanes are a prefix
     const uint32_t nvalid = __popcll(__ballot(valid));
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
       if (seen_bit(seen, cell)) reason = R_SKIP;       // smith_waterman.c:269
 #pragma unroll
       for (int s = 0; s < kPath; ++s) {
-        if (reason == R_NONE) {
+        if (reason == R_NONE) {   // (lanes that have stopped idle through the remaining steps)
           const uint32_t at = y * W + x;
           if (s > 0 && seen_bit(seen, at)) {
             reason = R_CLASH;
@@ -265,20 +265,25 @@ __global__ void __launch_bounds__(256) gather_strings_kernel(const char *src_a, 
 
 hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
                               const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,
-                              const uint64_t *seg_off /* n_pairs + 1 */, hipStream_t stream) {
-  // stable LSD radix sort: equal (score, column) keep the compaction's ascending cell index
+                              const uint64_t *seg_off /* n_pairs + 1 */, int key_bits, hipStream_t stream) {
+  // stable LSD radix sort over the key's used bits only (score span + column: ~20 bits, 3 passes
+  // instead of 8): equal (score, column) keep the compaction's ascending cell index
   return hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, *tmp_bytes, key_in, key_out, idx_in, idx_out,
-                                                     (int)total, (int)n_pairs, seg_off, seg_off + 1, 0, 64, stream);
+                                                     (int)total, (int)n_pairs, seg_off, seg_off + 1, 0, key_bits, stream);
 }
 
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  const size_t lds = (size_t)p.max_mask_words * 4;
+  // (staging the sequences' codes in LDS next to the bitmap was tried: slower -- flat loads and one
+  // workgroup less per CU -- C3 26.9 -> 36.1 ms)
+  const size_t mask = (size_t)p.max_mask_words * 4;
   const char *force = getenv("SEQALIGN_SW_ENUM");   // "lane": the one-lane-per-pair kernel (experiments)
-  if (lds <= 65536 && !(force && force[0] == 'l'))
-    hipLaunchKernelGGL(sa::sw_enumerate_wave_kernel, dim3(p.n_pairs), dim3(64), lds, stream, p);
-  else
+  if (mask <= 65536 && !(force && force[0] == 'l')) {
+    hipLaunchKernelGGL(sa::sw_enumerate_wave_kernel, dim3(p.n_pairs), dim3(64), mask, stream, p);
+  }
+  else {
     hipLaunchKernelGGL(sa::sw_enumerate_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+  }
   return hipGetLastError();
 }
 
