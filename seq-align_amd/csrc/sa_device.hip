@@ -338,6 +338,7 @@ static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_
   p.n_pairs = (uint32_t)b->n_pairs; p.K = s->flat.n_classes;
   p.gap_open = s->flat.gap_open; p.open1 = s->flat.open1; p.ext = s->flat.ext; p.floor = s->flat.floor;
   p.gen_eq = s->flat.gen_eq; p.gen_ne = s->flat.gen_ne; p.flags = s->flat.flags;
+  p.best_score = nullptr; p.best_index = nullptr;
   return p;
 }
 
@@ -351,14 +352,17 @@ static int pick_kernel(int kernel) {
   return SEQALIGN_KERNEL_STREAM;   // measured fastest (profiles/); falls back when not applicable
 }
 
-extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
-                                          const seqalign_dev_batch_t *batch, int kernel, void *stream) {
+// best_score / best_index (optional, SW): filled by the fill itself when the stream kernel runs
+// (*best_done = true); otherwise the caller runs the separate reduction
+static int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
+                       int kernel, void *stream, int32_t *best_score, uint64_t *best_index, bool *best_done) {
+  if (best_done) *best_done = false;
   if (!ctx || !scoring || !batch) return SEQALIGN_E_ARG;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   if (batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_E_ARG;
   if ((uint64_t)(batch->max_len_a + 1ull) * (batch->max_len_b + 1ull) >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  const SaFillParams p = make_params(scoring, batch);
+  SaFillParams p = make_params(scoring, batch);
   hipError_t e;
   int which = pick_kernel(kernel);
   // a positive gap_extend (legal, absurd) breaks the row scan's saturating-add
@@ -366,6 +370,11 @@ extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_de
   if (p.ext > 0) which = SEQALIGN_KERNEL_WAVEFRONT;
   if (which == SEQALIGN_KERNEL_STREAM && !sa_stream_kernel_applicable(p, batch->max_len_a))
     which = SEQALIGN_KERNEL_ROWSCAN;
+  if (which == SEQALIGN_KERNEL_STREAM && best_score && best_index) {
+    p.best_score = best_score; p.best_index = best_index;
+    if (sa_stream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b)) { if (best_done) *best_done = true; }
+    else p.best_score = nullptr, p.best_index = nullptr;
+  }
   switch (which) {
     case SEQALIGN_KERNEL_WAVEFRONT: e = sa_launch_fill_wavefront(p, batch->max_len_a, st); break;
     case SEQALIGN_KERNEL_STREAM: e = sa_launch_fill_stream(p, batch->max_len_a, st); break;
@@ -376,6 +385,11 @@ extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_de
   }
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
+                                          const seqalign_dev_batch_t *batch, int kernel, void *stream) {
+  return fill_device(ctx, scoring, batch, kernel, stream, nullptr, nullptr, nullptr);
 }
 
 extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
@@ -470,8 +484,10 @@ static std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget) 
 // Upload one chunk (sequences packed back to back, matrices packed in pair
 // order) and run the fill.  On return the device buffers of ctx hold the
 // results; the stream is NOT synchronised.
+// best_done (optional): ask the fill for the SW best cell per pair (into ctx->best_score / best_index);
+// *best_done tells whether the fill kernel delivered it.
 static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
-                     const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out) {
+                     const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done = nullptr) {
   const uint64_t n = c.count;
   int rc;
   // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
@@ -516,7 +532,14 @@ static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &
   d.mat_off = ctx->mat_off.as<uint64_t>();
   d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
   d.status = ctx->status.as<uint64_t>(); d.max_len_a = c.max_a; d.max_len_b = c.max_b;
-  if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st))) return rc;
+  if (best_done) {
+    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+    rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>(),
+                     ctx->best_index.as<uint64_t>(), best_done);
+  } else {
+    rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
+  }
+  if (rc) return rc;
   if (dev_out) *dev_out = d;
   return SEQALIGN_OK;
 }
@@ -1139,14 +1162,17 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     // best hit only: nothing but the strings crosses PCIe
     for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
       seqalign_dev_batch_t d;
-      if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
+      bool have_best = false;   // the stream kernel reports the best cell itself
+      if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) return rc;
       const uint64_t n = c.count;
-      if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
-      seqalign_sw_reduce_t r;
-      memset(&r, 0, sizeof(r));
-      r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
-      r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
-      if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
+      if (!have_best) {
+        if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+        seqalign_sw_reduce_t r;
+        memset(&r, 0, sizeof(r));
+        r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+        r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+        if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
+      }
       if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
       uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
       uint64_t total = 0;

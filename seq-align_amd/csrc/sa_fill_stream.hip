@@ -145,7 +145,13 @@ struct StreamOut {
 
 // LDS: the rings first (ring bases must be 4R-byte aligned), the substitution
 // table behind them
-template <int CPL, int SUBST, bool GENERAL, int R, int FB>
+// BEST (SW, p.best_score != nullptr): the kernel also reports the pair's best
+// match_scores cell in the reference's hit order (smith_waterman.c:81-85: score
+// desc, column asc, then index = row asc) -- 3 VALU ops per cell on data that is in
+// registers anyway, instead of sa_reduce.hip's second pass over the matrix.
+constexpr int kBestRowBits = 21;   // packed tie-break: column (11 bits) | row (21 bits)
+
+template <int CPL, int SUBST, bool GENERAL, int R, int FB, bool BEST>
 __global__ void __launch_bounds__(kWave * 8)
 fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -207,6 +213,12 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
     out.append_row(W, mv, av, bv);
   }
 
+  int best_s[BEST ? CPL : 1], best_r[BEST ? CPL : 1];   // per column: highest score, first row that reached it
+  if constexpr (BEST) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { best_s[c] = 0; best_r[c] = 0; }
+  }
+
   int chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
     const int q = (j - 1) & (kWave - 1);
@@ -218,8 +230,39 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
     int mv[CPL], av[CPL], bv[CPL];
     sw.row(k, j, lb, la, W, lane, col0, ncol, read_lane(chunk_code, q), 0, 0, mv, av, bv, bd.edge_gap(j));
     out.append_row(W, mv, av, bv);
+    if constexpr (BEST) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const bool up = mv[c] > best_s[c];   // strict: the first (lowest) row keeps a tie
+        best_s[c] = up ? mv[c] : best_s[c];
+        best_r[c] = up ? (int)j : best_r[c];
+      }
+    }
   }
   out.finish();
+
+  if constexpr (BEST) {
+    // lane: lowest column wins a tie (c ascending, strict >); lanes past the row's end hold garbage
+    int b = 0;
+    uint32_t tie = 0;   // (column << kBestRowBits) | row of the best cell
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      if (c < ncol && best_s[c] > b) { b = best_s[c]; tie = ((uint32_t)(lane * CPL + c) << kBestRowBits) | (uint32_t)best_r[c]; }
+    }
+    // wave: max score, then min (column, row)
+    unsigned long long key = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)~tie;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o);
+      key = other > key ? other : key;
+    }
+    if (lane == 0) {
+      const uint32_t t = ~(uint32_t)key, col = t >> kBestRowBits, row = t & ((1u << kBestRowBits) - 1);
+      const int score = (int)(key >> 32);
+      p.best_score[pair] = score;
+      p.best_index[pair] = score > 0 ? (uint64_t)row * W + col : 0;
+    }
+  }
 
 #ifdef SA_EXP_TRACE
   // status <- xcc(4) | HW_ID[15:0] (wave, simd, pipe, cu, sh, se) | t0 (22 bits) | t1 (22 bits), 10 ns ticks
@@ -235,8 +278,8 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
 #endif
 }
 
-template <int CPL, int R, int FB, int WPB = kWavesPerBlock>
-static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
+template <int CPL, int R, int FB, bool BEST, int WPB = kWavesPerBlock>
+static hipError_t launch_cpl_best(const SaFillParams &p, hipStream_t stream) {
   const bool general = needs_general(p);
   int wpb = WPB;   // pairs per workgroup; SEQALIGN_WPB in {1,2,4,8} (tuning experiments)
   if (const char *env = getenv("SEQALIGN_WPB")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8) wpb = v; }
@@ -244,17 +287,24 @@ static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
   size_t rings = (size_t)wpb * 3 * R * sizeof(int32_t);
   if (const char *env = getenv("SEQALIGN_LDS_PAD")) rings += (size_t)atoi(env);   // occupancy experiments
   if (p.K <= 1) {
-    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R, FB>), grid, block, rings, stream, p, 0u);
-    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R, FB>), grid, block, rings, stream, p, 0u);
+    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R, FB, BEST>), grid, block, rings, stream, p, 0u);
+    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R, FB, BEST>), grid, block, rings, stream, p, 0u);
   } else if (p.K <= SA_LDS_TABLE_MAX_K) {
-    const uint32_t tints = (p.K * p.K + 3u) & ~3u;   // keep the rings 16 B aligned
+    const uint32_t tints = (p.K * p.K + 3u) & ~3u;
     const size_t lds = rings + tints * sizeof(int32_t);
-    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, true, R, FB>), grid, block, lds, stream, p, tints);
-    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, false, R, FB>), grid, block, lds, stream, p, tints);
+    if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, true, R, FB, BEST>), grid, block, lds, stream, p, tints);
+    else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_LDS, false, R, FB, BEST>), grid, block, lds, stream, p, tints);
   } else {
-    hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_GLOBAL, true, R, FB>), grid, block, rings, stream, p, 0u);
+    hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_GLOBAL, true, R, FB, BEST>), grid, block, rings, stream, p, 0u);
   }
   return hipGetLastError();
+}
+
+template <int CPL, int R, int FB, int WPB = kWavesPerBlock>
+static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
+  // best-cell reporting: SW only (NW has no local maxima to report)
+  if (p.best_score && p.best_index && (p.flags & SA_F_IS_SW)) return launch_cpl_best<CPL, R, FB, true, WPB>(p, stream);
+  return launch_cpl_best<CPL, R, FB, false, WPB>(p, stream);
 }
 
 }  // namespace sa
@@ -265,21 +315,20 @@ bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
   return ((m ^ a) & 4095) == 0 && ((m ^ b) & 4095) == 0;          // arenas congruent mod 4 KiB
 }
 
-// flush unit: SEQALIGN_FLUSH_INTS in {256, 512} (tuning experiments)
-static int flush_ints() {
-  if (const char *env = getenv("SEQALIGN_FLUSH_INTS")) return atoi(env);
-  return 256;
+bool sa_stream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b) {
+  return p.best_score && p.best_index && (p.flags & SA_F_IS_SW) && sa_stream_kernel_applicable(p, max_len_a) &&
+         max_len_b < (1u << sa::kBestRowBits) && max_len_a + 1 < (1u << (32 - sa::kBestRowBits));
 }
 
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   // columns per lane: the border column is a column too
+  // (a 2 KiB flush unit -- <CPL, 1024, 512> -- was measured in round 1: no difference, removed)
   const uint32_t need = sa::columns_per_lane(max_len_a + 1);
-  const bool big = flush_ints() == 512;
-  if (need <= 1) return big ? sa::launch_cpl<1, 1024, 512>(p, stream) : sa::launch_cpl<1, 512, 256>(p, stream);
-  if (need <= 2) return big ? sa::launch_cpl<2, 1024, 512>(p, stream) : sa::launch_cpl<2, 512, 256>(p, stream);
-  if (need <= 3) return big ? sa::launch_cpl<3, 1024, 512>(p, stream) : sa::launch_cpl<3, 512, 256>(p, stream);
-  if (need <= 4) return big ? sa::launch_cpl<4, 1024, 512>(p, stream) : sa::launch_cpl<4, 512, 256>(p, stream);
+  if (need <= 1) return sa::launch_cpl<1, 512, 256>(p, stream);
+  if (need <= 2) return sa::launch_cpl<2, 512, 256>(p, stream);
+  if (need <= 3) return sa::launch_cpl<3, 512, 256>(p, stream);
+  if (need <= 4) return sa::launch_cpl<4, 512, 256>(p, stream);
   if (need <= 5) return sa::launch_cpl<5, 1024, 256>(p, stream);
   if (need <= 6) return sa::launch_cpl<6, 1024, 256>(p, stream);
   if (need <= 8) return sa::launch_cpl<8, 1024, 256>(p, stream);

@@ -21,6 +21,11 @@ struct SaFillParams {
   uint32_t K;
   int32_t gap_open, open1, ext, floor, gen_eq, gen_ne;
   uint32_t flags;         /* SA_F_* (sa_internal.h) */
+  /* optional (stream kernel, SW): the best match_scores cell per pair in the reference's
+   * hit order (score desc, column asc, index asc), as sa_reduce.hip reports it -- saves the
+   * separate pass over match_scores when only the best hit is wanted */
+  int32_t *best_score;
+  uint64_t *best_index;
 };
 
 struct SaReduceParams {
@@ -112,6 +117,8 @@ hipError_t sa_launch_fill_rowscan(const SaFillParams &p, uint32_t max_len_a,
 bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
                                  hipStream_t stream);
+/* whether sa_launch_fill_stream would also fill p.best_score / p.best_index */
+bool sa_stream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
                               const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,

@@ -391,7 +391,7 @@ def test_sw_enumeration_repeats_and_ties(ctx, enum_kernel, monkeypatch):
                       ({"init": [3, -3, -4, -2, 0, 0, 0, 0, 1, 0]}, 12)):
         sc = S.make_scoring(spec)
         osc = oracle_scoring_of(sc)
-        for max_hits in (3, 16):
+        for max_hits in (1, 3, 16):   # 1: the best cell comes from the fill kernel itself
             got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits)
             for p in range(batch.n_pairs):
                 rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
