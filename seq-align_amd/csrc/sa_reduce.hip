@@ -15,18 +15,22 @@
 
 namespace sa {
 
+// best cell so far; the column (idx % W, a ~25-instruction division) is only worked out
+// when two cells tie on the score
 struct Best {
   int score;
-  unsigned col;
   unsigned idx;
 };
 
-__device__ __forceinline__ bool better(int s, unsigned col, unsigned idx, const Best &b) {
+__device__ __forceinline__ bool better(int s, unsigned idx, const Best &b, unsigned W) {
   if (s != b.score) return s > b.score;
-  if (col != b.col) return col < b.col;
+  const unsigned col = idx % W, bcol = b.idx % W;
+  if (col != bcol) return col < bcol;
   return idx < b.idx;
 }
 
+// COMPACT = false: best cell + number of cells >= min_score only (no positions: no ballots)
+template <bool COMPACT>
 __global__ void __launch_bounds__(kWave *kWavesPerBlock)
 sw_reduce_kernel(const SaReduceParams p) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -42,15 +46,16 @@ sw_reduce_kernel(const SaReduceParams p) {
   int32_t *cscore = p.cand_score ? p.cand_score + p.cand_off[pair] : nullptr;
   uint64_t *ckey = p.cand_key ? p.cand_key + p.cand_off[pair] : nullptr;
 
-  Best best{0, 0, 0};                                   // cell 0 holds score 0
-  uint32_t count = 0;                                   // wave-uniform
+  Best best{0, 0};                                      // cell 0 holds score 0
+  uint32_t count = 0;                                   // COMPACT: wave-uniform; else per lane
 
-  // 4 independent 1 KiB loads per wave in flight per step: with one wave per pair
-  // (4 k - 10 k waves) a single load per step leaves HBM latency exposed
+  // kUnroll independent 1 KiB loads per wave per step, and the NEXT step's loads are issued
+  // before this step's values are examined (software pipeline): with one wave per pair
+  // (4 k - 10 k waves) anything less leaves HBM latency exposed (C4: 3.5 TB/s with a
+  // load-wait-compute loop)
   constexpr int kUnroll = 4;
   constexpr uint32_t kStep = kWave * 4 * kUnroll;
-  for (uint32_t base = 0; base < cells; base += kStep) {
-    int v[kUnroll][4];
+  auto load_step = [&](uint32_t base, int (&v)[kUnroll][4]) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
@@ -62,18 +67,29 @@ sw_reduce_kernel(const SaReduceParams p) {
         for (int k = 0; k < 4; ++k) v[u][k] = (i0 + k < cells) ? M[i0 + k] : 0;
       }
     }
+  };
+  int nxt[kUnroll][4];
+  load_step(0, nxt);
+  for (uint32_t base = 0; base < cells; base += kStep) {
+    int v[kUnroll][4];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[u][k] = nxt[u][k];
+    if (base + kStep < cells) load_step(base + kStep, nxt);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
       uint32_t mine = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (v[u][k] >= best.score && v[u][k] > 0) {
-          const unsigned idx = i0 + k, col = idx % W;
-          if (better(v[u][k], col, idx, best)) best = Best{v[u][k], col, idx};
-        }
+        // within a lane indices ascend, so a strictly higher score always wins; only a tie
+        // (rare) needs the columns
+        if (v[u][k] > best.score) best = Best{v[u][k], i0 + k};
+        else if (v[u][k] == best.score && v[u][k] > 0 && better(v[u][k], i0 + k, best, W)) best = Best{v[u][k], i0 + k};
         mine += (v[u][k] >= min_score);
       }
+      if constexpr (!COMPACT) { count += mine; continue; }
       // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
       const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
       if ((b0 | b1 | b2) == 0) continue;                // wave-uniform: no candidate in this KiB
@@ -99,9 +115,9 @@ sw_reduce_kernel(const SaReduceParams p) {
   // wave reduction of the best cell
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    Best other{__shfl_xor(best.score, o), (unsigned)__shfl_xor((int)best.col, o),
-               (unsigned)__shfl_xor((int)best.idx, o)};
-    if (better(other.score, other.col, other.idx, best)) best = other;
+    const Best other{__shfl_xor(best.score, o), (unsigned)__shfl_xor((int)best.idx, o)};
+    if (better(other.score, other.idx, best, W)) best = other;
+    if constexpr (!COMPACT) count += __shfl_xor((int)count, o);
   }
   if (lane == 0) {
     p.best_score[pair] = best.score;
@@ -116,6 +132,7 @@ hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock),
       block(sa::kWave * sa::kWavesPerBlock);
-  hipLaunchKernelGGL(sa::sw_reduce_kernel, grid, block, 0, stream, p);
+  if (p.cand_cap) hipLaunchKernelGGL(sa::sw_reduce_kernel<true>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(sa::sw_reduce_kernel<false>, grid, block, 0, stream, p);
   return hipGetLastError();
 }
