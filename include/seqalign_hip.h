@@ -117,10 +117,13 @@ enum {
   SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair  */
   SEQALIGN_KERNEL_ROWSCAN = 2,   /* row sweep + max-plus prefix scan for gap_b,
                                     rows stored straight from registers        */
-  SEQALIGN_KERNEL_STREAM = 3     /* same sweep, output through an LDS ring as
+  SEQALIGN_KERNEL_STREAM = 3,    /* same sweep, output through an LDS ring as
                                     aligned 1 KiB blocks (len_a <= 1023 and the
                                     three arenas congruent mod 4 KiB; otherwise
-                                    the call falls back to ROWSCAN)            */
+                                    the call falls back: AUTO -> STRIPS,
+                                    STREAM -> ROWSCAN)                         */
+  SEQALIGN_KERNEL_STRIPS = 4     /* long rows: the 512-column strips of a pair run
+                                    as a pipeline of waves, 64 rows apart      */
 };
 
 /* THE HOT PATH.  Replaces alignment_fill_matrices (src/alignment.c:28-168) for a

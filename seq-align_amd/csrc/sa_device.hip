@@ -175,6 +175,7 @@ struct seqalign_ctx {
   DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
   DevBuf e[12];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
+  DevBuf strip_progress;                        // sa_fill_strips.hip: rows done per (pair, strip)
   HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // cached flattened scoring for the legacy single-pair path
   seqalign_dev_scoring *cached = nullptr;
@@ -275,6 +276,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
                     &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
     b->release();
   for (DevBuf &b : ctx->e) b.release();
+  ctx->strip_progress.release();
   for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
                      &ctx->h_tb, &ctx->h_tmeta})
     b->release();
@@ -348,6 +350,7 @@ static int pick_kernel(int kernel) {
     if (!strcmp(env, "wavefront")) return SEQALIGN_KERNEL_WAVEFRONT;
     if (!strcmp(env, "rowscan")) return SEQALIGN_KERNEL_ROWSCAN;
     if (!strcmp(env, "stream")) return SEQALIGN_KERNEL_STREAM;
+    if (!strcmp(env, "strips")) return SEQALIGN_KERNEL_STRIPS;
   }
   return SEQALIGN_KERNEL_STREAM;   // measured fastest (profiles/); falls back when not applicable
 }
@@ -368,8 +371,16 @@ static int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scorin
   // a positive gap_extend (legal, absurd) breaks the row scan's saturating-add
   // identity; the wavefront kernel is exact for any sign
   if (p.ext > 0) which = SEQALIGN_KERNEL_WAVEFRONT;
-  if (which == SEQALIGN_KERNEL_STREAM && !sa_stream_kernel_applicable(p, batch->max_len_a))
-    which = SEQALIGN_KERNEL_ROWSCAN;
+  const bool stream_ok = sa_stream_kernel_applicable(p, batch->max_len_a);
+  if (kernel == SEQALIGN_KERNEL_AUTO && which == SEQALIGN_KERNEL_STREAM) {
+    // One wave per pair needs pairs to fill the chip.  Measured (seq-align_amd/tools/long_pairs.py,
+    // profiles/r01_long_pairs.txt): 64 x 1000x1000 -- strips 0.49 ms, rowscan 0.86, stream 2.09;
+    // 256 x 1000x1000 -- rowscan 0.99, strips 1.23, stream 2.09; 1000 x 1000x1000 -- stream 3.2,
+    // rowscan 4.7; 16 x 5000x5000 -- strips 2.9, rowscan 21; 512 x 2000x2000 -- rowscan 5.2, strips 10.5.
+    if (batch->max_len_a > 512 && batch->n_pairs < 256) which = SEQALIGN_KERNEL_STRIPS;
+    else if (!stream_ok || (batch->max_len_a > 767 && batch->n_pairs < 768)) which = SEQALIGN_KERNEL_ROWSCAN;
+  }
+  if (which == SEQALIGN_KERNEL_STREAM && !stream_ok) which = SEQALIGN_KERNEL_ROWSCAN;
   if (which == SEQALIGN_KERNEL_STREAM && best_score && best_index) {
     p.best_score = best_score; p.best_index = best_index;
     if (sa_stream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b)) { if (best_done) *best_done = true; }
@@ -381,6 +392,13 @@ static int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scorin
     case SEQALIGN_KERNEL_ROWSCAN:
       e = sa_launch_fill_rowscan(p, batch->max_len_a, st);
       break;
+    case SEQALIGN_KERNEL_STRIPS: {
+      const uint64_t words = batch->n_pairs * (uint64_t)sa_fill_strips_per_pair(batch->max_len_a);
+      int rc = ctx->strip_progress.reserve(words * 4 + 16);
+      if (rc) return rc;
+      e = sa_launch_fill_strips(p, batch->max_len_a, ctx->strip_progress.as<uint32_t>(), st);
+      break;
+    }
     default: return SEQALIGN_E_ARG;
   }
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");

@@ -17,7 +17,7 @@ from seqalign_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
-KERNELS = [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM]
+KERNELS = [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM, S.KERNEL_STRIPS]
 KID = lambda k: S.KERNEL_NAMES[k]
 
 
