@@ -97,8 +97,13 @@ fill_strips_kernel(const SaFillParams p, uint32_t *progress, const uint32_t stri
       if (q == 0) {
         if (strip > 0) {   // rows j .. j+63 of the strip to my left must be in memory
           const uint32_t need = min(j + kWave - 1, lb) + 1;
-          while (__hip_atomic_load(done + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
-            __builtin_amdgcn_s_sleep(4);
+          // (a strip only waits for a lower workgroup index of its own XCD queue, which is running or
+          // done; the bound turns a broken assumption into a failed launch instead of a hung GPU)
+          uint32_t spins = 0;
+          while (__hip_atomic_load(done + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 26)) __builtin_trap();   // ~20 s
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the boundary loads below see those rows
         }
         feed.load(p, k, bd, sb_, lb, W, i0, Mg, Ag, Bg, j + lane);
