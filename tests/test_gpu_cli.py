@@ -115,6 +115,19 @@ def test_nw_options_match_oracle(tmp_path):
             assert rc == 0 and blk == f"{ra.decode()}\n{rb.decode()}\nscore: {score}", (args, a, b)
 
 
+def test_long_pair_takes_the_strip_pipeline(tmp_path):
+    """One pair much longer than a wave's row (3 000 x 2 700, related): the fill runs as a
+    pipeline of column strips (sa_fill_strips.hip); alignment and score equal the oracle's."""
+    batch = W.dna_nw_150(1, seed=31, length=3000, related=True)
+    a, b = batch.seq_a(0), batch.seq_b(0)[:2700]
+    f = tmp_path / "long.txt"
+    f.write_text(f"{a.decode()}\n{b.decode()}\n")
+    sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    rc, score, ra, rb = O.oracle_nw(sc, a, b)
+    assert rc == 0
+    assert run(NW, "--printscores", "--file", str(f)) == f"{ra.decode()}\n{rb.decode()}\nscore: {score}\n\n"
+
+
 def expected_sw_text(index, a, b, hits, context=0, pretty=False):
     out = [f"== Alignment {index} lengths ({len(a)}, {len(b)}):", ""]
     for k, h in enumerate(hits):
