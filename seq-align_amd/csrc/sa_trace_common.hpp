@@ -24,14 +24,17 @@ struct TraceConsts {
 };
 
 // Moves (x,y,matrix,score) to the predecessor.  Returns 0, or SEQALIGN_E_UNKNOWN_PAIR
-// (5) / SEQALIGN_E_TRACEBACK (7).
-__device__ __forceinline__ uint32_t reverse_move(const PairView &v, const TraceConsts &k, uint32_t &x,
-                                                 uint32_t &y, int &matrix, int &score) {
+// (5) / SEQALIGN_E_TRACEBACK (7).  `acc` supplies the data: code_a(i) / code_b(j) =
+// code[seq_a[i]] / code[seq_b[j]], and cell(x, y, m, a, b) = the three matrices at (x, y)
+// -- straight from HBM (GlobalAccess) or from a tile staged in LDS (sa_traceback.hip).
+template <class Access>
+__device__ __forceinline__ uint32_t reverse_move_t(Access &acc, const TraceConsts &k, uint32_t la, uint32_t lb,
+                                                   uint32_t &x, uint32_t &y, int &matrix, int &score) {
   // gap costs for leaving (x,y) (alignment.c:261-272)
   long long open_a = k.open1, ext_a = k.ext, open_b = k.open1, ext_b = k.ext;
   if (k.no_end) {
-    if (x == v.la) open_a = ext_a = 0;
-    if (y == v.lb) open_b = ext_b = 0;
+    if (x == la) open_a = ext_a = 0;
+    if (y == lb) open_b = ext_b = 0;
   }
   if (k.no_start) {   // x, y >= 1 for every caller; kept for symmetry with the reference
     if (x == 0) open_a = ext_a = 0;
@@ -39,7 +42,7 @@ __device__ __forceinline__ uint32_t reverse_move(const PairView &v, const TraceC
   }
   long long via_m, via_a, via_b;
   if (matrix == MAT_MATCH) {
-    const int code_a = k.code[v.seq_a[x - 1]], code_b = k.code[v.seq_b[y - 1]];
+    const int code_a = acc.code_a(x - 1), code_b = acc.code_b(y - 1);
     int s = (k.K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
                        : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * k.K, code_b, k.table,
                                                       k.gen_eq, k.gen_ne);
@@ -53,13 +56,31 @@ __device__ __forceinline__ uint32_t reverse_move(const PairView &v, const TraceC
   } else {
     via_m = via_a = open_b; via_b = ext_b; --x;
   }
-  const uint32_t at = y * v.W + x;
-  const long long av = v.A[at], bv = v.B[at], mv = v.M[at], cur = score;
-  if ((!k.no_gaps_a || x == 0 || x == v.la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
-  else if ((!k.no_gaps_b || y == 0 || y == v.lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
+  int mi, ai, bi;
+  acc.cell(x, y, mi, ai, bi);
+  const long long av = ai, bv = bi, mv = mi, cur = score;
+  if ((!k.no_gaps_a || x == 0 || x == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
+  else if ((!k.no_gaps_b || y == 0 || y == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
   else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
   else return 7;
   return 0;
+}
+
+struct GlobalAccess {
+  const PairView &v;
+  const uint16_t *code;
+  __device__ __forceinline__ int code_a(uint32_t i) const { return code[v.seq_a[i]]; }
+  __device__ __forceinline__ int code_b(uint32_t j) const { return code[v.seq_b[j]]; }
+  __device__ __forceinline__ void cell(uint32_t x, uint32_t y, int &m, int &a, int &b) const {
+    const uint32_t at = y * v.W + x;
+    m = v.M[at]; a = v.A[at]; b = v.B[at];
+  }
+};
+
+__device__ __forceinline__ uint32_t reverse_move(const PairView &v, const TraceConsts &k, uint32_t &x,
+                                                 uint32_t &y, int &matrix, int &score) {
+  GlobalAccess acc{v, k.code};
+  return reverse_move_t(acc, k, v.la, v.lb, x, y, matrix, score);
 }
 
 }  // namespace sa

@@ -83,12 +83,172 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   p.trace_status[pair] = err;
 }
 
+// ---------------------------------------------------------------------------
+// One WAVE per pair, the walk's neighbourhood staged in LDS.
+//
+// A step needs the three matrices at ONE predecessor cell and the two sequence
+// codes: with one lane per pair every step is two or three dependent HBM round
+// trips (~1.5 us), so a 10 000 x 10 000 pair took 30 ms to trace after 5 ms of
+// fill, and the 157 waves of a 10 k-pair batch left the chip idle.  Here the wave
+// loads the kTile x kTile block of cells that ends at the current cell (one
+// dwordx4 per lane and matrix) plus the codes / characters of those rows and
+// columns; the walk then runs out of LDS -- it needs at least kTile steps to leave
+// a tile -- and reloads when it steps outside.  All 64 lanes walk redundantly
+// (uniform control flow), lane 0 writes the characters.
+constexpr int kTile = 16;
+
+struct TileAccess {
+  const PairView &v;
+  const uint16_t *code;
+  int32_t *cells;        // [3][kTile * kTile]
+  uint16_t *codes;       // [2][kTile]: code of seq_a[ox-1 + c], seq_b[oy-1 + r]
+  uint8_t *chars;        // [2][kTile]
+  uint32_t ox, oy;       // tile covers columns ox .. ox+kTile-1, rows oy .. oy+kTile-1
+  bool loaded;
+  int lane;
+
+  // make (x, y) the tile's bottom-right cell
+  __device__ __forceinline__ void refill(uint32_t x, uint32_t y) {
+    ox = x >= (uint32_t)(kTile - 1) ? x - (kTile - 1) : 0;
+    oy = y >= (uint32_t)(kTile - 1) ? y - (kTile - 1) : 0;
+    const uint32_t r = lane >> 2, c0 = (lane & 3) * 4, H = v.lb + 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tile
+    if (oy + r < H) {
+      const uint32_t at = (oy + r) * v.W + ox + c0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int32_t *src = (m == 0 ? v.M : m == 1 ? v.A : v.B) + at;
+        int32_t *dst = cells + m * (kTile * kTile) + r * kTile + c0;
+        if (ox + c0 + 4 <= v.W) {
+          const v4i_u q = *reinterpret_cast<const v4i_u *>(src);
+          dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = (ox + c0 + e < v.W) ? src[e] : 0;
+        }
+      }
+    }
+    // sequence characters / codes of the tile's columns (seq_a[ox-1+c]) and rows (seq_b[oy-1+r])
+    if (lane < 2 * kTile) {
+      const bool is_b = lane >= kTile;
+      const uint32_t i = (is_b ? oy : ox) + (lane & (kTile - 1));   // matrix coordinate; sequence index i-1
+      const uint32_t n = is_b ? v.lb : v.la;
+      uint8_t ch = 0;
+      if (i >= 1 && i <= n) ch = (is_b ? v.seq_b : v.seq_a)[i - 1];
+      chars[lane] = ch;
+      codes[lane] = code[ch];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);      // the tile is in LDS before anyone reads it (one wave: program order)
+    loaded = true;
+  }
+  __device__ __forceinline__ bool inside(uint32_t x, uint32_t y) const {
+    return loaded && x >= ox && x < ox + kTile && y >= oy && y < oy + kTile;
+  }
+  // sequence index i (matrix column i+1)
+  __device__ __forceinline__ int code_a(uint32_t i) const { return codes[i + 1 - ox]; }
+  __device__ __forceinline__ int code_b(uint32_t j) const { return codes[kTile + j + 1 - oy]; }
+  __device__ __forceinline__ char char_a(uint32_t i) const { return (char)chars[i + 1 - ox]; }
+  __device__ __forceinline__ char char_b(uint32_t j) const { return (char)chars[kTile + j + 1 - oy]; }
+  __device__ __forceinline__ void cell(uint32_t x, uint32_t y, int &m, int &a, int &b) const {
+    const uint32_t t = (y - oy) * kTile + (x - ox);
+    m = cells[t]; a = cells[kTile * kTile + t]; b = cells[2 * kTile * kTile + t];
+  }
+};
+
+// a step from (x, y) touches column x / row y (codes, characters) and the cell (x-1 | x, y-1 | y):
+// all inside the tile iff x-1 >= ox and y-1 >= oy (or the coordinate is 0 and so is the origin)
+__device__ __forceinline__ bool step_inside(const TileAccess &t, uint32_t x, uint32_t y) {
+  if (!t.inside(x, y)) return false;
+  return (x == 0 || x - 1 >= t.ox) && (y == 0 || y - 1 >= t.oy);
+}
+
+template <bool SW>
+__global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(const SaTraceParams p) {
+  __shared__ int32_t tile_cells[kWavesPerBlock][3 * kTile * kTile];
+  __shared__ uint16_t tile_codes[kWavesPerBlock][2 * kTile];
+  __shared__ uint8_t tile_chars[kWavesPerBlock][2 * kTile];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const uint32_t pair = blockIdx.x * kWavesPerBlock + wave;
+  if (pair >= p.n_pairs) return;
+
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint64_t mo = p.mat_off[pair];
+  const PairView v{p.arena + p.off_a[pair], p.arena + p.off_b[pair], p.M + mo, p.A + mo, p.B + mo, la, lb, W};
+  const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
+                      (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
+                      (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
+  char *oa = p.out_a + p.str_off[pair];
+  char *ob = p.out_b + p.str_off[pair];
+  TileAccess t{v, p.code, tile_cells[wave], tile_codes[wave], tile_chars[wave], 0, 0, false, lane};
+
+  int matrix = MAT_MATCH, score;
+  uint32_t x, y, head = la + lb, err = 0;
+  if constexpr (SW) {
+    const uint32_t end = (uint32_t)p.start_index[pair];
+    x = end % W; y = end / W;
+    t.refill(x, y);
+    int a_, b_;
+    t.cell(x, y, score, a_, b_);
+  } else {
+    // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
+    x = la; y = lb;
+    t.refill(x, y);
+    int m_, a_, b_;
+    t.cell(x, y, m_, a_, b_);
+    score = m_;
+    if (b_ >= score) { matrix = MAT_GAP_B; score = b_; }
+    if (a_ >= score) { matrix = MAT_GAP_A; score = a_; }
+  }
+  const int end_score = score;
+  const uint32_t end_x = x, end_y = y;
+
+  while (SW ? (score > 0) : (x > 0 && y > 0)) {
+    if (!step_inside(t, x, y)) t.refill(x, y);
+    --head;
+    if (lane == 0) {
+      oa[head] = (matrix == MAT_GAP_A) ? '-' : t.char_a(x - 1);
+      ob[head] = (matrix == MAT_GAP_B) ? '-' : t.char_b(y - 1);
+    }
+    if ((err = reverse_move_t(t, k, la, lb, x, y, matrix, score))) break;
+  }
+  if (lane == 0) {
+    if constexpr (!SW) {
+      if (!err) {   // needleman_wunsch.c:117-132: the rest of the longer sequence against gaps
+        for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)v.seq_b[y - 1]; }
+        for (; x > 0; --x) { --head; oa[head] = (char)v.seq_a[x - 1]; ob[head] = '-'; }
+      }
+    } else {
+      // smith_waterman.c:251-255: start position and consumed lengths
+      p.out_pos[4 * pair + 0] = x;
+      p.out_pos[4 * pair + 1] = y;
+      p.out_pos[4 * pair + 2] = end_x - x;
+      p.out_pos[4 * pair + 3] = end_y - y;
+    }
+    p.out_score[pair] = end_score;
+    p.out_head[pair] = head;
+    p.out_len[pair] = la + lb - head;
+    p.trace_status[pair] = err;
+  }
+}
+
 }  // namespace sa
 
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
-  if (p.start_index) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(sa::traceback_kernel<false>, grid, block, 0, stream, p);
+  // Measured (seq-align_amd/tools/long_e2e.py): the tiled wave-per-pair walker wins when there are few pairs
+  // (1 x 10 000^2: 9.5 -> 7.4 ms, 16 x 5 000^2: 6.6 -> 4.2 ms of traceback) and loses a little when the lanes of
+  // one-lane-per-pair waves are all busy (10 k x 150^2: +0.13 ms).  SEQALIGN_TRACE_KERNEL=lane|wave forces one.
+  const char *force = getenv("SEQALIGN_TRACE_KERNEL");
+  const bool lane_kernel = force ? force[0] == 'l' : p.n_pairs >= 2048;
+  if (lane_kernel) {
+    const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
+    if (p.start_index) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(sa::traceback_kernel<false>, grid, block, 0, stream, p);
+  } else {
+    const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock), block(sa::kWave * sa::kWavesPerBlock);
+    if (p.start_index) hipLaunchKernelGGL(sa::traceback_wave_kernel<true>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(sa::traceback_wave_kernel<false>, grid, block, 0, stream, p);
+  }
   return hipGetLastError();
 }

@@ -316,6 +316,33 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
             assert rc == 0 and res[p] == (s, ra, rb)
 
 
+@pytest.mark.parametrize("walker", ["lane", "wave"])
+def test_device_traceback_walkers_agree_with_oracle(ctx, walker, monkeypatch):
+    """Both device walkers (one lane per pair from HBM; one wave per pair from 16x16 LDS tiles)
+    on pairs that cross many tiles, hug the borders and end in long gap runs."""
+    monkeypatch.setenv("SEQALIGN_TRACE_KERNEL", walker)
+    pairs = [(b"ACGT" * 40, b"ACGT" * 40), (b"A" * 100, b"A" * 17), (b"C" * 5, b"G" * 90), (b"ACGTTGCA" * 9, b"TTTT" + b"ACGTTGCA" * 7),
+             (b"G", b"G"), (b"", b"ACGT"), (b"ACGT", b"")]
+    r = W.ragged(40, seed=91, max_len=260, lower_frac=0.1)
+    pairs += [(r.seq_a(p), r.seq_b(p)) for p in range(r.n_pairs)]
+    rel = W.dna_nw_150(6, seed=92, length=700, related=True)
+    pairs += [(rel.seq_a(p), rel.seq_b(p)[:650 + 7 * p]) for p in range(rel.n_pairs)]
+    batch = W.from_pairs(pairs)
+    for spec in ({"preset": "default"}, {"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0]}, {"init": [2, -3, -5, -2, 0, 0, 0, 1, 0, 0]}):
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        res = ctx.nw_batch(batch, sc)
+        for p in range(batch.n_pairs):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and res[p] == (s_, ra, rb), (walker, spec, p)
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = oracle_scoring_of(sc)
+    got = ctx.sw_batch(batch, sc, 6, max_hits=1)
+    for p in range(batch.n_pairs):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 6, 1)
+        assert rc == 0 and got[p] == want, (walker, p)
+
+
 @pytest.mark.parametrize("max_hits,where", [(5, "device"), (16, "device"), (1, "device"), (1, "host"), (5, "host"),
                                             (40, "device")])
 def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
