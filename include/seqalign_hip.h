@@ -240,6 +240,28 @@ int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                       uint64_t hit_cap, uint64_t *n_hits, char *out_a,
                       char *out_b, uint64_t str_cap);
 
+/* ---- several GPUs from one process -------------------------------------------- */
+/* The same three calls over n_ctx contexts (normally one per GPU of the node): the
+ * pairs are split into n_ctx contiguous index ranges, context g works on range g
+ * from its own host thread, nothing is exchanged between devices (the
+ * path shards by pair, no collective).  Results are exactly those of the
+ * single-context call.  hits/strings of the SW call come back in pair order; each
+ * range gets a share of hit_cap / str_cap proportional to its pairs
+ * (SEQALIGN_E_NOMEM if a range overflows its share). */
+int seqalign_fill_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
+                              const seqalign_batch_t *batch, const scoring_t *scoring,
+                              int is_sw, const uint64_t *mat_off, int32_t *match_scores,
+                              int32_t *gap_a_scores, int32_t *gap_b_scores, uint64_t *status);
+int seqalign_nw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
+                            const seqalign_batch_t *batch, const scoring_t *scoring,
+                            const uint64_t *str_off, char *out_a, char *out_b,
+                            uint32_t *out_len, int32_t *out_score);
+int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
+                            const seqalign_batch_t *batch, const scoring_t *scoring,
+                            const int32_t *min_score, uint32_t max_hits,
+                            seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits,
+                            char *out_a, char *out_b, uint64_t str_cap);
+
 /* ---- arena placement ----------------------------------------------------------- */
 /* Three device buffers of bytes_each for seqalign_dev_batch_t's match_scores /
  * gap_a_scores / gap_b_scores (the reference's three malloc'd matrices,

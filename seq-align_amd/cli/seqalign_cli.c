@@ -305,6 +305,9 @@ static void check(int rc, const char *what)
 }
 
 static size_t g_alignment_index = 0;
+/* SEQALIGN_GPUS=N: one context per device 0..N-1; every batch is split over them by pair index */
+static seqalign_ctx_t *g_ctxs[64];
+static int g_nctx = 1;
 
 static void run_nw(seqalign_ctx_t *ctx, const pairs_t *ps)
 {
@@ -318,7 +321,8 @@ static void run_nw(seqalign_ctx_t *ctx, const pairs_t *ps)
   build_batch(ps, 0, n, &b, &arena, &off_a, &off_b, &len_a, &len_b);
   for(i = 0; i < n; i++) { str_off[i] = total; total += (size_t)len_a[i] + len_b[i] + 1; }
   out_a = malloc(total + 1); out_b = malloc(total + 1);
-  check(seqalign_nw_batch(ctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch");
+  if(g_nctx > 1) check(seqalign_nw_batch_multi(g_ctxs, g_nctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch_multi");
+  else check(seqalign_nw_batch(ctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch");
   for(i = 0; i < n; i++) {
     if(opt.print_matrices) {   /* needs the matrices on the host: per-pair API */
       nw_aligner_t *nw = needleman_wunsch_new();
@@ -355,7 +359,8 @@ static void run_sw(seqalign_ctx_t *ctx, const pairs_t *ps)
   hit_cap = (uint64_t)n * (cap ? cap : 1) + 16;
   hits = malloc(hit_cap * sizeof(*hits));
   out_a = malloc(str_cap + 16); out_b = malloc(str_cap + 16);
-  if(cap) check(seqalign_sw_batch(ctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch");
+  if(cap && g_nctx > 1) check(seqalign_sw_batch_multi(g_ctxs, g_nctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch_multi");
+  else if(cap) check(seqalign_sw_batch(ctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch");
 
   for(i = 0, h0 = 0; i < n; i++) {
     size_t h1 = h0, k;
@@ -436,6 +441,20 @@ int main(int argc, char **argv)
     return EXIT_FAILURE;
   }
 
+  g_ctxs[0] = ctx;
+  if(getenv("SEQALIGN_GPUS")) {
+    int want = atoi(getenv("SEQALIGN_GPUS")), have = seqalign_device_count(), g;
+    if(want > have) want = have;
+    if(want > 64) want = 64;
+    for(g = 1; g < want; g++) {
+      if(seqalign_ctx_create(g, &g_ctxs[g]) != SEQALIGN_OK) {
+        fprintf(stderr, "seqalign: cannot open GPU %i: %s\n", g, seqalign_last_error());
+        return EXIT_FAILURE;
+      }
+      g_nctx = g + 1;
+    }
+  }
+
   if(opt.seq1) add_pair(&ps, "", opt.seq1, strlen(opt.seq1), "", opt.seq2, strlen(opt.seq2));
   for(f = 0; f < opt.n_files; f++) {
     seqalign_reader_t *r1 = seqalign_reader_open(opt.files1[f]), *r2 = NULL;
@@ -461,6 +480,7 @@ int main(int argc, char **argv)
   }
   flush(ctx, &ps);
   free(ps.a); free(ps.b);
+  for(f = 1; f < g_nctx; f++) seqalign_ctx_destroy(g_ctxs[f]);
   seqalign_ctx_destroy(ctx);
   return EXIT_SUCCESS;
 }

@@ -179,7 +179,12 @@ class Context:
         lib().seqalign_scoring_release(self._h, h)
 
     # ---- host-level --------------------------------------------------------
-    def fill_batch(self, batch, scoring: Scoring, is_sw: int, check: bool = True, out=None):
+    def _handles(self, peers):
+        """(ctx array, count) for the *_multi entry points: this context plus `peers`."""
+        ctxs = [self] + list(peers)
+        return (C.c_void_p * len(ctxs))(*[c._h for c in ctxs]), C.c_int(len(ctxs))
+
+    def fill_batch(self, batch, scoring: Scoring, is_sw: int, check: bool = True, out=None, peers=None):
         """H2D -> GPU fill -> D2H.  Returns (M, A, B, mat_off, status) numpy.
         out=(M, A, B) re-uses caller-owned (already touched) arrays."""
         cells = batch.matrix_cells()
@@ -194,13 +199,18 @@ class Context:
             M = np.empty(total, np.int32); A = np.empty(total, np.int32); B = np.empty(total, np.int32)
         status = np.zeros(batch.n_pairs, np.uint64)
         d = batch_desc(batch)
-        rc = lib().seqalign_fill_batch(self._h, C.byref(d), C.byref(scoring), C.c_int(is_sw), _ptr(mat_off),
-                                       _ptr(M), _ptr(A), _ptr(B), _ptr(status))
+        if peers:
+            hs, nh = self._handles(peers)
+            rc = lib().seqalign_fill_batch_multi(hs, nh, C.byref(d), C.byref(scoring), C.c_int(is_sw), _ptr(mat_off),
+                                                 _ptr(M), _ptr(A), _ptr(B), _ptr(status))
+        else:
+            rc = lib().seqalign_fill_batch(self._h, C.byref(d), C.byref(scoring), C.c_int(is_sw), _ptr(mat_off),
+                                           _ptr(M), _ptr(A), _ptr(B), _ptr(status))
         if check:
             _check(rc, "seqalign_fill_batch")
         return (M, A, B, mat_off, status) if check else (rc, M, A, B, mat_off, status)
 
-    def nw_batch(self, batch, scoring: Scoring, raw: bool = False):
+    def nw_batch(self, batch, scoring: Scoring, raw: bool = False, peers=None):
         """seqalign_nw_batch.  raw=True returns the C-side arrays (str_off, out_a,
         out_b, out_len, out_score) without building Python tuples per pair."""
         n = batch.n_pairs
@@ -212,8 +222,13 @@ class Context:
         out_a, out_b = np.zeros(total, np.uint8), np.zeros(total, np.uint8)
         out_len, out_score = np.zeros(n, np.uint32), np.zeros(n, np.int32)
         d = batch_desc(batch)
-        _check(lib().seqalign_nw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(str_off), _ptr(out_a),
-                                       _ptr(out_b), _ptr(out_len), _ptr(out_score)), "seqalign_nw_batch")
+        if peers:
+            hs, nh = self._handles(peers)
+            _check(lib().seqalign_nw_batch_multi(hs, nh, C.byref(d), C.byref(scoring), _ptr(str_off), _ptr(out_a),
+                                                 _ptr(out_b), _ptr(out_len), _ptr(out_score)), "seqalign_nw_batch_multi")
+        else:
+            _check(lib().seqalign_nw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(str_off), _ptr(out_a),
+                                           _ptr(out_b), _ptr(out_len), _ptr(out_score)), "seqalign_nw_batch")
         if raw:
             return str_off, out_a, out_b, out_len, out_score
         res = []
@@ -223,7 +238,7 @@ class Context:
         return res
 
     def sw_batch(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, hit_cap: int | None = None,
-                 raw: bool = False):
+                 raw: bool = False, peers=None):
         """seqalign_sw_batch.  raw=True returns (n_hits, hits array, out_a, out_b)
         without building Python dicts per hit."""
         n = batch.n_pairs
@@ -235,9 +250,16 @@ class Context:
         out_a, out_b = np.zeros(str_cap, np.uint8), np.zeros(str_cap, np.uint8)
         n_hits = C.c_uint64(0)
         d = batch_desc(batch)
-        _check(lib().seqalign_sw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
-                                       hits, C.c_uint64(hit_cap), C.byref(n_hits), _ptr(out_a), _ptr(out_b),
-                                       C.c_uint64(str_cap)), "seqalign_sw_batch")
+        if peers:
+            hs, nh = self._handles(peers)
+            _check(lib().seqalign_sw_batch_multi(hs, nh, C.byref(d), C.byref(scoring), _ptr(ms),
+                                                 C.c_uint32(min(max_hits, 0xFFFFFFFF)), hits, C.c_uint64(hit_cap),
+                                                 C.byref(n_hits), _ptr(out_a), _ptr(out_b), C.c_uint64(str_cap)),
+                   "seqalign_sw_batch_multi")
+        else:
+            _check(lib().seqalign_sw_batch(self._h, C.byref(d), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
+                                           hits, C.c_uint64(hit_cap), C.byref(n_hits), _ptr(out_a), _ptr(out_b),
+                                           C.c_uint64(str_cap)), "seqalign_sw_batch")
         if raw:
             return n_hits.value, hits, out_a, out_b
         per_pair = [[] for _ in range(n)]
@@ -422,6 +444,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
+    "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
     "seqalign_reader_next",

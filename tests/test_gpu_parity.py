@@ -366,6 +366,29 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
             assert rc == 0 and got[p] == want, (spec, p)
 
 
+def test_multi_context_calls_equal_single_context(ctx):
+    """seqalign_*_batch_multi: the pairs split over several contexts (here three on the one
+    device of the test box; one per GPU on a node) -- results identical to one context."""
+    peers = [S.Context(0), S.Context(0)]
+    try:
+        sc = S.make_scoring({"preset": "default"})
+        batch = W.ragged(101, seed=55, max_len=120, lower_frac=0.1)     # 101: uneven ranges
+        assert ctx.nw_batch(batch, sc, peers=peers) == ctx.nw_batch(batch, sc)
+        one = ctx.fill_batch(batch, sc, 0)
+        many = ctx.fill_batch(batch, sc, 0, peers=peers)
+        for x, y in zip(one, many):
+            assert np.array_equal(x, y)
+        sw = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+        sb = W.dna_sw_read_vs_ref(50, seed=56, read_len=40, ref_len=200)
+        for max_hits in (1, 5, 40):
+            assert ctx.sw_batch(sb, sw, 6, max_hits=max_hits, peers=peers) == ctx.sw_batch(sb, sw, 6, max_hits=max_hits)
+        tiny = W.from_pairs([(b"ACGT", b"AGGT")])                        # fewer pairs than contexts
+        assert ctx.nw_batch(tiny, sc, peers=peers) == ctx.nw_batch(tiny, sc)
+    finally:
+        for c in peers:
+            c.close()
+
+
 def test_arena_allocator(ctx):
     """seqalign_arenas_alloc: three 4 KiB-aligned device buffers the fill accepts; small
     requests are not probed (quality < 0), large ones report the write-probe ratio."""
