@@ -13,6 +13,9 @@ with S.Context(0) as ctx:
         if n > 125000: ctx.nw_batch(W.dna_nw_150(n, seed=2), sc, raw=True)   # warm the buffers
         batch = W.dna_nw_150(n, seed=1)
         ctx.nw_batch(batch, sc, raw=True) if n <= 125000 else None
-        t0 = time.perf_counter(); ctx.nw_batch(batch, sc, raw=True); dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(3):   # min of 3: the first calls after the arenas were (re)placed are slower
+            t0 = time.perf_counter(); ctx.nw_batch(batch, sc, raw=True); dts.append(time.perf_counter() - t0)
+        dt = min(dts)
         out[n] = dict(ms=dt * 1e3, gcups=batch.cells() / dt / 1e9, pairs_per_s=n / dt)
         print(n, out[n], flush=True)
