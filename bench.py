@@ -51,6 +51,8 @@ WORKLOADS = {
               "1k NW pairs, DNA 1000x1000 (long-sequence check, not a BASELINE config)"),
     "C4": ("protein_sw_300", dict(seed=3), 4000, 1, {"preset": "BLOSUM62"},
            "4k SW pairs, protein 300x300, BLOSUM62 (BASELINE configs[3])"),
+    "C5": ("dna_nw_150", dict(seed=5), 125000, 0, {"preset": "default"},
+           "1M NW pairs, DNA 150x150, sharded over 8 GPUs: 125k pairs (34 GB of matrices) per GPU (BASELINE configs[4])"),
 }
 
 
