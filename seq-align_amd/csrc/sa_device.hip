@@ -532,22 +532,19 @@ static int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &
     }
   });
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
-  if ((rc = ctx->off_a.reserve(n * 8)) || (rc = ctx->off_b.reserve(n * 8)) || (rc = ctx->mat_off.reserve(n * 8)) ||
-      (rc = ctx->len_a.reserve(n * 4)) || (rc = ctx->len_b.reserve(n * 4)) || (rc = ctx->status.reserve(n * 8)))
-    return rc;
+  // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
+  if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
   if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->arena.p, h_seq, c.seq_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, n * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->off_b.p, h_off_b, n * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->mat_off.p, h_mat, n * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->len_a.p, h_len_a, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->len_b.p, h_len_b, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
+  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
+  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
   seqalign_dev_batch_t d;
   d.n_pairs = n; d.arena = ctx->arena.as<uint8_t>();
-  d.off_a = ctx->off_a.as<uint64_t>(); d.len_a = ctx->len_a.as<uint32_t>();
-  d.off_b = ctx->off_b.as<uint64_t>(); d.len_b = ctx->len_b.as<uint32_t>();
-  d.mat_off = ctx->mat_off.as<uint64_t>();
+  d.off_a = dv_off_a; d.len_a = dv_len_a;
+  d.off_b = dv_off_b; d.len_b = dv_len_b;
+  d.mat_off = dv_mat;
   d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
   d.status = ctx->status.as<uint64_t>(); d.max_len_a = c.max_a; d.max_len_b = c.max_b;
   if (best_done) {
