@@ -1,0 +1,307 @@
+// sa_batch.hip -- host-level entry points over HOST batches: chunking, packing, the fill with the
+// matrices copied back (seqalign_fill_batch) and global alignment (seqalign_nw_batch).
+#include "sa_ctx.hpp"
+
+using namespace sa_host;
+
+// ------------------------------------------------- host-level: chunked fill ---
+
+// split the batch into chunks whose matrices (12 B/cell) fit the budget
+std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget) {
+  std::vector<Chunk> out;
+  Chunk c;
+  const uint64_t max_cells = std::max<uint64_t>(budget / 12, 1);
+  for (uint64_t p = 0; p < b->n_pairs; ++p) {
+    const uint64_t cells = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    if (c.count && c.cells + cells > max_cells) { out.push_back(c); c = Chunk(); c.first = p; }
+    c.count++; c.cells += cells; c.seq_bytes += (uint64_t)b->len_a[p] + b->len_b[p];
+    c.max_a = std::max(c.max_a, b->len_a[p]); c.max_b = std::max(c.max_b, b->len_b[p]);
+  }
+  if (c.count) out.push_back(c);
+  return out;
+}
+
+// Upload one chunk (sequences packed back to back, matrices packed in pair
+// order) and run the fill.  On return the device buffers of ctx hold the
+// results; the stream is NOT synchronised.
+// best_done (optional): ask the fill for the SW best cell per pair (into ctx->best_score / best_index);
+// *best_done tells whether the fill kernel delivered it.
+int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
+                       const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done) {
+  const uint64_t n = c.count;
+  int rc;
+  // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
+  const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t));
+  if ((rc = ctx->h_desc.reserve(desc_bytes))) return rc;
+  if ((rc = ctx->h_arena.reserve(c.seq_bytes + 16))) return rc;
+  uint64_t *h_off_a = ctx->h_desc.as<uint64_t>(), *h_off_b = h_off_a + n, *h_mat = h_off_b + n;
+  uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_mat + n), *h_len_b = h_len_a + n;
+  uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
+  uint64_t pos = 0, cell = 0;
+  for (uint64_t k = 0; k < n; ++k) {   // offsets: a sequential prefix
+    const uint64_t p = c.first + k;
+    h_off_a[k] = pos; pos += b->len_a[p];
+    h_off_b[k] = pos; pos += b->len_b[p];
+    h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
+    h_mat[k] = cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+  }
+  constexpr uint64_t kPack = 2048;     // bytes: in parallel, 2048 pairs per task
+  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
+    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
+      const uint64_t p = c.first + k;
+      memcpy(h_seq + h_off_a[k], b->arena + b->off_a[p], b->len_a[p]);
+      memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
+    }
+  });
+  if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
+  // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
+  if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
+  if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->arena.p, h_seq, c.seq_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
+  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
+  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
+  seqalign_dev_batch_t d;
+  d.n_pairs = n; d.arena = ctx->arena.as<uint8_t>();
+  d.off_a = dv_off_a; d.len_a = dv_len_a;
+  d.off_b = dv_off_b; d.len_b = dv_len_b;
+  d.mat_off = dv_mat;
+  d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+  d.status = ctx->status.as<uint64_t>(); d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+  if (best_done) {
+    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+    rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>(),
+                     ctx->best_index.as<uint64_t>(), best_done);
+  } else {
+    rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
+  }
+  if (rc) return rc;
+  if (dev_out) *dev_out = d;
+  return SEQALIGN_OK;
+}
+
+// fetch the per-pair status words; returns UNKNOWN_PAIR if any pair flagged
+int sa_host::fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out) {
+  int rc;
+  if ((rc = ctx->h_misc.reserve(c.count * 8))) return rc;
+  uint64_t *h = ctx->h_misc.as<uint64_t>();
+  HIP_TRY(hipMemcpyAsync(h, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  rc = SEQALIGN_OK;
+  for (uint64_t k = 0; k < c.count; ++k) {
+    if (status_out) status_out[c.first + k] = h[k];
+    if (h[k] != ~0ull) rc = SEQALIGN_E_UNKNOWN_PAIR;
+  }
+  return rc;
+}
+
+int sa_host::check_batch(const seqalign_batch_t *b) {
+  if (!b || (b->n_pairs && (!b->arena || !b->off_a || !b->off_b || !b->len_a || !b->len_b))) return SEQALIGN_E_ARG;
+  for (uint64_t p = 0; p < b->n_pairs; ++p)
+    if ((uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull) >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+  return SEQALIGN_OK;
+}
+
+
+// Device -> pageable host memory.  A plain hipMemcpy to pageable memory is staged
+// by the runtime at ~12 GB/s; large copies go through our own two pinned buffers
+// instead: the DMA of slice i+1 overlaps a multi-threaded memcpy of slice i into
+// the caller's buffer.  The stream must be idle w.r.t. `src` producers (it is
+// enqueued behind them) and is synchronised on return.
+static int copy_out_pipelined(seqalign_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
+  const size_t kSlice = (size_t)32 << 20;
+  if (bytes < (size_t)4 << 20) {
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SEQALIGN_OK;
+  }
+  int rc;
+  if ((rc = ctx->h_M.reserve(kSlice)) || (rc = ctx->h_A.reserve(kSlice))) return rc;
+  void *pin[2] = {ctx->h_M.p, ctx->h_A.p};
+  hipEvent_t ev[2];
+  HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i <= n_slices && e == hipSuccess; ++i) {
+    if (i < n_slices) {
+      const size_t off = i * kSlice, len = std::min(kSlice, bytes - off);
+      e = hipMemcpyAsync(pin[i & 1], static_cast<const char *>(src_dev) + off, len, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[i & 1], ctx->stream);
+    }
+    if (i > 0 && e == hipSuccess) {
+      const size_t j = i - 1, off = j * kSlice, len = std::min(kSlice, bytes - off);
+      e = hipEventSynchronize(ev[j & 1]);
+      if (e == hipSuccess) parallel_memcpy(static_cast<char *>(dst) + off, pin[j & 1], len);
+    }
+  }
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (e != hipSuccess) return fail_hip(e, "pipelined D2H");
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                   int is_sw, const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B,
+                                   uint64_t *status) {
+  if (!ctx || !scoring || !mat_off || !M || !A || !B) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &guard.h))) return rc;
+  return fill_batch_uploaded(ctx, batch, guard.h, mat_off, M, A, B, status);
+}
+
+int sa_host::fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
+                                 const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
+  int rc = SEQALIGN_OK;
+  int worst = SEQALIGN_OK;
+  for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
+    if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
+    // copy back: runs of pairs that are contiguous in the caller's arenas go in one piece
+    uint64_t k = 0, dev_cell = 0;
+    while (k < c.count) {
+      uint64_t run_cells = 0, j = k;
+      const uint64_t host0 = mat_off[c.first + k];
+      while (j < c.count && mat_off[c.first + j] == host0 + run_cells) {
+        run_cells += (uint64_t)(batch->len_a[c.first + j] + 1ull) * (batch->len_b[c.first + j] + 1ull);
+        ++j;
+      }
+      const size_t bytes = run_cells * 4;
+      if ((rc = copy_out_pipelined(ctx, M + host0, ctx->M.as<int32_t>() + dev_cell, bytes)) ||
+          (rc = copy_out_pipelined(ctx, A + host0, ctx->A.as<int32_t>() + dev_cell, bytes)) ||
+          (rc = copy_out_pipelined(ctx, B + host0, ctx->B.as<int32_t>() + dev_cell, bytes)))
+        break;
+      dev_cell += run_cells;
+      k = j;
+    }
+    if (rc) break;
+    int src = fetch_status(ctx, c, status);   // also synchronises the stream
+    if (src == SEQALIGN_E_UNKNOWN_PAIR) worst = src;
+    else if (src) { rc = src; break; }
+  }
+  return rc ? rc : worst;
+}
+
+// ----------------------------------------------- host-level: NW over a batch ---
+
+void sa_host::parallel_memcpy(void *dst, const void *src, size_t bytes) {
+  const size_t kPiece = (size_t)2 << 20;
+  const uint64_t pieces = (bytes + kPiece - 1) / kPiece;
+  parallel_for(pieces, [&](uint64_t i) {
+    const size_t off = i * kPiece;
+    memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(kPiece, bytes - off));
+  });
+}
+
+
+bool sa_host::traceback_on_host() {
+  const char *env = getenv("SEQALIGN_TRACEBACK");
+  return env && !strcmp(env, "host");
+}
+
+// device traceback of one already-filled chunk; strings land in the caller's buffers
+static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
+                                     const seqalign_dev_scoring *sc, const seqalign_dev_batch_t &d,
+                                     const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                                     int32_t *out_score) {
+  const uint64_t n = c.count;
+  int rc;
+  // per-pair slots of len_a+len_b chars in a compact device arena
+  if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 16))) return rc;
+  uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
+  uint64_t total = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    h_off[k] = total;
+    total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
+  }
+  if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
+      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
+      (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
+    return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
+  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status, n each
+  seqalign_trace_t t;
+  memset(&t, 0, sizeof(t));
+  t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+  t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
+  t.status = d_meta + 3 * n;
+  if ((rc = seqalign_nw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+  uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 16, hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  for (uint64_t k = 0; k < n; ++k)
+    if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
+  constexpr uint64_t kPack = 2048;
+  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
+    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
+      const uint64_t p = c.first + k;
+      const uint32_t head = h_meta[k], len = h_meta[n + k];
+      memcpy(out_a + str_off[p], ha + h_off[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
+      memcpy(out_b + str_off[p], hb + h_off[k] + head, len);
+      out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
+      out_len[p] = len;
+      out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+    }
+  });
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                                 int32_t *out_score) {
+  if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
+  const bool on_host = traceback_on_host();
+  // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
+  const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;
+  for (const Chunk &c : plan_chunks(batch, budget)) {
+    seqalign_dev_batch_t d;
+    if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
+    if (!on_host) {
+      if ((rc = nw_chunk_device_traceback(ctx, batch, c, sc, d, str_off, out_a, out_b, out_len, out_score))) return rc;
+      continue;
+    }
+    const size_t bytes = c.cells * 4;
+    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs; unknown pair is fatal for NW
+    std::vector<uint64_t> cell0(c.count);
+    { uint64_t cell = 0;
+      for (uint64_t k = 0; k < c.count; ++k) {
+        cell0[k] = cell;
+        cell += (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+      } }
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(c.count, [&](uint64_t k) {
+      const uint64_t p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = ctx->h_M.as<int32_t>() + cell0[k]; v.A = ctx->h_A.as<int32_t>() + cell0[k];
+      v.B = ctx->h_B.as<int32_t>() + cell0[k];
+      size_t n = 0;
+      int prc = sa_nw_traceback(&v, out_a + str_off[p], out_b + str_off[p], &n, &out_score[p]);
+      out_len[p] = (uint32_t)n;
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) return rc;
+  }
+  return SEQALIGN_OK;
+}
+

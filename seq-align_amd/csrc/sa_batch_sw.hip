@@ -1,0 +1,487 @@
+// sa_batch_sw.hip -- seqalign_sw_batch: local alignment over a HOST batch (best hit on the device,
+// multi-hit enumeration on the device, or the literal host enumeration).
+#include "sa_ctx.hpp"
+
+using namespace sa_host;
+
+// ----------------------------------------------- host-level: SW over a batch ---
+namespace {
+
+struct Cand { uint32_t idx; int32_t score; };
+
+struct PairHits {
+  std::vector<seqalign_sw_hit_t> hits;   // str_off relative to str_a / str_b below
+  std::string str_a, str_b;
+};
+
+
+}  // namespace
+
+namespace {
+
+// Successive local alignments of one pair in reference order (score desc, column
+// asc, index asc), fresh visited mask, at most max_hits (smith_waterman.c:165-277).
+// A high-scoring pair can have tens of thousands of cells above min_score and the
+// enumeration usually stops after a few hits, so the candidates are heaped (O(n))
+// and popped on demand instead of sorted (upstream sorts ~80 % of ALL cells, :159-161).
+static int enumerate_hits(const sa_view_t &v, std::vector<Cand> &cand, uint32_t max_hits, PairHits &out) {
+  const size_t W = v.len_a + 1, cells = W * (v.len_b + 1);
+  auto later = [W](const Cand &x, const Cand &y) {   // true if x comes AFTER y
+    if (x.score != y.score) return x.score < y.score;
+    const uint32_t cx = x.idx % W, cy = y.idx % W;
+    if (cx != cy) return cx > cy;
+    return x.idx > y.idx;
+  };
+  std::make_heap(cand.begin(), cand.end(), later);
+  std::vector<uint32_t> seen((cells + 31) / 32, 0u);
+  int rc = SEQALIGN_OK;
+  while (!cand.empty() && out.hits.size() < max_hits) {
+    std::pop_heap(cand.begin(), cand.end(), later);
+    const Cand cd = cand.back();
+    cand.pop_back();
+    if ((seen[cd.idx >> 5] >> (cd.idx & 31)) & 1u) continue;
+    size_t x = cd.idx % W, y = cd.idx / W, steps = 0;
+    int matrix = MATCH;
+    int32_t score = cd.score;
+    bool clash = false;
+    for (;; ++steps) {   // pass 1: walk to score 0, marking; abandon on a marked cell
+      const size_t at = y * W + x;
+      if ((seen[at >> 5] >> (at & 31)) & 1u) { clash = true; break; }
+      seen[at >> 5] |= 1u << (at & 31);
+      if (score == 0) break;
+      if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) return rc;
+    }
+    if (clash) continue;
+    const size_t off = out.str_a.size();
+    out.str_a.resize(off + steps + 1);
+    out.str_b.resize(off + steps + 1);
+    char *ra = &out.str_a[off], *rb = &out.str_b[off];
+    x = cd.idx % W; y = cd.idx / W; matrix = MATCH; score = cd.score;
+    for (size_t w = steps; score > 0;) {   // pass 2: replay, writing right to left
+      --w;
+      ra[w] = (matrix == GAP_A) ? '-' : v.a[x - 1];
+      rb[w] = (matrix == GAP_B) ? '-' : v.b[y - 1];
+      if ((rc = sa_reverse_move_rc(&v, &matrix, &score, &x, &y))) return rc;
+    }
+    ra[steps] = rb[steps] = '\0';
+    seqalign_sw_hit_t h;
+    h.pair = 0; h.score = cd.score;
+    h.pos_a = (uint32_t)x; h.pos_b = (uint32_t)y;
+    h.len_a = (uint32_t)(cd.idx % W - x); h.len_b = (uint32_t)(cd.idx / W - y);
+    h.length = (uint32_t)steps; h.str_off = off;
+    out.hits.push_back(h);
+  }
+  return SEQALIGN_OK;
+}
+
+}  // namespace
+
+
+// up to this many hits per pair the enumeration runs on the device
+static const uint32_t kDeviceEnumMaxHits = 16;
+
+// SW hits of one already-filled chunk, enumerated on the device (sa_sw_enum.hip):
+// reduce (count) -> reduce (compact + keys) -> segmented sort -> enumerate ->
+// gather strings -> D2H.  Appends to the caller's hit array / string buffers.
+//
+// want_hits > max_hits (the caller asked for more hits than the device slots hold): pairs that fill all
+// max_hits slots with candidates still left are finished on the host -- their matrices and candidates are
+// still in the context's scratch -- with the full limit; the others (nearly all, in practice) are done.
+static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
+                                     const scoring_t *scoring, const seqalign_dev_scoring *sc,
+                                     const seqalign_dev_batch_t &d, const int32_t *min_score, uint32_t max_hits,
+                                     uint32_t want_hits, seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *found,
+                                     char *out_a, char *out_b, uint64_t str_cap, uint64_t *used_str) {
+  const uint64_t n = c.count;
+  hipStream_t st = ctx->stream;
+  int rc;
+  DevBuf &d_min = ctx->e[0], &d_key_in = ctx->e[1], &d_key_out = ctx->e[2], &d_idx_out = ctx->e[3],
+         &d_tmp = ctx->e[4], &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
+         &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
+
+  int32_t thr = min_score[c.first];
+  for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
+
+  // pass 1: how many cells >= threshold per pair
+  if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
+      (rc = ctx->cand_count.reserve(n * 4)) || (rc = ctx->cand_off.reserve((n + 1) * 8)) ||
+      (rc = ctx->cand_cap.reserve(n * 4)) || (rc = d_min.reserve(n * 4)))
+    return rc;
+  SaReduceParams r;
+  memset(&r, 0, sizeof(r));
+  r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.min_score = thr;
+  r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+  r.cand_count = ctx->cand_count.as<uint32_t>(); r.n_pairs = (uint32_t)n;
+  hipError_t e = sa_launch_sw_reduce(r, st);
+  if (e != hipSuccess) return fail_hip(e, "sw reduce");
+  std::vector<uint32_t> count(n);
+  std::vector<int32_t> best(n);
+  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(best.data(), ctx->best_score.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // sort key = (cap - score) << column_bits | column: only its used bits are sorted
+  int32_t key_cap = thr;
+  uint32_t max_la = 1;
+  for (uint64_t k = 0; k < n; ++k) {
+    key_cap = std::max(key_cap, best[k]);
+    max_la = std::max(max_la, batch->len_a[c.first + k]);
+  }
+  uint32_t key_shift = 1, span_bits = 1;
+  while ((max_la >> key_shift) != 0) ++key_shift;                                   // column <= len_a
+  while (span_bits < 32 && (((uint64_t)key_cap - (uint64_t)(int64_t)thr) >> span_bits) != 0) ++span_bits;
+
+  // host prefixes: candidate segments, visited-bitmap words, string slots
+  std::vector<uint64_t> offs(4 * (n + 1));
+  uint64_t *cand_off = offs.data(), *mask_off = cand_off + n + 1, *str_off = mask_off + n + 1,
+           *dst_off = str_off + n + 1;
+  uint64_t total = 0, mask_words = 0, str_total = 0, max_mask_words = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k, la = batch->len_a[p], lb = batch->len_b[p];
+    cand_off[k] = total; total += count[k];
+    mask_off[k] = mask_words; mask_words += ((la + 1) * (lb + 1) + 31) / 32;
+    max_mask_words = std::max(max_mask_words, ((la + 1) * (lb + 1) + 31) / 32);
+    str_off[k] = str_total; str_total += (uint64_t)max_hits * (la + lb);
+  }
+  cand_off[n] = total; mask_off[n] = mask_words; str_off[n] = str_total;
+  if (total >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+
+  if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = d_key_in.reserve(total * 8 + 8)) ||
+      (rc = d_key_out.reserve(total * 8 + 8)) || (rc = d_idx_out.reserve(total * 4 + 4)) ||
+      (rc = d_mask.reserve(mask_words * 4 + 4)) || (rc = d_offs.reserve(offs.size() * 8)) ||
+      (rc = ctx->t_out_a.reserve(str_total + 16)) || (rc = ctx->t_out_b.reserve(str_total + 16)) ||
+      (rc = d_hits.reserve(n * max_hits * sizeof(SaDevHit) + 16)) || (rc = d_meta.reserve(n * 12)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 3 * (n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ctx->cand_cap.p, count.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
+  const uint64_t *dv_cand_off = d_offs.as<uint64_t>(), *dv_mask_off = dv_cand_off + n + 1,
+                 *dv_str_off = dv_mask_off + n + 1;
+
+  // pass 2: compaction with sort keys, then the stable segmented sort
+  r.cand_off = dv_cand_off; r.cand_cap = ctx->cand_cap.as<uint32_t>();
+  r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_key = d_key_in.as<uint64_t>();
+  r.key_cap = key_cap; r.key_shift = key_shift;
+  if ((e = sa_launch_sw_reduce(r, st)) != hipSuccess) return fail_hip(e, "sw reduce (compaction)");
+  if (total) {
+    size_t tmp_bytes = 0;
+    e = sa_sort_candidates(nullptr, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
+                           (int)(key_shift + span_bits), st);
+    if (e != hipSuccess) return fail_hip(e, "segmented sort (size query)");
+    if ((rc = d_tmp.reserve(tmp_bytes + 16))) return rc;
+    e = sa_sort_candidates(d_tmp.p, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
+                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
+                           (int)(key_shift + span_bits), st);
+    if (e != hipSuccess) return fail_hip(e, "segmented sort");
+  }
+
+  // enumeration: one lane per pair
+  SaEnumParams q;
+  memset(&q, 0, sizeof(q));
+  q.arena = d.arena; q.off_a = d.off_a; q.len_a = d.len_a; q.off_b = d.off_b; q.len_b = d.len_b;
+  q.mat_off = d.mat_off; q.M = d.match_scores; q.A = d.gap_a_scores; q.B = d.gap_b_scores;
+  q.code = sc->d_code; q.table = sc->d_table; q.cand_off = dv_cand_off; q.cand_count = ctx->cand_count.as<uint32_t>();
+  q.sorted_key = d_key_out.as<uint64_t>(); q.sorted_index = d_idx_out.as<uint32_t>(); q.min_score = d_min.as<int32_t>();
+  q.mask = d_mask.as<uint32_t>(); q.mask_off = dv_mask_off; q.str_off = dv_str_off;
+  q.out_a = ctx->t_out_a.as<char>(); q.out_b = ctx->t_out_b.as<char>(); q.hits = d_hits.as<SaDevHit>();
+  uint32_t *d_m = d_meta.as<uint32_t>();
+  q.hit_count = d_m; q.str_used = d_m + n; q.enum_status = d_m + 2 * n;
+  q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.max_hits = max_hits; q.open1 = sc->flat.open1;
+  q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
+  q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
+  q.key_cap = key_cap; q.key_shift = key_shift;
+  if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
+
+  std::vector<uint32_t> meta(3 * n);
+  std::vector<SaDevHit> dev_hits(n * max_hits);
+  HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  uint64_t gathered = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint32_t status = meta[2 * n + k] & 0x7fffffffu;
+    if (status) return (int)status;
+    dst_off[k] = gathered;
+    gathered += meta[n + k];
+  }
+  // pairs that ran into the slot limit while the caller wants more: host enumeration with the full limit
+  std::vector<uint64_t> capped;
+  if (want_hits > max_hits)
+    for (uint64_t k = 0; k < n; ++k)
+      if ((meta[2 * n + k] & 0x80000000u) && meta[k] >= max_hits) capped.push_back(k);
+  std::vector<PairHits> redo(capped.size());
+  std::vector<int64_t> redo_of(capped.empty() ? 0 : n, -1);
+  if (!capped.empty()) {
+    std::vector<uint64_t> cell0(n + 1, 0);
+    for (uint64_t k = 0; k < n; ++k)
+      cell0[k + 1] = cell0[k] + (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+    std::vector<uint64_t> m_off(capped.size() + 1, 0), c_off(capped.size() + 1, 0);
+    for (size_t j = 0; j < capped.size(); ++j) {
+      const uint64_t k = capped[j];
+      redo_of[k] = (int64_t)j;
+      m_off[j + 1] = m_off[j] + (cell0[k + 1] - cell0[k]);
+      c_off[j + 1] = c_off[j] + count[k];
+    }
+    std::vector<int32_t> hM(m_off.back() + 1), hA(m_off.back() + 1), hB(m_off.back() + 1);
+    std::vector<uint32_t> h_idx(c_off.back() + 1);
+    std::vector<uint64_t> h_key(c_off.back() + 1);
+    for (size_t j = 0; j < capped.size(); ++j) {
+      const uint64_t k = capped[j], cells = cell0[k + 1] - cell0[k];
+      HIP_TRY(hipMemcpyAsync(hM.data() + m_off[j], ctx->M.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hA.data() + m_off[j], ctx->A.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hB.data() + m_off[j], ctx->B.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
+      if (count[k]) {
+        HIP_TRY(hipMemcpyAsync(h_idx.data() + c_off[j], ctx->cand_index.as<uint32_t>() + cand_off[k], count[k] * 4ull,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_key.data() + c_off[j], d_key_in.as<uint64_t>() + cand_off[k], count[k] * 8ull,
+                               hipMemcpyDeviceToHost, st));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(capped.size(), [&](uint64_t j) {
+      const uint64_t k = capped[j], p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = hM.data() + m_off[j]; v.A = hA.data() + m_off[j]; v.B = hB.data() + m_off[j];
+      std::vector<Cand> cand;
+      cand.reserve(count[k]);
+      for (uint64_t q = 0; q < count[k]; ++q) {
+        const Cand cd{h_idx[c_off[j] + q], key_cap - (int32_t)(h_key[c_off[j] + q] >> key_shift)};
+        if (cd.score >= min_score[p]) cand.push_back(cd);
+      }
+      const int prc = enumerate_hits(v, cand, want_hits, redo[j]);
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) return rc;
+  }
+
+  // pack every pair's strings back to back and bring them over in one copy
+  if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
+      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+    return rc;
+  uint64_t *dv_dst_off = d_offs.as<uint64_t>() + 3 * (n + 1);
+  HIP_TRY(hipMemcpyAsync(dv_dst_off, dst_off, n * 8, hipMemcpyHostToDevice, st));
+  if ((e = sa_launch_gather_strings(q.out_a, q.out_b, dv_str_off, q.str_used, dv_dst_off, d_gath_a.as<char>(),
+                                    d_gath_b.as<char>(), (uint32_t)n, st)) != hipSuccess)
+    return fail_hip(e, "gather strings");
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  for (uint64_t k = 0; k < n; ++k) {
+    if (!capped.empty() && redo_of[k] >= 0) {   // finished on the host
+      const PairHits &ph = redo[(size_t)redo_of[k]];
+      for (const seqalign_sw_hit_t &src : ph.hits) {
+        if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
+        memcpy(out_a + *used_str, ph.str_a.data() + src.str_off, src.length + 1);
+        memcpy(out_b + *used_str, ph.str_b.data() + src.str_off, src.length + 1);
+        seqalign_sw_hit_t &h = hits[(*found)++];
+        h = src; h.pair = c.first + k; h.str_off = *used_str;
+        *used_str += src.length + 1;
+      }
+      continue;
+    }
+    for (uint32_t i = 0; i < meta[k]; ++i) {
+      const SaDevHit &src = dev_hits[k * max_hits + i];
+      if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
+      memcpy(out_a + *used_str, ha + dst_off[k] + src.str_off, src.length);
+      memcpy(out_b + *used_str, hb + dst_off[k] + src.str_off, src.length);
+      out_a[*used_str + src.length] = out_b[*used_str + src.length] = '\0';
+      seqalign_sw_hit_t &h = hits[(*found)++];
+      h.pair = c.first + k; h.score = src.score; h.pos_a = src.pos_a; h.pos_b = src.pos_b;
+      h.len_a = src.len_a; h.len_b = src.len_b; h.length = src.length; h.str_off = *used_str;
+      *used_str += src.length + 1;
+    }
+  }
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
+  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+  *n_hits = 0;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
+  uint64_t used_str = 0, found = 0;
+  if (max_hits == 0) return SEQALIGN_OK;
+  if (max_hits == 1 && !traceback_on_host()) {
+    // best hit only: nothing but the strings crosses PCIe
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
+      seqalign_dev_batch_t d;
+      bool have_best = false;   // the stream kernel reports the best cell itself
+      if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) return rc;
+      const uint64_t n = c.count;
+      if (!have_best) {
+        if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+        seqalign_sw_reduce_t r;
+        memset(&r, 0, sizeof(r));
+        r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+        r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+        if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
+      }
+      if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
+      uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
+      uint64_t total = 0;
+      for (uint64_t k = 0; k < n; ++k) {
+        h_off[k] = total;
+        total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
+      }
+      if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
+          (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)) ||
+          (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
+        return rc;
+      hipStream_t st = ctx->stream;
+      HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
+      uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
+      seqalign_trace_t t;
+      memset(&t, 0, sizeof(t));
+      t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+      t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
+      t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
+      if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+      uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
+      HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
+      if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+      const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+      for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t p = c.first + k;
+        const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
+        const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+        if (status) return (int)status;
+        if (score <= 0 || score < min_score[p]) continue;
+        if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
+        memcpy(out_a + used_str, ha + h_off[k] + head, len);
+        memcpy(out_b + used_str, hb + h_off[k] + head, len);
+        out_a[used_str + len] = out_b[used_str + len] = '\0';
+        seqalign_sw_hit_t &h = hits[found++];
+        const uint32_t *pos = h_meta + 4 * n + 4 * k;
+        h.pair = p; h.score = score; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+        h.length = len; h.str_off = used_str;
+        used_str += len + 1;
+      }
+    }
+    *n_hits = found;
+    return SEQALIGN_OK;
+  }
+  if (!traceback_on_host()) {
+    // up to kDeviceEnumMaxHits hits per pair on the device; a pair that needs more is finished on the host
+    const uint32_t slots = std::min(max_hits, kDeviceEnumMaxHits);
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
+      seqalign_dev_batch_t d;
+      if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
+      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, d, min_score, slots, max_hits, hits, hit_cap,
+                                          &found, out_a, out_b, str_cap, &used_str)))
+        break;
+    }
+    *n_hits = found;
+    return rc;
+  }
+  const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
+
+  // the reduction kernel takes one threshold per launch: group by threshold
+  // inside a chunk (the CLI default depends only on the lengths, so batches of
+  // equal-length pairs need a single launch)
+  for (const Chunk &c : plan_chunks(batch, budget)) {
+    seqalign_dev_batch_t d;
+    if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
+    const uint64_t n = c.count;
+    int32_t thr = min_score[c.first];
+    for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
+
+    // pass 1: counts (capacity 0), pass 2: compaction
+    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
+        (rc = ctx->cand_count.reserve(n * 4)) || (rc = ctx->cand_off.reserve(n * 8)) ||
+        (rc = ctx->cand_cap.reserve(n * 4)))
+      break;
+    seqalign_sw_reduce_t r;
+    memset(&r, 0, sizeof(r));
+    r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+    r.min_score = thr; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+    r.cand_count = ctx->cand_count.as<uint32_t>();
+    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) break;
+    if ((rc = ctx->h_misc.reserve(n * (4 + 8 + 4)))) break;
+    uint32_t *h_count = ctx->h_misc.as<uint32_t>();
+    HIP_TRY(hipMemcpyAsync(h_count, ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> c_off(n);
+    std::vector<uint32_t> c_cap(h_count, h_count + n);
+    uint64_t total = 0;
+    for (uint64_t k = 0; k < n; ++k) { c_off[k] = total; total += c_cap[k]; }
+    if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = ctx->cand_score.reserve(total * 4 + 4))) break;
+    HIP_TRY(hipMemcpyAsync(ctx->cand_off.p, c_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->cand_cap.p, c_cap.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    r.cand_off = ctx->cand_off.as<uint64_t>(); r.cand_cap = ctx->cand_cap.as<uint32_t>();
+    r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_score = ctx->cand_score.as<int32_t>();
+    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) break;
+
+    const size_t bytes = c.cells * 4;
+    if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) break;
+    std::vector<uint32_t> h_cidx(total + 1);
+    std::vector<int32_t> h_cscore(total + 1);
+    hipError_t e = hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(h_cidx.data(), ctx->cand_index.p, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(h_cscore.data(), ctx->cand_score.p, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) { rc = fail_hip(e, "D2H SW results"); break; }
+    if ((rc = fetch_status(ctx, c, nullptr))) break;
+
+    // host: hit enumeration with a fresh visited mask per pair (reference
+    // smith_waterman.c:165-277 semantics).  Pairs are independent -> host threads.
+    std::vector<uint64_t> cell0(n);
+    { uint64_t cell = 0;
+      for (uint64_t k = 0; k < n; ++k) {
+        cell0[k] = cell;
+        cell += (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
+      } }
+    std::vector<PairHits> per_pair(n);
+    std::atomic<int> first_error{SEQALIGN_OK};
+    parallel_for(n, [&](uint64_t k) {
+      const uint64_t p = c.first + k;
+      sa_view_t v;
+      v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
+      v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
+      v.M = ctx->h_M.as<int32_t>() + cell0[k]; v.A = ctx->h_A.as<int32_t>() + cell0[k];
+      v.B = ctx->h_B.as<int32_t>() + cell0[k];
+      std::vector<Cand> cand;
+      cand.reserve(c_cap[k]);
+      for (uint32_t q = 0; q < c_cap[k]; ++q) {
+        const Cand cd{h_cidx[c_off[k] + q], h_cscore[c_off[k] + q]};
+        if (cd.score >= min_score[p]) cand.push_back(cd);
+      }
+      int prc = enumerate_hits(v, cand, max_hits, per_pair[k]);
+      if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
+    });
+    if ((rc = first_error.load())) break;
+    for (uint64_t k = 0; k < n && rc == SEQALIGN_OK; ++k) {
+      const PairHits &ph = per_pair[k];
+      for (size_t i = 0; i < ph.hits.size(); ++i) {
+        const seqalign_sw_hit_t &src = ph.hits[i];
+        if (found >= hit_cap || used_str + src.length + 1 > str_cap) { rc = SEQALIGN_E_NOMEM; break; }
+        memcpy(out_a + used_str, ph.str_a.data() + src.str_off, src.length + 1);
+        memcpy(out_b + used_str, ph.str_b.data() + src.str_off, src.length + 1);
+        seqalign_sw_hit_t &h = hits[found++];
+        h = src;
+        h.pair = c.first + k;
+        h.str_off = used_str;
+        used_str += src.length + 1;
+      }
+    }
+    if (rc) break;
+  }
+  *n_hits = found;
+  return rc;
+}
+

@@ -1,0 +1,207 @@
+// sa_ctx.hpp -- what the translation units of the C-ABI shim share: the context, its grow-only
+// device / pinned buffers, the host worker pool and the chunk machinery of the host-level entry
+// points.  Internal: nothing here is part of include/seqalign_hip.h.
+//   sa_device.hip     context, scoring upload, the device-level entry points (the hot path), legacy
+//                     single-pair call
+//   sa_batch.hip      host-level chunking, seqalign_fill_batch, seqalign_nw_batch
+//   sa_batch_sw.hip   seqalign_sw_batch (best hit / device enumeration / host enumeration)
+//   sa_multi.hip      the same calls over several contexts (GPUs) from one process
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sa_kernels.h"
+
+extern "C" {
+#include "sa_internal.h"
+}
+
+namespace sa_host {
+
+
+// Persistent host worker pool: run fn(0..n-1) over the workers + the caller.
+// Pairs / memcpy pieces are independent.  SEQALIGN_HOST_THREADS overrides the
+// worker count (default min(hardware threads, 32)).  One job at a time.
+class HostPool {
+ public:
+  static HostPool &get() { static HostPool pool; return pool; }
+  void run(uint64_t n, const std::function<void(uint64_t)> &fn) {
+    if (n == 0) return;
+    if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
+    std::lock_guard<std::mutex> one_job(job_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = (unsigned)workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    for (uint64_t k; (k = next_.fetch_add(1)) < n;) fn(k);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned want = hw ? std::min(hw, 32u) : 4u;
+    if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
+    for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto &th : workers_) th.join();
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return generation_ != seen; });
+      seen = generation_;
+      if (stop_) return;
+      const std::function<void(uint64_t)> *fn = fn_;
+      const uint64_t n = n_;
+      lk.unlock();
+      for (uint64_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
+      lk.lock();
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(uint64_t)> *fn_ = nullptr;
+  uint64_t n_ = 0, generation_ = 0;
+  std::atomic<uint64_t> next_{0};
+  unsigned pending_ = 0;
+  bool stop_ = false;
+};
+
+template <class F>
+void parallel_for(uint64_t n, F fn) {
+  HostPool::get().run(n, std::function<void(uint64_t)>(fn));
+}
+
+
+// ------------------------------------------------------------------ errors ---
+int fail_hip(hipError_t e, const char *what);     // records the message, maps to SEQALIGN_E_*
+void set_last_error(const std::string &msg);
+#define HIP_TRY(expr)                                            \
+  do {                                                           \
+    hipError_t _e = (expr);                                      \
+    if (_e != hipSuccess) return sa_host::fail_hip(_e, #expr);   \
+  } while (0)
+
+
+struct DevBuf {   // grow-only device scratch
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return SEQALIGN_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipMalloc"); }
+    cap = want;
+    return SEQALIGN_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct HostBuf {  // grow-only pinned staging
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return SEQALIGN_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipHostMalloc"); }
+    cap = want;
+    return SEQALIGN_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+
+}  // namespace sa_host
+
+
+struct seqalign_dev_scoring {
+  sa_flat_scoring_t flat;   // host copy (table pointer owned)
+  uint16_t *d_code = nullptr;
+  int32_t *d_table = nullptr;
+};
+
+struct seqalign_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
+  // device scratch for the host-level entry points
+  sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
+  sa_host::DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
+  sa_host::DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
+  sa_host::DevBuf e[12];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
+  sa_host::DevBuf strip_progress;                        // sa_fill_strips.hip: rows done per (pair, strip)
+  sa_host::HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
+  // cached flattened scoring for the legacy single-pair path
+  seqalign_dev_scoring *cached = nullptr;
+  uint64_t cached_fp = 0;
+  int cached_is_sw = -1;
+};
+
+
+namespace sa_host {
+
+// grow the context's three matrix arenas together (spread placement, sa_placement.hip)
+int reserve_arenas(seqalign_ctx *ctx, size_t bytes);
+
+// releases an uploaded scoring on every exit path of the host-level entry points
+struct ScoringGuard {
+  seqalign_ctx *ctx;
+  seqalign_dev_scoring *h = nullptr;
+  explicit ScoringGuard(seqalign_ctx *c) : ctx(c) {}
+  ~ScoringGuard() { if (h) seqalign_scoring_release(ctx, h); }
+  ScoringGuard(const ScoringGuard &) = delete;
+  ScoringGuard &operator=(const ScoringGuard &) = delete;
+};
+
+// the fill on device-resident data; best_score / best_index (optional, SW): filled by the fill itself
+// when the stream kernel runs (*best_done = true), otherwise the caller runs the separate reduction
+int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
+                int kernel, void *stream, int32_t *best_score, uint64_t *best_index, bool *best_done);
+
+// ---- host-level chunking (sa_batch.hip)
+struct Chunk {
+  uint64_t first = 0, count = 0;   // pairs [first, first+count)
+  uint64_t cells = 0, seq_bytes = 0;
+  uint32_t max_a = 0, max_b = 0;
+};
+
+std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget);
+int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, const seqalign_dev_scoring *sc,
+              seqalign_dev_batch_t *dev_out, bool *best_done = nullptr);
+int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
+int check_batch(const seqalign_batch_t *b);
+// chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)
+int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
+                        const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status);
+bool traceback_on_host();
+void parallel_memcpy(void *dst, const void *src, size_t bytes);
+
+}  // namespace sa_host
