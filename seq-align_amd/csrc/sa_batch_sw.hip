@@ -300,94 +300,76 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   return SEQALIGN_OK;
 }
 
-extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
-                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
-                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
-  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
-  *n_hits = 0;
-  int rc = check_batch(batch);
-  if (rc) return rc;
-  if (batch->n_pairs == 0) return SEQALIGN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  ScoringGuard guard(ctx);
-  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
-  seqalign_dev_scoring *sc = guard.h;
-  uint64_t used_str = 0, found = 0;
-  if (max_hits == 0) return SEQALIGN_OK;
-  if (max_hits == 1 && !traceback_on_host()) {
-    // best hit only: nothing but the strings crosses PCIe
-    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
-      seqalign_dev_batch_t d;
-      bool have_best = false;   // the stream kernel reports the best cell itself
-      if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) return rc;
-      const uint64_t n = c.count;
-      if (!have_best) {
-        if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
-        seqalign_sw_reduce_t r;
-        memset(&r, 0, sizeof(r));
-        r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
-        r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
-        if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
-      }
-      if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
-      uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
-      uint64_t total = 0;
-      for (uint64_t k = 0; k < n; ++k) {
-        h_off[k] = total;
-        total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
-      }
-      if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
-          (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)) ||
-          (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
-        return rc;
-      hipStream_t st = ctx->stream;
-      HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
-      uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
-      seqalign_trace_t t;
-      memset(&t, 0, sizeof(t));
-      t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
-      t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
-      t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
-      if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
-      uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
-      HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
-      if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
-      const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
-      for (uint64_t k = 0; k < n; ++k) {
-        const uint64_t p = c.first + k;
-        const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
-        const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
-        if (status) return (int)status;
-        if (score <= 0 || score < min_score[p]) continue;
-        if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
-        memcpy(out_a + used_str, ha + h_off[k] + head, len);
-        memcpy(out_b + used_str, hb + h_off[k] + head, len);
-        out_a[used_str + len] = out_b[used_str + len] = '\0';
-        seqalign_sw_hit_t &h = hits[found++];
-        const uint32_t *pos = h_meta + 4 * n + 4 * k;
-        h.pair = p; h.score = score; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
-        h.length = len; h.str_off = used_str;
-        used_str += len + 1;
-      }
-    }
-    *n_hits = found;
-    return SEQALIGN_OK;
+// best hit of every pair of one chunk: fill (+ best cell) -> device traceback -> strings back
+static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
+                             const seqalign_dev_scoring *sc, const int32_t *min_score, seqalign_sw_hit_t *hits,
+                             uint64_t hit_cap, uint64_t *n_hits, uint64_t &found, char *out_a, char *out_b,
+                             uint64_t str_cap, uint64_t &used_str) {
+  int rc;
+  seqalign_dev_batch_t d;
+  bool have_best = false;   // the stream kernel reports the best cell itself
+  if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) return rc;
+  const uint64_t n = c.count;
+  if (!have_best) {
+    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+    seqalign_sw_reduce_t r;
+    memset(&r, 0, sizeof(r));
+    r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+    r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
+    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
   }
-  if (!traceback_on_host()) {
-    // up to kDeviceEnumMaxHits hits per pair on the device; a pair that needs more is finished on the host
-    const uint32_t slots = std::min(max_hits, kDeviceEnumMaxHits);
-    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
-      seqalign_dev_batch_t d;
-      if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
-      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, d, min_score, slots, max_hits, hits, hit_cap,
-                                          &found, out_a, out_b, str_cap, &used_str)))
-        break;
-    }
-    *n_hits = found;
+  if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
+  uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
+  uint64_t total = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    h_off[k] = total;
+    total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
+  }
+  if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
+      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)) ||
+      (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
     return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
+  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
+  seqalign_trace_t t;
+  memset(&t, 0, sizeof(t));
+  t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+  t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
+  t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
+  if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+  uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k;
+    const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
+    const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
+    if (status) return (int)status;
+    if (score <= 0 || score < min_score[p]) continue;
+    if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
+    memcpy(out_a + used_str, ha + h_off[k] + head, len);
+    memcpy(out_b + used_str, hb + h_off[k] + head, len);
+    out_a[used_str + len] = out_b[used_str + len] = '\0';
+    seqalign_sw_hit_t &h = hits[found++];
+    const uint32_t *pos = h_meta + 4 * n + 4 * k;
+    h.pair = p; h.score = score; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+    h.length = len; h.str_off = used_str;
+    used_str += len + 1;
   }
+  return SEQALIGN_OK;
+}
+
+// every pair through the host: matrices and compacted candidates copied back, hits enumerated by host threads
+static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                     const seqalign_dev_scoring *sc, const int32_t *min_score, uint32_t max_hits,
+                                     seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, char *out_a,
+                                     char *out_b, uint64_t str_cap) {
+  int rc = SEQALIGN_OK;
+  uint64_t used_str = 0, found = 0;
   const size_t budget = std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30);
 
   // the reduction kernel takes one threshold per launch: group by threshold
@@ -483,5 +465,44 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   }
   *n_hits = found;
   return rc;
+}
+
+extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
+  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+  *n_hits = 0;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  if (batch->n_pairs == 0) return SEQALIGN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
+  seqalign_dev_scoring *sc = guard.h;
+  uint64_t used_str = 0, found = 0;
+  if (max_hits == 0) return SEQALIGN_OK;
+  if (max_hits == 1 && !traceback_on_host()) {   // best hit only: nothing but the strings crosses PCIe
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget))
+      if ((rc = sw_chunk_best_hit(ctx, batch, c, sc, min_score, hits, hit_cap, n_hits, found, out_a, out_b, str_cap,
+                                  used_str)))
+        return rc;
+    *n_hits = found;
+    return SEQALIGN_OK;
+  }
+  if (!traceback_on_host()) {
+    // up to kDeviceEnumMaxHits hits per pair on the device; a pair that needs more is finished on the host
+    const uint32_t slots = std::min(max_hits, kDeviceEnumMaxHits);
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
+      seqalign_dev_batch_t d;
+      if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
+      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, d, min_score, slots, max_hits, hits, hit_cap,
+                                          &found, out_a, out_b, str_cap, &used_str)))
+        break;
+    }
+    *n_hits = found;
+    return rc;
+  }
+  return sw_batch_host_enumeration(ctx, batch, scoring, sc, min_score, max_hits, hits, hit_cap, n_hits, out_a, out_b,
+                                   str_cap);
 }
 
