@@ -122,8 +122,11 @@ enum {
                                     three arenas congruent mod 4 KiB; otherwise
                                     the call falls back: AUTO -> STRIPS,
                                     STREAM -> ROWSCAN)                         */
-  SEQALIGN_KERNEL_STRIPS = 4     /* long rows: the 512-column strips of a pair run
+  SEQALIGN_KERNEL_STRIPS = 4,    /* long rows: the 512-column strips of a pair run
                                     as a pipeline of waves, 64 rows apart      */
+  SEQALIGN_KERNEL_WGSTREAM = 5   /* rows of 1024..4095 columns: one workgroup per
+                                    pair, row split over four waves, shared LDS
+                                    ring (fast-path scorings; else ROWSCAN)    */
 };
 
 /* THE HOT PATH.  Replaces alignment_fill_matrices (src/alignment.c:28-168) for a

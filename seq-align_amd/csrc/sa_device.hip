@@ -191,6 +191,7 @@ static int pick_kernel(int kernel) {
     if (!strcmp(env, "rowscan")) return SEQALIGN_KERNEL_ROWSCAN;
     if (!strcmp(env, "stream")) return SEQALIGN_KERNEL_STREAM;
     if (!strcmp(env, "strips")) return SEQALIGN_KERNEL_STRIPS;
+    if (!strcmp(env, "wgstream")) return SEQALIGN_KERNEL_WGSTREAM;
   }
   return SEQALIGN_KERNEL_STREAM;   // measured fastest (profiles/); falls back when not applicable
 }
@@ -217,10 +218,17 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     // profiles/r01_long_pairs.txt): 64 x 1000x1000 -- strips 0.49 ms, rowscan 0.86, stream 2.09;
     // 256 x 1000x1000 -- rowscan 0.99, strips 1.23, stream 2.09; 1000 x 1000x1000 -- stream 3.2,
     // rowscan 4.7; 16 x 5000x5000 -- strips 2.9, rowscan 21; 512 x 2000x2000 -- rowscan 5.2, strips 10.5.
-    if (batch->max_len_a > 512 && batch->n_pairs < 256) which = SEQALIGN_KERNEL_STRIPS;
+    // 2 000 x 2 000^2 -- wgstream 15.1, rowscan 39.5, strips 43.1; 1 000 x 1 500^2 -- wgstream 5.8, rowscan 10.3;
+    // 500 x 4 000^2 -- rowscan 20.4, wgstream 22.3, strips 45.0; 64 x 2 000^2 -- strips 1.5, wgstream 3.3.
+    // 200 x 2 000^2 -- wgstream 3.3, strips 4.2.
+    const bool wg_ok = !stream_ok && batch->max_len_a + 1 <= 2048 && sa_wgstream_kernel_applicable(p, batch->max_len_a);
+    if (batch->max_len_a > 512 && batch->n_pairs < (wg_ok ? 128u : 256u)) which = SEQALIGN_KERNEL_STRIPS;
+    else if (wg_ok) which = SEQALIGN_KERNEL_WGSTREAM;
     else if (!stream_ok || (batch->max_len_a > 767 && batch->n_pairs < 768)) which = SEQALIGN_KERNEL_ROWSCAN;
   }
   if (which == SEQALIGN_KERNEL_STREAM && !stream_ok) which = SEQALIGN_KERNEL_ROWSCAN;
+  if (which == SEQALIGN_KERNEL_WGSTREAM && !sa_wgstream_kernel_applicable(p, batch->max_len_a))
+    which = SEQALIGN_KERNEL_ROWSCAN;
   if (which == SEQALIGN_KERNEL_STREAM && best_score && best_index) {
     p.best_score = best_score; p.best_index = best_index;
     if (sa_stream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b)) { if (best_done) *best_done = true; }
@@ -232,6 +240,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     case SEQALIGN_KERNEL_ROWSCAN:
       e = sa_launch_fill_rowscan(p, batch->max_len_a, st);
       break;
+    case SEQALIGN_KERNEL_WGSTREAM: e = sa_launch_fill_wgstream(p, batch->max_len_a, st); break;
     case SEQALIGN_KERNEL_STRIPS: {
       const uint64_t words = batch->n_pairs * (uint64_t)sa_fill_strips_per_pair(batch->max_len_a);
       int rc = ctx->strip_progress.reserve(words * 4 + 16);

@@ -23,9 +23,9 @@ import os as _os
 LIB_PATH = Path(_os.environ.get("SEQALIGN_LIB") or (PKG_ROOT / "lib" / "libseqalign_hip.so"))
 
 OK, E_NO_DEVICE, E_HIP, E_ARG, E_NOMEM, E_UNKNOWN_PAIR, E_DOMAIN, E_TRACEBACK, E_TOO_LARGE = range(9)
-KERNEL_AUTO, KERNEL_WAVEFRONT, KERNEL_ROWSCAN, KERNEL_STREAM, KERNEL_STRIPS = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_WAVEFRONT, KERNEL_ROWSCAN, KERNEL_STREAM, KERNEL_STRIPS, KERNEL_WGSTREAM = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = {KERNEL_AUTO: "auto", KERNEL_WAVEFRONT: "wavefront", KERNEL_ROWSCAN: "rowscan",
-                KERNEL_STREAM: "stream", KERNEL_STRIPS: "strips"}
+                KERNEL_STREAM: "stream", KERNEL_STRIPS: "strips", KERNEL_WGSTREAM: "wgstream"}
 STATUS_OK = 0xFFFFFFFFFFFFFFFF
 
 
