@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream", "strips", "wgstream"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
@@ -161,14 +161,15 @@ def main():
     # kernel choice: measured, not guessed
     if args.kernel == "auto":
         best = None
-        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM):
+        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM, S.KERNEL_STRIPS, S.KERNEL_WGSTREAM):
             ms = db.time_fill_ms(ctx, h, k, 6)[1:]
             m = float(np.median(ms))
             if best is None or m < best[1]:
                 best = (k, m)
         kernel = grp.broadcast_int(best[0], 0)   # all ranks run the same kernel
     else:
-        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM}[args.kernel]
+        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM,
+                  "strips": S.KERNEL_STRIPS, "wgstream": S.KERNEL_WGSTREAM}[args.kernel]
 
     barrier = grp.barrier
 

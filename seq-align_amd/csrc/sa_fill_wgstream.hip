@@ -1,4 +1,4 @@
-// sa_fill_wgstream.hip -- long rows (1 024 .. 4 095 columns), many pairs: ONE WORKGROUP
+// sa_fill_wgstream.hip -- long rows (513 .. 4 096 columns), many pairs: ONE WORKGROUP
 // per pair, the row split over four waves, output through a shared LDS ring in aligned
 // 1 KiB blocks.
 //
@@ -215,7 +215,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
 
 bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
   if (sa::needs_general(p)) return false;
-  if (max_len_a + 1 <= 1024 || max_len_a + 1 > 8 * sa::kWave * sa::kWgMaxWaves) return false;
+  if (max_len_a + 1 <= 512 || max_len_a + 1 > 8 * sa::kWave * sa::kWgMaxWaves) return false;
   const uintptr_t m = (uintptr_t)p.M, a = (uintptr_t)p.A, b = (uintptr_t)p.B;
   return ((m ^ a) & 4095) == 0 && ((m ^ b) & 4095) == 0;
 }
@@ -244,6 +244,8 @@ hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hi
   if (p.n_pairs == 0) return hipSuccess;
   // columns per lane from the batch's longest row: idle lanes still cost a ring slot and an issue slot
   const uint32_t W = max_len_a + 1;
+  if (W <= 3 * sa::kWave * 4) return sa::launch_wg<3, 4>(p, max_len_a, stream);
+  if (W <= 4 * sa::kWave * 4) return sa::launch_wg<4, 4>(p, max_len_a, stream);
   if (W <= 5 * sa::kWave * 4) return sa::launch_wg<5, 4>(p, max_len_a, stream);
   if (W <= 6 * sa::kWave * 4) return sa::launch_wg<6, 4>(p, max_len_a, stream);
   if (W <= 8 * sa::kWave * 4) return sa::launch_wg<8, 4>(p, max_len_a, stream);

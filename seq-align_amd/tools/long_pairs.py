@@ -17,6 +17,8 @@ ctx = S.Context(0)
 sc = S.make_scoring({"preset": "default"})
 h = ctx.upload_scoring(sc, 0)
 sizes = [(1, 10000), (1, 20000), (16, 5000), (200, 2000), (512, 2000), (2000, 2000), (1000, 1000), (256, 1000), (64, 1000), (64, 600), (512, 600), (4096, 600)]
+if len(sys.argv) > 1 and sys.argv[1] == 'mid':   # 513..1023 columns: stream (12/16 columns per lane) vs wgstream
+    sizes = [(64, 1000), (256, 1000), (1000, 1000), (4000, 1000), (512, 600), (4096, 600), (20000, 600), (2000, 800)]
 if len(sys.argv) > 1 and sys.argv[1] == 'wg':   # the regime of sa_fill_wgstream.hip
     sizes = [(16, 2000), (64, 2000), (200, 2000), (512, 2000), (2000, 2000), (100, 4000), (500, 4000), (64, 1500), (1000, 1500), (4000, 1200)]
 for n, length in sizes:

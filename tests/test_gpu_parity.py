@@ -368,7 +368,7 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
 
 @pytest.mark.parametrize("pad_cells", [32, 1])
 def test_workgroup_stream_kernel_long_rows(ctx, pad_cells):
-    """sa_fill_wgstream.hip: rows of 1 025 .. 4 095 columns split over 4 or 8 waves of one
+    """sa_fill_wgstream.hip: rows of 513 .. 4 096 columns split over 4 or 8 waves of one
     workgroup -- every columns-per-lane / wave-count instantiation, both ends of its range,
     NW / SW / protein table, pairs starting at arbitrary 4-byte offsets (pad_cells=1)."""
     rng = W.Rng(404)
@@ -376,13 +376,13 @@ def test_workgroup_stream_kernel_long_rows(ctx, pad_cells):
     def rand(n, alpha=b"ACGT"):
         return bytes(alpha[i] for i in rng.below(len(alpha), n))
 
-    lens = [1024, 1279, 1280, 1535, 1536, 2047, 2048, 2559, 2560, 3071, 3072, 4095]
+    lens = [512, 767, 768, 1023, 1024, 1279, 1280, 1535, 1536, 2047, 2048, 2559, 2560, 3071, 3072, 4095]
     for spec, is_sw, alpha in (({"preset": "default"}, 0, b"ACGT"), ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 1, b"ACGT"),
                                ({"preset": "BLOSUM62"}, 1, b"ARNDCQEGHILKMFPSTWYV")):
         sc = S.make_scoring(spec)
         osc = oracle_scoring_of(sc)
         h = ctx.upload_scoring(sc, is_sw)
-        for group in (lens[:3], lens[3:6], lens[6:9], lens[9:]):     # one launch per instantiation family
+        for group in (lens[:2], lens[2:4], lens[4:7], lens[7:10], lens[10:13], lens[13:]):   # one launch per family
             pairs = [(rand(la, alpha), rand(40 + (la % 37), alpha)) for la in group] + [(rand(group[0] - 300, alpha), b"")]
             batch = W.from_pairs(pairs)
             db = S.DeviceBatch(batch, 0, pad_cells=pad_cells, placement="packed")
