@@ -24,7 +24,7 @@ try:
 except OSError:
     pass
 
-OURS = ("fill_rowscan", "fill_wavefront", "fill_stream", "sw_reduce")
+OURS = ("fill_rowscan", "fill_wavefront", "fill_stream", "fill_wgstream", "fill_strips", "sw_reduce", "sw_enumerate", "traceback")
 
 
 def short(name):
