@@ -26,15 +26,16 @@
 //      (block k by wave k mod 4) -- every wave is past the barrier of this row, so all of
 //      the previous row is in LDS.
 //
-// Fast path only (no no_end_gap / no_gaps_in_* / sentinels, gap_open <= 0): other scorings
-// stay on the strip kernels.
+// GENERAL (no_end_gap / no_gaps_in_* / sentinels / gap_open > 0) is a template flag with the
+// case analysis of RowSweep<.., GENERAL>; a free last row combines without the penalties, a
+// forced row (no_gaps_in_b) is the floor.
 #include "sa_rowsweep.hpp"
 
 namespace sa {
 
 constexpr int kWgMaxWaves = 8;   // 4 waves up to 2 048 columns, 8 up to 4 096 (8 columns per lane)
 
-template <int CPL, int SUBST, int kWgWaves>
+template <int CPL, int SUBST, int kWgWaves, bool GENERAL>
 __global__ void __launch_bounds__(kWave *kWgWaves)
 fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per matrix */) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -59,6 +60,13 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   const uint32_t W = la + 1;
   const int floor_ = p.floor, open1 = p.open1, ext = p.ext;
   const Border bd{p.floor, p.gap_open, p.ext, (p.flags & SA_F_IS_SW) != 0, (p.flags & SA_F_NO_START_GAP) != 0};
+  // GENERAL (reference alignment.c:101-155): no_end_gap / no_gaps_in_a / no_gaps_in_b, sentinels in the
+  // substitution scores, gap_open > 0 -- same case analysis as RowSweep<.., GENERAL> in sa_rowsweep.hpp
+  const bool no_end = (p.flags & SA_F_NO_END_GAP) != 0, no_gaps_a = (p.flags & SA_F_NO_GAPS_A) != 0,
+             no_gaps_b = (p.flags & SA_F_NO_GAPS_B) != 0;
+  __shared__ unsigned long long s_err;          // first cell without a score (GENERAL)
+  if (threadIdx.x == 0) s_err = ~0ull;
+  unsigned long long err = ~0ull;
 
   // stream positions (all wave-uniform, identical in the four waves)
   const uint32_t a0 = (uint32_t)(((uintptr_t)(p.M + mo) >> 2) & 255u);   // arenas are congruent mod 4 KiB
@@ -69,6 +77,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   // my columns: g = L*CPL + c, L = wave*64 + lane
   const uint32_t g_first = (wave * kWave + (uint32_t)lane) * CPL;
   int fa[CPL], arow[CPL], X[CPL], Ap[CPL], c1[CPL], c2[CPL], c3[CPL];
+  int Y[GENERAL ? CPL : 1];                     // previous row: max(M, B) (GENERAL: gap_a opens from it)
   uint32_t wr[CPL];                             // ring index of my cells in the row being written
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
@@ -78,6 +87,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     arow[c] = (code >> 8) * (int)p.K;
     const int b0 = bd.edge_gap(g);              // row 0: M = A = floor, B = edge
     X[c] = (g == 0) ? 0 : max(floor_, b0);
+    if constexpr (GENERAL) Y[c] = X[c];
     Ap[c] = (g == 0) ? 0 : floor_;
     const int g_ext = (int)g * ext;
     c1[c] = open1 - g_ext; c2[c] = floor_ - g_ext; c3[c] = g_ext;
@@ -147,8 +157,21 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int s = subst_score<SUBST>(fa[c], arow[c], code_b, table, p.gen_eq, p.gen_ne);
-      int m = max(addw(xd, s), floor_);
-      int a = max3i(addw(X[c], open1), addw(Ap[c], ext), floor_);
+      int m, a;
+      if constexpr (GENERAL) {
+        const uint32_t g = g_first + c;
+        const int a_norm = max3i(addw(Y[c], open1), addw(Ap[c], ext), floor_);
+        m = (s == SA_S_BLOCKED) ? floor_ : max(addw(xd, s), floor_);
+        if (s == SA_S_UNKNOWN && g >= 1 && g <= la) {
+          m = floor_;
+          err = min(err, (unsigned long long)j * W + g);
+        }
+        const bool last_col = (g == la);
+        a = (last_col && no_end) ? max(Y[c], Ap[c]) : (!no_gaps_a || last_col) ? a_norm : floor_;
+      } else {
+        m = max(addw(xd, s), floor_);
+        a = max3i(addw(X[c], open1), addw(Ap[c], ext), floor_);
+      }
       if (c == 0) {   // border column (reference alignment.c:72-80): wave 0, lane 0
         const bool border = (wave == 0) && (lane == 0);
         m = border ? floor_ : m;
@@ -159,13 +182,21 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     }
 
     // ---- 2. gap_b: local part of the prefix max
+    bool free_row = false, forced = false;              // wave-uniform (reference alignment.c:139-155)
+    if constexpr (GENERAL) {
+      const bool last_row = (j == lb);
+      free_row = last_row && no_end;                    // max3 of the left cell: no penalty, no clamp
+      forced = no_gaps_b && !last_row;                  // gap_b is the floor
+    }
     const int zin = wave_shr1(z[CPL - 1], INT32_MIN);   // lane 0: the neighbour wave's term comes in step 3
     int P[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int zl = (c == 0) ? zin : z[c - 1];
-      int w = max(addw(zl, c1[c]), c2[c]);
-      if (c == 0) w = (lane == 0) ? c2[0] : w;          // wave 0: gap_b of (0, j) is the floor; others: step 3
+      int w = free_row ? zl : max(addw(zl, c1[c]), c2[c]);
+      // lane 0: wave 0 -- gap_b of (0, j) is the floor; other waves -- only the part that does not come
+      // from the neighbour (the floor term, or nothing at all on a free row)
+      if (c == 0) w = (lane == 0) ? (free_row ? (wave == 0 ? floor_ : INT32_MIN) : c2[0]) : w;
       P[c] = (c == 0) ? w : max(P[c - 1], w);
     }
     const int incl = wave_scan_max(P[CPL - 1]);
@@ -183,7 +214,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
         const int zu = slots[par + 2 * u], tu = slots[par + 2 * u + 1];
         // wave u+1's incoming term: z_last[u] + c1(first column of wave u+1)
         const int g_next = (u + 1) * kWave * CPL;
-        const int t_next = addw(zu, open1 - g_next * ext);
+        const int t_next = free_row ? zu : addw(zu, open1 - g_next * ext);
         if ((uint32_t)u + 1 == wave) { left_total = tu; left_carry = carry; left_z = zu; }
         carry = max(carry, max(tu, t_next));
       }
@@ -191,14 +222,16 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int pm = max(max(P[c], e), carry);
-      bv[c] = addw(pm, c3[c]);
+      bv[c] = forced ? floor_ : (free_row ? pm : addw(pm, c3[c]));
       X[c] = max(z[c], bv[c]);
+      if constexpr (GENERAL) Y[c] = max(mv[c], bv[c]);
       Ap[c] = av[c];
     }
     // ---- 4. my left neighbour column's max3 of this row, for the next row's diagonal
     if (wave > 0) {
       const int g_left = (int)(wave * kWave * CPL) - 1;
-      const int b_left = addw(max(left_total, left_carry), g_left * ext);
+      const int pm_left = max(left_total, left_carry);
+      const int b_left = forced ? floor_ : (free_row ? pm_left : addw(pm_left, g_left * ext));
       boundX = max(left_z, b_left);
     }
 
@@ -208,13 +241,18 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   }
   __syncthreads();
   flush_upto(vend, true);
-  if (threadIdx.x == 0) p.status[pair] = ~0ull;
+  if constexpr (GENERAL) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) err = min(err, __shfl_xor(err, o));
+    if (lane == 0 && err != ~0ull) atomicMin(&s_err, err);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.status[pair] = GENERAL ? s_err : ~0ull;
 }
 
 }  // namespace sa
 
 bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
-  if (sa::needs_general(p)) return false;
   if (max_len_a + 1 <= 512 || max_len_a + 1 > 8 * sa::kWave * sa::kWgMaxWaves) return false;
   const uintptr_t m = (uintptr_t)p.M, a = (uintptr_t)p.A, b = (uintptr_t)p.B;
   return ((m ^ a) & 4095) == 0 && ((m ^ b) & 4095) == 0;
@@ -228,13 +266,16 @@ static hipError_t launch_wg(const SaFillParams &p, uint32_t max_len_a, hipStream
   const uint32_t R = (256 + (max_len_a + 1) + span + 255) / 256 * 256;
   const dim3 grid(p.n_pairs), block(kWave * NW);
   size_t lds = ((size_t)3 * R + 2 * NW * 2) * sizeof(int32_t);
+  const bool general = needs_general(p);
   if (p.K <= 1) {
-    hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_SIMPLE, NW>), grid, block, lds, stream, p, R);
+    if (general) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_SIMPLE, NW, true>), grid, block, lds, stream, p, R);
+    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_SIMPLE, NW, false>), grid, block, lds, stream, p, R);
   } else if (p.K <= SA_LDS_TABLE_MAX_K) {
     lds += (size_t)p.K * p.K * sizeof(int32_t);
-    hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_LDS, NW>), grid, block, lds, stream, p, R);
+    if (general) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_LDS, NW, true>), grid, block, lds, stream, p, R);
+    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_LDS, NW, false>), grid, block, lds, stream, p, R);
   } else {
-    hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_GLOBAL, NW>), grid, block, lds, stream, p, R);
+    hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_GLOBAL, NW, true>), grid, block, lds, stream, p, R);
   }
   return hipGetLastError();
 }

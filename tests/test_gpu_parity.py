@@ -371,6 +371,7 @@ def test_workgroup_stream_kernel_long_rows(ctx, pad_cells):
     """sa_fill_wgstream.hip: rows of 513 .. 4 096 columns split over 4 or 8 waves of one
     workgroup -- every columns-per-lane / wave-count instantiation, both ends of its range,
     NW / SW / protein table, pairs starting at arbitrary 4-byte offsets (pad_cells=1)."""
+    import torch
     rng = W.Rng(404)
 
     def rand(n, alpha=b"ACGT"):
@@ -388,8 +389,57 @@ def test_workgroup_stream_kernel_long_rows(ctx, pad_cells):
             db = S.DeviceBatch(batch, 0, pad_cells=pad_cells, placement="packed")
             db.M.fill_(-7); db.A.fill_(-7); db.B.fill_(-7)
             db.fill(ctx, h, S.KERNEL_WGSTREAM)
+            torch.cuda.synchronize()
             assert_pairs_match_oracle(db, batch, osc, is_sw, range(batch.n_pairs), tag=f"wgstream {spec} {group}")
         ctx.release_scoring(h)
+
+
+def test_workgroup_stream_kernel_general_scorings(ctx):
+    """sa_fill_wgstream.hip, GENERAL instantiations: free end gaps, no gaps in a / b, no
+    mismatches, gap_open > 0, a missing pair (status = first failing cell) -- on long rows."""
+    import torch
+    rng = W.Rng(505)
+
+    def rand(n, alpha=b"ACGT"):
+        return bytes(alpha[i] for i in rng.below(len(alpha), n))
+
+    groups = ([767, 1023], [1536, 2047], [2560, 4095])
+    specs = [({"init": [1, -2, -4, -1, 0, 1, 0, 0, 0, 0]}, 0), ({"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0]}, 0),
+             ({"init": [1, -2, -4, -1, 0, 0, 1, 0, 0, 0]}, 0), ({"init": [1, -2, -4, -1, 0, 0, 0, 1, 0, 0]}, 0),
+             ({"init": [1, -2, -4, -1, 0, 1, 0, 1, 0, 0]}, 1), ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 1, 0]}, 1),
+             ({"init": [1, -2, 2, -3, 0, 0, 0, 0, 0, 0]}, 0),
+             ({"init": [1, -2, -4, -1, 0, 1, 0, 0, 0, 0], "wildcards": [["N", -1]]}, 0)]
+    for spec, is_sw in specs:
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        h = ctx.upload_scoring(sc, is_sw)
+        for group in groups:
+            alpha = b"ACGTN" if spec.get("wildcards") else b"ACGT"
+            pairs = [(rand(la, alpha), rand(23 + la % 11, alpha)) for la in group]
+            batch = W.from_pairs(pairs)
+            db = S.DeviceBatch(batch, 0, pad_cells=1, placement="packed")
+            db.M.fill_(-7); db.A.fill_(-7); db.B.fill_(-7)
+            db.fill(ctx, h, S.KERNEL_WGSTREAM)
+            torch.cuda.synchronize()
+            assert_pairs_match_oracle(db, batch, osc, is_sw, range(batch.n_pairs), tag=f"wgstream general {spec} {group}")
+            assert (db.status.cpu().numpy() == -1).all()
+        ctx.release_scoring(h)
+    # a pair without a score: the first failing cell in row-major order, as the other kernels report it
+    sc = S.make_scoring({"preset": "DNA_hybridization"})
+    h = ctx.upload_scoring(sc, 0)
+    a = bytearray(rand(1500)); a[700] = ord("N"); a[20] = ord("N")
+    b = bytearray(rand(30)); b[3] = ord("X")
+    batch = W.from_pairs([(bytes(a), rand(30)), (rand(1500), bytes(b)), (rand(900), rand(12))])
+    got = {}
+    for kid in (S.KERNEL_ROWSCAN, S.KERNEL_WGSTREAM):
+        db = S.DeviceBatch(batch, 0, placement="packed")
+        db.fill(ctx, h, kid)
+        torch.cuda.synchronize()
+        got[kid] = db.status.cpu().numpy().view(np.uint64).copy()
+    assert np.array_equal(got[S.KERNEL_ROWSCAN], got[S.KERNEL_WGSTREAM])
+    assert got[S.KERNEL_WGSTREAM][0] == 1 * 1501 + 21 and got[S.KERNEL_WGSTREAM][1] == 4 * 1501 + 1
+    assert got[S.KERNEL_WGSTREAM][2] == S.STATUS_OK
+    ctx.release_scoring(h)
 
 
 def test_multi_context_calls_equal_single_context(ctx):
