@@ -35,6 +35,9 @@ namespace sa {
 
 constexpr int kWgMaxWaves = 8;   // 4 waves up to 2 048 columns, 8 up to 4 096 (8 columns per lane)
 
+// TIGHT (8 waves): the ring only holds the backlog plus ONE row (not the extra row of all lanes), so three
+// workgroups fit a CU instead of one: idle lanes do not write, and a second barrier separates the flush of
+// the previous rows from the append of the next.
 template <int CPL, int SUBST, int kWgWaves, bool GENERAL>
 __global__ void __launch_bounds__(kWave *kWgWaves)
 fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per matrix */) {
@@ -97,10 +100,11 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   if (wave > 0) { const uint32_t g = wave * kWave * CPL - 1; boundX = max(floor_, bd.edge_gap(g)); }
   __builtin_amdgcn_s_waitcnt(kWaitVm0);
 
+  constexpr bool TIGHT = kWgWaves > 4;
   auto append = [&](const int (&mv)[CPL], const int (&av)[CPL], const int (&bv)[CPL]) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      ring[wr[c]] = mv[c]; ring[R + wr[c]] = av[c]; ring[2 * R + wr[c]] = bv[c];
+      if (!TIGHT || g_first + c < W) { ring[wr[c]] = mv[c]; ring[R + wr[c]] = av[c]; ring[2 * R + wr[c]] = bv[c]; }
       uint32_t n = wr[c] + W;                   // W <= R
       wr[c] = n >= R ? n - R : n;
     }
@@ -237,6 +241,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
 
     // ---- 5. flush what the previous rows completed, then append this row
     flush_upto(a0 + j * W, false);                      // rows 0 .. j-1 are in LDS (barrier above)
+    if constexpr (TIGHT) __syncthreads();               // nobody overwrites a block that is still being flushed
     append(mv, av, bv);
   }
   __syncthreads();
@@ -261,9 +266,11 @@ bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a) {
 namespace sa {
 template <int CPL, int NW>
 static hipError_t launch_wg(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
-  // ring: the unflushed backlog (< 256 + W) plus one row written by all NW*64*CPL lanes, in whole blocks
+  // ring: the unflushed backlog (< 256 + W) plus one row written by all NW*64*CPL lanes, in whole blocks;
+  // TIGHT (8 waves): the backlog after the flush (< 256) plus one row of W cells
   const uint32_t span = NW * kWave * CPL;
-  const uint32_t R = (256 + (max_len_a + 1) + span + 255) / 256 * 256;
+  const uint32_t R = NW > 4 ? (256 + (max_len_a + 1) + 255) / 256 * 256
+                            : (256 + (max_len_a + 1) + span + 255) / 256 * 256;
   const dim3 grid(p.n_pairs), block(kWave * NW);
   size_t lds = ((size_t)3 * R + 2 * NW * 2) * sizeof(int32_t);
   const bool general = needs_general(p);
