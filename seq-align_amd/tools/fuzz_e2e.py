@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the end-to-end calls (device traceback, device multi-hit enumeration)
+against the oracle: seqalign_nw_batch scores + strings, seqalign_sw_batch hit lists.
+
+    python seq-align_amd/tools/fuzz_e2e.py --seconds 300
+"""
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "seq-align_amd" / "python"))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402,F401
+
+import orclib as O  # noqa: E402
+import seqalign_amd as S  # noqa: E402
+from seqalign_amd import workloads as W  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = W.Rng(args.seed)
+ctx = S.Context(0)
+t_end = time.time() + args.seconds
+trials = nw_checked = sw_checked = 0
+
+
+def rand(n, alpha=b"ACGT"):
+    return bytes(alpha[i] for i in rng.below(len(alpha), n)) if n else b""
+
+
+while time.time() < t_end:
+    v = rng.below(1 << 20, 16).astype(int)
+    flags = [int(v[0] >> k) & 1 for k in range(5)]
+    match, mismatch = int(1 + v[1] % 4), -int(v[2] % 5)
+    go, ge = -int(v[3] % 8), -int(v[4] % 3)
+    if flags[2] and flags[3]:
+        mismatch = min(mismatch, go + ge)
+    spec = {"init": [match, mismatch, go, ge, *flags, int(v[5] & 1)], "wildcards": [["N", int(v[6] % 3) - 1]] if v[6] & 1 else []}
+    sc = S.make_scoring(spec)
+    osc = O.Scoring.from_buffer_copy(bytes(sc))
+    # pairs: random, related, and tandem repeats (many equal-score candidates, several hits)
+    pairs = []
+    for k in range(12):
+        kind = int(v[7] + k) % 3
+        la = int(2 + (v[8] * (k + 1)) % (260 if k % 4 else 900))
+        if kind == 0:
+            a, b = rand(la), rand(int(2 + (v[9] * (k + 3)) % 200))
+        elif kind == 1:
+            a = rand(la)
+            cut = int(v[10] % max(1, len(a)))
+            b = rand(int(v[11] % 30)) + a[cut:cut + 120] + rand(int(v[12] % 30))
+        else:
+            unit = rand(int(2 + v[13] % 7))
+            a, b = unit * int(2 + v[14] % 20), rand(3) + unit * int(2 + v[15] % 25)
+        if spec["wildcards"] and k % 5 == 0:
+            a = a[:len(a) // 2] + b"N" + a[len(a) // 2:]
+        pairs.append((a, b))
+    batch = W.from_pairs(pairs)
+    os.environ["SEQALIGN_TRACE_KERNEL"] = ("lane", "wave")[int(v[0] >> 7) & 1]
+    os.environ["SEQALIGN_SW_ENUM"] = ("wave", "lane", "wave")[int(v[0] >> 9) % 3]
+    if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
+        res = ctx.nw_batch(batch, sc)
+        for p, (a, b) in enumerate(pairs):
+            rc, s_, ra, rb = O.oracle_nw(osc, a, b)
+            if rc != 0 or res[p] != (s_, ra, rb):
+                print("NW MISMATCH", spec, p, pairs[p], res[p], (s_, ra, rb), flush=True)
+                sys.exit(1)
+        nw_checked += len(pairs)
+    thr = int(1 + v[5] % (6 * match))
+    max_hits = (1, 2, 5, 16, 40, 1 << 20)[int(v[4] >> 4) % 6]
+    got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=400000)
+    for p, (a, b) in enumerate(pairs):
+        rc, want = O.oracle_sw(osc, a, b, thr, max_hits)
+        if rc != 0 or got[p] != want:
+            print("SW MISMATCH", spec, "thr", thr, "max_hits", max_hits, p, pairs[p], flush=True)
+            sys.exit(1)
+    sw_checked += len(pairs)
+    trials += 1
+print(f"fuzz_e2e ok: {trials} random scorings x batches; {nw_checked} NW alignments, {sw_checked} SW hit lists identical to the oracle (seed {args.seed})")
