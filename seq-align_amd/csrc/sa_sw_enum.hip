@@ -172,12 +172,22 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
     __syncthreads();
 
     // ---- apply, in candidate order
+    // Nearly half of the candidates that get this far are "simple": the walk recorded one cell and met a
+    // marked one right after it.  All such a candidate ever does is set its own bit (its second cell was
+    // and stays marked), so a run of consecutive simple candidates commutes: one LDS atomic OR per lane for
+    // the whole run.  Only the others (longer recorded walks, walks that reached 0 or ran out of
+    // recording) are taken one by one, each after the simple ones in front of it.
+    const bool simple = valid && reason == R_CLASH && plen == 1;
+    const unsigned long long others = __ballot(valid && reason != R_SKIP && !simple);
     uint32_t cur = 0;
-    while (cur < nvalid) {
-      const bool want = valid && (uint32_t)lane >= cur && reason != R_SKIP && !seen_bit(seen, cell);
-      const unsigned long long m = __ballot(want);
-      if (m == 0) break;
-      const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+    for (;;) {
+      const unsigned long long rest = cur < 64 ? (others >> cur) << cur : 0ull;
+      const int i = rest ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest)) : 64;
+      if (simple && (uint32_t)lane >= cur && lane < i) atomicOr(&seen[cell >> 5], 1u << (cell & 31));
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (i >= 64) break;
+      cur = i + 1;
+      if (seen_bit(seen, (uint32_t)__builtin_amdgcn_readlane(cell, i))) continue;   // smith_waterman.c:269
       const int r_i = __builtin_amdgcn_readlane(reason, i), plen_i = __builtin_amdgcn_readlane(plen, i);
       bool clash = false;
 #pragma unroll
@@ -188,7 +198,6 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
           else seen[at >> 5] |= 1u << (at & 31);       // every lane writes the same word: same value
         }
       }
-      cur = i + 1;
       if (clash || r_i == R_CLASH) continue;
       if (r_i == R_ERR) { err = __builtin_amdgcn_readlane(lerr, i); done = true; break; }
 
