@@ -187,15 +187,15 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       if (i >= 64) break;
       cur = i + 1;
-      if (seen_bit(seen, (uint32_t)__builtin_amdgcn_readlane(cell, i))) continue;   // smith_waterman.c:269
       const int r_i = __builtin_amdgcn_readlane(reason, i), plen_i = __builtin_amdgcn_readlane(plen, i);
-      bool clash = false;
+      bool clash = false;   // a marked cell stops the replay; at s = 0 that is the "already marked" skip (:269)
 #pragma unroll
       for (int s = 0; s < kPath; ++s) {
         if (s < plen_i && !clash) {
           const uint32_t at = __builtin_amdgcn_readlane(path[s], i);
-          if (s > 0 && seen_bit(seen, at)) clash = true;
-          else seen[at >> 5] |= 1u << (at & 31);       // every lane writes the same word: same value
+          const uint32_t word = seen[at >> 5], bit = 1u << (at & 31);   // one read per cell: test and set
+          if (word & bit) clash = true;
+          else seen[at >> 5] = word | bit;               // every lane writes the same word: same value
         }
       }
       if (clash || r_i == R_CLASH) continue;
