@@ -7,8 +7,9 @@
  *   align_scoring_load_pairwise reference src/alignment_scoring_load.c:223-306
  *   the seq_file based pair iteration of align_from_file
  *                               reference src/alignment_cmdline.c:578-640
- * (seq_file / string_buffer / zlib are not vendored upstream; plain text only
- * here, no gzip.)  Implementation: seq-align_amd/host/sa_io.c.
+ * (seq_file / string_buffer are not vendored upstream; the sequence reader goes
+ * through zlib like upstream's, so files may be gzip-compressed; the scoring
+ * loaders take a FILE*.)  Implementation: seq-align_amd/host/sa_io.c.
  */
 #ifndef SEQALIGN_IO_H
 #define SEQALIGN_IO_H

@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <zlib.h>
 
 #include "seqalign_io.h"
 
@@ -30,6 +32,28 @@ static int read_line(FILE *f, line_t *ln)
     ln->b[ln->len++] = (char)c;
   }
   if(c == EOF && ln->len == 0) return 0;
+  while(ln->len && (ln->b[ln->len-1] == '\r' || ln->b[ln->len-1] == '\n')) ln->len--;
+  if(!ln->b) { ln->cap = 16; ln->b = malloc(ln->cap); }
+  ln->b[ln->len] = '\0';
+  return 1;
+}
+
+/* the same from a gzFile: zlib reads plain files as they are, so one reader serves .fa and .fa.gz
+   (the reference reads its sequence files through zlib too, alignment_cmdline.c via seq_file) */
+static int read_line_gz(gzFile f, line_t *ln)
+{
+  int c;
+  ln->len = 0;
+  while((c = gzgetc(f)) != -1) {
+    if(ln->len + 2 > ln->cap) {
+      ln->cap = ln->cap ? 2 * ln->cap : 256;
+      ln->b = realloc(ln->b, ln->cap);
+      if(!ln->b) { fprintf(stderr, "seqalign: out of memory\n"); exit(EXIT_FAILURE); }
+    }
+    if(c == '\n') break;
+    ln->b[ln->len++] = (char)c;
+  }
+  if(c == -1 && ln->len == 0) return 0;
   while(ln->len && (ln->b[ln->len-1] == '\r' || ln->b[ln->len-1] == '\n')) ln->len--;
   if(!ln->b) { ln->cap = 16; ln->b = malloc(ln->cap); }
   ln->b[ln->len] = '\0';
@@ -186,8 +210,7 @@ out:
 /* --------------------------------------------------------- sequence files */
 
 struct seqalign_reader {
-  FILE *f;
-  int owns;
+  gzFile f;            /* plain or gzip-compressed, zlib tells them apart */
   line_t line, name, seq;
   int have_line;       /* line holds an unread line */
 };
@@ -196,16 +219,16 @@ seqalign_reader_t *seqalign_reader_open(const char *path)
 {
   seqalign_reader_t *r = calloc(1, sizeof(*r));
   if(!r) return NULL;
-  if(strcmp(path, "-") == 0) r->f = stdin;
-  else { r->f = fopen(path, "r"); r->owns = 1; }
+  r->f = strcmp(path, "-") == 0 ? gzdopen(dup(STDIN_FILENO), "rb") : gzopen(path, "rb");
   if(!r->f) { free(r); return NULL; }
+  gzbuffer(r->f, 1 << 20);
   return r;
 }
 
 void seqalign_reader_close(seqalign_reader_t *r)
 {
   if(!r) return;
-  if(r->owns) fclose(r->f);
+  gzclose(r->f);
   free(r->line.b); free(r->name.b); free(r->seq.b);
   free(r);
 }
@@ -229,7 +252,7 @@ static void append_line(line_t *dst, const char *s, size_t n)
 static int next_line(seqalign_reader_t *r)
 {
   if(r->have_line) { r->have_line = 0; return 1; }
-  return read_line(r->f, &r->line);
+  return read_line_gz(r->f, &r->line);
 }
 
 int seqalign_reader_next(seqalign_reader_t *r, const char **name, const char **seq, size_t *seq_len)

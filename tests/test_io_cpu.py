@@ -131,3 +131,11 @@ def test_sequence_reader_fasta_fastq_plain(tmp_path):
     assert read_all(p) == [("@r1", "ACGT", 4), ("@r2 desc", "TTGA", 4)]
     p.write_text("ACGT\n\nTTGCA\r\nGG")
     assert read_all(p) == [("", "ACGT", 4), ("", "TTGCA", 5), ("", "GG", 2)]
+    # gzip-compressed input, as the reference reads through zlib (alignment_cmdline.c / seq_file)
+    import gzip
+    gz = tmp_path / "dna.fa.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(">seqA\nACAATAGAC\n>seqB\nACGAATAGAT\n" + ">long\n" + "ACGT" * 50000 + "\n")
+    got = read_all(gz)
+    assert got[:2] == [(">seqA", "ACAATAGAC", 9), (">seqB", "ACGAATAGAT", 10)]
+    assert got[2][0] == ">long" and got[2][2] == 200000 and got[2][1] == "ACGT" * 50000
