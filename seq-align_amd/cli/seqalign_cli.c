@@ -28,7 +28,7 @@ enum { TOOL_NW, TOOL_SW };
 
 typedef struct {
   int tool;
-  int case_sensitive, print_scores, print_seq, print_matrices, print_fasta, print_pretty, print_colour;
+  int case_sensitive, print_scores, print_seq, print_matrices, print_fasta, print_pretty, print_colour, zam;
   int min_score, min_score_set;
   unsigned max_hits; int max_hits_set;
   unsigned context;
@@ -135,6 +135,7 @@ static void parse_args(int argc, char **argv)
     else if(!strcasecmp(a, "--printfasta")) opt.print_fasta = 1;
     else if(!strcasecmp(a, "--pretty")) opt.print_pretty = 1;
     else if(!strcasecmp(a, "--colour")) opt.print_colour = 1;
+    else if(!strcasecmp(a, "--zam")) { if(opt.tool != TOOL_NW) die("--zam only valid with Needleman-Wunsch%s", ""); opt.zam = 1; }
     else if(!strcasecmp(a, "--stdin")) { opt.files1[opt.n_files] = "-"; opt.files2[opt.n_files++] = NULL; }
     else if(i + 1 >= argc) die("%s takes an argument", a);
     else if(!strcasecmp(a, "--match")) { if(!parse_int(argv[++i], &scoring.match)) die("Invalid --match argument ('%s') must be an int", argv[i]); match_set = 1; }
@@ -178,6 +179,8 @@ static void parse_args(int argc, char **argv)
   if(opt.tool == TOOL_NW && scoring.no_mismatches && (scoring.no_gaps_in_a || scoring.no_gaps_in_b))
     die("--nogaps.. --nomismatches cannot be used at together%s", "");
   if(!opt.seq1 && !opt.n_files) die("No input specified%s", "");
+  if(opt.zam && (opt.print_pretty || opt.print_scores || opt.print_colour || opt.print_fasta))
+    die("Cannot use --printscore, --printfasta, --pretty or --colour with --zam%s", "");
 
   /* keep min/max_penalty covering every penalty in use (see file header) */
   {
@@ -197,9 +200,29 @@ static void put_line(const char *mine, const char *other)
   else fputs(mine, stdout);
 }
 
+/* --zam (nw_cmdline.c:36-76): gaps as '_', a spacer line (' ' indel, '*' mismatch, '|' match), then the
+   number of mismatches and of indel columns */
+static void print_zam(const char *res_a, const char *res_b)
+{
+  size_t i, mismatches = 0, indels = 0;
+  fputs("Br1:", stdout);
+  for(i = 0; res_a[i]; i++) putc(res_a[i] == '-' ? '_' : res_a[i], stdout);
+  fputs("\n    ", stdout);
+  for(i = 0; res_a[i]; i++) {
+    const char x = res_a[i], y = res_b[i];
+    if(x == '-' || y == '-') { putc(' ', stdout); indels++; }
+    else if((scoring.case_sensitive && x != y) || tolower((unsigned char)x) != tolower((unsigned char)y)) { putc('*', stdout); mismatches++; }
+    else putc('|', stdout);
+  }
+  fputs("\nBr2:", stdout);
+  for(i = 0; res_b[i]; i++) putc(res_b[i] == '-' ? '_' : res_b[i], stdout);
+  printf("\n%zu %zu\n\n", mismatches, indels);
+}
+
 /* nw_cmdline.c:78-149 */
 static void print_nw(const rec_t *ra, const rec_t *rb, const char *res_a, const char *res_b, int score)
 {
+  if(opt.zam) { print_zam(res_a, res_b); return; }
   const char *na = ra->name[0] ? ra->name : NULL, *nb = rb->name[0] ? rb->name : NULL;
   if(opt.print_fasta && na) { fputs(na, stdout); putc('\n', stdout); }
   if(opt.print_fasta && opt.print_pretty && nb) { fputs(nb, stdout); putc('\n', stdout); }

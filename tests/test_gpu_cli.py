@@ -115,6 +115,17 @@ def test_nw_options_match_oracle(tmp_path):
             assert rc == 0 and blk == f"{ra.decode()}\n{rb.decode()}\nscore: {score}", (args, a, b)
 
 
+def test_zam_output():
+    """--zam (nw_cmdline.c:36-76): '_' for gaps, spacer line, mismatch and indel counts."""
+    sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    a, b = b"ACGTTTGACCA", b"ACGATTGCA"
+    rc, score, ra, rb = O.oracle_nw(sc, a, b)
+    ra, rb = ra.decode(), rb.decode()
+    sp = "".join(" " if "-" in (x, y) else "|" if x.lower() == y.lower() else "*" for x, y in zip(ra, rb))
+    want = f"Br1:{ra.replace('-', '_')}\n    {sp}\nBr2:{rb.replace('-', '_')}\n{sp.count('*')} {sp.count(' ')}\n\n"
+    assert run(NW, "--zam", a.decode(), b.decode()) == want
+
+
 def test_long_pair_takes_the_strip_pipeline(tmp_path):
     """One pair much longer than a wave's row (3 000 x 2 700, related): the fill runs as a
     pipeline of column strips (sa_fill_strips.hip); alignment and score equal the oracle's."""
