@@ -208,6 +208,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   SaFillParams p = make_params(scoring, batch);
   hipError_t e;
+  (void)hipGetLastError();   // the launchers report hipGetLastError(): start from a clean slate
   int which = pick_kernel(kernel);
   // a positive gap_extend (legal, absurd) breaks the row scan's saturating-add
   // identity; the wavefront kernel is exact for any sign

@@ -170,6 +170,7 @@ hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream
     if (best_q < 0 || best_q >= 0.97f) break;   // probe unavailable, or good enough (0.92-0.96 still costs 5-8 %)
   }
   if (!best[0]) return e != hipSuccess ? e : hipErrorOutOfMemory;
+  (void)hipGetLastError();   // a failed later attempt must not surface as the next launch's error
   for (int k = 0; k < 3; ++k) out[k] = best[k];
   if (quality) *quality = best_q;
   return hipSuccess;
