@@ -115,6 +115,13 @@ def test_nw_options_match_oracle(tmp_path):
             assert rc == 0 and blk == f"{ra.decode()}\n{rb.decode()}\nscore: {score}", (args, a, b)
 
 
+def test_plain_c_batch_example():
+    """seq-align_amd/examples/batch_example.c: the batch C-ABI from plain C (README.md:79-88's pairs)."""
+    exe = ROOT / "seq-align_amd" / "bin" / "batch_example"
+    want = "AC-AATAGAC\nACGAATAGAT\nscore: 1\n\nACGTGAC-AGAT\nGTG-GACGAGTA\nscore: -12\n\nC-AGACGT\nCGATA---\nscore: -11\n\n"
+    assert run(exe) == want
+
+
 def test_zam_output():
     """--zam (nw_cmdline.c:36-76): '_' for gaps, spacer line, mismatch and indel counts."""
     sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
