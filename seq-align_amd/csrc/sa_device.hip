@@ -224,7 +224,9 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     // 200 x 2 000^2 -- wgstream 3.3, strips 4.2; 4 000 x 1 000^2 -- wgstream 7.5, stream (16 columns per lane) 13.3;
     // 2 000 x 800^2 -- wgstream 2.6, stream 5.8; 20 000 x 600^2 -- stream (12 per lane) 13.1, wgstream 15.1.
     // 500 x 4 000^2 (8 waves, one-row ring) -- wgstream 18.3, rowscan 20.2; 100 x 4 000^2 -- strips 9.4, wgstream 12.4.
-    const bool wg_ok = batch->max_len_a + 1 > 768 && sa_wgstream_kernel_applicable(p, batch->max_len_a);
+    // 513..768 columns (stream: 12 per lane): 4 096 x 600^2 -- wgstream 2.89, stream 3.04; 20 000 x 600^2 -- 13.1 vs 15.1.
+    const bool wg_ok = sa_wgstream_kernel_applicable(p, batch->max_len_a) &&
+                       (batch->max_len_a + 1 > 768 || batch->n_pairs < 8192);
     const uint32_t few = !wg_ok ? 256u : (batch->max_len_a + 1 <= 2048 ? 128u : 256u);
     if (batch->max_len_a > 512 && batch->n_pairs < few) which = SEQALIGN_KERNEL_STRIPS;
     else if (wg_ok) which = SEQALIGN_KERNEL_WGSTREAM;
