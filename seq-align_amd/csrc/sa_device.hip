@@ -235,9 +235,12 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
   if (which == SEQALIGN_KERNEL_STREAM && !stream_ok) which = SEQALIGN_KERNEL_ROWSCAN;
   if (which == SEQALIGN_KERNEL_WGSTREAM && !sa_wgstream_kernel_applicable(p, batch->max_len_a))
     which = SEQALIGN_KERNEL_ROWSCAN;
-  if (which == SEQALIGN_KERNEL_STREAM && best_score && best_index) {
+  if ((which == SEQALIGN_KERNEL_STREAM || which == SEQALIGN_KERNEL_WGSTREAM) && best_score && best_index) {
     p.best_score = best_score; p.best_index = best_index;
-    if (sa_stream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b)) { if (best_done) *best_done = true; }
+    const bool reports = which == SEQALIGN_KERNEL_STREAM
+                             ? sa_stream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b)
+                             : sa_wgstream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b);
+    if (reports) { if (best_done) *best_done = true; }
     else p.best_score = nullptr, p.best_index = nullptr;
   }
   switch (which) {

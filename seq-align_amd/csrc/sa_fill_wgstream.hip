@@ -38,7 +38,7 @@ constexpr int kWgMaxWaves = 8;   // 4 waves up to 2 048 columns, 8 up to 4 096 (
 // TIGHT (8 waves): the ring only holds the backlog plus ONE row (not the extra row of all lanes), so three
 // workgroups fit a CU instead of one: idle lanes do not write, and a second barrier separates the flush of
 // the previous rows from the append of the next.
-template <int CPL, int SUBST, int kWgWaves, bool GENERAL>
+template <int CPL, int SUBST, int kWgWaves, bool GENERAL, bool BEST>
 __global__ void __launch_bounds__(kWave *kWgWaves)
 fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per matrix */) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -68,7 +68,8 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   const bool no_end = (p.flags & SA_F_NO_END_GAP) != 0, no_gaps_a = (p.flags & SA_F_NO_GAPS_A) != 0,
              no_gaps_b = (p.flags & SA_F_NO_GAPS_B) != 0;
   __shared__ unsigned long long s_err;          // first cell without a score (GENERAL)
-  if (threadIdx.x == 0) s_err = ~0ull;
+  __shared__ unsigned long long s_best;         // BEST: max over the workgroup of score << 32 | ~(column << 21 | row)
+  if (threadIdx.x == 0) { s_err = ~0ull; s_best = 0ull; }
   unsigned long long err = ~0ull;
 
   // stream positions (all wave-uniform, identical in the four waves)
@@ -144,6 +145,14 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     append(mv, av, bv);
   }
 
+  // BEST (SW, p.best_score set): the pair's best match_scores cell in the reference's hit order, as in
+  // sa_fill_stream.hip -- per column the highest score and the first row that reached it
+  int best_s[BEST ? CPL : 1], best_r[BEST ? CPL : 1];
+  if constexpr (BEST) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { best_s[c] = 0; best_r[c] = 0; }
+  }
+
   int chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
     const int q = (j - 1) & (kWave - 1);
@@ -183,6 +192,15 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
       }
       xd = X[c];
       mv[c] = m; av[c] = a; z[c] = max(m, a);
+    }
+
+    if constexpr (BEST) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const bool up = mv[c] > best_s[c];
+        best_s[c] = up ? mv[c] : best_s[c];
+        best_r[c] = up ? (int)j : best_r[c];
+      }
     }
 
     // ---- 2. gap_b: local part of the prefix max
@@ -253,6 +271,30 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     __syncthreads();
   }
   if (threadIdx.x == 0) p.status[pair] = GENERAL ? s_err : ~0ull;
+  if constexpr (BEST) {
+    int b = 0;
+    uint32_t tie = 0;   // (column << 21) | row of the best cell; lowest column, then lowest row, wins a tie
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t g = g_first + c;
+      if (g >= 1 && g <= la && best_s[c] > b) { b = best_s[c]; tie = (g << 21) | (uint32_t)best_r[c]; }
+    }
+    unsigned long long key = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)~tie;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o);
+      key = other > key ? other : key;
+    }
+    if (lane == 0 && (key >> 32) != 0) atomicMax(&s_best, key);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long k = s_best;
+      const uint32_t t = ~(uint32_t)k, col = t >> 21, row = t & ((1u << 21) - 1);
+      const int score = (int)(k >> 32);
+      p.best_score[pair] = score;
+      p.best_index[pair] = score > 0 ? (uint64_t)row * W + col : 0;
+    }
+  }
 }
 
 }  // namespace sa
@@ -274,19 +316,32 @@ static hipError_t launch_wg(const SaFillParams &p, uint32_t max_len_a, hipStream
   const dim3 grid(p.n_pairs), block(kWave * NW);
   size_t lds = ((size_t)3 * R + 2 * NW * 2) * sizeof(int32_t);
   const bool general = needs_general(p);
+  // best-cell reporting: SW only, rows / columns that fit the packed tie-break (21 / 11+ bits)
+  const bool best = p.best_score && p.best_index && (p.flags & SA_F_IS_SW);
+#define SA_WG_LAUNCH(SUBST_, GEN_, LDS_)                                                                              \
+  do {                                                                                                                \
+    if (best) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, true>), grid, block, LDS_, stream, p, R); \
+    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, false>), grid, block, LDS_, stream, p, R);     \
+  } while (0)
   if (p.K <= 1) {
-    if (general) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_SIMPLE, NW, true>), grid, block, lds, stream, p, R);
-    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_SIMPLE, NW, false>), grid, block, lds, stream, p, R);
+    if (general) SA_WG_LAUNCH(SA_SUBST_SIMPLE, true, lds);
+    else SA_WG_LAUNCH(SA_SUBST_SIMPLE, false, lds);
   } else if (p.K <= SA_LDS_TABLE_MAX_K) {
     lds += (size_t)p.K * p.K * sizeof(int32_t);
-    if (general) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_LDS, NW, true>), grid, block, lds, stream, p, R);
-    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_LDS, NW, false>), grid, block, lds, stream, p, R);
+    if (general) SA_WG_LAUNCH(SA_SUBST_LDS, true, lds);
+    else SA_WG_LAUNCH(SA_SUBST_LDS, false, lds);
   } else {
-    hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SA_SUBST_GLOBAL, NW, true>), grid, block, lds, stream, p, R);
+    SA_WG_LAUNCH(SA_SUBST_GLOBAL, true, lds);
   }
+#undef SA_WG_LAUNCH
   return hipGetLastError();
 }
 }  // namespace sa
+
+bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b) {
+  return p.best_score && p.best_index && (p.flags & SA_F_IS_SW) && sa_wgstream_kernel_applicable(p, max_len_a) &&
+         max_len_b < (1u << 21) && max_len_a + 1 <= (1u << 11);   // (column << 21 | row) must fit 32 bits
+}
 
 hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;

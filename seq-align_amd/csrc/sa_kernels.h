@@ -126,6 +126,7 @@ hipError_t sa_launch_fill_strips(const SaFillParams &p, uint32_t max_len_a, uint
 /* long rows (1024..4095 columns), fast-path scorings: one workgroup per pair, shared LDS ring */
 bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream);
+bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
                               const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,

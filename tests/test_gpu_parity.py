@@ -442,6 +442,31 @@ def test_workgroup_stream_kernel_general_scorings(ctx):
     ctx.release_scoring(h)
 
 
+def test_sw_best_hit_on_long_rows(ctx):
+    """sw_batch(max_hits=1) with the long sequence as seq_a: the workgroup kernel reports the best cell
+    itself (<= 2 048 columns; beyond that the separate reduction runs) -- hits equal the oracle's."""
+    rng = W.Rng(606)
+
+    def rand(n):
+        return bytes(b"ACGT"[i] for i in rng.below(4, n))
+
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = oracle_scoring_of(sc)
+    pairs = []
+    for la in (600, 900, 1024, 1500, 2047, 2600):
+        ref = rand(la)
+        cut = int(rng.below(la - 80, 1)[0])
+        read = ref[cut:cut + 60] + rand(5) + ref[cut + 65:cut + 80]
+        pairs.append((ref, read))
+    pairs += [(b"ACGT" * 300, b"ACGT" * 10), (rand(1300), b"")]         # ties across many columns; an empty read
+    for group in (pairs[:2] * 70, pairs[2:5] * 50, pairs[5:] * 50):      # >= 128 pairs: AUTO takes the workgroup kernel
+        batch = W.from_pairs(group)
+        got = ctx.sw_batch(batch, sc, 20, max_hits=1)
+        for p in range(0, batch.n_pairs, 7):
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 20, 1)
+            assert rc == 0 and got[p] == want, p
+
+
 def test_multi_context_calls_equal_single_context(ctx):
     """seqalign_*_batch_multi: the pairs split over several contexts (here three on the one
     device of the test box; one per GPU on a node) -- results identical to one context."""
