@@ -116,6 +116,7 @@ __device__ __forceinline__ bool seen_bit(const uint32_t *seen, uint32_t at) { re
 
 __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParams p) {
   extern __shared__ uint32_t seen[];
+  __shared__ uint32_t claim[256];   // per round: which lane owns a cell (light candidates, see "apply")
   const uint32_t pair = blockIdx.x;
   const int lane = threadIdx.x;
 
@@ -172,18 +173,35 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
     __syncthreads();
 
     // ---- apply, in candidate order
-    // Nearly half of the candidates that get this far are "simple": the walk recorded one cell and met a
-    // marked one right after it.  All such a candidate ever does is set its own bit (its second cell was
-    // and stays marked), so a run of consecutive simple candidates commutes: one LDS atomic OR per lane for
-    // the whole run.  Only the others (longer recorded walks, walks that reached 0 or ran out of
-    // recording) are taken one by one, each after the simple ones in front of it.
-    const bool simple = valid && reason == R_CLASH && plen == 1;
-    const unsigned long long others = __ballot(valid && reason != R_SKIP && !simple);
+    // Two thirds of the candidates that get this far are "light": the walk recorded one or two cells
+    // and then met a marked one.  All such a candidate does is test-and-set its first cell and, if that
+    // was free, set its second (the cell after it was and stays marked).  Light candidates whose cells
+    // are pairwise different commute, so a run of them is applied at once with LDS atomics; overlaps are
+    // found with a 256-slot claim table (the lowest lane keeps a slot; anyone else on that slot -- a true
+    // overlap or a hash collision -- is taken one by one instead, which is always exact).  Everything
+    // else (longer recorded walks, walks that reached 0 or ran out of recording) goes one by one, each
+    // after the light ones in front of it.
+    const bool light = valid && reason == R_CLASH && plen <= 2;   // (longer recordings: no gain, more collisions)
+    bool bulk = light;
+    {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) claim[lane * 4 + t] = 0xffffffffu;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const uint32_t h0 = (path[0] * 2654435761u) >> 24, h1 = (path[plen == 2 ? 1 : 0] * 2654435761u) >> 24;
+      if (light) { atomicMin(&claim[h0], (uint32_t)lane); atomicMin(&claim[h1], (uint32_t)lane); }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (light) bulk = claim[h0] == (uint32_t)lane && claim[h1] == (uint32_t)lane;
+    }
+    const unsigned long long others = __ballot(valid && reason != R_SKIP && !bulk);
     uint32_t cur = 0;
     for (;;) {
       const unsigned long long rest = cur < 64 ? (others >> cur) << cur : 0ull;
       const int i = rest ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest)) : 64;
-      if (simple && (uint32_t)lane >= cur && lane < i) atomicOr(&seen[cell >> 5], 1u << (cell & 31));
+      if (bulk && (uint32_t)lane >= cur && lane < i) {
+        const uint32_t b0 = 1u << (path[0] & 31);
+        const uint32_t was = atomicOr(&seen[path[0] >> 5], b0);        // smith_waterman.c:269 if it was set
+        if (!(was & b0) && plen == 2) atomicOr(&seen[path[1] >> 5], 1u << (path[1] & 31));
+      }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       if (i >= 64) break;
       cur = i + 1;
