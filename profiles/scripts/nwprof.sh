@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /root/repo/gpurun_out/nwprof -o s -- python /root/repo/seq-align_amd/tools/nw_profile.py 10000 > /root/repo/gpurun_out/nwprof.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /root/repo/gpurun_out/nwprof -o s -- python /root/repo/seq-align_amd/tools/nw_profile.py ${NW_PAIRS:-10000} > /root/repo/gpurun_out/nwprof.log 2>&1
 grep nw_batch /root/repo/gpurun_out/nwprof.log
 python - <<'PY'
 import csv,glob

@@ -4,6 +4,20 @@
 
 using namespace sa_host;
 
+namespace {
+// SEQALIGN_TIMING=1: wall-clock of the host-level stages on stderr (development aid)
+struct StageTimer {
+  bool on = getenv("SEQALIGN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[seqalign timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
+
 // ------------------------------------------------- host-level: chunked fill ---
 
 // split the batch into chunks whose matrices (12 B/cell) fit the budget
@@ -30,6 +44,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
                        const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done) {
   const uint64_t n = c.count;
   int rc;
+  StageTimer tm;
   // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
   const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t));
   if ((rc = ctx->h_desc.reserve(desc_bytes))) return rc;
@@ -53,6 +68,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
       memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
     }
   });
+  tm.lap("run_chunk: pack");
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
@@ -77,6 +93,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
   }
   if (rc) return rc;
+  tm.lap("run_chunk: enqueue H2D + fill");
   if (dev_out) *dev_out = d;
   return SEQALIGN_OK;
 }
@@ -210,6 +227,7 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
                                      int32_t *out_score) {
   const uint64_t n = c.count;
   int rc;
+  StageTimer tm;
   // per-pair slots of len_a+len_b chars in a compact device arena
   if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 16))) return rc;
   uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
@@ -235,7 +253,9 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
   HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 16, hipMemcpyDeviceToHost, st));
+  tm.lap("nw: enqueue traceback + D2H");
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  tm.lap("nw: wait for the GPU");
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
   for (uint64_t k = 0; k < n; ++k)
     if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
@@ -251,6 +271,7 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
       out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
     }
   });
+  tm.lap("nw: unpack strings");
   return SEQALIGN_OK;
 }
 
