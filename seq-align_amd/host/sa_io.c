@@ -31,7 +31,7 @@ static int read_line(FILE *f, line_t *ln)
     if(c == '\n') break;
     ln->b[ln->len++] = (char)c;
   }
-  if(c == EOF && ln->len == 0) return 0;
+  if(c == EOF && ln->len == 0) { if(ln->b) ln->b[0] = '\0'; return 0; }
   while(ln->len && (ln->b[ln->len-1] == '\r' || ln->b[ln->len-1] == '\n')) ln->len--;
   if(!ln->b) { ln->cap = 16; ln->b = malloc(ln->cap); }
   ln->b[ln->len] = '\0';
@@ -53,7 +53,7 @@ static int read_line_gz(gzFile f, line_t *ln)
     if(c == '\n') break;
     ln->b[ln->len++] = (char)c;
   }
-  if(c == -1 && ln->len == 0) return 0;
+  if(c == -1 && ln->len == 0) { if(ln->b) ln->b[0] = '\0'; return 0; }
   while(ln->len && (ln->b[ln->len-1] == '\r' || ln->b[ln->len-1] == '\n')) ln->len--;
   if(!ln->b) { ln->cap = 16; ln->b = malloc(ln->cap); }
   ln->b[ln->len] = '\0';
@@ -270,8 +270,12 @@ int seqalign_reader_next(seqalign_reader_t *r, const char **name, const char **s
   } else if(r->line.b[0] == '@') {                   /* FASTQ: 4-line records */
     set_line(&r->name, r->line.b, r->line.len);
     if(next_line(r)) set_line(&r->seq, r->line.b, r->line.len);
-    if(next_line(r) && r->line.b[0] == '+') (void)next_line(r);   /* quality line */
-    else r->have_line = 1;
+    /* '+' line and quality line; a line that is not '+' (truncated record) starts the next record.
+       At end of file there is no line to push back. */
+    if(next_line(r)) {
+      if(r->line.b[0] == '+') (void)next_line(r);
+      else r->have_line = 1;
+    }
   } else {                                           /* plain */
     set_line(&r->seq, r->line.b, r->line.len);
   }

@@ -161,6 +161,17 @@ def dna_nw_150(n_pairs: int, seed: int = 1, related: bool = False,
     return _fixed_batch(a, b)
 
 
+def dna_nw_indexed(first: int, n_pairs: int, seed: int = 5, length: int = 150) -> Batch:
+    """C5: pairs [first, first + n_pairs) of an unbounded stream of iid ACGT pairs.  Pair p draws
+    its 2*length letters from splitmix64 counter positions [p*2*length, (p+1)*2*length), so a
+    rank generates exactly its own shard of the 1 M-pair batch (contiguous pair-index
+    blocks) without materialising the rest, and every shard size sees the same pair p."""
+    rng = Rng(seed)
+    rng.counter = first * 2 * length
+    m = DNA[rng.below(4, n_pairs * 2 * length).astype(np.int64)].reshape(n_pairs, 2 * length)
+    return _fixed_batch(m[:, :length], m[:, length:])
+
+
 def dna_sw_read_vs_ref(n_pairs: int, seed: int = 2, read_len: int = 150,
                        ref_len: int = 1000) -> Batch:
     """C3: a = read (150) cut from b = ref (1000) with 5% subs + 1% indels."""
@@ -200,6 +211,14 @@ def ragged(n_pairs: int, seed: int, max_len: int, alphabet: bytes = b"ACGT",
             seqs.append(s.tobytes())
         pairs.append((seqs[0], seqs[1]))
     return from_pairs(pairs)
+
+
+def make(gen: str, n_pairs: int, kwargs: dict) -> Batch:
+    """Generator by name, as the golden fixtures record it (tests/golden/configs.json)."""
+    kw = dict(kwargs)
+    if gen == "dna_nw_indexed":
+        return dna_nw_indexed(kw.pop("first", 0), n_pairs, **kw)
+    return globals()[gen](n_pairs, **kw)
 
 
 def default_minscore(match: int, len_a: int, len_b: int) -> int:

@@ -17,8 +17,8 @@ Files written next to this script:
   fill_small.json all 32 flag combinations x NW/SW on short ragged pairs, with
                   the three full matrices from aligner_align and, for NW, the
                   score + alignment strings from needleman_wunsch_align2.
-  configs.json    64 seeded pairs for each BASELINE config C2..C4: matrix
-                  digests from aligner_align, NW score/strings (C2).  SW hit
+  configs.json    64 seeded pairs for each BASELINE config C2..C5: matrix
+                  digests from aligner_align, NW score/strings (C2, C5).  SW hit
                   lists cannot come from the reference here (smith_waterman.c is
                   unbuildable without sort_r) and are therefore NOT in this file.
   prng.json       splitmix64 self-test so both sides regenerate equal inputs.
@@ -215,6 +215,10 @@ CONFIG_SPECS = {
     "C3": dict(gen="dna_sw_read_vs_ref", kwargs=dict(seed=2), is_sw=1,
                scoring={"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}),
     "C4": dict(gen="protein_sw_300", kwargs=dict(seed=3), is_sw=1, scoring={"preset": "BLOSUM62"}),
+    # C5 = 1 M pairs, seed 5, sharded 8 ways (workloads.dna_nw_indexed: pair p is the same in every shard
+    # size).  Two windows: the head of rank 0's share and the head of rank 7's share (pair 875 000).
+    "C5": dict(gen="dna_nw_indexed", kwargs=dict(first=0, seed=5), is_sw=0, scoring={"preset": "default"}),
+    "C5_rank7": dict(gen="dna_nw_indexed", kwargs=dict(first=875000, seed=5), is_sw=0, scoring={"preset": "default"}),
 }
 
 
@@ -222,7 +226,7 @@ def configs():
     out = {}
     for name, cfg in CONFIG_SPECS.items():
         sc = O.build_scoring(cfg["scoring"], "ref")
-        batch = getattr(W, cfg["gen"])(64, **cfg["kwargs"])
+        batch = W.make(cfg["gen"], 64, cfg["kwargs"])
         pairs = []
         for p in range(batch.n_pairs):
             a, b = batch.seq_a(p), batch.seq_b(p)

@@ -200,18 +200,93 @@ def test_sw_cli_text_and_perl_wrapper_grammar(tmp_path):
     assert n_hits >= 1
 
 
-def test_sw_cli_protein_matrix_file(tmp_path):
-    """--substitution_matrix with a file rendered from the BLOSUM62 preset gives
-    the hits of --scoring BLOSUM62 when match/mismatch are supplied too."""
-    import seqalign_amd as S
-    preset = S.make_scoring({"preset": "BLOSUM62"})
+def _matrix_text(letters, score):
+    """A substitution-matrix file as alignment_scoring_load.c:39-220 reads it: header line of column
+    characters, then one row per character."""
+    return ("# test matrix\n   " + "  ".join(letters) + "\n"
+            + "".join(a + " " + " ".join(str(score(a, b)) for b in letters) + "\n" for a in letters))
+
+
+def _sw_blocks(out):
+    """The CLI's text, one string per pair (each block ends with the '==' line)."""
+    return [b + "==\n" for b in out.split("==\n") if b]
+
+
+def test_sw_cli_substitution_matrix_file_vs_oracle(tmp_path):
+    """SURVEY 8f-4 (alignment_scoring_load.c:39-220 + the fill it feeds): scores loaded from a matrix FILE
+    by the CLI give the hits of an oracle scoring built independently from the same numbers -- (1) the
+    BLOSUM62 table rendered from tests/golden/presets.json (values extracted from the compiled reference),
+    (2) an asymmetric made-up DNA matrix with large entries, upper-case file vs mixed-case sequences."""
+    import json
+    spec62 = json.loads((ROOT / "tests" / "golden" / "presets.json").read_text())["BLOSUM62"]["spec"]
+    table = {(a, b): s for a, b, s in spec62["mutations"]}
     letters = "ARNDCQEGHILKMFPSTWYVBZX*"
     m = tmp_path / "b62.txt"
-    m.write_text("   " + "  ".join(letters) + "\n" + "".join(
-        a + " " + " ".join(str(preset.swap_scores[ord(a.lower())][ord(b.lower())]) for b in letters) + "\n" for a in letters))
-    batch = W.protein_sw_300(6, seed=4, length=80)
+    m.write_text(_matrix_text(letters, lambda a, b: table[(a.lower(), b.lower())]))
+    batch = W.protein_sw_300(12, seed=4, length=80)
     f = tmp_path / "prot.txt"
-    f.write_text("".join(f"{batch.seq_a(p).decode()}\n{batch.seq_b(p).decode()}\n" for p in range(6)))
-    common = ["--gapopen", "-10", "--gapextend", "-1", "--minscore", "15", "--maxhits", "3", "--file", str(f)]
-    assert run(SW, "--scoring", "BLOSUM62", *common) == \
-        run(SW, "--substitution_matrix", str(m), "--match", "1", "--mismatch", "-4", *common)
+    f.write_text("".join(f"{batch.seq_a(p).decode()}\n{batch.seq_b(p).decode()}\n" for p in range(12)))
+    # the CLI starts from the SW defaults 2/-2/-2/-1 (sw_cmdline.c:37-46); a matrix without --match switches
+    # the match/mismatch fallback off (alignment_cmdline.c: use_match_mismatch = 0)
+    osc = O.build_scoring({"init": [2, -2, -10, -1, 0, 0, 0, 0, 0, 0], "mutations": spec62["mutations"],
+                           "use_match_mismatch": 0}, "oracle")
+    for maxhits in (1, 3, 1 << 20):
+        out = run(SW, "--substitution_matrix", str(m), "--gapopen", "-10", "--gapextend", "-1", "--minscore", "15",
+                  *( ["--maxhits", str(maxhits)] if maxhits < (1 << 20) else []), "--file", str(f))
+        blocks = _sw_blocks(out)
+        assert len(blocks) == 12
+        for p, blk in enumerate(blocks):
+            a, b = batch.seq_a(p), batch.seq_b(p)
+            rc, hits = O.oracle_sw(osc, a, b, 15, maxhits)
+            assert rc == 0 and blk == expected_sw_text(p, a.decode(), b.decode(), hits), (maxhits, p)
+
+    def dna_score(a, b):
+        return 37 if a == b else -((ord(a) * 5 + ord(b) * 3) % 9) - 1   # asymmetric: (A,C) != (C,A)
+    m2 = tmp_path / "dna.txt"
+    m2.write_text(_matrix_text("ACGTN", dna_score))
+    rb = W.ragged(40, seed=12, max_len=90, alphabet=b"ACGT", lower_frac=0.3, extra=b"N")
+    pairs = [((rb.seq_a(p) or b"A"), (rb.seq_b(p) or b"c")) for p in range(40)]
+    f2 = tmp_path / "dna_pairs.txt"
+    f2.write_text("".join(f"{a.decode()}\n{b.decode()}\n" for a, b in pairs))
+    muts = [[a.lower(), b.lower(), dna_score(a, b)] for a in "ACGTN" for b in "ACGTN"]
+    osc = O.build_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0], "mutations": muts, "use_match_mismatch": 0}, "oracle")
+    blocks = _sw_blocks(run(SW, "--substitution_matrix", str(m2), "--minscore", "40", "--file", str(f2)))
+    assert len(blocks) == 40
+    for p, ((a, b), blk) in enumerate(zip(pairs, blocks)):
+        rc, hits = O.oracle_sw(osc, a, b, 40)
+        assert rc == 0 and blk == expected_sw_text(p, a.decode(), b.decode(), hits), p
+    # the same file through the global aligner: score + strings (min_penalty follows the loaded scores)
+    onw = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0], "mutations": muts, "use_match_mismatch": 0}, "oracle")
+    blocks = run(NW, "--printscores", "--substitution_matrix", str(m2), "--file", str(f2)).strip("\n").split("\n\n")
+    assert len(blocks) == 40
+    for (a, b), blk in zip(pairs, blocks):
+        rc, score, ra, rb_ = O.oracle_nw(onw, a, b)
+        assert rc == 0 and blk == f"{ra.decode()}\n{rb_.decode()}\nscore: {score}", (a, b)
+
+
+def test_cli_substitution_pairs_file_vs_oracle(tmp_path):
+    """alignment_scoring_load.c:223-306: a pair list ("a b score" per line, or with a one-character
+    separator) on top of --match/--mismatch; pairs not listed fall back to match/mismatch."""
+    listed = [["a", "c", -1], ["c", "a", 4], ["g", "t", 1], ["t", "t", 7], ["n", "a", 0], ["a", "n", 0]]
+    f1 = tmp_path / "pairs_ws.txt"
+    f1.write_text("# pairs\n" + "".join(f"{a.upper()} {b.upper()} {s}\n" for a, b, s in listed))
+    f2 = tmp_path / "pairs_sep.txt"
+    f2.write_text("".join(f"{a},{b},{s}\n" for a, b, s in listed))
+    rb = W.ragged(60, seed=13, max_len=70, alphabet=b"ACGT", lower_frac=0.2, extra=b"N")
+    pairs = [((rb.seq_a(p) or b"T"), (rb.seq_b(p) or b"t")) for p in range(60)]
+    seqs = tmp_path / "seqs.txt"
+    seqs.write_text("".join(f"{a.decode()}\n{b.decode()}\n" for a, b in pairs))
+    osw = O.build_scoring({"init": [3, -3, -2, -1, 0, 0, 0, 0, 0, 0], "mutations": listed}, "oracle")
+    onw = O.build_scoring({"init": [3, -3, -4, -1, 0, 0, 0, 0, 0, 0], "mutations": listed}, "oracle")
+    for pf in (f1, f2):
+        blocks = _sw_blocks(run(SW, "--substitution_pairs", str(pf), "--match", "3", "--mismatch", "-3", "--minscore", "12",
+                                "--file", str(seqs)))
+        assert len(blocks) == 60
+        for p, ((a, b), blk) in enumerate(zip(pairs, blocks)):
+            rc, hits = O.oracle_sw(osw, a, b, 12)
+            assert rc == 0 and blk == expected_sw_text(p, a.decode(), b.decode(), hits), (pf.name, p)
+        blocks = run(NW, "--printscores", "--substitution_pairs", str(pf), "--match", "3", "--mismatch", "-3",
+                     "--file", str(seqs)).strip("\n").split("\n\n")
+        for (a, b), blk in zip(pairs, blocks):
+            rc, score, ra, rb_ = O.oracle_nw(onw, a, b)
+            assert rc == 0 and blk == f"{ra.decode()}\n{rb_.decode()}\nscore: {score}", (pf.name, a, b)

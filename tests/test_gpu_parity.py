@@ -108,12 +108,12 @@ def test_fill_small_golden_all_flag_combinations(ctx, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KID)
-@pytest.mark.parametrize("name", ["C2", "C2_related", "C3", "C4"])
+@pytest.mark.parametrize("name", ["C2", "C2_related", "C3", "C4", "C5", "C5_rank7"])
 def test_config_golden_digests(ctx, kernel, name):
     """64 seeded pairs per BASELINE config: FNV digests from the compiled reference."""
     cfg = load("configs.json")[name]
     sc = S.make_scoring(cfg["scoring"])
-    batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
+    batch = W.make(cfg["gen"], cfg["n"], cfg["kwargs"])
     db = device_fill(ctx, batch, sc, cfg["is_sw"], kernel)
     for p, g in enumerate(cfg["pairs"]):
         M, A, B = db.pair_matrices(p)
@@ -201,6 +201,9 @@ FULL = {
     "C3": dict(gen=W.dna_sw_read_vs_ref, n=10000, kwargs=dict(seed=2), is_sw=1,
                scoring={"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}),
     "C4": dict(gen=W.protein_sw_300, n=4000, kwargs=dict(seed=3), is_sw=1, scoring={"preset": "BLOSUM62"}),
+    # BASELINE configs[4]: 1 M pairs over 8 GPUs = 125 000 pairs (34 GB of matrices) per GPU; rank 7's share
+    "C5": dict(gen=lambda n, **kw: W.dna_nw_indexed(875000, n, **kw), n=125000, kwargs=dict(seed=5), is_sw=0,
+               scoring={"preset": "default"}),
 }
 
 
@@ -220,7 +223,7 @@ def test_full_size_config_properties(ctx, name):
         batch.off_a[-1 - k], batch.off_b[-1 - k] = batch.off_a[k], batch.off_b[k]
     db1 = device_fill(ctx, batch, sc, cfg["is_sw"], S.KERNEL_WAVEFRONT)
     sums1 = [int(t.to(torch.int64).sum().item()) for t in (db1.M, db1.A, db1.B)]
-    M1 = db1.M.clone(); A1 = db1.A.clone(); B1 = db1.B.clone()
+    M1 = db1.M.clone(); A1 = db1.A.clone(); B1 = db1.B.clone()   # (C5: 3 x 11.4 GB, twice -- 288 GB of HBM)
     del db1
     for other in (S.KERNEL_ROWSCAN, S.KERNEL_STREAM):
         db2 = device_fill(ctx, batch, sc, cfg["is_sw"], other)
@@ -253,6 +256,51 @@ def test_full_size_config_properties(ctx, name):
         for p in sample:
             rc, s, _, _ = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
             assert rc == 0 and s == end[p]
+        if name == "C5":
+            # the share through the host-level call (H2D -> fill -> device traceback -> strings): the head of
+            # the share equals the compiled reference's strings (golden), a strided sample equals the oracle's
+            del db2
+            gold = load("configs.json")["C5_rank7"]["pairs"]
+            str_off, out_a, out_b, out_len, out_score = ctx.nw_batch(batch, sc, raw=True)
+
+            def got(p):
+                o, ln = int(str_off[p]), int(out_len[p])
+                return int(out_score[p]), out_a[o:o + ln].tobytes(), out_b[o:o + ln].tobytes()
+            for p, g in enumerate(gold):
+                assert got(p) == (g["score"], g["result_a"].encode(), g["result_b"].encode()), p
+            for p in list(range(8, batch.n_pairs, batch.n_pairs // 200)) + [batch.n_pairs - 9]:
+                rc, s, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+                assert rc == 0 and got(p) == (s, ra, rb), p
+            for k in range(8):   # the duplicated pairs
+                assert got(k) == got(batch.n_pairs - 1 - k)
+
+
+@pytest.mark.parametrize("kernel", [S.KERNEL_AUTO] + KERNELS, ids=KID)
+def test_positive_gap_extend(ctx, kernel):
+    """gap_extend > 0 (legal upstream: scoring_init takes any int, alignment_scoring.c:21-55).  The row-scan
+    kernels' de-trended prefix max assumes ext <= 0, so EVERY kernel request -- AUTO and explicit ones alike --
+    is served by the anti-diagonal kernel (sa_device.hip: fill_device); the matrices must still be the
+    reference recurrence's, and so must the alignments built from them."""
+    for spec in ({"init": [1, -2, -4, 1, 0, 0, 0, 0, 0, 0]}, {"init": [2, -3, -6, 2, 0, 1, 0, 0, 0, 0]},
+                 {"init": [1, -1, 0, 3, 1, 0, 0, 0, 0, 1]}):
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        batch = W.ragged(20, seed=spec["init"][3] * 11 + 1, max_len=130, lower_frac=0.2)
+        for is_sw in (0, 1):
+            db = device_fill(ctx, batch, sc, is_sw, kernel)
+            assert_pairs_match_oracle(db, batch, osc, is_sw, range(batch.n_pairs), tag=f"ext>0 {KID(kernel)} {spec}")
+    if kernel == S.KERNEL_AUTO:   # end to end: both device walkers' decision order with a positive extension
+        sc = S.make_scoring({"init": [1, -2, -4, 1, 0, 0, 0, 0, 0, 0]})
+        osc = oracle_scoring_of(sc)
+        batch = W.ragged(30, seed=8, max_len=90)
+        res = ctx.nw_batch(batch, sc)
+        got1, got5 = ctx.sw_batch(batch, sc, 5, max_hits=1), ctx.sw_batch(batch, sc, 5, max_hits=5)
+        for p in range(batch.n_pairs):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and res[p] == (s_, ra, rb), p
+            for got, mh in ((got1, 1), (got5, 5)):
+                rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 5, mh)
+                assert rc == 0 and got[p] == want, (p, mh)
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KID)
@@ -299,7 +347,7 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
     monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
     cfg = load("configs.json")["C2_related"]
     sc = S.make_scoring(cfg["scoring"])
-    batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
+    batch = W.make(cfg["gen"], cfg["n"], cfg["kwargs"])
     res = ctx.nw_batch(batch, sc)
     for p, g in enumerate(cfg["pairs"]):
         assert res[p] == (g["score"], g["result_a"].encode(), g["result_b"].encode())
@@ -364,6 +412,29 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
         for p in range(batch.n_pairs):
             rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
             assert rc == 0 and got[p] == want, (spec, p)
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_sw_batch_hit_lists_at_config_size(ctx, name, where, monkeypatch):
+    """seqalign_sw_batch at the BASELINE dimensions (150x1000 DNA / 300x300 BLOSUM62, --minscore 60): the ordered
+    hit lists of 64 seeded pairs, max_hits 1 and unlimited, against the committed ORACLE-DERIVED lists
+    (tests/golden/sw_hits_oracle.json -- the reference's smith_waterman.c cannot be built here) and a live
+    oracle run.  Reference: src/smith_waterman.c:137-277."""
+    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
+    g = load("sw_hits_oracle.json")[name]
+    sc = S.make_scoring({"preset": "BLOSUM62"} if g["scoring"] == "BLOSUM62" else g["scoring"])
+    osc = oracle_scoring_of(sc)
+    batch = W.make(g["gen"], g["n"], g["kwargs"])
+    for max_hits in (1, 1 << 20):
+        got = ctx.sw_batch(batch, sc, g["min_score"], max_hits=max_hits)
+        for p in range(batch.n_pairs):
+            want = [dict(score=h[0], pos_a=h[1], pos_b=h[2], len_a=h[3], len_b=h[4], a=h[5], b=h[6])
+                    for h in g["hits"][p][:max_hits]]
+            assert got[p] == want, (name, max_hits, p)
+            if p % 8 == 0:
+                rc, live = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), g["min_score"], max_hits)
+                assert rc == 0 and live == want
 
 
 @pytest.mark.parametrize("pad_cells", [32, 1])

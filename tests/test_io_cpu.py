@@ -129,6 +129,11 @@ def test_sequence_reader_fasta_fastq_plain(tmp_path):
                            (">seqC", "ACGTGACAGAT", 11), (">seqD", "GTGGACGAGTA", 11)]
     p.write_text("@r1\nACGT\n+\nIIII\n@r2 desc\nTTGA\n+r2\n@@II\n")
     assert read_all(p) == [("@r1", "ACGT", 4), ("@r2 desc", "TTGA", 4)]
+    # a FASTQ file that ends right after a sequence line (truncated record): no phantom record follows
+    p.write_text("@r1\nACGT\n+\nIIII\n@r2\nTTGA\n")
+    assert read_all(p) == [("@r1", "ACGT", 4), ("@r2", "TTGA", 4)]
+    p.write_text("@r1\nACGT")
+    assert read_all(p) == [("@r1", "ACGT", 4)]
     p.write_text("ACGT\n\nTTGCA\r\nGG")
     assert read_all(p) == [("", "ACGT", 4), ("", "TTGCA", 5), ("", "GG", 2)]
     # gzip-compressed input, as the reference reads through zlib (alignment_cmdline.c / seq_file)

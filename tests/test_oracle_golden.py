@@ -86,11 +86,11 @@ def test_fill_small_all_flag_combinations():
     assert n_mat > 700
 
 
-@pytest.mark.parametrize("name", ["C2", "C2_related", "C3", "C4"])
+@pytest.mark.parametrize("name", ["C2", "C2_related", "C3", "C4", "C5", "C5_rank7"])
 def test_config_vectors(name):
     cfg = load("configs.json")[name]
     sc = oracle_scoring(cfg["scoring"])
-    batch = getattr(W, cfg["gen"])(cfg["n"], **cfg["kwargs"])
+    batch = W.make(cfg["gen"], cfg["n"], cfg["kwargs"])
     for p, g in enumerate(cfg["pairs"]):
         a, b = batch.seq_a(p), batch.seq_b(p)
         assert f"{O.fnv(np.frombuffer(a + b'|' + b, np.uint8)):016x}" == g["input"]
@@ -120,3 +120,16 @@ def test_unknown_pair_is_reported_not_fatal():
     sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0], "use_match_mismatch": 0}, "oracle")
     rc, *_ = O.oracle_fill(sc, b"AC", b"AG", 0)
     assert rc == 1
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_oracle_derived_sw_hit_lists_are_current(name):
+    """tests/golden/sw_hits_oracle.json (ORACLE-derived, see make_sw_hits.py) equals a live oracle run."""
+    g = load("sw_hits_oracle.json")[name]
+    spec = load("presets.json")["BLOSUM62"]["spec"] if g["scoring"] == "BLOSUM62" else g["scoring"]
+    sc = O.build_scoring(spec, "oracle")
+    batch = W.make(g["gen"], g["n"], g["kwargs"])
+    for p in range(0, batch.n_pairs, 4):
+        rc, hits = O.oracle_sw(sc, batch.seq_a(p), batch.seq_b(p), g["min_score"])
+        assert rc == 0
+        assert [[h["score"], h["pos_a"], h["pos_b"], h["len_a"], h["len_b"], h["a"], h["b"]] for h in hits] == g["hits"][p]
