@@ -3,21 +3,31 @@
 
 A "step" = one pass of the hot path (seqalign_fill_batch_device: the fill of the
 match / gap_a / gap_b matrices, reference src/alignment.c:28-168) over one
-synthetic batch that is already resident in HBM.  Workload at N=1: BASELINE
-configs[1] -- 10 000 NW pairs, DNA 150x150, default scoring 1/-2/-4/-1.
-For N>1 (launched by torch.distributed.run, one rank per GPU) every rank fills
-its own 10 000-pair shard of a 10 000*N-pair batch: weak scaling, independent
-pairs, NO collective on the data path (the only collectives are the barrier and
-the MAX over ranks of the elapsed time).
+synthetic batch that is already resident in HBM.
+
+  N = 1 : BASELINE configs[1] (C2) -- 10 000 NW pairs, DNA 150x150, 1/-2/-4/-1.
+  N > 1 : BASELINE configs[4] (C5) -- 1 M NW pairs, DNA 150x150, seed 5, sharded by
+          contiguous pair index: rank g fills pairs [g*125 000, (g+1)*125 000) of the
+          1 M-pair stream (34 GB of matrices per GPU).  Per-GPU work is fixed, so
+          `scaling` is "weak"; at N = 8 the job is exactly C5.  `--scaling strong`
+          shards the whole 1 M pairs over N ranks instead (N >= 2: a shard must fit HBM).
+          Pairs are independent: NO collective on the data path.  The control plane
+          (barrier, MAX of the elapsed time, SUM of the cells) is two scalars over
+          torch.distributed "gloo" -- no RCCL needed (SEQALIGN_DIST_BACKEND=nccl uses it).
 
     python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus 8                     # launches its 8 ranks itself
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # or under a launcher
 
 Prints ONE JSON line (rank 0).  `value` = all ranks' cells / max-rank seconds.
-`roofline`  : algorithmic bytes per launch / mean kernel duration (HIP events on
-              the launch stream, recorded inside the timed region) vs 8 TB/s.
-`cpu_baseline`: the reference itself (oracle/_ref, built from /root/reference in
-              the authoring container) or, if absent, our C restatement
-              (oracle/), timed on this box's host cores on a bounded sample.
+`roofline`    : algorithmic bytes per launch / mean kernel duration (HIP events on
+                the launch stream, recorded inside the timed region) vs 8 TB/s.
+`e2e`         : wall clock of the host-level call on the same batch (host buffers in ->
+                H2D -> fill -> device traceback -> strings out), PCIe inclusive; never `value`.
+`cpu_baseline`: the reference itself (oracle/_ref, built from /root/reference in the
+                authoring container) or, if absent, our C restatement (oracle/), timed
+                on this box's host cores by a pthread harness (oracle/cpu_bench.c) on a
+                bounded sample: 1 pinned thread, and one thread per physical core.
 """
 from __future__ import annotations
 
@@ -25,6 +35,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,13 +48,14 @@ for p in (ROOT / "seq-align_amd" / "python", ROOT / "tests"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
-import seqalign_amd as S                     # noqa: E402
-from seqalign_amd import workloads as W      # noqa: E402
+from seqalign_amd import workloads as W      # noqa: E402  (numpy only; the HIP library loads in run())
 
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+C5_TOTAL_PAIRS = 1_000_000
+C5_RANKS = 8
 
 WORKLOADS = {
-    # name: (generator, kwargs, pairs per GPU, is_sw, scoring spec)
+    # name: (generator, kwargs, pairs per GPU, is_sw, scoring spec, description)
     "C2": ("dna_nw_150", dict(seed=1), 10000, 0, {"preset": "default"},
            "10k NW pairs, DNA 150x150, default scoring 1/-2/-4/-1 (BASELINE configs[1])"),
     "C3": ("dna_sw_read_vs_ref", dict(seed=2), 10000, 1, {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]},
@@ -51,108 +64,186 @@ WORKLOADS = {
               "1k NW pairs, DNA 1000x1000 (long-sequence check, not a BASELINE config)"),
     "C4": ("protein_sw_300", dict(seed=3), 4000, 1, {"preset": "BLOSUM62"},
            "4k SW pairs, protein 300x300, BLOSUM62 (BASELINE configs[3])"),
-    "C5": ("dna_nw_150", dict(seed=5), 125000, 0, {"preset": "default"},
-           "1M NW pairs, DNA 150x150, sharded over 8 GPUs: 125k pairs (34 GB of matrices) per GPU (BASELINE configs[4])"),
+    "C5": ("dna_nw_indexed", dict(seed=5), C5_TOTAL_PAIRS // C5_RANKS, 0, {"preset": "default"},
+           "1M NW pairs, DNA 150x150, seed 5, sharded over 8 GPUs: 125k pairs (34 GB of matrices) per GPU "
+           "(BASELINE configs[4])"),
 }
 
 
-def _ref_worker(args):
-    """aligner_align of the compiled reference over a slice of pairs, own aligner_t
-    (the reference is re-entrant per aligner object, SURVEY 8b threading).  ctypes
-    releases the GIL for the duration of each call, so threads run in parallel."""
-    import orclib as O
-    ref, sc, pairs, isw, deadline = args
-    al = O.Aligner()
-    C.memset(C.byref(al), 0, C.sizeof(al))
-    cells = done = 0
-    while time.perf_counter() < deadline:
-        for a, b in pairs:
-            ref.aligner_align(C.byref(al), a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), isw)
-            cells += len(a) * len(b)
-            done += 1
-    ref.aligner_destroy(C.byref(al))
-    return cells, done
+# ------------------------------------------------------------------ launcher ---
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def cpu_baseline(batch, spec, is_sw, budget_s=20.0):
-    """Reference CPU path on THIS host, bounded sample.  checker code: allowed here."""
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside any launcher: start the N ranks ourselves, one process per
+    GPU, same environment contract as torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Rank 0 owns stdout (the one JSON line); the others only stderr."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("SEQALIGN_BENCH_TIMEOUT", "3000"))
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:           # a rank that died leaves the others in the barrier: kill exactly our children
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
+def make_shard(name: str, rank: int, world: int, pairs: int, scaling: str):
+    """(batch of THIS rank, global pair count, first global pair index)."""
+    gen, kwargs, per_gpu, *_ = WORKLOADS[name]
+    if name == "C5":
+        total = (pairs * world) if pairs else (C5_TOTAL_PAIRS if scaling == "strong" else per_gpu * world)
+        lo, hi = W.shard_range(total, rank, world)
+        return W.dna_nw_indexed(lo, hi - lo, **kwargs), total, lo
+    per_gpu = pairs or per_gpu
+    total = per_gpu * world
+    full = getattr(W, gen)(total, **kwargs)
+    lo, hi = W.shard_range_cells(full.matrix_cells(), rank, world)
+    return full.slice(lo, hi), total, lo
+
+
+# -------------------------------------------------------------- cpu baseline ---
+def host_cpu_info() -> dict:
+    info = {"logical_cpus": os.cpu_count() or 1, "model": None, "physical_cores": None, "governor": None,
+            "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    try:
+        cores, phys, core = set(), None, None
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and not info["model"]:
+                info["model"] = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    try:
+        info["governor"] = Path("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor").read_text().strip()
+    except OSError:
+        info["governor"] = "unknown (no cpufreq sysfs)"
+    return info
+
+
+def cpu_baseline(batch, spec, is_sw, budget_s=18.0):
+    """Reference CPU path on THIS host, bounded sample.  Checker code (oracle/): allowed here, and only here
+    plus the out-of-timed-region spot check."""
     import orclib as O
-    n = batch.n_pairs
+    lib_path = ROOT / "oracle" / "libcpubench.so"
+    if not lib_path.exists():
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "libcpubench.so"], check=True, stdout=subprocess.DEVNULL)
+    hb = C.CDLL(str(lib_path))
+    hb.cpubench_run.restype = C.c_double
     ref = O.ref()
     if ref is not None:
+        kind, mode = "reference", 0
         sc = O.build_scoring(spec, "ref")
-        bufs = [(batch.seq_a(p), batch.seq_b(p)) for p in range(n)]
-        isw = C.c_char(bytes([is_sw]))
-        t0 = time.perf_counter()
-        cells, done = _ref_worker((ref, sc, bufs, isw, t0 + budget_s * 0.4))
-        dt = time.perf_counter() - t0
-        out = dict(value=cells / dt / 1e9, unit="GCUPS", cores=1, kind="reference",
-                   sample=f"{done} pairs ({cells} cells) through aligner_align of the compiled reference "
-                          f"(oracle/_ref), 1 thread, {dt:.1f} s")
-        # the same on every host core (one aligner_t per thread), reported next to the 1-thread figure
-        from concurrent.futures import ThreadPoolExecutor
-        cores = os.cpu_count() or 1
-        per = max(1, n // cores)
-        slices = [bufs[i * per:(i + 1) * per] or bufs[:per] for i in range(cores)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            res = list(ex.map(_ref_worker, [(ref, sc, sl, isw, t0 + budget_s * 0.25) for sl in slices]))
-        dt = time.perf_counter() - t0
-        out["all_cores"] = dict(value=sum(r[0] for r in res) / dt / 1e9, unit="GCUPS", cores=cores,
-                                sample=f"{sum(r[1] for r in res)} pairs over {cores} threads, {dt:.1f} s")
-        return out
-    import seqalign_amd
-    sc = O.Scoring.from_buffer_copy(bytes(seqalign_amd.make_scoring(spec)))
-    cells, secs, reps = 0, 0.0, 0
-    while secs < budget_s * 0.5:
-        chk = C.c_uint64(0)
-        secs += O.oracle().orc_time_fill_batch(C.byref(sc), batch.arena.ctypes.data_as(C.c_char_p),
-                                               batch.off_a.ctypes.data_as(C.c_void_p), batch.len_a.ctypes.data_as(C.c_void_p),
-                                               batch.off_b.ctypes.data_as(C.c_void_p), batch.len_b.ctypes.data_as(C.c_void_p),
-                                               C.c_size_t(n), C.c_int(is_sw), C.byref(chk))
-        cells += batch.cells()
-        reps += 1
-    return dict(value=cells / secs / 1e9, unit="GCUPS", cores=1, kind="port",
-                sample=f"{reps}x{n} pairs ({cells} cells) through orc_fill (oracle/, C restatement), 1 thread, {secs:.1f} s")
+        fn, destroy = C.cast(ref.aligner_align, C.c_void_p), C.cast(ref.aligner_destroy, C.c_void_p)
+        what = "aligner_align of the compiled reference (oracle/_ref, src/alignment.c:170-193)"
+    else:
+        kind, mode = "port", 1
+        import seqalign_amd
+        sc = O.Scoring.from_buffer_copy(bytes(seqalign_amd.make_scoring(spec)))
+        fn, destroy = C.cast(O.oracle().orc_fill, C.c_void_p), C.c_void_p(0)
+        what = "orc_fill of the C restatement (oracle/seqalign_oracle.c)"
+    n = min(batch.n_pairs, 20000)     # the sample the threads cycle over
+
+    def run(threads, seconds):
+        cells, pairs = C.c_uint64(0), C.c_uint64(0)
+        dt = hb.cpubench_run(fn, destroy, C.c_int(mode), C.byref(sc), batch.arena.ctypes.data_as(C.c_char_p),
+                             batch.off_a.ctypes.data_as(C.c_void_p), batch.len_a.ctypes.data_as(C.c_void_p),
+                             batch.off_b.ctypes.data_as(C.c_void_p), batch.len_b.ctypes.data_as(C.c_void_p),
+                             C.c_size_t(n), C.c_int(is_sw), C.c_int(threads), C.c_double(seconds),
+                             C.byref(cells), C.byref(pairs))
+        return cells.value / dt / 1e9, pairs.value, dt
+
+    cpu = host_cpu_info()
+    v1, p1, d1 = run(1, budget_s * 0.45)
+    out = dict(value=v1, unit="GCUPS", cores=1, kind=kind,
+               sample=f"{p1} pairs through {what}, fill only, 1 pinned thread, {d1:.1f} s (pthread harness oracle/cpu_bench.c)",
+               host=cpu)
+    cores = cpu["physical_cores"] or cpu["logical_cpus"]
+    if cpu.get("affinity_cpus"):
+        cores = min(cores, cpu["affinity_cpus"])
+    vn, pn, dn = run(cores, budget_s * 0.35)
+    out["all_cores"] = dict(value=vn, unit="GCUPS", cores=cores,
+                            sample=f"{pn} pairs, one aligner per thread, {cores} pinned threads (one per physical core), {dn:.1f} s")
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream", "strips", "wgstream"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
-                    help="output arenas: the library's spread allocator (seqalign_arenas_alloc) or one packed allocation")
-    args = ap.parse_args()
+# ----------------------------------------------------------------- plumbing ---
+def plumbing_test(args, rank, world, grp):
+    """CPU-only self-test of the multi-rank PLUMBING (launcher, sharding, reductions) -- NOT a measurement
+    and not the product: the oracle fills a handful of pairs so that tests/test_multigpu_cpu.py can check that
+    the ranks' shards concatenate to the single-process result.  Prints a line that says so."""
+    import orclib as O
+    batch, total, first = make_shard(args.workload, rank, world, args.pairs or 5, args.scaling)
+    sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    digests = []
+    for p in range(batch.n_pairs):
+        rc, M, A, B = O.oracle_fill(sc, batch.seq_a(p), batch.seq_b(p), 0)
+        digests.append([first + p, O.fnv(M), O.fnv(A), O.fnv(B)])
+    grp.barrier()
+    elapsed = grp.max_float(1.0 + rank)
+    cells = grp.sum_int(batch.cells())
+    gathered = grp.gather_objects(digests)
+    if rank == 0:
+        print(json.dumps({"metric": "PLUMBING_TEST_NOT_A_MEASUREMENT", "n_gpus": world, "global_pairs": total,
+                          "elapsed_max": elapsed, "cells_sum": cells,
+                          "digests": [d for part in gathered for d in part]}), flush=True)
+    grp.close()
+    return 0
 
-    import torch
+
+# ----------------------------------------------------------------------- run ---
+def run(args) -> int:
     from seqalign_amd.dist import Group, env_world
 
     rank, local, world = env_world()
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+    workload = args.workload or ("C2" if world == 1 else "C5")
+    args.workload = workload
+    backend = os.environ.get("SEQALIGN_DIST_BACKEND", "gloo")
+    if args.plumbing_test:
+        return plumbing_test(args, rank, world, Group("gloo"))
+
+    import torch
+    import seqalign_amd as S
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
-    # SEQALIGN_DIST_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to
-    # exercise the multi-process path on a 1-GPU box; the driver's runs use RCCL.
-    backend = os.environ.get("SEQALIGN_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    folded = world > n_dev            # fewer GPUs than ranks (1-GPU development box): ranks share devices
+    local = local % n_dev
     torch.cuda.set_device(local)
-    grp = Group(backend, torch.device("cuda", local) if backend == "nccl" else None)   # "nccl" is RCCL on ROCm
+    grp = Group(backend, torch.device("cuda", local) if backend == "nccl" else None)
 
-    gen, kwargs, per_gpu, is_sw, spec, desc = WORKLOADS[args.workload]
-    per_gpu = args.pairs or per_gpu
-    # one global batch, sharded by contiguous pair index: rank g owns [g*n/G, (g+1)*n/G)
-    batch = getattr(W, gen)(per_gpu * world, **kwargs).shard(rank, world)
+    gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
+    batch, global_pairs, first_pair = make_shard(workload, rank, world, args.pairs, args.scaling)
 
-    lib = S.lib()
+    lib = S.lib()                                    # raises if the HIP library is missing: no fallback
     ctx = S.Context(local)
     sc = S.make_scoring(spec)
     h = ctx.upload_scoring(sc, is_sw)
@@ -168,16 +259,13 @@ def main():
                 best = (k, m)
         kernel = grp.broadcast_int(best[0], 0)   # all ranks run the same kernel
     else:
-        kernel = {"wavefront": S.KERNEL_WAVEFRONT, "rowscan": S.KERNEL_ROWSCAN, "stream": S.KERNEL_STREAM,
-                  "strips": S.KERNEL_STRIPS, "wgstream": S.KERNEL_WGSTREAM}[args.kernel]
-
-    barrier = grp.barrier
+        kernel = {v: k for k, v in S.KERNEL_NAMES.items()}[args.kernel]
 
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         db.fill(ctx, h, kernel, order_after_current=False)
     torch.cuda.synchronize()
-    barrier()
+    grp.barrier()
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -188,54 +276,78 @@ def main():
         db.fill(ctx, h, kernel, order_after_current=False)
         ends[i].record(db.stream)
     torch.cuda.synchronize()
-    barrier()
+    grp.barrier()
     elapsed = time.perf_counter() - t0
 
     elapsed = grp.max_float(elapsed)               # MAX over ranks
     total_cells = grp.sum_int(batch.cells())       # whole-job cells per step
-
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    kern_ms_max = grp.max_float(kern_ms)
 
     # parity spot check outside the timed region (checker = oracle): bit-exact int32
-    bit_exact = None
-    if rank == 0:
-        import orclib as O
-        osc = O.Scoring.from_buffer_copy(bytes(sc))
-        bit_exact = True
-        for p in range(0, batch.n_pairs, max(1, batch.n_pairs // 16)):
-            rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
-            gM, gA, gB = db.pair_matrices(p)
-            bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
+    import orclib as O
+    osc = O.Scoring.from_buffer_copy(bytes(sc))
+    bit_exact = True
+    for p in range(0, batch.n_pairs, max(1, batch.n_pairs // 16)):
+        rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
+        gM, gA, gB = db.pair_matrices(p)
+        bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
+    bit_exact = grp.sum_int(0 if bit_exact else 1) == 0
+
+    # end to end through the host-level entry point on the same batch (never `value`)
+    e2e = None
+    if not args.no_e2e:
+        if is_sw:
+            thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
+            call, fn = "seqalign_sw_batch(max_hits=1)", lambda: ctx.sw_batch(batch, sc, thr, max_hits=1, raw=True)
+        else:
+            call, fn = "seqalign_nw_batch", lambda: ctx.nw_batch(batch, sc, raw=True)
+        fn()                                         # sizes the context's scratch buffers
+        walls = []
+        for _ in range(3):
+            grp.barrier()
+            t1 = time.perf_counter()
+            fn()
+            walls.append(time.perf_counter() - t1)
+        wall = grp.max_float(float(np.median(walls)))
+        e2e = {"call": call, "ms": wall * 1e3, "value": total_cells / wall / 1e9, "unit": "GCUPS",
+               "includes": "host pack, H2D, fill, device traceback, D2H of the strings, host unpack"}
 
     if rank == 0:
         alg_bytes = db.algorithmic_bytes()
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         prof = ROOT / "profiles" / "pmc_traffic.json"
         if prof.exists():
             try:
                 t = json.loads(prof.read_text())
-                key = f"{args.workload}:{S.KERNEL_NAMES[kernel]}:{batch.n_pairs}"
-                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+                key = f"{workload}:{S.KERNEL_NAMES[kernel]}:{batch.n_pairs}"
+                if key in t:
+                    traffic = t[key].get("hbm_bytes_per_launch")
+                    traffic_source = (f"static: profiles/pmc_traffic.json[{key}] <- {t[key].get('source', 'rocprofv3 --pmc passes')}"
+                                      " (PMC counters cannot be read from inside this process)")
             except Exception:
                 traffic = None
         out = {
             "metric": "dp_cell_updates_per_sec", "value": total_cells * args.steps / elapsed / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu": batch.n_pairs,
-                       "global_pairs": batch.n_pairs * world, "kernel": S.KERNEL_NAMES[kernel],
-                       "parallelism": f"pair-sharded x{world}, no collective",
+            "config": {"workload": f"{workload}: {desc}", "pairs_per_gpu": batch.n_pairs,
+                       "global_pairs": global_pairs, "kernel": S.KERNEL_NAMES[kernel],
+                       "parallelism": f"pair-sharded x{world}, no data-path collective; control plane: {backend}",
                        "arena_placement": args.placement, "arena_placement_quality": round(db.placement_quality, 3),
-                       "cells_per_step_per_gpu": batch.cells()},
+                       "cells_per_step_per_gpu": batch.cells(), "ranks_share_devices": folded},
             "bit_exact_vs_oracle": bool(bit_exact),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "kernel_ms_slowest_rank": kern_ms_max,
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if e2e:
+            out["e2e"] = e2e
         if is_sw:
-            # the SW local-maxima reduction, a separate kernel (4 B/cell read)
+            # the SW local-maxima reduction as a separate kernel (4 B/cell read)
             thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
             for i in range(11):
@@ -253,10 +365,38 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw)
         print(json.dumps(out), flush=True)
 
+    grp.barrier()
     ctx.release_scoring(h)
+    del db
     ctx.close()
     grp.close()
+    return 0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
+                    help="default: C2 at --gpus 1, C5 (125k pairs per GPU of the 1M-pair batch) at --gpus N > 1")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="C5 at N > 1: weak = 125k pairs per GPU (default), strong = 1M pairs over the N ranks")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream", "strips", "wgstream"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
+                    help="output arenas: the library's spread allocator (seqalign_arenas_alloc) or one packed allocation")
+    ap.add_argument("--plumbing-test", action="store_true",
+                    help="CPU-only check of launcher + sharding + reductions (tests/test_multigpu_cpu.py); not a measurement")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])      # no launcher around us: start the ranks ourselves
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

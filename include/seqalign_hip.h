@@ -245,7 +245,8 @@ int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
 
 /* ---- several GPUs from one process -------------------------------------------- */
 /* The same three calls over n_ctx contexts (normally one per GPU of the node): the
- * pairs are split into n_ctx contiguous index ranges, context g works on range g
+ * pairs are split into n_ctx contiguous index ranges of (nearly) equal DP cells --
+ * sum of (len_a+1)*(len_b+1), so ragged batches stay balanced -- context g works on range g
  * from its own host thread, nothing is exchanged between devices (the
  * path shards by pair, no collective).  Results are exactly those of the
  * single-context call.  hits/strings of the SW call come back in pair order; each

@@ -15,14 +15,36 @@ seqalign_batch_t sub_batch(const seqalign_batch_t *b, uint64_t first, uint64_t c
   return s;
 }
 
+// n_ctx + 1 pair indices cutting the batch into contiguous ranges of (nearly) equal DP cells
+// (balance ragged batches by W*H; contiguous, so results stay in pair order): edge k is the
+// pair boundary nearest to k/n_ctx of the cell total, ties to the later boundary -- the rule of
+// workloads.shard_edges_cells on the Python side.
+std::vector<uint64_t> shard_edges(const seqalign_batch_t *b, int n_ctx) {
+  const uint64_t n = b->n_pairs;
+  std::vector<uint64_t> cum(n + 1, 0);
+  for (uint64_t p = 0; p < n; ++p) cum[p + 1] = cum[p] + (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+  const uint64_t total = cum[n];
+  std::vector<uint64_t> edges((size_t)n_ctx + 1, 0);
+  for (int k = 1; k < n_ctx; ++k) {
+    const uint64_t t = (uint64_t)(((unsigned __int128)total * (unsigned)k) / (unsigned)n_ctx);
+    uint64_t i = (uint64_t)(std::lower_bound(cum.begin(), cum.end(), t) - cum.begin());
+    if (i > n) i = n;
+    if (i > 0 && t - cum[i - 1] < cum[i] - t) --i;
+    edges[k] = std::max(i, edges[k - 1]);
+  }
+  edges[n_ctx] = n;
+  return edges;
+}
+
 // run fn(g, first, count) for the n_ctx contiguous ranges, one host thread each; first error wins
 template <class F>
-int for_each_shard(int n_ctx, uint64_t n_pairs, F fn) {
+int for_each_shard(const std::vector<uint64_t> &edges, F fn) {
+  const int n_ctx = (int)edges.size() - 1;
   std::vector<int> rc((size_t)n_ctx, SEQALIGN_OK);
   std::vector<std::string> msg((size_t)n_ctx);
   std::vector<std::thread> th;
   for (int g = 0; g < n_ctx; ++g) {
-    const uint64_t first = n_pairs * (uint64_t)g / (uint64_t)n_ctx, last = n_pairs * (uint64_t)(g + 1) / (uint64_t)n_ctx;
+    const uint64_t first = edges[g], last = edges[g + 1];
     th.emplace_back([&, g, first, last] {
       rc[g] = last > first ? fn(g, first, last - first) : SEQALIGN_OK;
       if (rc[g]) msg[g] = seqalign_last_error();   // the message lives in the worker's thread
@@ -50,7 +72,7 @@ extern "C" int seqalign_fill_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
   if (bad_ctx_list(ctxs, n_ctx) || !batch || !mat_off) return SEQALIGN_E_ARG;
   int rc = check_batch(batch);
   if (rc) return rc;
-  return for_each_shard(n_ctx, batch->n_pairs, [&](int g, uint64_t first, uint64_t count) {
+  return for_each_shard(shard_edges(batch, n_ctx), [&](int g, uint64_t first, uint64_t count) {
     const seqalign_batch_t s = sub_batch(batch, first, count);   // mat_off[] are absolute cell offsets: shared arenas
     return seqalign_fill_batch(ctxs[g], &s, scoring, is_sw, mat_off + first, match_scores, gap_a_scores, gap_b_scores,
                                status ? status + first : nullptr);
@@ -63,7 +85,7 @@ extern "C" int seqalign_nw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   if (bad_ctx_list(ctxs, n_ctx) || !batch || !str_off || !out_len || !out_score) return SEQALIGN_E_ARG;
   int rc = check_batch(batch);
   if (rc) return rc;
-  return for_each_shard(n_ctx, batch->n_pairs, [&](int g, uint64_t first, uint64_t count) {
+  return for_each_shard(shard_edges(batch, n_ctx), [&](int g, uint64_t first, uint64_t count) {
     const seqalign_batch_t s = sub_batch(batch, first, count);   // str_off[] are absolute: shared string buffers
     return seqalign_nw_batch(ctxs[g], &s, scoring, str_off + first, out_a, out_b, out_len + first, out_score + first);
   });
@@ -81,12 +103,13 @@ extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   if (n == 0) return SEQALIGN_OK;
   // every range writes into its own slice of the caller's buffers; the slices are closed up afterwards
   std::vector<uint64_t> h0((size_t)n_ctx + 1), s0((size_t)n_ctx + 1), got((size_t)n_ctx, 0), used((size_t)n_ctx, 0);
+  const std::vector<uint64_t> edges = shard_edges(batch, n_ctx);
   for (int g = 0; g <= n_ctx; ++g) {
-    const uint64_t first = n * (uint64_t)g / (uint64_t)n_ctx;
+    const uint64_t first = edges[g];
     h0[g] = (uint64_t)((long double)hit_cap * first / n);
     s0[g] = (uint64_t)((long double)str_cap * first / n);
   }
-  rc = for_each_shard(n_ctx, n, [&](int g, uint64_t first, uint64_t count) {
+  rc = for_each_shard(edges, [&](int g, uint64_t first, uint64_t count) {
     const seqalign_batch_t s = sub_batch(batch, first, count);
     uint64_t found = 0;
     const int r = seqalign_sw_batch(ctxs[g], &s, scoring, min_score + first, max_hits, hits + h0[g], h0[g + 1] - h0[g],
@@ -101,7 +124,7 @@ extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   if (rc) return rc;
   uint64_t nh = 0, ns = 0;
   for (int g = 0; g < n_ctx; ++g) {
-    const uint64_t first = n * (uint64_t)g / (uint64_t)n_ctx;
+    const uint64_t first = edges[g];
     if (s0[g] != ns) {
       memmove(out_a + ns, out_a + s0[g], used[g]);
       memmove(out_b + ns, out_b + s0[g], used[g]);

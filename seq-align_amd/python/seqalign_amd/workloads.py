@@ -76,16 +76,43 @@ class Batch:
         o, n = int(self.off_b[p]), int(self.len_b[p])
         return self.arena[o:o + n].tobytes()
 
-    def shard(self, rank: int, world: int) -> "Batch":
-        """Contiguous pair-index block for one rank; no collective."""
-        lo, hi = shard_range(self.n_pairs, rank, world)
+    def slice(self, lo: int, hi: int) -> "Batch":
         return Batch(self.arena, self.off_a[lo:hi].copy(), self.len_a[lo:hi].copy(),
                      self.off_b[lo:hi].copy(), self.len_b[lo:hi].copy())
 
+    def shard(self, rank: int, world: int) -> "Batch":
+        """Contiguous pair-index block for one rank, cut at equal DP CELLS (balance
+        ragged batches by W*H, keep pair order); no collective."""
+        return self.slice(*shard_range_cells(self.matrix_cells(), rank, world))
+
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
-    """Pairs [lo, hi) owned by `rank`: block g gets [g*n/G, (g+1)*n/G)."""
+    """Pairs [lo, hi) owned by `rank` when every pair costs the same: block g gets [g*n/G, (g+1)*n/G)."""
     return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def shard_edges_cells(cells, world: int) -> list[int]:
+    """world+1 pair indices cutting a batch into contiguous blocks of (nearly) equal total cells:
+    edge k is the pair boundary nearest to k/world of the cell total (ties: the later boundary).
+    The same rule as for_each_shard in seq-align_amd/csrc/sa_multi.hip."""
+    cells = np.asarray(cells, dtype=np.uint64)
+    n = int(cells.shape[0])
+    cum = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cells, dtype=np.uint64)])
+    total = int(cum[-1])
+    edges = [0]
+    for k in range(1, world):
+        t = total * k // world
+        i = int(np.searchsorted(cum, np.uint64(t), side="left"))
+        if i > 0 and t - int(cum[i - 1]) < int(cum[min(i, n)]) - t:
+            i -= 1
+        edges.append(max(min(i, n), edges[-1]))
+    edges.append(n)
+    return edges
+
+
+def shard_range_cells(cells, rank: int, world: int) -> tuple[int, int]:
+    e = shard_edges_cells(cells, world)
+    return e[rank], e[rank + 1]
 
 
 def from_pairs(pairs: list[tuple[bytes, bytes]]) -> Batch:

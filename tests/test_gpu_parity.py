@@ -554,6 +554,11 @@ def test_multi_context_calls_equal_single_context(ctx):
         sb = W.dna_sw_read_vs_ref(50, seed=56, read_len=40, ref_len=200)
         for max_hits in (1, 5, 40):
             assert ctx.sw_batch(sb, sw, 6, max_hits=max_hits, peers=peers) == ctx.sw_batch(sb, sw, 6, max_hits=max_hits)
+        # ranges are cut at equal cells (sa_multi.hip: shard_edges): second half 10x longer sequences
+        r1, r2 = W.ragged(40, seed=57, max_len=30), W.dna_nw_150(40, seed=58, length=300, related=True)
+        lop = W.from_pairs([(r1.seq_a(p), r1.seq_b(p)) for p in range(40)] + [(r2.seq_a(p), r2.seq_b(p)) for p in range(40)])
+        assert ctx.nw_batch(lop, sc, peers=peers) == ctx.nw_batch(lop, sc)
+        assert ctx.sw_batch(lop, sw, 8, max_hits=3, peers=peers) == ctx.sw_batch(lop, sw, 8, max_hits=3)
         tiny = W.from_pairs([(b"ACGT", b"AGGT")])                        # fewer pairs than contexts
         assert ctx.nw_batch(tiny, sc, peers=peers) == ctx.nw_batch(tiny, sc)
     finally:

@@ -93,3 +93,45 @@ def test_two_ranks_gloo_reproduce_single_process():
     assert res["cells"] == full.cells()            # SUM over ranks
     assert res["elapsed"] == 2.0                   # MAX over ranks
     assert res["kernel"] == 3                      # broadcast from rank 0
+
+
+def test_cell_balanced_shards_on_a_ragged_batch():
+    """SURVEY 8e: a batch whose second half is 10x longer is cut at equal CELLS, not equal pair counts;
+    blocks stay contiguous (results keep pair order) and cover the batch."""
+    cells = np.array([100] * 1000 + [1000] * 1000, dtype=np.uint64)
+    for world in (2, 3, 8):
+        e = W.shard_edges_cells(cells, world)
+        assert e[0] == 0 and e[-1] == 2000 and all(a <= b for a, b in zip(e, e[1:]))
+        loads = [int(cells[e[g]:e[g + 1]].sum()) for g in range(world)]
+        assert max(loads) - min(loads) <= 1000            # within one (largest) pair
+        by_count = [int(cells[W.shard_range(2000, g, world)[0]:W.shard_range(2000, g, world)[1]].sum()) for g in range(world)]
+        assert max(loads) < max(by_count)                 # strictly better than splitting by pair count
+    # uniform batches: identical to the count-based split
+    assert W.shard_edges_cells(np.full(10000, 22801), 8) == [W.shard_range(10000, g, 8)[0] for g in range(8)] + [10000]
+    # degenerate: fewer pairs than ranks, empty batch
+    assert W.shard_edges_cells([7], 3)[-1] == 1 and W.shard_edges_cells([], 4) == [0, 0, 0, 0, 0]
+    b = W.ragged(50, seed=3, max_len=60)
+    parts = [b.shard(g, 4) for g in range(4)]
+    assert sum(p.n_pairs for p in parts) == 50
+    assert b"".join(p.seq_a(i) for p in parts for i in range(p.n_pairs)) == b"".join(b.seq_a(i) for i in range(50))
+
+
+def test_bench_launches_its_own_ranks_and_shards_c5():
+    """`python bench.py --gpus 2` outside any launcher starts two ranks itself (no torchrun, gloo control
+    plane, no RCCL) and shards BASELINE config 5's pair stream by contiguous index.  CPU box: --plumbing-test
+    makes the oracle fill a handful of pairs; what is checked is launcher + sharding + MAX/SUM reductions."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--plumbing-test", "--pairs", "5"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                 # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["global_pairs"] == 10 and res["elapsed_max"] == 2.0
+    full = W.dna_nw_indexed(0, 10, seed=5)                 # C5's stream: pair p is the same in every shard size
+    sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    want = []
+    for p in range(10):
+        rc, M, A, B = O.oracle_fill(sc, full.seq_a(p), full.seq_b(p), 0)
+        want.append([p, O.fnv(M), O.fnv(A), O.fnv(B)])
+    assert res["digests"] == want and res["cells_sum"] == full.cells()
