@@ -136,9 +136,11 @@ static int copy_out_pipelined(seqalign_ctx *ctx, void *dst, const void *src_dev,
   int rc;
   if ((rc = ctx->h_M.reserve(kSlice)) || (rc = ctx->h_A.reserve(kSlice))) return rc;
   void *pin[2] = {ctx->h_M.p, ctx->h_A.p};
-  hipEvent_t ev[2];
-  HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  EventList events;   // destroyed on every exit path
+  HIP_TRY(events.add(hipEventDisableTiming));
+  HIP_TRY(events.add(hipEventDisableTiming));
+  const hipEvent_t *ev = events.ev.data();
+  StreamSyncOnExit sync(ctx->stream);   // the pinned slices are read by host threads: never leave with a DMA in flight
   const size_t n_slices = (bytes + kSlice - 1) / kSlice;
   hipError_t e = hipSuccess;
   for (size_t i = 0; i <= n_slices && e == hipSuccess; ++i) {
@@ -153,8 +155,6 @@ static int copy_out_pipelined(seqalign_ctx *ctx, void *dst, const void *src_dev,
       if (e == hipSuccess) parallel_memcpy(static_cast<char *>(dst) + off, pin[j & 1], len);
     }
   }
-  (void)hipEventDestroy(ev[0]);
-  (void)hipEventDestroy(ev[1]);
   if (e != hipSuccess) return fail_hip(e, "pipelined D2H");
   return SEQALIGN_OK;
 }

@@ -105,6 +105,29 @@ void set_last_error(const std::string &msg);
   } while (0)
 
 
+// On every exit path of a function that has enqueued asynchronous copies into (or out of) memory
+// it owns -- function-local vectors, events -- wait for the stream first, so that a DMA never
+// lands in freed memory after an early error return.
+struct StreamSyncOnExit {
+  hipStream_t st;
+  explicit StreamSyncOnExit(hipStream_t s) : st(s) {}
+  ~StreamSyncOnExit() { (void)hipStreamSynchronize(st); }
+  StreamSyncOnExit(const StreamSyncOnExit &) = delete;
+  StreamSyncOnExit &operator=(const StreamSyncOnExit &) = delete;
+};
+
+// hipEvent_t's destroyed on scope exit
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  ~EventList() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  hipError_t add(unsigned flags = hipEventDefault) {
+    hipEvent_t e;
+    const hipError_t rc = hipEventCreateWithFlags(&e, flags);
+    if (rc == hipSuccess) ev.push_back(e);
+    return rc;
+  }
+};
+
 struct DevBuf {   // grow-only device scratch
   void *p = nullptr;
   size_t cap = 0;

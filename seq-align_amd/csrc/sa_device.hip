@@ -251,7 +251,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
       break;
     case SEQALIGN_KERNEL_WGSTREAM: e = sa_launch_fill_wgstream(p, batch->max_len_a, st); break;
     case SEQALIGN_KERNEL_STRIPS: {
-      const uint64_t words = batch->n_pairs * (uint64_t)sa_fill_strips_per_pair(batch->max_len_a);
+      const uint64_t words = ((batch->n_pairs + 7) / 8 * 8) * (uint64_t)sa_fill_strips_per_pair(batch->max_len_a) + 1;
       int rc = ctx->strip_progress.reserve(words * 4 + 16);
       if (rc) return rc;
       e = sa_launch_fill_strips(p, batch->max_len_a, ctx->strip_progress.as<uint32_t>(), st);
@@ -273,8 +273,10 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
                                      int repeats, float *ms_each) {
   if (!ctx || repeats <= 0 || !ms_each) return SEQALIGN_E_ARG;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  std::vector<hipEvent_t> ev(2 * (size_t)repeats);
-  for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
+  EventList events;   // destroyed on every exit path
+  for (int r = 0; r < 2 * repeats; ++r) HIP_TRY(events.add());
+  const std::vector<hipEvent_t> &ev = events.ev;
+  StreamSyncOnExit sync(st);
   int rc = SEQALIGN_OK;
   for (int r = 0; r < repeats && rc == SEQALIGN_OK; ++r) {
     HIP_TRY(hipEventRecord(ev[2 * r], st));
@@ -283,7 +285,6 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
   }
   HIP_TRY(hipStreamSynchronize(st));
   for (int r = 0; r < repeats && rc == SEQALIGN_OK; ++r) HIP_TRY(hipEventElapsedTime(&ms_each[r], ev[2 * r], ev[2 * r + 1]));
-  for (auto &x : ev) (void)hipEventDestroy(x);
   return rc;
 }
 

@@ -16,13 +16,15 @@
 //   * strip s therefore runs 64 rows behind s-1: a pair with S strips takes
 //     len_b + 64*S row steps instead of len_b * S.
 //
-// Workgroup = one wave; workgroup index = (group of 8 pairs, strip, pair in
-// group), so that a strip always has a LOWER index than the strips that wait for
-// it -- workgroups are dispatched in index order, so a waiting wave only ever
-// waits for waves that are already running or finished (no deadlock, no
-// cooperative launch) -- and so that the strips of one pair are 8 indices apart:
-// consecutive workgroup indices go round-robin over the 8 XCDs, hence one pair's
-// strips share an XCD and its L2.
+// Workgroup = one wave.  A workgroup does NOT take its (pair, strip) from blockIdx:
+// it draws a TICKET from an atomic counter when it starts running, and ticket =
+// (group of 8 pairs, strip, pair in group).  A strip's ticket is therefore always
+// higher than the ticket of the strip it waits for, and a ticket only exists once
+// its workgroup is resident on a CU -- so a waiting wave only ever waits for waves
+// that are running or finished, whatever order the hardware dispatches workgroups
+// in (other contexts' kernels, CU masks, preemption).  No cooperative launch, no
+// dispatch-order assumption, no watchdog.  Tickets are drawn roughly in dispatch
+// order, so one pair's strips (8 tickets apart) still tend to land on one XCD.
 #include "sa_rowsweep.hpp"
 
 namespace sa {
@@ -43,8 +45,11 @@ fill_strips_kernel(const SaFillParams p, uint32_t *progress, const uint32_t stri
   }
 
   const int lane = threadIdx.x;
-  // blockIdx = (group * strips_per_pair + strip) * 8 + pair_in_group
-  const uint32_t in_group = blockIdx.x & 7u, gs = blockIdx.x >> 3;
+  // ticket = (group * strips_per_pair + strip) * 8 + pair_in_group; the counter sits behind the progress words
+  uint32_t ticket = 0;
+  if (lane == 0) ticket = atomicAdd(progress + (uint64_t)gridDim.x, 1u);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  const uint32_t in_group = ticket & 7u, gs = ticket >> 3;
   const uint32_t strip = gs % strips_per_pair, pair = (gs / strips_per_pair) * 8 + in_group;
   if (pair >= p.n_pairs) return;
 
@@ -97,13 +102,9 @@ fill_strips_kernel(const SaFillParams p, uint32_t *progress, const uint32_t stri
       if (q == 0) {
         if (strip > 0) {   // rows j .. j+63 of the strip to my left must be in memory
           const uint32_t need = min(j + kWave - 1, lb) + 1;
-          // (a strip only waits for a lower workgroup index of its own XCD queue, which is running or
-          // done; the bound turns a broken assumption into a failed launch instead of a hung GPU)
-          uint32_t spins = 0;
-          while (__hip_atomic_load(done + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          // (the strip to my left holds a lower ticket: it is resident or done, see the header)
+          while (__hip_atomic_load(done + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 26)) __builtin_trap();   // ~20 s
-          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the boundary loads below see those rows
         }
         feed.load(p, k, bd, sb_, lb, W, i0, Mg, Ag, Bg, j + lane);
@@ -134,7 +135,7 @@ fill_strips_kernel(const SaFillParams p, uint32_t *progress, const uint32_t stri
 __global__ void __launch_bounds__(256) strips_init_kernel(uint32_t *progress, uint64_t n_progress, uint64_t *status,
                                                           uint32_t n_pairs) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_progress) progress[i] = 0;
+  if (i <= n_progress) progress[i] = 0;   // the progress words + the ticket counter behind them
   if (i < n_pairs) status[i] = ~0ull;
 }
 
@@ -144,16 +145,16 @@ uint32_t sa_fill_strips_per_pair(uint32_t max_len_a) {
   return max_len_a ? (max_len_a + sa::kStripCols - 1) / sa::kStripCols : 1;
 }
 
-// progress: n_pairs * sa_fill_strips_per_pair(max_len_a) uint32 of scratch
+// progress: 8 * ceil(n_pairs / 8) * sa_fill_strips_per_pair(max_len_a) + 1 uint32 of scratch
 hipError_t sa_launch_fill_strips(const SaFillParams &p, uint32_t max_len_a, uint32_t *progress, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   const uint32_t spp = sa_fill_strips_per_pair(max_len_a);
-  const uint64_t n_progress = (uint64_t)p.n_pairs * spp;
-  const uint64_t init_n = n_progress > p.n_pairs ? n_progress : p.n_pairs;
-  hipLaunchKernelGGL(sa::strips_init_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
-                     progress, n_progress, p.status, p.n_pairs);
   const uint64_t groups = (p.n_pairs + 7) / 8, blocks = groups * spp * 8;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const uint64_t n_progress = blocks;   // the ticket counter is progress[gridDim.x]
+  const uint64_t init_n = n_progress + 1 > p.n_pairs ? n_progress + 1 : p.n_pairs;
+  hipLaunchKernelGGL(sa::strips_init_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, stream,
+                     progress, n_progress, p.status, p.n_pairs);
   const dim3 grid((unsigned)blocks), block(sa::kWave);
   const bool general = sa::needs_general(p);
   using namespace sa;

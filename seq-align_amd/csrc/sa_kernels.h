@@ -120,7 +120,8 @@ hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
 /* whether sa_launch_fill_stream would also fill p.best_score / p.best_index */
 bool sa_stream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 /* few long pairs: the column strips of a pair as a pipeline of waves (any len_a);
- * progress = n_pairs * sa_fill_strips_per_pair(max_len_a) uint32 of scratch */
+ * progress = 8 * ceil(n_pairs / 8) * sa_fill_strips_per_pair(max_len_a) + 1 uint32 of scratch (the last one is
+ * the ticket counter, sa_fill_strips.hip) */
 uint32_t sa_fill_strips_per_pair(uint32_t max_len_a);
 hipError_t sa_launch_fill_strips(const SaFillParams &p, uint32_t max_len_a, uint32_t *progress, hipStream_t stream);
 /* long rows (1024..4095 columns), fast-path scorings: one workgroup per pair, shared LDS ring */
