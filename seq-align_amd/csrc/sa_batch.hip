@@ -20,11 +20,11 @@ struct StageTimer {
 
 // ------------------------------------------------- host-level: chunked fill ---
 
-// split the batch into chunks whose matrices (12 B/cell) fit the budget
-std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget) {
+// split the batch into chunks whose matrices (12 B/cell, plus whatever else the caller keeps per cell) fit the budget
+std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell) {
   std::vector<Chunk> out;
   Chunk c;
-  const uint64_t max_cells = std::max<uint64_t>(budget / 12, 1);
+  const uint64_t max_cells = std::max<uint64_t>(budget / std::max<size_t>(bytes_per_cell, 12), 1);
   for (uint64_t p = 0; p < b->n_pairs; ++p) {
     const uint64_t cells = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
     if (c.count && c.cells + cells > max_cells) { out.push_back(c); c = Chunk(); c.first = p; }
@@ -41,7 +41,8 @@ std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget
 // best_done (optional): ask the fill for the SW best cell per pair (into ctx->best_score / best_index);
 // *best_done tells whether the fill kernel delivered it.
 int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
-                       const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done) {
+                       const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done,
+                       const SaCandKeys *cand, bool *cand_done) {
   const uint64_t n = c.count;
   int rc;
   StageTimer tm;
@@ -89,6 +90,8 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
     rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>(),
                      ctx->best_index.as<uint64_t>(), best_done);
+  } else if (cand) {
+    rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr, cand, cand_done);
   } else {
     rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
   }

@@ -80,117 +80,149 @@ static int enumerate_hits(const sa_view_t &v, std::vector<Cand> &cand, uint32_t 
 // up to this many hits per pair the enumeration runs on the device
 static const uint32_t kDeviceEnumMaxHits = 16;
 
-// SW hits of one already-filled chunk, enumerated on the device (sa_sw_enum.hip):
-// reduce (count) -> reduce (compact + keys) -> segmented sort -> enumerate ->
-// gather strings -> D2H.  Appends to the caller's hit array / string buffers.
+static uint32_t bits_for(uint64_t v) {   // bits needed to hold values 0..v
+  uint32_t b = 1;
+  while (b < 64 && (v >> b) != 0) ++b;
+  return b;
+}
+
+// How a chunk's candidate keys are laid out (SaFillParams): row and column fields sized by the chunk's longest
+// sequences, the score field by the largest score the scoring can produce on them.
+static SaKeyLayout key_layout(const seqalign_dev_scoring *sc, const Chunk &c, int32_t thr_min) {
+  const sa_flat_scoring_t &f = sc->flat;
+  int64_t best_step = std::max<int64_t>(1, std::max(f.gen_eq, f.gen_ne));
+  for (uint64_t k = 0; k < (uint64_t)f.n_classes * f.n_classes; ++k)
+    if (f.table[k] != SA_S_BLOCKED && f.table[k] != SA_S_UNKNOWN) best_step = std::max<int64_t>(best_step, f.table[k]);
+  // every move adds at most best_step; gaps only add when a gap score is positive (legal, absurd)
+  int64_t cap = (int64_t)std::min(c.max_a, c.max_b) * best_step;
+  if (f.ext > 0 || f.open1 > 0)
+    cap = ((int64_t)c.max_a + c.max_b) * std::max<int64_t>(best_step, std::max(f.ext, f.open1));
+  cap = std::min<int64_t>(std::max<int64_t>(cap, thr_min), INT32_MAX);
+  SaKeyLayout l;
+  l.cap = (int32_t)cap;
+  l.row_bits = bits_for(c.max_b);
+  l.col_bits = bits_for(c.max_a);
+  l.score_bits = bits_for((uint64_t)(cap - std::min<int64_t>(cap, std::max(thr_min, 1))));
+  l.key64 = (l.row_bits + l.col_bits + l.score_bits > 32) ? 1u : 0u;
+  return l;
+}
+
+// SW hits of one chunk, enumerated on the device:
+//   fill (emits the candidate keys) -> per-pair key sort (sa_sort.hip) -> enumeration (sa_sw_enum_window.hip,
+//   generic kernel for the pairs it flags) -> gather strings -> D2H.
+// One host round trip in the middle (the candidates' bounding boxes size the enumeration's LDS window).
+// Appends to the caller's hit array / string buffers.
 //
 // want_hits > max_hits (the caller asked for more hits than the device slots hold): pairs that fill all
-// max_hits slots with candidates still left are finished on the host -- their matrices and candidates are
+// max_hits slots with candidates still left are finished on the host -- their matrices and sorted keys are
 // still in the context's scratch -- with the full limit; the others (nearly all, in practice) are done.
 static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
                                      const scoring_t *scoring, const seqalign_dev_scoring *sc,
-                                     const seqalign_dev_batch_t &d, const int32_t *min_score, uint32_t max_hits,
+                                     const int32_t *min_score, uint32_t max_hits,
                                      uint32_t want_hits, seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *found,
                                      char *out_a, char *out_b, uint64_t str_cap, uint64_t *used_str) {
   const uint64_t n = c.count;
   hipStream_t st = ctx->stream;
   int rc;
-  DevBuf &d_min = ctx->e[0], &d_key_in = ctx->e[1], &d_key_out = ctx->e[2], &d_idx_out = ctx->e[3],
-         &d_tmp = ctx->e[4], &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
+  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_tmp = ctx->e[2], &d_box = ctx->e[3],
+         &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
          &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
+  StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
 
   int32_t thr = min_score[c.first];
   for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
+  const SaKeyLayout layout = key_layout(sc, c, thr);
+  const size_t key_bytes = layout.key64 ? 8 : 4;
 
-  // pass 1: how many cells >= threshold per pair
-  if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
-      (rc = ctx->cand_count.reserve(n * 4)) || (rc = ctx->cand_off.reserve((n + 1) * 8)) ||
-      (rc = ctx->cand_cap.reserve(n * 4)) || (rc = d_min.reserve(n * 4)))
+  // ---- fill + candidate keys
+  if ((rc = d_min.reserve(n * 4)) || (rc = ctx->cand_count.reserve(n * 4)) || (rc = d_box.reserve(n * 16)) ||
+      (rc = d_keys.reserve(c.cells * key_bytes + 16)) || (rc = d_tmp.reserve(c.cells * key_bytes + 16)))
     return rc;
-  SaReduceParams r;
-  memset(&r, 0, sizeof(r));
-  r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.min_score = thr;
-  r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
-  r.cand_count = ctx->cand_count.as<uint32_t>(); r.n_pairs = (uint32_t)n;
-  hipError_t e = sa_launch_sw_reduce(r, st);
-  if (e != hipSuccess) return fail_hip(e, "sw reduce");
-  std::vector<uint32_t> count(n);
-  std::vector<int32_t> best(n);
-  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(best.data(), ctx->best_score.p, n * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  // sort key = (cap - score) << column_bits | column: only its used bits are sorted
-  int32_t key_cap = thr;
-  uint32_t max_la = 1;
-  for (uint64_t k = 0; k < n; ++k) {
-    key_cap = std::max(key_cap, best[k]);
-    max_la = std::max(max_la, batch->len_a[c.first + k]);
+  SaCandKeys cand;
+  cand.keys = d_keys.p; cand.tmp = d_tmp.p; cand.cand_count = ctx->cand_count.as<uint32_t>();
+  cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>(); cand.layout = layout;
+  seqalign_dev_batch_t d;
+  bool emitted = false;
+  if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &emitted))) return rc;
+  hipError_t e;
+  if (!emitted) {   // a fill kernel that cannot emit keys itself: one pass over match_scores
+    SaReduceParams r;
+    memset(&r, 0, sizeof(r));
+    r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.n_pairs = (uint32_t)n;
+    if ((e = sa_launch_sw_emit(r, cand, st)) != hipSuccess) return fail_hip(e, "sw candidate emission");
   }
-  uint32_t key_shift = 1, span_bits = 1;
-  while ((max_la >> key_shift) != 0) ++key_shift;                                   // column <= len_a
-  while (span_bits < 32 && (((uint64_t)key_cap - (uint64_t)(int64_t)thr) >> span_bits) != 0) ++span_bits;
+  SaSortParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sa_sort_plan(layout, &sp);
+  sp.mat_off = d.mat_off; sp.cand_count = cand.cand_count; sp.keys = cand.keys; sp.tmp = cand.tmp; sp.n_pairs = (uint32_t)n;
+  if ((e = sa_launch_sort_keys(sp, st)) != hipSuccess) return fail_hip(e, "candidate sort");
+  const void *sorted = (sp.n_passes & 1) ? cand.tmp : cand.keys;
 
-  // host prefixes: candidate segments, visited-bitmap words, string slots
-  std::vector<uint64_t> offs(4 * (n + 1));
-  uint64_t *cand_off = offs.data(), *mask_off = cand_off + n + 1, *str_off = mask_off + n + 1,
-           *dst_off = str_off + n + 1;
-  uint64_t total = 0, mask_words = 0, str_total = 0, max_mask_words = 0;
+  // ---- the one round trip: counts + bounding boxes
+  std::vector<uint32_t> count(n), box(4 * n);
+  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(box.data(), d_box.p, n * 16, hipMemcpyDeviceToHost, st));
+
+  // host prefixes meanwhile: visited-bitmap words (generic lane kernel), string slots
+  std::vector<uint64_t> offs(3 * (n + 1)), cell0(n + 1, 0);
+  uint64_t *mask_off = offs.data(), *str_off = mask_off + n + 1, *dst_off = str_off + n + 1;
+  uint64_t mask_words = 0, str_total = 0, max_mask_words = 0;
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k, la = batch->len_a[p], lb = batch->len_b[p];
-    cand_off[k] = total; total += count[k];
+    cell0[k + 1] = cell0[k] + (la + 1) * (lb + 1);
     mask_off[k] = mask_words; mask_words += ((la + 1) * (lb + 1) + 31) / 32;
     max_mask_words = std::max(max_mask_words, ((la + 1) * (lb + 1) + 31) / 32);
     str_off[k] = str_total; str_total += (uint64_t)max_hits * (la + lb);
   }
-  cand_off[n] = total; mask_off[n] = mask_words; str_off[n] = str_total;
-  if (total >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
-
-  if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = d_key_in.reserve(total * 8 + 8)) ||
-      (rc = d_key_out.reserve(total * 8 + 8)) || (rc = d_idx_out.reserve(total * 4 + 4)) ||
-      (rc = d_mask.reserve(mask_words * 4 + 4)) || (rc = d_offs.reserve(offs.size() * 8)) ||
-      (rc = ctx->t_out_a.reserve(str_total + 16)) || (rc = ctx->t_out_b.reserve(str_total + 16)) ||
-      (rc = d_hits.reserve(n * max_hits * sizeof(SaDevHit) + 16)) || (rc = d_meta.reserve(n * 12)))
+  mask_off[n] = mask_words; str_off[n] = str_total;
+  const bool lane_kernel = max_mask_words * 4 > 65536;   // generic kernel with the bitmap in HBM
+  if ((rc = d_offs.reserve(offs.size() * 8)) || (rc = ctx->t_out_a.reserve(str_total + 16)) ||
+      (rc = ctx->t_out_b.reserve(str_total + 16)) || (rc = d_hits.reserve(n * max_hits * sizeof(SaDevHit) + 16)) ||
+      (rc = d_meta.reserve(n * 12)) || (lane_kernel && (rc = d_mask.reserve(mask_words * 4 + 4))))
     return rc;
-  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 3 * (n + 1) * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ctx->cand_cap.p, count.data(), n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
-  const uint64_t *dv_cand_off = d_offs.as<uint64_t>(), *dv_mask_off = dv_cand_off + n + 1,
-                 *dv_str_off = dv_mask_off + n + 1;
+  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 2 * (n + 1) * 8, hipMemcpyHostToDevice, st));
+  if (lane_kernel) HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
+  const uint64_t *dv_mask_off = d_offs.as<uint64_t>(), *dv_str_off = dv_mask_off + n + 1;
+  HIP_TRY(hipStreamSynchronize(st));
 
-  // pass 2: compaction with sort keys, then the stable segmented sort
-  r.cand_off = dv_cand_off; r.cand_cap = ctx->cand_cap.as<uint32_t>();
-  r.cand_index = ctx->cand_index.as<uint32_t>(); r.cand_key = d_key_in.as<uint64_t>();
-  r.key_cap = key_cap; r.key_shift = key_shift;
-  if ((e = sa_launch_sw_reduce(r, st)) != hipSuccess) return fail_hip(e, "sw reduce (compaction)");
-  if (total) {
-    size_t tmp_bytes = 0;
-    e = sa_sort_candidates(nullptr, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
-                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
-                           (int)(key_shift + span_bits), st);
-    if (e != hipSuccess) return fail_hip(e, "segmented sort (size query)");
-    if ((rc = d_tmp.reserve(tmp_bytes + 16))) return rc;
-    e = sa_sort_candidates(d_tmp.p, &tmp_bytes, d_key_in.as<uint64_t>(), d_key_out.as<uint64_t>(),
-                           ctx->cand_index.as<uint32_t>(), d_idx_out.as<uint32_t>(), total, (uint32_t)n, dv_cand_off,
-                           (int)(key_shift + span_bits), st);
-    if (e != hipSuccess) return fail_hip(e, "segmented sort");
+  // window the enumeration wants: the candidates' box plus room for the part of a hit that lies below
+  // min_score (the kernel extends it further where LDS allows and flags a pair whose walk leaves it)
+  const sa_flat_scoring_t &f = sc->flat;
+  int64_t best_step = std::max<int64_t>(1, std::max(f.gen_eq, f.gen_ne));
+  for (uint64_t k = 0; k < (uint64_t)f.n_classes * f.n_classes; ++k)
+    if (f.table[k] != SA_S_BLOCKED && f.table[k] != SA_S_UNKNOWN) best_step = std::max<int64_t>(best_step, f.table[k]);
+  uint64_t window = 1024;
+  for (uint64_t k = 0; k < n; ++k) {
+    if (!count[k]) continue;
+    const uint64_t rmin = box[4 * k], rmax = box[4 * k + 1], cmin = box[4 * k + 2], cmax = box[4 * k + 3];
+    const uint64_t margin = 64 + 2 * (uint64_t)((std::max(min_score[c.first + k], 1) + best_step - 1) / best_step);
+    const uint64_t r0 = rmin > margin ? rmin - margin : 0, c0 = cmin > margin ? cmin - margin : 0;
+    window = std::max(window, (rmax - r0 + 1) * (cmax - c0 + 1));
   }
 
-  // enumeration: one lane per pair
+  // ---- enumeration
   SaEnumParams q;
   memset(&q, 0, sizeof(q));
   q.arena = d.arena; q.off_a = d.off_a; q.len_a = d.len_a; q.off_b = d.off_b; q.len_b = d.len_b;
   q.mat_off = d.mat_off; q.M = d.match_scores; q.A = d.gap_a_scores; q.B = d.gap_b_scores;
-  q.code = sc->d_code; q.table = sc->d_table; q.cand_off = dv_cand_off; q.cand_count = ctx->cand_count.as<uint32_t>();
-  q.sorted_key = d_key_out.as<uint64_t>(); q.sorted_index = d_idx_out.as<uint32_t>(); q.min_score = d_min.as<int32_t>();
-  q.mask = d_mask.as<uint32_t>(); q.mask_off = dv_mask_off; q.str_off = dv_str_off;
+  q.code = sc->d_code; q.table = sc->d_table; q.keys = sorted; q.cand_count = cand.cand_count;
+  q.cand_box = cand.cand_box; q.min_score = d_min.as<int32_t>();
+  q.mask = lane_kernel ? d_mask.as<uint32_t>() : nullptr; q.mask_off = dv_mask_off; q.str_off = dv_str_off;
   q.out_a = ctx->t_out_a.as<char>(); q.out_b = ctx->t_out_b.as<char>(); q.hits = d_hits.as<SaDevHit>();
   uint32_t *d_m = d_meta.as<uint32_t>();
   q.hit_count = d_m; q.str_used = d_m + n; q.enum_status = d_m + 2 * n;
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.max_hits = max_hits; q.open1 = sc->flat.open1;
   q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
-  q.key_cap = key_cap; q.key_shift = key_shift;
+  q.layout = layout;
+  q.window_bytes = (uint32_t)std::min<uint64_t>(window, sa_enum_window_lds_limit());
+  const char *force = getenv("SEQALIGN_SW_ENUM");   // "wave" / "lane": the generic kernels for every pair (tests, experiments)
+  const bool generic_only = force && (force[0] == 'w' || force[0] == 'l');
+  if (!generic_only) {
+    if ((e = sa_launch_sw_enumerate_window(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window)");
+    q.only_flagged = 1;
+  }
   if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
 
   std::vector<uint32_t> meta(3 * n);
@@ -200,8 +232,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
   uint64_t gathered = 0;
   for (uint64_t k = 0; k < n; ++k) {
-    const uint32_t status = meta[2 * n + k] & 0x7fffffffu;
-    if (status) return (int)status;
+    const uint32_t status = meta[2 * n + k] & ~SA_ENUM_STOPPED_AT_MAX;
+    if (status) return status == SA_ENUM_FALLBACK ? SEQALIGN_E_HIP : (int)status;
     dst_off[k] = gathered;
     gathered += meta[n + k];
   }
@@ -209,13 +241,10 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint64_t> capped;
   if (want_hits > max_hits)
     for (uint64_t k = 0; k < n; ++k)
-      if ((meta[2 * n + k] & 0x80000000u) && meta[k] >= max_hits) capped.push_back(k);
+      if ((meta[2 * n + k] & SA_ENUM_STOPPED_AT_MAX) && meta[k] >= max_hits) capped.push_back(k);
   std::vector<PairHits> redo(capped.size());
   std::vector<int64_t> redo_of(capped.empty() ? 0 : n, -1);
   if (!capped.empty()) {
-    std::vector<uint64_t> cell0(n + 1, 0);
-    for (uint64_t k = 0; k < n; ++k)
-      cell0[k + 1] = cell0[k] + (uint64_t)(batch->len_a[c.first + k] + 1ull) * (batch->len_b[c.first + k] + 1ull);
     std::vector<uint64_t> m_off(capped.size() + 1, 0), c_off(capped.size() + 1, 0);
     for (size_t j = 0; j < capped.size(); ++j) {
       const uint64_t k = capped[j];
@@ -224,19 +253,15 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       c_off[j + 1] = c_off[j] + count[k];
     }
     std::vector<int32_t> hM(m_off.back() + 1), hA(m_off.back() + 1), hB(m_off.back() + 1);
-    std::vector<uint32_t> h_idx(c_off.back() + 1);
-    std::vector<uint64_t> h_key(c_off.back() + 1);
+    std::vector<unsigned char> h_keys((c_off.back() + 1) * key_bytes);
     for (size_t j = 0; j < capped.size(); ++j) {
       const uint64_t k = capped[j], cells = cell0[k + 1] - cell0[k];
       HIP_TRY(hipMemcpyAsync(hM.data() + m_off[j], ctx->M.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(hA.data() + m_off[j], ctx->A.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(hB.data() + m_off[j], ctx->B.as<int32_t>() + cell0[k], cells * 4, hipMemcpyDeviceToHost, st));
-      if (count[k]) {
-        HIP_TRY(hipMemcpyAsync(h_idx.data() + c_off[j], ctx->cand_index.as<uint32_t>() + cand_off[k], count[k] * 4ull,
-                               hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(h_key.data() + c_off[j], d_key_in.as<uint64_t>() + cand_off[k], count[k] * 8ull,
-                               hipMemcpyDeviceToHost, st));
-      }
+      if (count[k])
+        HIP_TRY(hipMemcpyAsync(h_keys.data() + c_off[j] * key_bytes, static_cast<const char *>(sorted) + cell0[k] * key_bytes,
+                               count[k] * key_bytes, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     std::atomic<int> first_error{SEQALIGN_OK};
@@ -246,13 +271,18 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       v.sc = scoring; v.a = batch->arena + batch->off_a[p]; v.b = batch->arena + batch->off_b[p];
       v.len_a = batch->len_a[p]; v.len_b = batch->len_b[p];
       v.M = hM.data() + m_off[j]; v.A = hA.data() + m_off[j]; v.B = hB.data() + m_off[j];
-      std::vector<Cand> cand;
-      cand.reserve(count[k]);
-      for (uint64_t q = 0; q < count[k]; ++q) {
-        const Cand cd{h_idx[c_off[j] + q], key_cap - (int32_t)(h_key[c_off[j] + q] >> key_shift)};
-        if (cd.score >= min_score[p]) cand.push_back(cd);
+      const uint64_t W = v.len_a + 1;
+      std::vector<Cand> cand_list;
+      cand_list.reserve(count[k]);
+      for (uint64_t q2 = 0; q2 < count[k]; ++q2) {
+        uint64_t key;
+        if (layout.key64) memcpy(&key, h_keys.data() + (c_off[j] + q2) * 8, 8);
+        else { uint32_t k32; memcpy(&k32, h_keys.data() + (c_off[j] + q2) * 4, 4); key = k32; }
+        const uint64_t row = key & ((1ull << layout.row_bits) - 1), col = (key >> layout.row_bits) & ((1ull << layout.col_bits) - 1);
+        const Cand cd{(uint32_t)(row * W + col), layout.cap - (int32_t)(uint32_t)(key >> (layout.row_bits + layout.col_bits))};
+        if (cd.score >= min_score[p]) cand_list.push_back(cd);
       }
-      const int prc = enumerate_hits(v, cand, want_hits, redo[j]);
+      const int prc = enumerate_hits(v, cand_list, want_hits, redo[j]);
       if (prc != SEQALIGN_OK) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, prc); }
     });
     if ((rc = first_error.load())) return rc;
@@ -262,7 +292,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
       (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
     return rc;
-  uint64_t *dv_dst_off = d_offs.as<uint64_t>() + 3 * (n + 1);
+  uint64_t *dv_dst_off = d_offs.as<uint64_t>() + 2 * (n + 1);
   HIP_TRY(hipMemcpyAsync(dv_dst_off, dst_off, n * 8, hipMemcpyHostToDevice, st));
   if ((e = sa_launch_gather_strings(q.out_a, q.out_b, dv_str_off, q.str_used, dv_dst_off, d_gath_a.as<char>(),
                                     d_gath_b.as<char>(), (uint32_t)n, st)) != hipSuccess)
@@ -297,6 +327,67 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       *used_str += src.length + 1;
     }
   }
+  return SEQALIGN_OK;
+}
+
+// Test hook (not part of include/seqalign_hip.h): the candidate keys of a batch that fits one chunk, after the
+// fill's emission (or, emit_pass != 0, the separate pass over match_scores) and the per-pair sort.
+// keys_out: one uint64 per matrix cell (pair p's sorted keys at its cell offset), count_out[n], box_out[4n],
+// layout_out = {cap, row_bits, col_bits, score_bits, key64}.
+extern "C" int sa_sw_candidates_debug(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                      const int32_t *min_score, int emit_pass, uint64_t *keys_out,
+                                      uint32_t *count_out, uint32_t *box_out, int32_t *layout_out) {
+  if (!ctx || !batch || !scoring || !min_score || !keys_out || !count_out || !box_out || !layout_out) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  const std::vector<Chunk> chunks = plan_chunks(batch, ctx->chunk_budget, 12 + 16);
+  if (chunks.size() != 1) return SEQALIGN_E_ARG;
+  const Chunk &c = chunks[0];
+  HIP_TRY(hipSetDevice(ctx->device));
+  ScoringGuard guard(ctx);
+  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
+  const uint64_t n = c.count;
+  int32_t thr = min_score[0];
+  for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[k]);
+  const SaKeyLayout layout = key_layout(guard.h, c, thr);
+  const size_t kb = layout.key64 ? 8 : 4;
+  hipStream_t st = ctx->stream;
+  StreamSyncOnExit sync_on_exit(st);
+  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_tmp = ctx->e[2], &d_box = ctx->e[3];
+  if ((rc = d_min.reserve(n * 4)) || (rc = ctx->cand_count.reserve(n * 4)) || (rc = d_box.reserve(n * 16)) ||
+      (rc = d_keys.reserve(c.cells * kb + 16)) || (rc = d_tmp.reserve(c.cells * kb + 16)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_min.p, min_score, n * 4, hipMemcpyHostToDevice, st));
+  SaCandKeys cand;
+  cand.keys = d_keys.p; cand.tmp = d_tmp.p; cand.cand_count = ctx->cand_count.as<uint32_t>();
+  cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>(); cand.layout = layout;
+  seqalign_dev_batch_t d;
+  bool emitted = false;
+  if ((rc = run_chunk(ctx, batch, c, guard.h, &d, nullptr, emit_pass ? nullptr : &cand, &emitted))) return rc;
+  hipError_t e;
+  if (!emitted) {
+    SaReduceParams r;
+    memset(&r, 0, sizeof(r));
+    r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.n_pairs = (uint32_t)n;
+    if ((e = sa_launch_sw_emit(r, cand, st)) != hipSuccess) return fail_hip(e, "sw candidate emission");
+  }
+  SaSortParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sa_sort_plan(layout, &sp);
+  sp.mat_off = d.mat_off; sp.cand_count = cand.cand_count; sp.keys = cand.keys; sp.tmp = cand.tmp; sp.n_pairs = (uint32_t)n;
+  if ((e = sa_launch_sort_keys(sp, st)) != hipSuccess) return fail_hip(e, "candidate sort");
+  const void *sorted = (sp.n_passes & 1) ? cand.tmp : cand.keys;
+  std::vector<unsigned char> raw(c.cells * kb);
+  HIP_TRY(hipMemcpyAsync(raw.data(), sorted, c.cells * kb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(count_out, cand.cand_count, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(box_out, cand.cand_box, n * 16, hipMemcpyDeviceToHost, st));
+  if ((rc = fetch_status(ctx, c, nullptr))) return rc;
+  for (uint64_t i = 0; i < c.cells; ++i) {
+    if (layout.key64) memcpy(&keys_out[i], raw.data() + i * 8, 8);
+    else { uint32_t k32; memcpy(&k32, raw.data() + i * 4, 4); keys_out[i] = k32; }
+  }
+  layout_out[0] = layout.cap; layout_out[1] = (int32_t)layout.row_bits; layout_out[2] = (int32_t)layout.col_bits;
+  layout_out[3] = (int32_t)layout.score_bits; layout_out[4] = (int32_t)layout.key64;
   return SEQALIGN_OK;
 }
 
@@ -492,10 +583,9 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if (!traceback_on_host()) {
     // up to kDeviceEnumMaxHits hits per pair on the device; a pair that needs more is finished on the host
     const uint32_t slots = std::min(max_hits, kDeviceEnumMaxHits);
-    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget / 2)) {
-      seqalign_dev_batch_t d;
-      if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
-      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, d, min_score, slots, max_hits, hits, hit_cap,
+    // per cell: the three matrices + two key buffers (8-byte keys assumed: the layout is per chunk)
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 12 + 2 * 8)) {
+      if ((rc = sw_chunk_device_enumerate(ctx, batch, c, scoring, sc, min_score, slots, max_hits, hits, hit_cap,
                                           &found, out_a, out_b, str_cap, &used_str)))
         break;
     }

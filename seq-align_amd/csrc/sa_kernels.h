@@ -26,6 +26,25 @@ struct SaFillParams {
    * separate pass over match_scores when only the best hit is wanted */
   int32_t *best_score;
   uint64_t *best_index;
+  /* optional (stream kernel, SW): candidate emission for the multi-hit path.  Every match_scores cell
+   * with score >= max(cand_min[pair], 1) is appended, in row-major order, to the pair's key list, which
+   * starts at ELEMENT mat_off[pair] of cand_key (capacity = the pair's cell count, so no sizing pass):
+   *     key = (key_cap - score) << (key_row_bits + key_col_bits) | column << key_row_bits | row
+   * uint32 elements, or uint64 when key64 (the fields do not fit 32 bits).  Ascending key order IS the
+   * reference's hit order (score desc, column asc, then cell index = row asc; smith_waterman.c:71-86).
+   * cand_box[4*pair..] = first row, last row, lowest column, highest column holding a candidate. */
+  const int32_t *cand_min;
+  void *cand_key;
+  uint32_t *cand_count;
+  uint32_t *cand_box;
+  int32_t key_cap;
+  uint32_t key_row_bits, key_col_bits, key64;
+};
+
+/* how seqalign_sw_batch's multi-hit path lays out a candidate key (see SaFillParams) */
+struct SaKeyLayout {
+  int32_t cap;
+  uint32_t row_bits, col_bits, score_bits, key64;
 };
 
 struct SaReduceParams {
@@ -40,10 +59,7 @@ struct SaReduceParams {
   const uint32_t *cand_cap;
   uint32_t *cand_index;
   int32_t *cand_score;
-  uint64_t *cand_key;     /* optional: (key_cap - score) << key_shift | column, for the device sort */
   uint32_t n_pairs;
-  int32_t key_cap;        /* >= every score in the batch: keys ascend as scores descend      */
-  uint32_t key_shift;     /* bits of the column field                                        */
 };
 
 /* one SW hit as the enumeration kernel reports it (smith_waterman.c:249-255) */
@@ -51,6 +67,25 @@ struct SaDevHit {
   int32_t score;
   uint32_t pos_a, pos_b, len_a, len_b, length;
   uint32_t str_off;       /* into the pair's string slot */
+};
+
+/* candidate keys of a batch, as the stream fill (SA_STREAM_CAND) or sa_launch_sw_emit leaves them */
+struct SaCandKeys {
+  void *keys;                 /* pair p: elements [mat_off[p], mat_off[p] + cand_count[p]) */
+  void *tmp;                  /* same size: the sort's second buffer                       */
+  uint32_t *cand_count;       /* [n]                                                       */
+  uint32_t *cand_box;         /* [4n] rmin, rmax, cmin, cmax                               */
+  const int32_t *cand_min;    /* [n] per-pair min_score                                    */
+  SaKeyLayout layout;
+};
+
+struct SaSortParams {
+  const uint64_t *mat_off;
+  const uint32_t *cand_count;
+  void *keys, *tmp;
+  uint32_t n_pairs, key64;
+  uint32_t n_passes;          /* stable counting-sort passes, least significant first        */
+  uint8_t shift[8], bits[8];  /* digit of pass k = (key >> shift[k]) & ((1 << bits[k]) - 1)  */
 };
 
 struct SaEnumParams {
@@ -63,12 +98,11 @@ struct SaEnumParams {
   const int32_t *M, *A, *B;
   const uint16_t *code;
   const int32_t *table;
-  const uint64_t *cand_off;      /* [n] start of the pair's sorted candidates       */
+  const void *keys;              /* SORTED candidate keys, pair p at element mat_off[p]  */
   const uint32_t *cand_count;    /* [n]                                            */
-  const uint64_t *sorted_key;
-  const uint32_t *sorted_index;
+  const uint32_t *cand_box;      /* [4n] (window kernel)                            */
   const int32_t *min_score;      /* [n]                                            */
-  uint32_t *mask;                /* visited bits, zeroed by the caller              */
+  uint32_t *mask;                /* visited bits in HBM (lane kernel), zeroed by the caller */
   const uint64_t *mask_off;      /* [n] in 32-bit words                            */
   const uint64_t *str_off;       /* [n] slot of max_hits*(len_a+len_b) chars        */
   char *out_a, *out_b;
@@ -78,9 +112,14 @@ struct SaEnumParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t max_mask_words;       /* largest per-pair bitmap, 32-bit words            */
-  int32_t key_cap;               /* sorted_key = (key_cap - score) << key_shift | column */
-  uint32_t key_shift;
+  SaKeyLayout layout;
+  uint32_t only_flagged;         /* generic kernels: run only pairs whose enum_status == SA_ENUM_FALLBACK */
+  uint32_t window_bytes;         /* window kernel: LDS bytes for the direction window */
+  uint32_t claim_bits;           /* window kernel: log2 of the claim slots            */
 };
+/* enum_status values besides SEQALIGN_E_*: */
+#define SA_ENUM_STOPPED_AT_MAX 0x80000000u   /* top bit: stopped at max_hits with candidates left */
+#define SA_ENUM_FALLBACK 0x40000000u         /* window kernel: this pair needs the generic kernel */
 
 struct SaTraceParams {
   const uint8_t *arena;
@@ -117,6 +156,8 @@ hipError_t sa_launch_fill_rowscan(const SaFillParams &p, uint32_t max_len_a,
 bool sa_stream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_stream(const SaFillParams &p, uint32_t max_len_a,
                                  hipStream_t stream);
+/* whether sa_launch_fill_stream would also emit the candidate keys (p.cand_*) */
+bool sa_stream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a);
 /* whether sa_launch_fill_stream would also fill p.best_score / p.best_index */
 bool sa_stream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 /* few long pairs: the column strips of a pair as a pipeline of waves (any len_a);
@@ -129,9 +170,16 @@ bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream);
 bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
-hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
-                              const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,
-                              const uint64_t *seg_off, int key_bits, hipStream_t stream);
+/* candidate keys from match_scores already in HBM (fills that cannot emit them themselves): one pass over M */
+hipError_t sa_launch_sw_emit(const SaReduceParams &p, const SaCandKeys &c, hipStream_t stream);
+/* per-pair stable LSD radix sort of the candidate keys (sa_sort.hip); the result is in `keys` after an even
+ * number of passes, else in `tmp` */
+void sa_sort_plan(const SaKeyLayout &l, SaSortParams *p);
+hipError_t sa_launch_sort_keys(const SaSortParams &p, hipStream_t stream);
+/* SW multi-hit enumeration: the LDS-window kernel (sa_sw_enum_window.hip) for every pair, flagging the pairs it
+ * cannot take; the generic kernels (sa_sw_enum.hip) for flagged pairs (only_flagged) or for all */
+size_t sa_enum_window_lds_limit();
+hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,
                                     const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,

@@ -9,23 +9,45 @@
 // completed walk is a hit.  The CLI stops at the first hit below min_score and
 // after max_hits (sw_cmdline.c:214-217).
 //
-// Here: sa_reduce.hip compacts the cells >= min_score (ascending index) together
-// with the sort key (cap - score) << column_bits | column; a stable segmented radix sort
-// (hipCUB -- not the hot path) orders each pair's candidates; then the sequential
-// enumeration runs per pair against a visited bitmap (fresh per call, SURVEY
-// A.3-2) and writes its hits' strings left-aligned into the pair's slot: one WAVE
-// per pair with the bitmap in LDS and 64 speculative walks per round
-// (sw_enumerate_wave_kernel, below), or -- for pairs too large for that -- one
-// LANE per pair with the bitmap in HBM (sw_enumerate_kernel, the literal procedure).
-#include <hipcub/hipcub.hpp>
-
+// Here: the fill emits the cells >= min_score as sort keys (sa_fill_stream.hpp), sa_sort.hip
+// orders each pair's keys, and the enumeration proper runs in sa_sw_enum_window.hip (one
+// workgroup per pair, everything in LDS).  THIS file holds the GENERIC kernels, which walk
+// the matrices in HBM and make no assumption about where a walk goes: they take the pairs
+// the window kernel flags (a walk left its window, the candidates' box does not fit LDS, a
+// traceback error to report) or, with SEQALIGN_SW_ENUM=wave|lane, every pair: one WAVE per
+// pair with the visited bitmap in LDS and 64 speculative walks per round
+// (sw_enumerate_wave_kernel), or -- bitmap over 64 KiB -- one LANE per pair with the
+// bitmap in HBM (sw_enumerate_kernel, the literal procedure).  Hits' strings are written
+// left-aligned into the pair's slot.
 #include "sa_trace_common.hpp"
 
 namespace sa {
 
+// a sorted candidate key -> score and cell (SaFillParams: key layout)
+struct KeyReader {
+  const void *base;
+  uint32_t key64, cshift, sshift, rmask, cmask, W;
+  int cap;
+  __device__ __forceinline__ KeyReader(const SaEnumParams &p, uint64_t mo, uint32_t W_)
+      : base(p.layout.key64 ? (const void *)(static_cast<const unsigned long long *>(p.keys) + mo)
+                            : (const void *)(static_cast<const uint32_t *>(p.keys) + mo)),
+        key64(p.layout.key64), cshift(p.layout.row_bits), sshift(p.layout.row_bits + p.layout.col_bits),
+        rmask((1u << p.layout.row_bits) - 1u), cmask((1u << p.layout.col_bits) - 1u), W(W_), cap(p.layout.cap) {}
+  __device__ __forceinline__ void get(uint32_t i, int &score, uint32_t &cell) const {
+    const unsigned long long k = key64 ? static_cast<const unsigned long long *>(base)[i]
+                                       : (unsigned long long)static_cast<const uint32_t *>(base)[i];
+    score = cap - (int)(uint32_t)(k >> sshift);
+    cell = ((uint32_t)k & rmask) * W + ((uint32_t)(k >> cshift) & cmask);
+  }
+};
+
+__device__ __forceinline__ bool skip_pair(const SaEnumParams &p, uint32_t pair) {
+  return p.only_flagged && p.enum_status[pair] != SA_ENUM_FALLBACK;
+}
+
 __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) {
   const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pair >= p.n_pairs) return;
+  if (pair >= p.n_pairs || skip_pair(p, pair)) return;
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
@@ -34,8 +56,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) 
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
   uint32_t *seen = p.mask + p.mask_off[pair];
-  const uint64_t *keys = p.sorted_key + p.cand_off[pair];
-  const uint32_t *cells = p.sorted_index + p.cand_off[pair];
+  const KeyReader keys(p, mo, W);
   const uint32_t n_cand = p.cand_count[pair];
   const int min_score = p.min_score[pair];
   char *oa = p.out_a + p.str_off[pair];
@@ -46,9 +67,10 @@ __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) 
   bool exhausted = true;
   for (; kpos < n_cand; ++kpos) {
     if (emitted >= p.max_hits) { exhausted = false; break; }
-    const int cscore = p.key_cap - (int)(keys[kpos] >> p.key_shift);
+    int cscore;
+    uint32_t end;
+    keys.get(kpos, cscore, end);
     if (cscore < min_score) break;                     // sorted: nothing later qualifies
-    const uint32_t end = cells[kpos];
     if ((seen[end >> 5] >> (end & 31)) & 1u) continue; // smith_waterman.c:269
 
     // pass 1 (:187-199): walk to score 0, marking; abandon on a marked cell
@@ -83,7 +105,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) 
   }
   p.hit_count[pair] = emitted;
   p.str_used[pair] = used;
-  p.enum_status[pair] = err ? err : (exhausted ? 0u : 0x80000000u);   // top bit: stopped at max_hits
+  p.enum_status[pair] = err ? err : (exhausted ? 0u : SA_ENUM_STOPPED_AT_MAX);
 }
 
 // ---------------------------------------------------------------------------
@@ -119,6 +141,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   __shared__ uint32_t claim[256];   // per round: which lane owns a cell (light candidates, see "apply")
   const uint32_t pair = blockIdx.x;
   const int lane = threadIdx.x;
+  if (skip_pair(p, pair)) return;
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
@@ -130,8 +153,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   for (uint32_t i = lane; i < words; i += 64) seen[i] = 0;   // fresh mask per call
   __syncthreads();
 
-  const uint64_t *keys = p.sorted_key + p.cand_off[pair];
-  const uint32_t *cells = p.sorted_index + p.cand_off[pair];
+  const KeyReader keys(p, mo, W);
   const uint32_t n_cand = p.cand_count[pair];
   const int min_score = p.min_score[pair];
   char *oa = p.out_a + p.str_off[pair];
@@ -143,8 +165,9 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   for (uint32_t base = 0; base < n_cand && !done; base += 64) {
     const uint32_t idx = base + lane;
     bool valid = idx < n_cand;
-    const int cscore = valid ? p.key_cap - (int)(keys[idx] >> p.key_shift) : INT32_MIN;
-    const uint32_t cell = valid ? cells[idx] : 0u;
+    int cscore = INT32_MIN;
+    uint32_t cell = 0u;
+    if (valid) keys.get(idx, cscore, cell);
     valid = valid && cscore >= min_score;              // sorted: the valid lanes are a prefix
     const uint32_t nvalid = __popcll(__ballot(valid));
     if (nvalid == 0) break;                            // nothing later qualifies
@@ -270,7 +293,7 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   if (lane == 0) {
     p.hit_count[pair] = emitted;
     p.str_used[pair] = used;
-    p.enum_status[pair] = err ? err : (exhausted ? 0u : 0x80000000u);   // top bit: stopped at max_hits
+    p.enum_status[pair] = err ? err : (exhausted ? 0u : SA_ENUM_STOPPED_AT_MAX);
   }
 }
 
@@ -289,15 +312,6 @@ __global__ void __launch_bounds__(256) gather_strings_kernel(const char *src_a, 
 }
 
 }  // namespace sa
-
-hipError_t sa_sort_candidates(void *tmp, size_t *tmp_bytes, const uint64_t *key_in, uint64_t *key_out,
-                              const uint32_t *idx_in, uint32_t *idx_out, uint64_t total, uint32_t n_pairs,
-                              const uint64_t *seg_off /* n_pairs + 1 */, int key_bits, hipStream_t stream) {
-  // stable LSD radix sort over the key's used bits only (score span + column: ~20 bits, 3 passes
-  // instead of 8): equal (score, column) keep the compaction's ascending cell index
-  return hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, *tmp_bytes, key_in, key_out, idx_in, idx_out,
-                                                     (int)total, (int)n_pairs, seg_off, seg_off + 1, 0, key_bits, stream);
-}
 
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
