@@ -124,7 +124,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   const uint64_t n = c.count;
   hipStream_t st = ctx->stream;
   int rc;
-  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_tmp = ctx->e[2], &d_box = ctx->e[3],
+  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_tmp = ctx->e[2], &d_box = ctx->e[3], &d_dir = ctx->e[4],
          &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
          &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
   StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
@@ -176,11 +176,15 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     str_off[k] = str_total; str_total += (uint64_t)max_hits * (la + lb);
   }
   mask_off[n] = mask_words; str_off[n] = str_total;
-  const bool lane_kernel = max_mask_words * 4 > 65536;   // generic kernel with the bitmap in HBM
+  const char *force = getenv("SEQALIGN_SW_ENUM");   // "wave" / "lane": the generic kernels for every pair (tests, experiments)
+  const bool lane_kernel = max_mask_words * 4 > 65536 || (force && force[0] == 'l');   // generic kernel, bitmap in HBM
   if ((rc = d_offs.reserve(offs.size() * 8)) || (rc = ctx->t_out_a.reserve(str_total + 16)) ||
       (rc = ctx->t_out_b.reserve(str_total + 16)) || (rc = d_hits.reserve(n * max_hits * sizeof(SaDevHit) + 16)) ||
-      (rc = d_meta.reserve(n * 12)) || (lane_kernel && (rc = d_mask.reserve(mask_words * 4 + 4))))
+      (rc = d_meta.reserve(n * 12)) || (lane_kernel && (rc = d_mask.reserve(mask_words * 4 + 4))) ||
+      (rc = d_dir.reserve(sa_dir_bytes(c.cells, n))))
     return rc;
+  const bool trace = getenv("SEQALIGN_ENUM_TRACE") != nullptr;   // development aid: per-pair phase cycles on stderr
+  HIP_TRY(hipMemsetAsync(d_meta.p, 0, n * 12, st));   // enum_status starts clean: the direction kernel may flag pairs
   HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 2 * (n + 1) * 8, hipMemcpyHostToDevice, st));
   if (lane_kernel) HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
   const uint64_t *dv_mask_off = d_offs.as<uint64_t>(), *dv_str_off = dv_mask_off + n + 1;
@@ -192,14 +196,40 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   int64_t best_step = std::max<int64_t>(1, std::max(f.gen_eq, f.gen_ne));
   for (uint64_t k = 0; k < (uint64_t)f.n_classes * f.n_classes; ++k)
     if (f.table[k] != SA_S_BLOCKED && f.table[k] != SA_S_UNKNOWN) best_step = std::max<int64_t>(best_step, f.table[k]);
-  uint64_t window = 1024;
+  // LDS class of every pair with candidates (sa_enum_classes): the first whose window holds the box + margin
+  SaEnumClass cls[4];
+  const int n_cls = sa_enum_classes(layout.key64, cls);
+  if (const char *env = getenv("SEQALIGN_ENUM_THREADS")) {   // tests: one class with that many threads for every pair
+    const int t = atoi(env);
+    if (t == 256 || t == 512 || t == 1024) {
+      for (int k = 0; k < n_cls; ++k) { cls[k] = cls[2]; cls[k].threads = (uint32_t)t; }
+    }
+  }
+  std::vector<std::vector<uint32_t>> members((size_t)n_cls);
+  std::vector<uint64_t> need_of(trace ? n : 0, 0);
+  uint64_t unplaced = 0;
   for (uint64_t k = 0; k < n; ++k) {
     if (!count[k]) continue;
     const uint64_t rmin = box[4 * k], rmax = box[4 * k + 1], cmin = box[4 * k + 2], cmax = box[4 * k + 3];
-    const uint64_t margin = 64 + 2 * (uint64_t)((std::max(min_score[c.first + k], 1) + best_step - 1) / best_step);
+    const uint64_t margin = 16 + 2 * (uint64_t)((std::max(min_score[c.first + k], 1) + best_step - 1) / best_step);
     const uint64_t r0 = rmin > margin ? rmin - margin : 0, c0 = cmin > margin ? cmin - margin : 0;
-    window = std::max(window, (rmax - r0 + 1) * (cmax - c0 + 1));
+    const uint64_t need = (rmax - r0 + 2) * (cmax - c0 + 2);   // stored with a sentinel row and column
+    const uint64_t bare = (rmax - rmin + 2) * (cmax - cmin + 2);
+    if (trace) need_of[k] = need;
+    int pick = -1;
+    for (int q2 = 0; q2 < n_cls && pick < 0; ++q2)
+      if (need <= cls[q2].window_bytes) pick = q2;
+    if (pick < 0 && bare <= cls[n_cls - 1].window_bytes) pick = n_cls - 1;   // no room for the full margin
+    if (pick < 0) { ++unplaced; continue; }                    // generic kernel (flagged below)
+    members[(size_t)pick].push_back((uint32_t)k);
   }
+  std::vector<uint32_t> pair_list;
+  pair_list.reserve(n);
+  for (int q2 = 0; q2 < n_cls; ++q2) pair_list.insert(pair_list.end(), members[(size_t)q2].begin(), members[(size_t)q2].end());
+  DevBuf &d_list = ctx->e[11];
+  if ((rc = d_list.reserve(n * 4 + 128 * n * (trace ? 1 : 0) + 32))) return rc;
+  if (!pair_list.empty())
+    HIP_TRY(hipMemcpyAsync(d_list.p, pair_list.data(), pair_list.size() * 4, hipMemcpyHostToDevice, st));
 
   // ---- enumeration
   SaEnumParams q;
@@ -216,24 +246,89 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.ext = sc->flat.ext; q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
   q.layout = layout;
-  q.window_bytes = (uint32_t)std::min<uint64_t>(window, sa_enum_window_lds_limit());
-  const char *force = getenv("SEQALIGN_SW_ENUM");   // "wave" / "lane": the generic kernels for every pair (tests, experiments)
+  q.best_step = (uint32_t)std::min<int64_t>(best_step, INT32_MAX);
+  q.dir = d_dir.as<uint8_t>();
+  unsigned long long *d_trace = reinterpret_cast<unsigned long long *>(d_list.as<char>() + ((n * 4 + 15) & ~(uint64_t)15));
+  q.trace = trace ? d_trace : nullptr;
+  if (trace) HIP_TRY(hipMemsetAsync(d_trace, 0, n * 128, st));
   const bool generic_only = force && (force[0] == 'w' || force[0] == 'l');
+  std::vector<uint32_t> flags;   // (function scope: the copy below is asynchronous)
+  if (!generic_only && unplaced) {   // pairs whose candidates' box fits no window: flagged for the generic kernel
+    flags.assign(n, 0u);
+    std::vector<char> placed(n, 0);
+    for (uint32_t k : pair_list) placed[k] = 1;
+    for (uint64_t k = 0; k < n; ++k) flags[k] = (count[k] && !placed[k]) ? SA_ENUM_GENERIC : 0u;
+    HIP_TRY(hipMemcpyAsync(q.enum_status, flags.data(), n * 4, hipMemcpyHostToDevice, st));   // before the window kernels
+  }
   if (!generic_only) {
-    if ((e = sa_launch_sw_enumerate_window(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window)");
+    uint32_t first = 0;
+    for (int q2 = 0; q2 < n_cls; ++q2) {
+      const uint32_t cnt = (uint32_t)members[(size_t)q2].size();
+      if (!cnt) continue;
+      SaEnumParams w = q;
+      w.pair_list = d_list.as<uint32_t>() + first; w.n_list = cnt;
+      w.threads = cls[q2].threads; w.claim_bits = cls[q2].claim_bits; w.window_bytes = cls[q2].window_bytes;
+      if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window)");
+      first += cnt;
+    }
     q.only_flagged = 1;
   }
-  if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
-
   std::vector<uint32_t> meta(3 * n);
   std::vector<SaDevHit> dev_hits(n * max_hits);
+  if (generic_only && (e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
   HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  if (!generic_only) {
+    // second phase, only when a pair was flagged: escaped walks run again in the largest window, what the window
+    // kernels cannot take goes to the generic kernel; then the results are fetched again
+    std::vector<uint32_t> again;
+    bool any_generic = false;
+    for (uint64_t k = 0; k < n; ++k) {
+      if (meta[2 * n + k] & SA_ENUM_FALLBACK) again.push_back((uint32_t)k);
+      any_generic |= (meta[2 * n + k] & SA_ENUM_GENERIC) != 0;
+    }
+    if (!again.empty() || any_generic) {
+      if (!again.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_list.p, again.data(), again.size() * 4, hipMemcpyHostToDevice, st));
+        SaEnumParams w = q;
+        w.only_flagged = 0; w.retry = 1;
+        w.pair_list = d_list.as<uint32_t>(); w.n_list = (uint32_t)again.size();
+        w.threads = cls[2].threads; w.claim_bits = cls[2].claim_bits; w.window_bytes = cls[2].window_bytes;
+        if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window, retry)");
+      }
+      if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");   // only_flagged
+      HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+  if (trace) {
+    std::sort(need_of.begin(), need_of.end());
+    fprintf(stderr, "[seqalign enum trace] window need (bytes): p10 %llu  p50 %llu  p90 %llu  p99 %llu  max %llu\n",
+            (unsigned long long)need_of[n / 10], (unsigned long long)need_of[n / 2], (unsigned long long)need_of[n * 9 / 10],
+            (unsigned long long)need_of[n * 99 / 100], (unsigned long long)need_of[n - 1]);
+    std::vector<unsigned long long> t(16 * n);
+    HIP_TRY(hipMemcpy(t.data(), d_trace, n * 128, hipMemcpyDeviceToHost));
+    double load = 0, rounds_c = 0, iters = 0, rounds = 0, fallback = 0, cands = 0, ph[5] = {0, 0, 0, 0, 0};
+    for (uint64_t k = 0; k < n; ++k) {
+      load += (double)t[16 * k]; rounds_c += (double)t[16 * k + 1]; iters += (double)t[16 * k + 2]; rounds += (double)t[16 * k + 3];
+      for (int q2 = 0; q2 < 5; ++q2) ph[q2] += (double)t[16 * k + 4 + q2];
+      cands += count[k];
+      fallback += t[16 * k + 3] == 0 && count[k] != 0;
+    }
+    fprintf(stderr, "[seqalign enum trace] cycles per pair by phase: hand-out+clear %.0f, claim inline %.0f, claim queue %.0f, "
+                    "commit inline %.0f, commit queue+end %.0f\n", ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n);
+    fprintf(stderr, "[seqalign enum trace] pairs %llu  candidates/pair %.0f  classes (pairs): %zu %zu %zu %zu  per pair: load %.0f cycles, "
+                    "walks %.0f cycles, %.1f iterations  (pairs not finished by the window kernel: %.0f)\n",
+            (unsigned long long)n, cands / n, members[0].size(), members[1].size(), members[2].size(), members[3].size(),
+            load / n, rounds_c / n, iters / n, fallback);
+    (void)rounds;
+  }
   uint64_t gathered = 0;
   for (uint64_t k = 0; k < n; ++k) {
     const uint32_t status = meta[2 * n + k] & ~SA_ENUM_STOPPED_AT_MAX;
-    if (status) return status == SA_ENUM_FALLBACK ? SEQALIGN_E_HIP : (int)status;
+    if (status) return (status & (SA_ENUM_FALLBACK | SA_ENUM_GENERIC)) ? SEQALIGN_E_HIP : (int)status;
     dst_off[k] = gathered;
     gathered += meta[n + k];
   }

@@ -113,13 +113,29 @@ struct SaEnumParams {
   uint32_t flags;
   uint32_t max_mask_words;       /* largest per-pair bitmap, 32-bit words            */
   SaKeyLayout layout;
-  uint32_t only_flagged;         /* generic kernels: run only pairs whose enum_status == SA_ENUM_FALLBACK */
+  uint32_t only_flagged;         /* generic kernels: run only pairs flagged SA_ENUM_FALLBACK / SA_ENUM_GENERIC */
   uint32_t window_bytes;         /* window kernel: LDS bytes for the direction window */
   uint32_t claim_bits;           /* window kernel: log2 of the claim slots            */
+  uint32_t best_step;            /* largest score one move can add (sizes the window's margin) */
+  uint8_t *dir;                  /* direction bytes of every pair's window (sw_direction_kernel -> window kernel),
+                                    pair p at byte dir_offset(mat_off[p], p), sa_sw_enum_window.hip                               */
+  unsigned long long *trace;     /* optional [16n]: load cycles, walk cycles, iterations, 1, 5 phase totals (SEQALIGN_ENUM_TRACE) */
+  const uint32_t *pair_list;     /* window kernels: the pairs of this launch (n_list of them); NULL = all n_pairs */
+  uint32_t n_list;
+  uint32_t threads;              /* window kernel: threads per workgroup of this launch (256 / 512 / 1024)      */
+  uint32_t retry;                /* window kernels: second attempt at flagged pairs, margin as large as LDS allows */
 };
+
+/* LDS configurations of the window kernel, smallest first: a pair goes to the first one whose window holds what
+ * it needs; several workgroups per CU for the small ones (sa_sw_enum_window.hip) */
+struct SaEnumClass {
+  uint32_t threads, claim_bits, window_bytes;
+};
+int sa_enum_classes(uint32_t key64, SaEnumClass out[4]);
 /* enum_status values besides SEQALIGN_E_*: */
 #define SA_ENUM_STOPPED_AT_MAX 0x80000000u   /* top bit: stopped at max_hits with candidates left */
-#define SA_ENUM_FALLBACK 0x40000000u         /* window kernel: this pair needs the generic kernel */
+#define SA_ENUM_FALLBACK 0x40000000u         /* window kernel: a walk left the window -- retry with the largest one */
+#define SA_ENUM_GENERIC 0x20000000u          /* window kernels cannot take this pair: the generic kernel does    */
 
 struct SaTraceParams {
   const uint8_t *arena;
@@ -179,6 +195,9 @@ hipError_t sa_launch_sort_keys(const SaSortParams &p, hipStream_t stream);
 /* SW multi-hit enumeration: the LDS-window kernel (sa_sw_enum_window.hip) for every pair, flagging the pairs it
  * cannot take; the generic kernels (sa_sw_enum.hip) for flagged pairs (only_flagged) or for all */
 size_t sa_enum_window_lds_limit();
+/* bytes of SaEnumParams::dir for a chunk of n pairs and `cells` matrix cells */
+static inline size_t sa_dir_bytes(uint64_t cells, uint64_t n) { return (size_t)(2 * cells + 8 * n + 16); }
+/* direction bytes first (sw_direction_kernel), then the enumeration: both launched by this call */
 hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,

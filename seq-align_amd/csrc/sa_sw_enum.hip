@@ -42,7 +42,7 @@ struct KeyReader {
 };
 
 __device__ __forceinline__ bool skip_pair(const SaEnumParams &p, uint32_t pair) {
-  return p.only_flagged && p.enum_status[pair] != SA_ENUM_FALLBACK;
+  return p.only_flagged && !(p.enum_status[pair] & (SA_ENUM_FALLBACK | SA_ENUM_GENERIC));
 }
 
 __global__ void __launch_bounds__(64) sw_enumerate_kernel(const SaEnumParams p) {
