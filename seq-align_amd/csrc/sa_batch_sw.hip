@@ -247,18 +247,30 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.max_mask_words = (uint32_t)std::min<uint64_t>(max_mask_words, 0xffffffffu);
   q.layout = layout;
   q.best_step = (uint32_t)std::min<int64_t>(best_step, INT32_MAX);
+  q.max_len_a = c.max_a; q.max_len_b = c.max_b;
   q.dir = d_dir.as<uint8_t>();
   unsigned long long *d_trace = reinterpret_cast<unsigned long long *>(d_list.as<char>() + ((n * 4 + 15) & ~(uint64_t)15));
   q.trace = trace ? d_trace : nullptr;
   if (trace) HIP_TRY(hipMemsetAsync(d_trace, 0, n * 128, st));
   const bool generic_only = force && (force[0] == 'w' || force[0] == 'l');
   std::vector<uint32_t> flags;   // (function scope: the copy below is asynchronous)
+  EventList side_events;
   if (!generic_only && unplaced) {   // pairs whose candidates' box fits no window: flagged for the generic kernel
     flags.assign(n, 0u);
     std::vector<char> placed(n, 0);
     for (uint32_t k : pair_list) placed[k] = 1;
     for (uint64_t k = 0; k < n; ++k) flags[k] = (count[k] && !placed[k]) ? SA_ENUM_GENERIC : 0u;
     HIP_TRY(hipMemcpyAsync(q.enum_status, flags.data(), n * 4, hipMemcpyHostToDevice, st));   // before the window kernels
+    // these pairs are few and slow (one wave each): start them now on the side stream, under the window kernels
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIP_TRY(side_events.add(hipEventDisableTiming));
+    HIP_TRY(side_events.add(hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(side_events.ev[0], st));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream2, side_events.ev[0], 0));
+    SaEnumParams g = q;
+    g.only_flagged = 1;
+    if ((e = sa_launch_sw_enumerate(g, ctx->stream2)) != hipSuccess) return fail_hip(e, "sw enumerate (generic, side stream)");
+    HIP_TRY(hipEventRecord(side_events.ev[1], ctx->stream2));
   }
   if (!generic_only) {
     uint32_t first = 0;
@@ -276,6 +288,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint32_t> meta(3 * n);
   std::vector<SaDevHit> dev_hits(n * max_hits);
   if (generic_only && (e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
+  if (side_events.ev.size() == 2) HIP_TRY(hipStreamWaitEvent(st, side_events.ev[1], 0));   // the side stream's pairs are done
   HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream

@@ -175,6 +175,7 @@ struct seqalign_dev_scoring {
 struct seqalign_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // side stream (created on first use): work that overlaps the main stream's kernels
   size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
   // device scratch for the host-level entry points
   sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;

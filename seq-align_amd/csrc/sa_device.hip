@@ -131,6 +131,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
                      &ctx->h_tb, &ctx->h_tmeta})
     b->release();
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

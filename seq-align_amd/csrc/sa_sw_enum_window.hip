@@ -87,48 +87,126 @@ __device__ __forceinline__ Window window_of(const SaEnumParams &p, uint32_t pair
   return w;
 }
 
-// ---- 1. predecessor bits of every state of every pair's window: one thread per cell, kDirItems cells per thread
-constexpr int kDirThreads = 256, kDirItems = 4;
+// ---- 1. predecessor bits of every state of every pair's window.
+// One workgroup per band of R window rows: the band's match / gap_a / gap_b values (plus the row above and the
+// column to the left, where the predecessors live) and the sequences' codes are staged in LDS with coalesced
+// loads -- every value is fetched from HBM once, 12 B per cell -- and the three decisions per cell are the
+// traceback's own code (reverse_move_t) reading from the tile.  Bound: HBM reads of the window.
+constexpr int kDirThreads = 256;
+constexpr uint32_t kDirTileBytes = 24u * 1024u;
+constexpr uint32_t kDirBandsPerBlock = 8;
 
-__global__ void __launch_bounds__(kDirThreads) sw_direction_kernel(const SaEnumParams p, const uint32_t blocks_per_pair,
-                                                                   const uint32_t pair0) {
-  const uint32_t slot = pair0 + blockIdx.x / blocks_per_pair, block = blockIdx.x % blocks_per_pair;
+struct TileAccess {
+  const int32_t *tm, *ta, *tb;   // (rows) x TW planes: tile row 0 = matrix row yb, tile column 0 = matrix column xb
+  const uint16_t *ca, *cb;       // codes of seq_a[x - 1] at [x - xb], of seq_b[y - 1] at [y - yb]
+  int TW, xb, yb;
+  __device__ __forceinline__ int code_a(uint32_t i) const { return ca[(int)i + 1 - xb]; }
+  __device__ __forceinline__ int code_b(uint32_t j) const { return cb[(int)j + 1 - yb]; }
+  __device__ __forceinline__ void cell(uint32_t x, uint32_t y, int &m, int &a, int &b) const {
+    const int at = ((int)y - yb) * TW + ((int)x - xb);
+    m = tm[at]; a = ta[at]; b = tb[at];
+  }
+};
+
+__global__ void __launch_bounds__(kDirThreads) sw_direction_kernel(const SaEnumParams p, const uint32_t bands_per_pair,
+                                                                   const uint32_t R, const uint32_t pair0) {
+  extern __shared__ int32_t tile_lds[];
+  const uint32_t slot = pair0 + blockIdx.x / bands_per_pair, band = blockIdx.x % bands_per_pair;
   const uint32_t pair = p.pair_list ? p.pair_list[slot] : slot;
   if (p.cand_count[pair] == 0) return;
   const Window w = window_of(p, pair);
   if (!w.ok) return;                                   // the enumeration kernel flags the pair
-  const uint32_t Wp = w.Ww + 1, wcells = Wp * (w.Hw + 1), first = block * (kDirThreads * kDirItems);
-  if (first >= wcells) return;
+  const uint32_t Wp = w.Ww + 1, Hp = w.Hw + 1;
+  if (band * kDirBandsPerBlock * R >= Hp) return;
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
-  const PairView v{p.arena + p.off_a[pair], p.arena + p.off_b[pair], p.M + mo, p.A + mo, p.B + mo, la, lb, W};
+  const int32_t *Mg = p.M + mo, *Ag = p.A + mo, *Bg = p.B + mo;
+  const uint8_t *sa_ = p.arena + p.off_a[pair], *sb_ = p.arena + p.off_b[pair];
   const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
-  uint8_t *dir = p.dir + dir_offset(mo, pair);
   bool bad = false;
+  // a workgroup takes kDirBandsPerBlock consecutive bands: the set-up above (dependent loads) is paid once
+  for (uint32_t sub = 0; sub < kDirBandsPerBlock; ++sub) {
+  const uint32_t py0 = (band * kDirBandsPerBlock + sub) * R;
+  if (py0 >= Hp) break;
+  const uint32_t rows = min(R, Hp - py0);              // padded rows [py0, py0 + rows) are mine
+  if (sub) __syncthreads();                            // the previous band's tile is no longer read
+  // tile: matrix rows yb .. yb + rows (one more than mine: the row above), columns xb .. xb + Wp - 1 (tile column
+  // = padded window column: the sentinel column's place holds the real column left of the window)
+  const int TW = (int)Wp, xb = (int)w.c0 - 1, yb = (int)(w.r0 + py0) - 2;
+  const uint32_t plane = (rows + 1) * Wp;
+  int32_t *tm = tile_lds, *ta = tm + plane, *tb = ta + plane;
+  uint16_t *ca = reinterpret_cast<uint16_t *>(tb + plane), *cb = ca + Wp;
+  // (idx -> (row, column) without a division per element: one at the start, then steps of kDirThreads)
+  const uint32_t step_r = kDirThreads / Wp, step_c = kDirThreads - step_r * Wp;
+  for (uint32_t ty = threadIdx.x / Wp, tx = threadIdx.x - ty * Wp, idx = threadIdx.x; idx < plane; idx += kDirThreads) {
+    const int x = xb + (int)tx, y = yb + (int)ty;
+    const bool inside = x >= 0 && y >= 0;
+    const uint32_t at = inside ? (uint32_t)y * W + (uint32_t)x : 0u;
+    tm[idx] = inside ? Mg[at] : 0; ta[idx] = inside ? Ag[at] : 0; tb[idx] = inside ? Bg[at] : 0;
+    tx += step_c; ty += step_r;
+    if (tx >= Wp) { tx -= Wp; ++ty; }
+  }
+  for (uint32_t tx = threadIdx.x; tx < Wp; tx += kDirThreads) { const int x = xb + (int)tx; ca[tx] = x >= 1 ? p.code[sa_[x - 1]] : 0; }
+  for (uint32_t ty = threadIdx.x; ty <= rows; ty += kDirThreads) { const int y = yb + (int)ty; cb[ty] = y >= 1 ? p.code[sb_[y - 1]] : 0; }
+  __syncthreads();
+
+  TileAccess acc{tm, ta, tb, ca, cb, TW, xb, yb};
+  uint8_t *dir = p.dir + dir_offset(mo, pair) + (uint64_t)py0 * Wp;
+  // plain scorings (no free / forbidden gaps, no sentinel scores): the three decisions of alignment_reverse_move
+  // (alignment.c:311-327: GAP_A, then GAP_B, then MATCH) written out on 32-bit values -- SW scores are >= 0 and far
+  // from the int range, so this is the 64-bit code's result; everything else goes through reverse_move_t
+  const bool plain = !(p.flags & (SA_F_NO_START_GAP | SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_NO_MISMATCH |
+                                  SA_F_HAS_SENTINEL));
+  for (uint32_t pr = threadIdx.x / Wp, px = threadIdx.x - pr * Wp, idx = threadIdx.x; idx < rows * Wp;
+       idx += kDirThreads, px += step_c, pr += step_r) {
+    if (px >= Wp) { px -= Wp; ++pr; }
+    const uint32_t py = py0 + pr;
+    uint32_t byte = kEsc;                                // sentinel row / column
+    if (py != 0 && px != 0) {
+      const uint32_t x = w.c0 + px - 1, y = w.r0 + py - 1;
+      byte = 0x3f;                                       // border cells: every SW border score is 0
+      if (x > 0 && y > 0) {
+        const uint32_t at = (pr + 1) * Wp + px;          // (x, y) in the tile
+        const int s[3] = {tm[at], ta[at], tb[at]};
+        if (plain) {
+          if (s[0] > 0) {                                // MATCH <- (x-1, y-1), every move costs the substitution score
+            const int code_a = ca[px], code_b = cb[pr + 1];
+            const int sub = (k.K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
+                                       : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * k.K, code_b, k.table,
+                                                                      k.gen_eq, k.gen_ne);
+            const uint32_t d = at - Wp - 1;
+            const uint32_t f = (ta[d] + sub == s[0]) ? 1u : (tb[d] + sub == s[0]) ? 2u : 0u;
+            if (f == 0u && tm[d] + sub != s[0]) bad = true;
+            byte = (byte & ~3u) | f;
+          }
+          if (s[1] > 0) {                                // GAP_A <- (x, y-1): extend from gap_a, open from the others
+            const uint32_t d = at - Wp;
+            const uint32_t f = (ta[d] + k.ext == s[1]) ? 1u : (tb[d] + k.open1 == s[1]) ? 2u : 0u;
+            if (f == 0u && tm[d] + k.open1 != s[1]) bad = true;
+            byte = (byte & ~(3u << 2)) | (f << 2);
+          }
+          if (s[2] > 0) {                                // GAP_B <- (x-1, y): extend from gap_b, open from the others
+            const uint32_t d = at - 1;
+            const uint32_t f = (ta[d] + k.open1 == s[2]) ? 1u : (tb[d] + k.ext == s[2]) ? 2u : 0u;
+            if (f == 0u && tm[d] + k.open1 != s[2]) bad = true;
+            byte = (byte & ~(3u << 4)) | (f << 4);
+          }
+        } else
 #pragma unroll
-  for (int it = 0; it < kDirItems; ++it) {
-    const uint32_t idx = first + it * kDirThreads + threadIdx.x;
-    if (idx >= wcells) break;
-    const uint32_t py = idx / Wp, px = idx - py * Wp;
-    if (py == 0 || px == 0) { dir[idx] = (uint8_t)kEsc; continue; }   // sentinel row / column
-    const uint32_t x = w.c0 + px - 1, y = w.r0 + py - 1;
-    uint32_t byte = 0x3f;                              // border cells: every SW border score is 0
-    if (x > 0 && y > 0) {
-      const uint32_t at = y * W + x;
-      const int s[3] = {v.M[at], v.A[at], v.B[at]};
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        if (s[m] > 0) {
-          uint32_t px = x, py = y;
-          int pm = m, ps = s[m];
-          if (reverse_move(v, k, px, py, pm, ps)) bad = true;   // the generic kernel reports the error
-          byte = (byte & ~(3u << (2 * m))) | ((uint32_t)pm << (2 * m));
+        for (int m = 0; m < 3; ++m) {
+          if (s[m] > 0) {
+            uint32_t qx = x, qy = y;
+            int pm = m, ps = s[m];
+            if (reverse_move_t(acc, k, la, lb, qx, qy, pm, ps)) bad = true;   // the generic kernel reports the error
+            byte = (byte & ~(3u << (2 * m))) | ((uint32_t)pm << (2 * m));
+          }
         }
       }
     }
     dir[idx] = (uint8_t)byte;
+  }
   }
   if (bad) p.enum_status[pair] = SA_ENUM_GENERIC;
 }
@@ -481,13 +559,21 @@ hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p_in, hipStream_t s
   }
   const size_t lds = ((size_t)4 << p.claim_bits) + (size_t)12 * p.threads + (size_t)2 * p.threads * (p.layout.key64 ? 8 : 4) +
                      ((p.window_bytes + 15u) & ~(size_t)15u);
-  {   // direction bytes of every window (blocks beyond a pair's window return at once)
-    const unsigned per_block = sa::kDirThreads * sa::kDirItems;
-    const uint32_t bpp = (uint32_t)((p.window_bytes + per_block - 1) / per_block);
+  {   // direction bytes of every window: bands of R rows (bands beyond a pair's window return at once)
+    const uint32_t wp_max = std::min<uint32_t>(p.max_len_a + 2u, p.window_bytes / 2u);
+    const uint32_t hp_max = std::min<uint32_t>(p.max_len_b + 2u, p.window_bytes / 2u);
+    const uint32_t R = std::max<uint32_t>(2u, std::min<uint32_t>(32u, sa::kDirTileBytes / (12u * wp_max + 2u)) ) - 1u;
+    const size_t tile_lds = (size_t)12 * (R + 1) * wp_max + 2 * (wp_max + R + 2) + 16;
+    const uint32_t bpp = (hp_max + R * sa::kDirBandsPerBlock - 1) / (R * sa::kDirBandsPerBlock);
     const uint32_t pairs_per_launch = std::max<uint32_t>(1u, 0x7fffffffu / bpp);
+    if (tile_lds > 48u * 1024u) {
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa::sw_direction_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
+      if (ea != hipSuccess) return ea;
+    }
     for (uint32_t pair0 = 0; pair0 < n; pair0 += pairs_per_launch) {
       const uint32_t np = std::min(pairs_per_launch, n - pair0);
-      hipLaunchKernelGGL(sa::sw_direction_kernel, dim3(np * bpp), dim3(sa::kDirThreads), 0, stream, p, bpp, pair0);
+      hipLaunchKernelGGL(sa::sw_direction_kernel, dim3(np * bpp), dim3(sa::kDirThreads), tile_lds, stream, p, bpp, R, pair0);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
