@@ -129,7 +129,20 @@ extern const char align_col_mismatch[], align_col_indel[], align_col_context[], 
 
 /* THE BOUNDARY of the hot path (reference src/alignment.c:170-193): records the
  * borrowed pointers, grows the matrices, fills them -- here on the GPU, as a batch
- * of one.  No CPU fallback: without a gfx950 device it prints and exits. */
+ * of one.  No CPU fallback: without a gfx950 device it prints and exits.
+ * Where this call prints and exit()s although upstream would return (all are inputs
+ * on which upstream's own result is undefined or impractical; the batch API reports
+ * them as SEQALIGN_E_* codes instead):
+ *   - (len_a+1)*(len_b+1) >= 2^31 cells (24 GB of matrices for ONE pair);
+ *   - global alignment with a gap or substitution penalty below -|min_penalty|: upstream
+ *     computes INT_MIN + |min_penalty| + penalty, a signed overflow.  This
+ *     happens when penalties are edited after scoring_init without updating min_penalty,
+ *     and for scoring_init(..., no_gaps_in_a = no_gaps_in_b = 1) with gap penalties below
+ *     the mismatch score (upstream leaves them out of min_penalty, alignment_scoring.c:49-54,
+ *     but still applies them in the last row and column, alignment.c:128,146).
+ * All calls of the legacy API share one device context behind a mutex: an aligner_t per
+ * thread stays correct, but the fills run one after the other -- batches belong in
+ * seqalign_hip.h. */
 void aligner_align(aligner_t *aligner, const char *seq_a, const char *seq_b,
                    size_t len_a, size_t len_b, const scoring_t *scoring, char is_sw);
 void aligner_destroy(aligner_t *aligner);

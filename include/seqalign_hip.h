@@ -114,7 +114,11 @@ typedef struct {
 /* Which fill kernel family to launch. */
 enum {
   SEQALIGN_KERNEL_AUTO = 0,
-  SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair  */
+  SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair.
+                                    CORRECTNESS path: exact for any sign of
+                                    gap_extend (a positive one is always served
+                                    by it), 4-5x slower than the row sweeps: each
+                                    lane stores to a different row             */
   SEQALIGN_KERNEL_ROWSCAN = 2,   /* row sweep + max-plus prefix scan for gap_b,
                                     rows stored straight from registers        */
   SEQALIGN_KERNEL_STREAM = 3,    /* same sweep, output through an LDS ring as
@@ -220,12 +224,14 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * score >= min_score[p], at most max_hits per pair, into the caller's hit array
  * (hit_cap entries total).
  *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit.
- *   max_hits >= 2: GPU fill + GPU candidate compaction + segmented sort + GPU
- *       enumeration with 16 hit slots per pair (one wave per pair, visited bitmap
- *       in LDS; one lane per pair with the bitmap in HBM for pairs over 524 k
- *       cells).  Only the strings cross PCIe.  A pair that fills all 16 slots
- *       while max_hits asks for more is finished on the host from its matrices
- *       and candidates (rare: that pair's data only).
+ *   max_hits >= 2: GPU fill that also emits every cell >= min_score as a sort key
+ *       (smith_waterman.c:152-156) -> per-pair key sort (:159-161) -> enumeration
+ *       on the device with 16 hit slots per pair: one workgroup per pair, the
+ *       predecessor of every state and the visited bits in LDS (pairs whose
+ *       candidates do not fit an LDS window: one wave per pair walking the
+ *       matrices in HBM).  Only the strings cross PCIe.  A pair that fills all
+ *       16 slots while max_hits asks for more is finished on the host from its
+ *       matrices and sorted keys (rare: that pair's data only).
  *   SEQALIGN_TRACEBACK=host: the matrices and the compacted candidates of every
  *       pair are copied back and the hits are enumerated on the host (threaded
  *       over pairs). */
@@ -276,7 +282,10 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
  * is only the fast way to get it.  The context's own scratch (host-level entry
  * points) is allocated the same way.  The placement is checked with a write
  * probe and re-tried a few times (up to a few seconds the first time; arenas are
- * meant to be kept and reused); *quality, if not NULL, receives the probe's
+ * meant to be kept and reused).  While it searches, the call holds up to 6 arenas + 2
+ * spacers of 24..48 GiB -- never more than half of the device memory that is free at
+ * that moment (beyond that it allocates plainly); SEQALIGN_ARENA_SPREAD_GIB=0 switches
+ * the search off (the command-line tools do).  *quality, if not NULL, receives the probe's
  * 3-stream / 1-stream bandwidth ratio (~0.95 good, ~0.75 arenas disturb each other,
  * < 0 not probed: arenas under 256 MiB or over 12 GiB).  Free with seqalign_arenas_free. */
 int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);

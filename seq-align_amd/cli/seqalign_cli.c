@@ -10,9 +10,10 @@
  * deliberate: (1) --match/--mismatch/--gapopen/--gapextend also lower
  * min_penalty, so the NW floor stays defined (upstream leaves it stale: UB,
  * SURVEY A.3-3); (2) every pair's local hits come from a fresh visited mask
- * (SURVEY A.3-2); (3) no gzip input, no interactive stepping; (4) --zam is not
- * provided.  --printmatrices uses the per-pair API (it needs the matrices on the
- * host).
+ * (SURVEY A.3-2); (3) no interactive stepping through the hits (every hit is
+ * printed, as upstream does for non-interactive input).  Sequence files may be
+ * gzip-compressed (zlib, like upstream's seq_file); --zam is provided for the global
+ * tool.  --printmatrices uses the per-pair API (it needs the matrices on the host).
  */
 #define _POSIX_C_SOURCE 200809L
 #include <ctype.h>

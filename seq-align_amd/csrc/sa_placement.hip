@@ -152,9 +152,13 @@ hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream
   for (int attempt = 0; attempt < tries; ++attempt) {
     // the best placement so far stays allocated while the next one is made: different physical memory
     const size_t sp = spacer + (size_t)attempt * ((size_t)8 << 30);
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * bytes + 2 * sp + ((size_t)2 << 30)) {
+    // Transient footprint of an attempt: the three arenas + two spacers (+ the best placement so far, which stays
+    // allocated).  It must fit in HALF of what is free right now, so that another context / process on the same
+    // GPU is never pushed out of memory by a placement search; otherwise allocate plainly.
+    const size_t transient = 3 * bytes + 2 * sp + (best[0] ? 3 * bytes : 0);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || transient > free_b / 2) {
       if (best[0]) break;
-      return alloc3(bytes, 0, out);   // not enough room to spread at all
+      return alloc3(bytes, 0, out);   // not enough room to spread without crowding the device
     }
     void *cand[3];
     e = alloc3(bytes, sp, cand);

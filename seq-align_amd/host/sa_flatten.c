@@ -108,8 +108,10 @@ int sa_flatten_scoring(const scoring_t *sc, int is_sw, sa_flat_scoring_t *out)
    * hold the floor must be >= -|min_penalty|, else the reference overflows. */
   if(!is_sw) {
     int lim = -abs(sc->min_penalty);
-    int gaps_used = !(sc->no_gaps_in_a && sc->no_gaps_in_b) || 1; /* last row/col still open gaps */
-    if(gaps_used && (out->open1 < lim || out->ext < lim)) bad = 1;
+    /* gap penalties are always in use: even with no_gaps_in_a AND no_gaps_in_b the last column / row still
+     * opens and extends gaps (alignment.c:128,146), while scoring_init leaves them out of min_penalty in
+     * exactly that case (alignment_scoring.c:49-54) -- upstream then wraps around in the last row / column */
+    if(out->open1 < lim || out->ext < lim) bad = 1;
     if(out->gen_eq > SA_S_UNKNOWN && out->gen_eq < lim) bad = 1;
     if(out->gen_ne > SA_S_UNKNOWN && out->gen_ne < lim) bad = 1;
     for(uint32_t k = 0; k < K*K; k++)
