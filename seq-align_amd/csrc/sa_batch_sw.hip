@@ -206,6 +206,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     }
   }
   std::vector<std::vector<uint32_t>> members((size_t)n_cls);
+  uint64_t class_need[4] = {0, 0, 0, 0};   // largest window a member asks for
   std::vector<uint64_t> need_of(trace ? n : 0, 0);
   uint64_t unplaced = 0;
   for (uint64_t k = 0; k < n; ++k) {
@@ -222,6 +223,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     if (pick < 0 && bare <= cls[n_cls - 1].window_bytes) pick = n_cls - 1;   // no room for the full margin
     if (pick < 0) { ++unplaced; continue; }                    // generic kernel (flagged below)
     members[(size_t)pick].push_back((uint32_t)k);
+    class_need[pick] = std::max(class_need[pick], std::min<uint64_t>(need, cls[pick].window_bytes));
+  }
+  // LDS a class's members leave unused goes to its claim table (fewer hash collisions, fewer iterations)
+  for (int q2 = 0; q2 < n_cls; ++q2) {
+    const size_t per_cu = q2 == 0 ? 3 : q2 == 1 ? 2 : 1, total = std::min<size_t>(160u * 1024u / per_cu - 2048u, sa_enum_window_lds_limit());
+    const size_t other = (size_t)12 * cls[q2].threads + (size_t)2 * cls[q2].threads * key_bytes + ((class_need[q2] + 15) & ~(uint64_t)15);
+    while (cls[q2].claim_bits < 13 && ((size_t)4 << (cls[q2].claim_bits + 1)) + other <= total) ++cls[q2].claim_bits;
+    // ... and what is left after that is the window (room for a larger margin than the members asked for)
+    const size_t fixed_part = ((size_t)4 << cls[q2].claim_bits) + (size_t)12 * cls[q2].threads + (size_t)2 * cls[q2].threads * key_bytes;
+    if (total > fixed_part) cls[q2].window_bytes = (uint32_t)std::max<size_t>(class_need[q2], (total - fixed_part) & ~(size_t)15);
   }
   std::vector<uint32_t> pair_list;
   pair_list.reserve(n);
