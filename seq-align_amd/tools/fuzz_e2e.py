@@ -63,7 +63,19 @@ while time.time() < t_end:
         pairs.append((a, b))
     batch = W.from_pairs(pairs)
     os.environ["SEQALIGN_TRACE_KERNEL"] = ("lane", "wave")[int(v[0] >> 7) & 1]
-    os.environ["SEQALIGN_SW_ENUM"] = ("wave", "lane", "wave")[int(v[0] >> 9) % 3]
+    # multi-hit enumeration: the LDS-window kernel with 256 / 512 / 1024 threads (default path), with a window too
+    # small for the walks (flag -> retry -> generic kernel), or the generic kernels for every pair
+    for key in ("SEQALIGN_SW_ENUM", "SEQALIGN_ENUM_THREADS", "SEQALIGN_ENUM_WINDOW_BYTES"):
+        os.environ.pop(key, None)
+    mode = int(v[0] >> 9) % 8
+    if mode < 3:
+        os.environ["SEQALIGN_ENUM_THREADS"] = ("256", "512", "1024")[mode]
+    elif mode == 3:
+        os.environ["SEQALIGN_ENUM_WINDOW_BYTES"] = str(int(512 + v[1] % 20000))
+    elif mode == 4:
+        os.environ["SEQALIGN_SW_ENUM"] = "wave"
+    elif mode == 5:
+        os.environ["SEQALIGN_SW_ENUM"] = "lane"
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
         res = ctx.nw_batch(batch, sc)
         for p, (a, b) in enumerate(pairs):
