@@ -4,19 +4,6 @@
 
 using namespace sa_host;
 
-namespace {
-// SEQALIGN_TIMING=1: wall-clock of the host-level stages on stderr (development aid)
-struct StageTimer {
-  bool on = getenv("SEQALIGN_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char *what) {
-    if (!on) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[seqalign timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-    t = now;
-  }
-};
-}  // namespace
 
 // ------------------------------------------------- host-level: chunked fill ---
 

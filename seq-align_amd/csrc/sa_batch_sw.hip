@@ -128,6 +128,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
          &d_mask = ctx->e[5], &d_offs = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
          &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
   StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
+  StageTimer tm;
 
   int32_t thr = min_score[c.first];
   for (uint64_t k = 1; k < n; ++k) thr = std::min(thr, min_score[c.first + k]);
@@ -158,6 +159,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   sp.mat_off = d.mat_off; sp.cand_count = cand.cand_count; sp.keys = cand.keys; sp.tmp = cand.tmp; sp.n_pairs = (uint32_t)n;
   if ((e = sa_launch_sort_keys(sp, st)) != hipSuccess) return fail_hip(e, "candidate sort");
   const void *sorted = (sp.n_passes & 1) ? cand.tmp : cand.keys;
+  tm.lap("sw: enqueue fill + emit + sort");
 
   // ---- the one round trip: counts + bounding boxes
   std::vector<uint32_t> count(n), box(4 * n);
@@ -189,6 +191,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (lane_kernel) HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
   const uint64_t *dv_mask_off = d_offs.as<uint64_t>(), *dv_str_off = dv_mask_off + n + 1;
   HIP_TRY(hipStreamSynchronize(st));
+  tm.lap("sw: wait (fill, sort), boxes");
 
   // window the enumeration wants: the candidates' box plus room for the part of a hit that lies below
   // min_score (the kernel extends it further where LDS allows and flags a pair whose walk leaves it)
@@ -296,13 +299,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     }
     q.only_flagged = 1;
   }
-  std::vector<uint32_t> meta(3 * n);
-  std::vector<SaDevHit> dev_hits(n * max_hits);
+  tm.lap("sw: classes + enqueue enumeration");
+  // per pair: hit count | string bytes used | status -- through pinned memory; the hit records themselves come
+  // back later, packed (16 slots of 28 B per pair would be 4.5 MB for 10 000 pairs that have one hit each)
+  if ((rc = ctx->h_tmeta.reserve(n * 12 + n * 16 + 64))) return rc;
+  uint32_t *meta = ctx->h_tmeta.as<uint32_t>();
   if (generic_only && (e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
   if (side_events.ev.size() == 2) HIP_TRY(hipStreamWaitEvent(st, side_events.ev[1], 0));   // the side stream's pairs are done
-  HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(meta, d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
+  tm.lap("sw: wait (enumeration), meta + hits");
   if (!generic_only) {
     // second phase, only when a pair was flagged: escaped walks run again in the largest window, what the window
     // kernels cannot take goes to the generic kernel; then the results are fetched again
@@ -318,12 +324,13 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
         SaEnumParams w = q;
         w.only_flagged = 0; w.retry = 1;
         w.pair_list = d_list.as<uint32_t>(); w.n_list = (uint32_t)again.size();
-        w.threads = cls[2].threads; w.claim_bits = cls[2].claim_bits; w.window_bytes = cls[2].window_bytes;
+        SaEnumClass big[4];   // the configuration with the largest window LDS can hold at all
+        sa_enum_classes(layout.key64, big);
+        w.threads = big[3].threads; w.claim_bits = big[3].claim_bits; w.window_bytes = big[3].window_bytes;
         if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window, retry)");
       }
       if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");   // only_flagged
-      HIP_TRY(hipMemcpyAsync(meta.data(), d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(dev_hits.data(), d_hits.p, n * max_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(meta, d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
     }
   }
@@ -349,12 +356,15 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
             load / n, rounds_c / n, iters / n, fallback);
     (void)rounds;
   }
-  uint64_t gathered = 0;
+  uint64_t gathered = 0, n_dev_hits = 0;
+  uint64_t *hit_dst = reinterpret_cast<uint64_t *>(meta + 3 * n + (n & 1));   // pinned, behind meta (8-byte aligned)
   for (uint64_t k = 0; k < n; ++k) {
     const uint32_t status = meta[2 * n + k] & ~SA_ENUM_STOPPED_AT_MAX;
     if (status) return (status & (SA_ENUM_FALLBACK | SA_ENUM_GENERIC)) ? SEQALIGN_E_HIP : (int)status;
     dst_off[k] = gathered;
     gathered += meta[n + k];
+    hit_dst[k] = n_dev_hits;
+    n_dev_hits += meta[k];
   }
   // pairs that ran into the slot limit while the caller wants more: host enumeration with the full limit
   std::vector<uint64_t> capped;
@@ -407,19 +417,29 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     if ((rc = first_error.load())) return rc;
   }
 
-  // pack every pair's strings back to back and bring them over in one copy
+  tm.lap("sw: second phase (if any)");
+  // pack every pair's strings and hit records back to back and bring them over in one copy each
+  DevBuf &d_hits_packed = ctx->t_meta, &d_hit_dst = ctx->t_str_off;
   if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
-      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)) ||
+      (rc = d_hits_packed.reserve(n_dev_hits * sizeof(SaDevHit) + 16)) || (rc = d_hit_dst.reserve(n * 8 + 16)) ||
+      (rc = ctx->h_misc.reserve(n_dev_hits * sizeof(SaDevHit) + 16)))
     return rc;
   uint64_t *dv_dst_off = d_offs.as<uint64_t>() + 2 * (n + 1);
   HIP_TRY(hipMemcpyAsync(dv_dst_off, dst_off, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_hit_dst.p, hit_dst, n * 8, hipMemcpyHostToDevice, st));
   if ((e = sa_launch_gather_strings(q.out_a, q.out_b, dv_str_off, q.str_used, dv_dst_off, d_gath_a.as<char>(),
-                                    d_gath_b.as<char>(), (uint32_t)n, st)) != hipSuccess)
+                                    d_gath_b.as<char>(), q.hits, q.hit_count, d_hit_dst.as<uint64_t>(),
+                                    d_hits_packed.as<SaDevHit>(), max_hits, (uint32_t)n, st)) != hipSuccess)
     return fail_hip(e, "gather strings");
   HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+  if (n_dev_hits)
+    HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, d_hits_packed.p, n_dev_hits * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  const SaDevHit *dev_hits = ctx->h_misc.as<SaDevHit>();
 
+  tm.lap("sw: gather + strings D2H");
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
   for (uint64_t k = 0; k < n; ++k) {
     if (!capped.empty() && redo_of[k] >= 0) {   // finished on the host
@@ -435,7 +455,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       continue;
     }
     for (uint32_t i = 0; i < meta[k]; ++i) {
-      const SaDevHit &src = dev_hits[k * max_hits + i];
+      const SaDevHit &src = dev_hits[hit_dst[k] + i];
       if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
       memcpy(out_a + *used_str, ha + dst_off[k] + src.str_off, src.length);
       memcpy(out_b + *used_str, hb + dst_off[k] + src.str_off, src.length);
@@ -446,6 +466,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       *used_str += src.length + 1;
     }
   }
+  tm.lap("sw: unpack hits");
   return SEQALIGN_OK;
 }
 

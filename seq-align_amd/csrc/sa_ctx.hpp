@@ -95,6 +95,18 @@ void parallel_for(uint64_t n, F fn) {
 }
 
 
+// SEQALIGN_TIMING=1: wall-clock of the host-level stages on stderr (development aid)
+struct StageTimer {
+  bool on = getenv("SEQALIGN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[seqalign timing] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 // ------------------------------------------------------------------ errors ---
 int fail_hip(hipError_t e, const char *what);     // records the message, maps to SEQALIGN_E_*
 void set_last_error(const std::string &msg);

@@ -201,9 +201,11 @@ static inline size_t sa_dir_bytes(uint64_t cells, uint64_t n) { return (size_t)(
 /* direction bytes first (sw_direction_kernel), then the enumeration: both launched by this call */
 hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
+/* every pair's strings (and, hits_out != NULL, its hit records) packed back to back: dst_off / hit_dst = prefixes */
 hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,
                                     const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,
-                                    uint32_t n_pairs, hipStream_t stream);
+                                    const SaDevHit *hits_in, const uint32_t *hit_count, const uint64_t *hit_dst,
+                                    SaDevHit *hits_out, uint32_t max_hits, uint32_t n_pairs, hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
 /* three device allocations of `bytes`, spread over HBM and checked (sa_placement.hip);
  * *quality (may be NULL): 3-stream / 1-stream write bandwidth ratio of the result, < 0 if not probed */

@@ -297,11 +297,13 @@ __global__ void __launch_bounds__(64) sw_enumerate_wave_kernel(const SaEnumParam
   }
 }
 
-// strings of all pairs packed back to back for one D2H: one wave per pair
+// strings and hit records of all pairs packed back to back for one D2H each: one wave per pair
 __global__ void __launch_bounds__(256) gather_strings_kernel(const char *src_a, const char *src_b,
                                                              const uint64_t *str_off, const uint32_t *used,
                                                              const uint64_t *dst_off, char *dst_a, char *dst_b,
-                                                             uint32_t n_pairs) {
+                                                             const SaDevHit *hits_in, const uint32_t *hit_count,
+                                                             const uint64_t *hit_dst, SaDevHit *hits_out,
+                                                             uint32_t max_hits, uint32_t n_pairs) {
   const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= n_pairs) return;
   const int lane = threadIdx.x & 63;
@@ -309,6 +311,10 @@ __global__ void __launch_bounds__(256) gather_strings_kernel(const char *src_a, 
   const char *sa_ = src_a + str_off[pair], *sb_ = src_b + str_off[pair];
   char *da = dst_a + dst_off[pair], *db = dst_b + dst_off[pair];
   for (uint32_t i = lane; i < n; i += 64) { da[i] = sa_[i]; db[i] = sb_[i]; }
+  if (hits_out) {
+    const uint32_t nh = hit_count[pair];
+    for (uint32_t i = lane; i < nh; i += 64) hits_out[hit_dst[pair] + i] = hits_in[(uint64_t)pair * max_hits + i];
+  }
 }
 
 }  // namespace sa
@@ -330,9 +336,10 @@ hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream) {
 
 hipError_t sa_launch_gather_strings(const char *src_a, const char *src_b, const uint64_t *str_off,
                                     const uint32_t *used, const uint64_t *dst_off, char *dst_a, char *dst_b,
-                                    uint32_t n_pairs, hipStream_t stream) {
+                                    const SaDevHit *hits_in, const uint32_t *hit_count, const uint64_t *hit_dst,
+                                    SaDevHit *hits_out, uint32_t max_hits, uint32_t n_pairs, hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
   hipLaunchKernelGGL(sa::gather_strings_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, stream, src_a, src_b,
-                     str_off, used, dst_off, dst_a, dst_b, n_pairs);
+                     str_off, used, dst_off, dst_a, dst_b, hits_in, hit_count, hit_dst, hits_out, max_hits, n_pairs);
   return hipGetLastError();
 }
