@@ -15,7 +15,7 @@ synthetic batch that is already resident in HBM.
           (barrier, MAX of the elapsed time, SUM of the cells) is two scalars over
           torch.distributed "gloo" -- no RCCL needed (SEQALIGN_DIST_BACKEND=nccl uses it).
 
-    python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus 1 --steps 1000 --warmup 10
     python bench.py --gpus 8                     # launches its 8 ranks itself
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8   # or under a launcher
 
@@ -376,7 +376,7 @@ def run(args) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)   # C2: ~0.42 s of kernels; the whole default run stays under a minute
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
                     help="default: C2 at --gpus 1, C5 (125k pairs per GPU of the 1M-pair batch) at --gpus N > 1")
