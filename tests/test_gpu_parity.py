@@ -693,6 +693,29 @@ def test_sw_enumeration_window_kernel(ctx, threads, window, monkeypatch):
     for p in range(prot.n_pairs):
         rc, want = O.oracle_sw(osc, prot.seq_a(p), prot.seq_b(p), 25)
         assert rc == 0 and got[p] == want, (threads, window, "BLOSUM62", p)
+    # scores in the tens of thousands: the candidate keys need 64 bits (another instantiation of every kernel)
+    sc = S.make_scoring({"init": [30000, -20000, -25000, -5000, 0, 0, 0, 0, 0, 0]})
+    osc = oracle_scoring_of(sc)
+    got = ctx.sw_batch(dna, sc, 250000, max_hits=5)
+    for p in range(dna.n_pairs):
+        rc, want = O.oracle_sw(osc, dna.seq_a(p), dna.seq_b(p), 250000, 5)
+        assert rc == 0 and got[p] == want, (threads, window, "64-bit keys", p)
+
+
+def test_sw_batch_multi_hit_in_several_chunks(ctx, monkeypatch):
+    """seqalign_sw_batch(max_hits > 1) on a batch that does not fit one chunk (tiny chunk budget): the per-chunk
+    scratch (key arenas, direction bytes, class lists) is reused chunk after chunk; hits equal the one-chunk call's."""
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    batch = W.dna_sw_read_vs_ref(120, seed=73, read_len=80, ref_len=300)
+    one = ctx.sw_batch(batch, sc, 16, max_hits=6)
+    monkeypatch.setenv("SEQALIGN_CHUNK_BYTES", str(6 << 20))     # ~30 pairs per chunk
+    with S.Context(0) as small:
+        many = small.sw_batch(batch, sc, 16, max_hits=6)
+    assert one == many
+    osc = oracle_scoring_of(sc)
+    for p in range(0, batch.n_pairs, 9):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 16, 6)
+        assert rc == 0 and one[p] == want, p
 
 
 @pytest.mark.parametrize("enum_kernel", ["window", "wave", "lane"])
