@@ -208,6 +208,13 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       for (int k = 0; k < n_cls; ++k) { cls[k] = cls[2]; cls[k].threads = (uint32_t)t; }
     }
   }
+  // margin the class decision reserves above / left of the candidates' box, in cells: base + mult * (min_score / best
+  // move) -- the part of a hit that lies below min_score; SEQALIGN_ENUM_MARGIN="base,mult" (tuning experiments)
+  uint64_t margin_base = 16, margin_mult = 1;
+  if (const char *env = getenv("SEQALIGN_ENUM_MARGIN")) {
+    unsigned long long b = 0, m = 0;
+    if (sscanf(env, "%llu,%llu", &b, &m) == 2) { margin_base = b; margin_mult = m; }
+  }
   std::vector<std::vector<uint32_t>> members((size_t)n_cls);
   uint64_t class_need[4] = {0, 0, 0, 0};   // largest window a member asks for
   std::vector<uint64_t> need_of(trace ? n : 0, 0);
@@ -215,7 +222,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   for (uint64_t k = 0; k < n; ++k) {
     if (!count[k]) continue;
     const uint64_t rmin = box[4 * k], rmax = box[4 * k + 1], cmin = box[4 * k + 2], cmax = box[4 * k + 3];
-    const uint64_t margin = 16 + 2 * (uint64_t)((std::max(min_score[c.first + k], 1) + best_step - 1) / best_step);
+    const uint64_t margin = margin_base + margin_mult * (uint64_t)((std::max(min_score[c.first + k], 1) + best_step - 1) / best_step);
     const uint64_t r0 = rmin > margin ? rmin - margin : 0, c0 = cmin > margin ? cmin - margin : 0;
     const uint64_t need = (rmax - r0 + 2) * (cmax - c0 + 2);   // stored with a sentinel row and column
     const uint64_t bare = (rmax - rmin + 2) * (cmax - cmin + 2);

@@ -72,7 +72,7 @@ __device__ __forceinline__ Window window_of(const SaEnumParams &p, uint32_t pair
   Window w{0, 0, 0, 0, false};
   if (area(0) > budget) return w;
   const uint32_t thr = (uint32_t)max(p.min_score[pair], 1);
-  // (the host picks the LDS class with a margin of 16 + 2 * thr / best_step; whatever room the class leaves is used)
+  // (the host picks the LDS class with a margin of 16 + thr / best_step; whatever room the class leaves is used)
   const uint32_t want = p.retry ? 0xffffffffu : 64u + 4u * ((thr + p.best_step - 1u) / p.best_step);
   uint32_t lo = 0, hi = min(want, max(rmin, cmin));
   while (lo < hi) {   // largest margin <= want with area <= budget
