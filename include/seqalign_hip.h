@@ -291,6 +291,16 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
 int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);
 int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]);
 
+/* ---- CIGAR -------------------------------------------------------------------- */
+/* The reference has no CIGAR output (its result is the pair of gapped strings, src/alignment.h:33-40); this
+ * is the derived format: run-length encoding of the alignment's columns with seq_a as the query and seq_b as
+ * the reference -- both letters: M (extended = 0) or '=' / 'X' (extended != 0; letters compared as they are,
+ * or case-folded when case_insensitive), '-' in result_b: I (insertion to the reference), '-' in result_a: D.
+ * Writes a NUL-terminated string; returns its length, or (size_t)-1 when cap is too small or a column has a
+ * gap in both strings.  Host only, no device involved. */
+size_t seqalign_cigar(const char *result_a, const char *result_b, size_t length, int extended,
+                      int case_insensitive, char *out, size_t cap);
+
 /* ---- misc ---------------------------------------------------------------------- */
 /* Event pair on a stream for kernel timing (HIP events; bench.py). */
 int seqalign_time_fill_ms(seqalign_ctx_t *ctx,

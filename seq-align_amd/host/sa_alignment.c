@@ -214,3 +214,29 @@ void alignment_print_spacer(const char* alignment_a, const char* alignment_b,
     else putc('*', stdout);
   }
 }
+
+/* CIGAR of an alignment (include/seqalign_hip.h): a derived format, the reference prints the gapped strings only */
+size_t seqalign_cigar(const char *ra, const char *rb, size_t length, int extended, int case_insensitive,
+                      char *out, size_t cap)
+{
+  size_t i = 0, used = 0;
+  if(!ra || !rb || !out || cap == 0) return (size_t)-1;
+  while(i < length) {
+    char op;
+    size_t run = 0;
+    char tmp[24];
+    int n;
+    #define SA_OP(k) ((ra[k] == '-' && rb[k] == '-') ? '?' : ra[k] == '-' ? 'D' : rb[k] == '-' ? 'I' : !extended ? 'M' : \
+                      ((case_insensitive ? tolower((unsigned char)ra[k]) == tolower((unsigned char)rb[k]) : ra[k] == rb[k]) ? '=' : 'X'))
+    op = SA_OP(i);
+    if(op == '?') return (size_t)-1;
+    while(i < length && SA_OP(i) == op) { run++; i++; }
+    #undef SA_OP
+    n = snprintf(tmp, sizeof tmp, "%zu%c", run, op);
+    if(n < 0 || used + (size_t)n + 1 > cap) return (size_t)-1;
+    memcpy(out + used, tmp, (size_t)n);
+    used += (size_t)n;
+  }
+  out[used] = '\0';
+  return used;
+}

@@ -161,3 +161,40 @@ def test_host_traceback_matches_oracle_on_oracle_matrices():
             n, score = C.c_size_t(0), C.c_int32(0)
             rc = S.lib().sa_nw_traceback(C.byref(v), ra, rb, C.byref(n), C.byref(score))
             assert (rc, score.value, ra.value, rb.value) == want
+
+
+def test_cigar_of_reference_alignments():
+    """north_star asks for identical CIGAR / alignment strings; the reference has no CIGAR, so it is the derived format
+    of the two gapped strings (seqalign_cigar).  Checked on the golden NW alignments of the compiled reference against a
+    Python run-length encoding, plain and extended ops, and on the error paths."""
+    lib = S.lib()
+    lib.seqalign_cigar.restype = C.c_size_t
+
+    def rle(a, b, extended, fold):
+        ops = []
+        for x, y in zip(a, b):
+            op = "D" if x == "-" else "I" if y == "-" else "M" if not extended else \
+                ("=" if (x.lower() == y.lower() if fold else x == y) else "X")
+            if ops and ops[-1][1] == op:
+                ops[-1][0] += 1
+            else:
+                ops.append([1, op])
+        return "".join(f"{n}{o}" for n, o in ops)
+
+    cfg = json.loads((GOLD / "configs.json").read_text())
+    n = 0
+    for name in ("C2_related", "C5"):
+        for g in cfg[name]["pairs"][:32]:
+            a, b = g["result_a"], g["result_b"]
+            for ext, fold in ((0, 0), (1, 0), (1, 1)):
+                out = C.create_string_buffer(4 * len(a) + 8)
+                ln = lib.seqalign_cigar(a.encode(), b.encode(), C.c_size_t(len(a)), ext, fold, out, C.c_size_t(len(out)))
+                assert ln == len(out.value) and out.value.decode() == rle(a, b, ext, fold), (name, a, b)
+                n += 1
+    assert n == 192
+    out = C.create_string_buffer(64)
+    assert lib.seqalign_cigar(b"AC-T", b"ACGT", C.c_size_t(4), 0, 0, out, C.c_size_t(64)) == 6 and out.value == b"2M1D1M"
+    assert lib.seqalign_cigar(b"acgt", b"ACGA", C.c_size_t(4), 1, 1, out, C.c_size_t(64)) == 4 and out.value == b"3=1X"
+    assert lib.seqalign_cigar(b"", b"", C.c_size_t(0), 0, 0, out, C.c_size_t(64)) == 0 and out.value == b""
+    assert lib.seqalign_cigar(b"A-", b"A-", C.c_size_t(2), 0, 0, out, C.c_size_t(64)) == C.c_size_t(-1).value
+    assert lib.seqalign_cigar(b"ACGT", b"ACGT", C.c_size_t(4), 0, 0, out, C.c_size_t(2)) == C.c_size_t(-1).value
