@@ -125,6 +125,7 @@ struct SaEnumParams {
   uint32_t threads;              /* window kernel: threads per workgroup of this launch (256 / 512 / 1024)      */
   uint32_t retry;                /* window kernels: second attempt at flagged pairs, margin as large as LDS allows */
   uint32_t max_len_a, max_len_b; /* of the chunk (sizes the direction kernel's tiles)                              */
+  uint32_t inline_steps;         /* window kernel: cells a thread walks itself before queueing (0 = default)        */
 };
 
 /* LDS configurations of the window kernel, smallest first: a pair goes to the first one whose window holds what

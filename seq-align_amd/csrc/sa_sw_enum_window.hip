@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(T) sw_enumerate_window_kernel(const SaEnumPara
   };
 
   // ---- 2. a pool of T walks in flight; a thread whose candidate is done takes the next one
+  const uint32_t inline_steps = p.inline_steps ? p.inline_steps : (uint32_t)kInlineSteps;
   bool active = false;                      // this thread holds an unfinished candidate
   uint32_t rank = 0, at = 0, m2 = 0, done_len = 0;
   uint32_t n_iter = 0;
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(T) sw_enumerate_window_kernel(const SaEnumPara
       if (byte & kVis) {
         active = false;                       // already marked (smith_waterman.c:269), or the walk ran into a mark
       } else {
-        cres = claim_walk(rank, cat, cm2, byte, plen, kInlineSteps);
+        cres = claim_walk(rank, cat, cm2, byte, plen, inline_steps);
         if (cres == 2) {
           qslot = atomicAdd(&s_nq[0], 1u);
           if (qslot < (uint32_t)kQueueCap) { s_q0[qslot] = cat | (cm2 << 24); s_q1[qslot] = rank; s_q2[qslot] = plen; }
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(T) sw_enumerate_window_kernel(const SaEnumPara
     int mres = 0;
     qslot = 0xffffffffu;
     if (active) {
-      mres = commit_walk(rank, at, m2, left_cells, kInlineSteps);
+      mres = commit_walk(rank, at, m2, left_cells, inline_steps);
       if (mres == 2) {
         qslot = atomicAdd(&s_nq[1], 1u);
         if (qslot < (uint32_t)kQueueCap) { s_q0[qslot] = at | (m2 << 24); s_q1[qslot] = rank; s_q2[qslot] = left_cells; }
@@ -553,6 +554,7 @@ hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p_in, hipStream_t s
   SaEnumParams p = p_in;
   const uint32_t n = p.pair_list ? p.n_list : p.n_pairs;
   if (n == 0) return hipSuccess;
+  if (const char *env = getenv("SEQALIGN_ENUM_INLINE")) p.inline_steps = (uint32_t)std::max(1, atoi(env));   // tuning experiments
   if (const char *env = getenv("SEQALIGN_ENUM_WINDOW_BYTES")) {   // tests: a window too small for the walks -> fallback path
     const long v = atol(env);
     if (v >= 16) p.window_bytes = (uint32_t)std::min<long>(v, (long)p.window_bytes);
