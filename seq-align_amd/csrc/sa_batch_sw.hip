@@ -153,18 +153,29 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.n_pairs = (uint32_t)n;
     if ((e = sa_launch_sw_emit(r, cand, st)) != hipSuccess) return fail_hip(e, "sw candidate emission");
   }
+  // Two streams from here on.  Main: key sort, then the enumeration.  Side: everything that needs the fill's
+  // matrices and boxes but not the sorted keys -- the boxes' way to the host, the class decision, the direction
+  // bytes -- so that the direction kernels run next to the sort instead of after it.
+  if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  hipStream_t side = ctx->stream2;
+  StreamSyncOnExit sync_side_on_exit(side);
+  EventList events;   // 0: fill done, 1: sort done, 2: direction bytes done, 3: side stream's generic kernel done
+  for (int k = 0; k < 4; ++k) HIP_TRY(events.add(hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(events.ev[0], st));
   SaSortParams sp;
   memset(&sp, 0, sizeof(sp));
   sa_sort_plan(layout, &sp);
   sp.mat_off = d.mat_off; sp.cand_count = cand.cand_count; sp.keys = cand.keys; sp.tmp = cand.tmp; sp.n_pairs = (uint32_t)n;
   if ((e = sa_launch_sort_keys(sp, st)) != hipSuccess) return fail_hip(e, "candidate sort");
+  HIP_TRY(hipEventRecord(events.ev[1], st));
   const void *sorted = (sp.n_passes & 1) ? cand.tmp : cand.keys;
   tm.lap("sw: enqueue fill + emit + sort");
 
-  // ---- the one round trip: counts + bounding boxes
+  // ---- the one round trip: counts + bounding boxes (as soon as the fill is done)
   std::vector<uint32_t> count(n), box(4 * n);
-  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(box.data(), d_box.p, n * 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamWaitEvent(side, events.ev[0], 0));
+  HIP_TRY(hipMemcpyAsync(count.data(), ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, side));
+  HIP_TRY(hipMemcpyAsync(box.data(), d_box.p, n * 16, hipMemcpyDeviceToHost, side));
 
   // host prefixes meanwhile: visited-bitmap words (generic lane kernel), string slots
   std::vector<uint64_t> offs(3 * (n + 1)), cell0(n + 1, 0);
@@ -186,12 +197,12 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       (rc = d_dir.reserve(sa_dir_bytes(c.cells, n))))
     return rc;
   const bool trace = getenv("SEQALIGN_ENUM_TRACE") != nullptr;   // development aid: per-pair phase cycles on stderr
-  HIP_TRY(hipMemsetAsync(d_meta.p, 0, n * 12, st));   // enum_status starts clean: the direction kernel may flag pairs
-  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 2 * (n + 1) * 8, hipMemcpyHostToDevice, st));
-  if (lane_kernel) HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, st));
+  HIP_TRY(hipMemsetAsync(d_meta.p, 0, n * 12, side));   // enum_status starts clean: the direction kernel may flag pairs
+  HIP_TRY(hipMemcpyAsync(d_offs.p, offs.data(), 2 * (n + 1) * 8, hipMemcpyHostToDevice, side));
+  if (lane_kernel) HIP_TRY(hipMemsetAsync(d_mask.p, 0, mask_words * 4, side));
   const uint64_t *dv_mask_off = d_offs.as<uint64_t>(), *dv_str_off = dv_mask_off + n + 1;
-  HIP_TRY(hipStreamSynchronize(st));
-  tm.lap("sw: wait (fill, sort), boxes");
+  HIP_TRY(hipStreamSynchronize(side));
+  tm.lap("sw: wait (fill), boxes");
 
   // window the enumeration wants: the candidates' box plus room for the part of a hit that lies below
   // min_score (the kernel extends it further where LDS allows and flags a pair whose walk leaves it)
@@ -250,7 +261,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   DevBuf &d_list = ctx->e[11];
   if ((rc = d_list.reserve(n * 4 + 128 * n * (trace ? 1 : 0) + 32))) return rc;
   if (!pair_list.empty())
-    HIP_TRY(hipMemcpyAsync(d_list.p, pair_list.data(), pair_list.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_list.p, pair_list.data(), pair_list.size() * 4, hipMemcpyHostToDevice, side));
 
   // ---- enumeration
   SaEnumParams q;
@@ -272,28 +283,20 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.dir = d_dir.as<uint8_t>();
   unsigned long long *d_trace = reinterpret_cast<unsigned long long *>(d_list.as<char>() + ((n * 4 + 15) & ~(uint64_t)15));
   q.trace = trace ? d_trace : nullptr;
-  if (trace) HIP_TRY(hipMemsetAsync(d_trace, 0, n * 128, st));
+  if (trace) HIP_TRY(hipMemsetAsync(d_trace, 0, n * 128, side));
   const bool generic_only = force && (force[0] == 'w' || force[0] == 'l');
   std::vector<uint32_t> flags;   // (function scope: the copy below is asynchronous)
-  EventList side_events;
+  bool side_generic = false;
   if (!generic_only && unplaced) {   // pairs whose candidates' box fits no window: flagged for the generic kernel
     flags.assign(n, 0u);
     std::vector<char> placed(n, 0);
     for (uint32_t k : pair_list) placed[k] = 1;
     for (uint64_t k = 0; k < n; ++k) flags[k] = (count[k] && !placed[k]) ? SA_ENUM_GENERIC : 0u;
-    HIP_TRY(hipMemcpyAsync(q.enum_status, flags.data(), n * 4, hipMemcpyHostToDevice, st));   // before the window kernels
-    // these pairs are few and slow (one wave each): start them now on the side stream, under the window kernels
-    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    HIP_TRY(side_events.add(hipEventDisableTiming));
-    HIP_TRY(side_events.add(hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(side_events.ev[0], st));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream2, side_events.ev[0], 0));
-    SaEnumParams g = q;
-    g.only_flagged = 1;
-    if ((e = sa_launch_sw_enumerate(g, ctx->stream2)) != hipSuccess) return fail_hip(e, "sw enumerate (generic, side stream)");
-    HIP_TRY(hipEventRecord(side_events.ev[1], ctx->stream2));
+    HIP_TRY(hipMemcpyAsync(q.enum_status, flags.data(), n * 4, hipMemcpyHostToDevice, side));   // before the window kernels
   }
   if (!generic_only) {
+    // direction bytes, class by class, on the side stream (next to the sort) ...
+    std::vector<SaEnumParams> launches;
     uint32_t first = 0;
     for (int q2 = 0; q2 < n_cls; ++q2) {
       const uint32_t cnt = (uint32_t)members[(size_t)q2].size();
@@ -301,10 +304,27 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       SaEnumParams w = q;
       w.pair_list = d_list.as<uint32_t>() + first; w.n_list = cnt;
       w.threads = cls[q2].threads; w.claim_bits = cls[q2].claim_bits; w.window_bytes = cls[q2].window_bytes;
-      if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window)");
+      if ((e = sa_launch_sw_direction(w, side)) != hipSuccess) return fail_hip(e, "sw direction bytes");
+      launches.push_back(w);
       first += cnt;
     }
+    HIP_TRY(hipEventRecord(events.ev[2], side));
+    // ... then the enumeration on the main stream, behind the sort
+    HIP_TRY(hipStreamWaitEvent(st, events.ev[2], 0));
+    for (const SaEnumParams &w : launches)
+      if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window)");
     q.only_flagged = 1;
+    if (unplaced) {
+      // the few pairs no window takes are slow (one wave each): start them on the side stream, under the window
+      // kernels; they read the sorted keys
+      HIP_TRY(hipStreamWaitEvent(side, events.ev[1], 0));
+      if ((e = sa_launch_sw_enumerate(q, side)) != hipSuccess) return fail_hip(e, "sw enumerate (generic, side stream)");
+      HIP_TRY(hipEventRecord(events.ev[3], side));
+      side_generic = true;
+    }
+  } else {
+    HIP_TRY(hipEventRecord(events.ev[2], side));
+    HIP_TRY(hipStreamWaitEvent(st, events.ev[2], 0));   // offsets / cleared status come from the side stream
   }
   tm.lap("sw: classes + enqueue enumeration");
   // per pair: hit count | string bytes used | status -- through pinned memory; the hit records themselves come
@@ -312,7 +332,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if ((rc = ctx->h_tmeta.reserve(n * 12 + n * 16 + 64))) return rc;
   uint32_t *meta = ctx->h_tmeta.as<uint32_t>();
   if (generic_only && (e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");
-  if (side_events.ev.size() == 2) HIP_TRY(hipStreamWaitEvent(st, side_events.ev[1], 0));   // the side stream's pairs are done
+  if (side_generic) HIP_TRY(hipStreamWaitEvent(st, events.ev[3], 0));   // the side stream's pairs are done
   HIP_TRY(hipMemcpyAsync(meta, d_meta.p, n * 12, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
   tm.lap("sw: wait (enumeration), meta + hits");
@@ -334,7 +354,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
         SaEnumClass big[4];   // the configuration with the largest window LDS can hold at all
         sa_enum_classes(layout.key64, big);
         w.threads = big[3].threads; w.claim_bits = big[3].claim_bits; w.window_bytes = big[3].window_bytes;
-        if ((e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess) return fail_hip(e, "sw enumerate (window, retry)");
+        if ((e = sa_launch_sw_direction(w, st)) != hipSuccess || (e = sa_launch_sw_enumerate_window(w, st)) != hipSuccess)
+          return fail_hip(e, "sw enumerate (window, retry)");
       }
       if ((e = sa_launch_sw_enumerate(q, st)) != hipSuccess) return fail_hip(e, "sw enumerate");   // only_flagged
       HIP_TRY(hipMemcpyAsync(meta, d_meta.p, n * 12, hipMemcpyDeviceToHost, st));

@@ -199,7 +199,8 @@ hipError_t sa_launch_sort_keys(const SaSortParams &p, hipStream_t stream);
 size_t sa_enum_window_lds_limit();
 /* bytes of SaEnumParams::dir for a chunk of n pairs and `cells` matrix cells */
 static inline size_t sa_dir_bytes(uint64_t cells, uint64_t n) { return (size_t)(2 * cells + 8 * n + 16); }
-/* direction bytes first (sw_direction_kernel), then the enumeration: both launched by this call */
+/* one class of pairs: direction bytes (needs matrices + boxes, not the sorted keys), then the enumeration */
+hipError_t sa_launch_sw_direction(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p, hipStream_t stream);
 hipError_t sa_launch_sw_enumerate(const SaEnumParams &p, hipStream_t stream);
 /* every pair's strings (and, hits_out != NULL, its hit records) packed back to back: dst_off / hit_dst = prefixes */

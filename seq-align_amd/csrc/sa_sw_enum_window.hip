@@ -548,38 +548,48 @@ int sa_enum_classes(uint32_t key64, SaEnumClass out[4]) {
   return 4;
 }
 
-// One class of pairs (p.pair_list / p.n_list, or all pairs): direction bytes, then the enumeration.
-// p.threads / p.claim_bits / p.window_bytes come from sa_enum_classes.
-hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p_in, hipStream_t stream) {
+static SaEnumParams with_env_overrides(const SaEnumParams &p_in) {
   SaEnumParams p = p_in;
-  const uint32_t n = p.pair_list ? p.n_list : p.n_pairs;
-  if (n == 0) return hipSuccess;
   if (const char *env = getenv("SEQALIGN_ENUM_INLINE")) p.inline_steps = (uint32_t)std::max(1, atoi(env));   // tuning experiments
   if (const char *env = getenv("SEQALIGN_ENUM_WINDOW_BYTES")) {   // tests: a window too small for the walks -> fallback path
     const long v = atol(env);
     if (v >= 16) p.window_bytes = (uint32_t)std::min<long>(v, (long)p.window_bytes);
   }
+  return p;
+}
+
+// Direction bytes of every window of one class: bands of R rows (bands beyond a pair's window return at once).
+// Needs the fill's matrices and the candidates' boxes, NOT the sorted keys: the caller may run it next to the sort.
+hipError_t sa_launch_sw_direction(const SaEnumParams &p_in, hipStream_t stream) {
+  const SaEnumParams p = with_env_overrides(p_in);
+  const uint32_t n = p.pair_list ? p.n_list : p.n_pairs;
+  if (n == 0) return hipSuccess;
+  const uint32_t wp_max = std::min<uint32_t>(p.max_len_a + 2u, p.window_bytes / 2u);
+  const uint32_t hp_max = std::min<uint32_t>(p.max_len_b + 2u, p.window_bytes / 2u);
+  const uint32_t R = std::max<uint32_t>(2u, std::min<uint32_t>(32u, sa::kDirTileBytes / (12u * wp_max + 2u)) ) - 1u;
+  const size_t tile_lds = (size_t)12 * (R + 1) * wp_max + 2 * (wp_max + R + 2) + 16;
+  const uint32_t bpp = (hp_max + R * sa::kDirBandsPerBlock - 1) / (R * sa::kDirBandsPerBlock);
+  const uint32_t pairs_per_launch = std::max<uint32_t>(1u, 0x7fffffffu / bpp);
+  if (tile_lds > 48u * 1024u) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa::sw_direction_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
+    if (ea != hipSuccess) return ea;
+  }
+  for (uint32_t pair0 = 0; pair0 < n; pair0 += pairs_per_launch) {
+    const uint32_t np = std::min(pairs_per_launch, n - pair0);
+    hipLaunchKernelGGL(sa::sw_direction_kernel, dim3(np * bpp), dim3(sa::kDirThreads), tile_lds, stream, p, bpp, R, pair0);
+  }
+  return hipGetLastError();
+}
+
+// The enumeration of one class of pairs (p.pair_list / p.n_list, or all pairs); their direction bytes must be there
+// (sa_launch_sw_direction with the same parameters).  p.threads / p.claim_bits / p.window_bytes: sa_enum_classes.
+hipError_t sa_launch_sw_enumerate_window(const SaEnumParams &p_in, hipStream_t stream) {
+  const SaEnumParams p = with_env_overrides(p_in);
+  const uint32_t n = p.pair_list ? p.n_list : p.n_pairs;
+  if (n == 0) return hipSuccess;
   const size_t lds = ((size_t)4 << p.claim_bits) + (size_t)12 * p.threads + (size_t)2 * p.threads * (p.layout.key64 ? 8 : 4) +
                      ((p.window_bytes + 15u) & ~(size_t)15u);
-  {   // direction bytes of every window: bands of R rows (bands beyond a pair's window return at once)
-    const uint32_t wp_max = std::min<uint32_t>(p.max_len_a + 2u, p.window_bytes / 2u);
-    const uint32_t hp_max = std::min<uint32_t>(p.max_len_b + 2u, p.window_bytes / 2u);
-    const uint32_t R = std::max<uint32_t>(2u, std::min<uint32_t>(32u, sa::kDirTileBytes / (12u * wp_max + 2u)) ) - 1u;
-    const size_t tile_lds = (size_t)12 * (R + 1) * wp_max + 2 * (wp_max + R + 2) + 16;
-    const uint32_t bpp = (hp_max + R * sa::kDirBandsPerBlock - 1) / (R * sa::kDirBandsPerBlock);
-    const uint32_t pairs_per_launch = std::max<uint32_t>(1u, 0x7fffffffu / bpp);
-    if (tile_lds > 48u * 1024u) {
-      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa::sw_direction_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
-      if (ea != hipSuccess) return ea;
-    }
-    for (uint32_t pair0 = 0; pair0 < n; pair0 += pairs_per_launch) {
-      const uint32_t np = std::min(pairs_per_launch, n - pair0);
-      hipLaunchKernelGGL(sa::sw_direction_kernel, dim3(np * bpp), dim3(sa::kDirThreads), tile_lds, stream, p, bpp, R, pair0);
-    }
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-  }
   if (p.threads == 256) return sa::launch_window<256>(p, lds, stream);
   if (p.threads == 512) return sa::launch_window<512>(p, lds, stream);
   return sa::launch_window<1024>(p, lds, stream);
