@@ -29,7 +29,7 @@ std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget
 // *best_done tells whether the fill kernel delivered it.
 int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
                        const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done,
-                       const SaCandKeys *cand, bool *cand_done) {
+                       const SaCandBox *cand, bool *cand_done) {
   const uint64_t n = c.count;
   int rc;
   StageTimer tm;

@@ -224,7 +224,7 @@ struct ScoringGuard {
 // kernel emitted them (the stream kernel does), otherwise the caller runs sa_launch_sw_emit over match_scores
 int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                 int kernel, void *stream, int32_t *best_score, uint64_t *best_index, bool *best_done,
-                const SaCandKeys *cand = nullptr, bool *cand_done = nullptr);
+                const SaCandBox *cand = nullptr, bool *cand_done = nullptr);
 
 // ---- host-level chunking (sa_batch.hip)
 struct Chunk {
@@ -235,7 +235,7 @@ struct Chunk {
 
 std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell = 12);
 int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, const seqalign_dev_scoring *sc,
-              seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandKeys *cand = nullptr,
+              seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
               bool *cand_done = nullptr);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int check_batch(const seqalign_batch_t *b);

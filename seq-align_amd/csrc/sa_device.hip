@@ -182,8 +182,7 @@ static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_
   p.gap_open = s->flat.gap_open; p.open1 = s->flat.open1; p.ext = s->flat.ext; p.floor = s->flat.floor;
   p.gen_eq = s->flat.gen_eq; p.gen_ne = s->flat.gen_ne; p.flags = s->flat.flags;
   p.best_score = nullptr; p.best_index = nullptr;
-  p.cand_min = nullptr; p.cand_key = nullptr; p.cand_count = nullptr; p.cand_box = nullptr;
-  p.key_cap = 0; p.key_row_bits = p.key_col_bits = p.key64 = 0;
+  p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr;
   return p;
 }
 
@@ -203,7 +202,7 @@ static int pick_kernel(int kernel) {
 // (*best_done = true); otherwise the caller runs the separate reduction
 int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                          int kernel, void *stream, int32_t *best_score, uint64_t *best_index, bool *best_done,
-                         const SaCandKeys *cand, bool *cand_done) {
+                         const SaCandBox *cand, bool *cand_done) {
   if (best_done) *best_done = false;
   if (cand_done) *cand_done = false;
   if (!ctx || !scoring || !batch) return SEQALIGN_E_ARG;
@@ -248,12 +247,10 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     if (reports) { if (best_done) *best_done = true; }
     else p.best_score = nullptr, p.best_index = nullptr;
   }
-  if (which == SEQALIGN_KERNEL_STREAM && cand) {   // candidate keys straight from the fill's registers
-    p.cand_min = cand->cand_min; p.cand_key = cand->keys; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box;
-    p.key_cap = cand->layout.cap; p.key_row_bits = cand->layout.row_bits; p.key_col_bits = cand->layout.col_bits;
-    p.key64 = cand->layout.key64;
+  if (which == SEQALIGN_KERNEL_STREAM && cand) {   // candidates' count and box straight from the fill's registers
+    p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box;
     if (sa_stream_kernel_emits_candidates(p, batch->max_len_a)) { if (cand_done) *cand_done = true; }
-    else p.cand_key = nullptr;
+    else p.cand_count = nullptr;
   }
   switch (which) {
     case SEQALIGN_KERNEL_WAVEFRONT: e = sa_launch_fill_wavefront(p, batch->max_len_a, st); break;

@@ -157,11 +157,10 @@ constexpr int kBestRowBits = 21;   // packed tie-break: column (11 bits) | row (
 
 // What else the kernel reports about match_scores while the values are in registers (SW only):
 //   SA_STREAM_BEST  the best cell per pair (above) -- seqalign_sw_batch with max_hits = 1
-//   SA_STREAM_CAND  every cell with score >= cand_min[pair] as a SORT KEY, appended in row-major order to the
-//                   pair's key list (SaFillParams::cand_key) -- the candidate scan of smith_waterman.c:152-156
-//                   for the multi-hit path, instead of two more passes over the matrix (sa_reduce.hip).  Per row:
-//                   one ballot per column slot, the lane's offset from v_mbcnt, one scattered-but-dense store per
-//                   candidate; rows without a candidate cost the ballots and one scalar branch.
+//   SA_STREAM_CAND  how many cells have score >= cand_min[pair] and their bounding box -- the candidate scan of
+//                   smith_waterman.c:152-156 for the multi-hit path, which then sweeps only the box's rows
+//                   (sa_sw_sweep.hip).  Per row: one ballot per column slot; rows without a candidate cost the
+//                   ballots and one scalar branch.
 enum { SA_STREAM_PLAIN = 0, SA_STREAM_BEST = 1, SA_STREAM_CAND = 2 };
 
 template <int CPL, int SUBST, bool GENERAL, int R, int FB, int MODE>
@@ -232,13 +231,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   // candidate emission: wave-uniform running count and bounding box of the pair's candidates
   uint32_t cand_n = 0, box_rmin = 0xffffffffu, box_rmax = 0, box_cmin = 0xffffffffu, box_cmax = 0;
   int cand_thr = INT32_MAX;
-  uint32_t *key32 = nullptr;
-  unsigned long long *key64 = nullptr;
-  if constexpr (CAND) {
-    cand_thr = max(p.cand_min[pair], 1);   // candidates need match_scores > 0 (smith_waterman.c:154)
-    if (p.key64) key64 = static_cast<unsigned long long *>(p.cand_key) + mo;
-    else key32 = static_cast<uint32_t *>(p.cand_key) + mo;
-  }
+  if constexpr (CAND) cand_thr = max(p.cand_min[pair], 1);   // candidates need match_scores > 0 (smith_waterman.c:154)
   if constexpr (BEST) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { best_s[c] = 0; best_r[c] = 0; }
@@ -271,29 +264,14 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
         any |= bal[c];
       }
       if (any) {   // wave-uniform
-        // row-major order: all of lane l's columns come before lane l+1's
-        uint32_t pos = cand_n, total = 0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[c], pos));
-          total += (uint32_t)__popcll(bal[c]);
+          cand_n += (uint32_t)__popcll(bal[c]);
           if (bal[c]) {
             box_cmin = min(box_cmin, (uint32_t)__builtin_ctzll(bal[c]) * CPL + c);
             box_cmax = max(box_cmax, (uint32_t)(63 - __builtin_clzll(bal[c])) * CPL + c);
           }
         }
-        const uint32_t cshift = p.key_row_bits, sshift = p.key_row_bits + p.key_col_bits;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          if (c < ncol && mv[c] >= cand_thr) {
-            const unsigned long long key = ((unsigned long long)(uint32_t)(p.key_cap - mv[c]) << sshift) |
-                                           ((unsigned long long)(uint32_t)(lane * CPL + c) << cshift) | j;
-            if (key64) key64[pos] = key;
-            else key32[pos] = (uint32_t)key;
-            ++pos;
-          }
-        }
-        cand_n += total;
         box_rmin = min(box_rmin, j);
         box_rmax = j;
       }

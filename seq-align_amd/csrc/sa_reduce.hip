@@ -124,23 +124,19 @@ sw_reduce_kernel(const SaReduceParams p) {
   }
 }
 
-// Candidate keys (SaFillParams: the multi-hit path's sort keys, row-major order, count, bounding box) from a
-// match_scores matrix that is already in HBM -- for fills that cannot emit them while the values are in registers
-// (anything but the stream kernel).  Same streaming loop as above: 4 B per cell read, one wave per pair.
-template <typename KeyT>
+// The candidates' count and bounding box (SaFillParams::cand_*) from a match_scores matrix that is already in HBM
+// -- for fills that cannot report them while the values are in registers (anything but the stream kernel).  Same
+// streaming loop as above: 4 B per cell read, one wave per pair.
 __global__ void __launch_bounds__(kWave *kWavesPerBlock)
-sw_emit_kernel(const SaReduceParams p, const SaCandKeys c) {
+sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t pair = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (pair >= p.n_pairs) return;
   const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1;
   const uint32_t cells = W * H;
-  const uint64_t mo = p.mat_off[pair];
-  const int32_t *__restrict__ M = p.M + mo;
-  KeyT *keys = static_cast<KeyT *>(c.keys) + mo;
+  const int32_t *__restrict__ M = p.M + p.mat_off[pair];
   const int thr = max(c.cand_min[pair], 1);
-  const uint32_t cshift = c.layout.row_bits, sshift = c.layout.row_bits + c.layout.col_bits;
-  uint32_t count = 0;                                     // wave-uniform
+  uint32_t count = 0;                                                    // per lane, reduced at the end
   uint32_t rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;   // per lane, reduced at the end
   constexpr uint32_t kStep = kWave * 4;
   for (uint32_t base = 0; base < cells; base += kStep) {
@@ -153,21 +149,12 @@ sw_emit_kernel(const SaReduceParams p, const SaCandKeys c) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = (i0 + k < cells) ? M[i0 + k] : 0;
     }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mine += (v[k] >= thr);
-    const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
-    if ((b0 | b1 | b2) == 0) continue;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t pos = count + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-    count += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-    if (mine) {
+    if (v[0] >= thr || v[1] >= thr || v[2] >= thr || v[3] >= thr) {
       uint32_t row = i0 / W, col = i0 - row * W;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (v[k] >= thr) {
-          keys[pos++] = (KeyT)(((unsigned long long)(uint32_t)(c.layout.cap - v[k]) << sshift) |
-                               ((unsigned long long)col << cshift) | row);
+          ++count;
           rmin = min(rmin, row); rmax = max(rmax, row); cmin = min(cmin, col); cmax = max(cmax, col);
         }
         if (++col == W) { col = 0; ++row; }
@@ -176,6 +163,7 @@ sw_emit_kernel(const SaReduceParams p, const SaCandKeys c) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
+    count += (uint32_t)__shfl_xor((int)count, o);
     rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, o)); rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, o));
     cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, o)); cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o));
   }
@@ -188,11 +176,10 @@ sw_emit_kernel(const SaReduceParams p, const SaCandKeys c) {
 
 }  // namespace sa
 
-hipError_t sa_launch_sw_emit(const SaReduceParams &p, const SaCandKeys &c, hipStream_t stream) {
+hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock), block(sa::kWave * sa::kWavesPerBlock);
-  if (c.layout.key64) hipLaunchKernelGGL(sa::sw_emit_kernel<unsigned long long>, grid, block, 0, stream, p, c);
-  else hipLaunchKernelGGL(sa::sw_emit_kernel<uint32_t>, grid, block, 0, stream, p, c);
+  hipLaunchKernelGGL(sa::sw_box_kernel, grid, block, 0, stream, p, c);
   return hipGetLastError();
 }
 

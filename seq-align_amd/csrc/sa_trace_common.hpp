@@ -41,6 +41,7 @@ __device__ __forceinline__ uint32_t reverse_move_t(Access &acc, const TraceConst
     if (y == 0) open_b = ext_b = 0;
   }
   long long via_m, via_a, via_b;
+  uint32_t nx = x, ny = y;   // the predecessor cell (locals: x / y stay in registers for every caller)
   if (matrix == MAT_MATCH) {
     const int code_a = acc.code_a(x - 1), code_b = acc.code_b(y - 1);
     int s = (k.K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
@@ -50,17 +51,18 @@ __device__ __forceinline__ uint32_t reverse_move_t(Access &acc, const TraceConst
     // a blocked pair (no_mismatches, not a match) looks up as score 0 upstream
     // (alignment_scoring.c:148-153 with no wildcard involved)
     if (s == SA_S_BLOCKED) s = 0;
-    via_m = via_a = via_b = s; --x; --y;
+    via_m = via_a = via_b = s; nx = x - 1; ny = y - 1;
   } else if (matrix == MAT_GAP_A) {
-    via_m = via_b = open_a; via_a = ext_a; --y;
+    via_m = via_b = open_a; via_a = ext_a; ny = y - 1;
   } else {
-    via_m = via_a = open_b; via_b = ext_b; --x;
+    via_m = via_a = open_b; via_b = ext_b; nx = x - 1;
   }
   int mi, ai, bi;
-  acc.cell(x, y, mi, ai, bi);
+  acc.cell(nx, ny, mi, ai, bi);
+  x = nx; y = ny;
   const long long av = ai, bv = bi, mv = mi, cur = score;
-  if ((!k.no_gaps_a || x == 0 || x == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
-  else if ((!k.no_gaps_b || y == 0 || y == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
+  if ((!k.no_gaps_a || nx == 0 || nx == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
+  else if ((!k.no_gaps_b || ny == 0 || ny == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
   else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
   else return 7;
   return 0;

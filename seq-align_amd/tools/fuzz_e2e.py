@@ -63,19 +63,15 @@ while time.time() < t_end:
         pairs.append((a, b))
     batch = W.from_pairs(pairs)
     os.environ["SEQALIGN_TRACE_KERNEL"] = ("lane", "wave")[int(v[0] >> 7) & 1]
-    # multi-hit enumeration: the LDS-window kernel with 256 / 512 / 1024 threads (default path), with a window too
-    # small for the walks (flag -> retry -> generic kernel), or the generic kernels for every pair
-    for key in ("SEQALIGN_SW_ENUM", "SEQALIGN_ENUM_THREADS", "SEQALIGN_ENUM_WINDOW_BYTES"):
+    # multi-hit enumeration (the reverse sweep): a pair's row in registers (default path), column segments of
+    # 128 / 192 columns with the records in HBM, or behind a fill that cannot report the candidates' box
+    for key in ("SEQALIGN_SWEEP_SEGMENTS", "SEQALIGN_KERNEL"):
         os.environ.pop(key, None)
     mode = int(v[0] >> 9) % 8
-    if mode < 3:
-        os.environ["SEQALIGN_ENUM_THREADS"] = ("256", "512", "1024")[mode]
-    elif mode == 3:
-        os.environ["SEQALIGN_ENUM_WINDOW_BYTES"] = str(int(512 + v[1] % 20000))
-    elif mode == 4:
-        os.environ["SEQALIGN_SW_ENUM"] = "wave"
-    elif mode == 5:
-        os.environ["SEQALIGN_SW_ENUM"] = "lane"
+    if mode in (0, 1):
+        os.environ["SEQALIGN_SWEEP_SEGMENTS"] = ("2", "3")[mode]
+    elif mode == 2:
+        os.environ["SEQALIGN_KERNEL"] = "rowscan"
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
         res = ctx.nw_batch(batch, sc)
         for p, (a, b) in enumerate(pairs):

@@ -593,78 +593,25 @@ def test_arena_allocator(ctx):
     ctx.release_scoring(h)
 
 
-def sw_candidates(ctx, batch, sc, min_score, emit_pass):
-    """sa_sw_candidates_debug: the sorted candidate keys the multi-hit path feeds its enumeration with."""
-    n = batch.n_pairs
-    cells = batch.matrix_cells()
-    keys = np.zeros(int(cells.sum()) + 1, np.uint64)
-    count, box, layout = np.zeros(n, np.uint32), np.zeros(4 * n, np.uint32), np.zeros(5, np.int32)
-    ms = np.full(n, min_score, np.int32)
-    d = S.batch_desc(batch)
-    rc = S.lib().sa_sw_candidates_debug(ctx._h, C.byref(d), C.byref(sc), C.c_void_p(ms.ctypes.data), C.c_int(emit_pass),
-                                        C.c_void_p(keys.ctypes.data), C.c_void_p(count.ctypes.data),
-                                        C.c_void_p(box.ctypes.data), C.c_void_p(layout.ctypes.data))
-    assert rc == 0, rc
-    off = np.concatenate([[0], np.cumsum(cells)])
-    return keys, count, box.reshape(n, 4), layout, off
+SWEEP_VARIANTS = {
+    "registers": {},                                  # a pair's row in one wave's registers (up to 512 columns)
+    "segments-128": {"SEQALIGN_SWEEP_SEGMENTS": "2"},   # column segments of 128 / 192 columns, records in HBM
+    "segments-192": {"SEQALIGN_SWEEP_SEGMENTS": "3"},
+    "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box itself
+}
 
 
-@pytest.mark.parametrize("emit_pass", [0, 1], ids=["fill-emits", "separate-pass"])
-def test_sw_candidate_keys_and_sort(ctx, emit_pass):
-    """smith_waterman.c:152-161 on the device: every match_scores cell >= min_score, as sort keys
-    (cap - score | column | row), ordered (score desc, column asc, row asc) by sa_sort.hip -- emitted by the
-    stream fill itself or by the separate pass (fills that cannot), 32- and 64-bit keys, 1..16 columns per lane,
-    rows beyond the stream kernel (1 200 columns).  Expected keys are built with numpy from the oracle's matrix."""
-    rng = W.Rng(4242)
-
-    def rand(n, alpha=b"ACGT"):
-        return bytes(alpha[i] for i in rng.below(len(alpha), n)) if n else b""
-
-    def planted(la, lb, alpha=b"ACGT"):
-        ref = rand(lb, alpha)
-        cut = int(rng.below(max(1, lb - min(la, lb) + 1), 1)[0])
-        return (ref[cut:cut + la] + rand(max(0, la - (lb - cut)), alpha))[:la], ref
-
-    cases = [
-        ("dna ragged", {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 6,
-         [planted(40 + 13 * k, 90 + 7 * k) for k in range(12)] + [(b"", b"ACGT"), (b"ACGT", b""), (b"A", b"A"), (b"ACGT" * 20, b"ACGT" * 45)]),
-        ("blosum62", {"preset": "BLOSUM62"}, 20, [planted(120, 140, b"ARNDCQEGHILKMFPSTWYV") for _ in range(6)]),
-        ("wide rows", {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 30, [planted(la, 60 + la % 50) for la in (300, 520, 800, 1000)]),
-        ("beyond the stream kernel", {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 30, [planted(1200, 80), planted(90, 70)]),
-        ("64-bit keys", {"init": [30000, -20000, -25000, -5000, 0, 0, 0, 0, 0, 0]}, 50000, [planted(200, 230) for _ in range(4)]),
-    ]
-    for name, spec, thr, pairs in cases:
-        sc = S.make_scoring(spec)
-        osc = oracle_scoring_of(sc)
-        batch = W.from_pairs(pairs)
-        keys, count, box, layout, off = sw_candidates(ctx, batch, sc, thr, emit_pass)
-        cap, rb, cb, sb, k64 = (int(x) for x in layout)
-        assert k64 == (1 if rb + cb + sb > 32 else 0) and (name != "64-bit keys" or k64 == 1)
-        for p in range(batch.n_pairs):
-            rc, M, _, _ = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), 1)
-            Wd = len(batch.seq_a(p)) + 1
-            idx = np.nonzero(M >= thr)[0]
-            rows, cols, sco = idx // Wd, idx % Wd, M[idx].astype(np.int64)
-            order = np.lexsort((rows, cols, -sco))
-            want = (((cap - sco[order]).astype(np.uint64) << np.uint64(rb + cb)) | (cols[order].astype(np.uint64) << np.uint64(rb))
-                    | rows[order].astype(np.uint64))
-            assert count[p] == idx.size, (name, p)
-            got = keys[off[p]:off[p] + idx.size]
-            assert np.array_equal(got, want), (name, p, int(np.nonzero(got != want)[0][0]) if idx.size else -1)
-            if idx.size:
-                assert box[p].tolist() == [rows.min(), rows.max(), cols.min(), cols.max()], (name, p)
+@pytest.fixture(params=list(SWEEP_VARIANTS))
+def sweep_variant(request, monkeypatch):
+    for k, v in SWEEP_VARIANTS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
 
 
-@pytest.mark.parametrize("threads", ["256", "512", "1024"])
-@pytest.mark.parametrize("window", ["auto", "tiny"])
-def test_sw_enumeration_window_kernel(ctx, threads, window, monkeypatch):
-    """sa_sw_enum_window.hip: rounds of 256 / 512 / 1 024 candidates per workgroup with claim-and-commit, against
-    the sequential procedure (oracle) -- plume-heavy pairs (planted homologs, low thresholds), tandem repeats
-    (ties, many hits), the max_hits cut inside a round; and with a window too small for the walks ("tiny"), where
-    pairs are handed to the generic kernel one by one."""
-    monkeypatch.setenv("SEQALIGN_ENUM_THREADS", threads)
-    if window == "tiny":
-        monkeypatch.setenv("SEQALIGN_ENUM_WINDOW_BYTES", "2048")
+def test_sw_sweep_enumeration(ctx, sweep_variant):
+    """sa_sw_sweep.hip: every hit of a pair from one reverse sweep over the matrices, against the sequential
+    procedure (oracle) -- plume-heavy pairs (planted homologs, low thresholds), tandem repeats (ties, many hits),
+    the max_hits cut, BLOSUM62, scores in the tens of thousands (wide key fields), empty sequences."""
     rng = W.Rng(909)
 
     def rand(n, alpha=b"ACGT"):
@@ -675,36 +622,67 @@ def test_sw_enumeration_window_kernel(ctx, threads, window, monkeypatch):
     for k in range(16):
         unit = rand(4 + k % 6)
         pairs.append((unit * (5 + k % 7) + rand(k % 9), rand(k % 5) + unit * (8 + k % 11)))
-    pairs += [(b"ACGT" * 40, b"ACGT" * 70), (b"A" * 120, b"A" * 150), (b"", b"ACGT"), (b"ACGT", b"")]
+    pairs += [(b"ACGT" * 40, b"ACGT" * 70), (b"A" * 120, b"A" * 150), (b"", b"ACGT"), (b"ACGT", b""), (b"A", b"A")]
     batch = W.from_pairs(pairs)
     for spec, thr in (({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, 10), ({"init": [1, -1, -3, -1, 0, 0, 0, 0, 0, 0]}, 4),
-                      ({"init": [3, -3, -4, -2, 0, 0, 0, 0, 1, 0]}, 9)):
+                      ({"init": [3, -3, -4, -2, 0, 0, 0, 0, 1, 0]}, 9), ({"init": [1, 0, 0, 0, 0, 0, 0, 0, 0, 0]}, 3)):
         sc = S.make_scoring(spec)
         osc = oracle_scoring_of(sc)
         for max_hits in (2, 7, 16, 1 << 20):
-            got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=40000)
+            got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=400000)
             for p in range(batch.n_pairs):
                 rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
-                assert rc == 0 and got[p] == want, (threads, window, spec, max_hits, p)
+                assert rc == 0 and got[p] == want, (sweep_variant, spec, max_hits, p)
     prot = W.protein_sw_300(10, seed=72, length=150)
     sc = S.make_scoring({"preset": "BLOSUM62"})
     osc = oracle_scoring_of(sc)
     got = ctx.sw_batch(prot, sc, 25, max_hits=1 << 20)
     for p in range(prot.n_pairs):
         rc, want = O.oracle_sw(osc, prot.seq_a(p), prot.seq_b(p), 25)
-        assert rc == 0 and got[p] == want, (threads, window, "BLOSUM62", p)
-    # scores in the tens of thousands: the candidate keys need 64 bits (another instantiation of every kernel)
+        assert rc == 0 and got[p] == want, (sweep_variant, "BLOSUM62", p)
     sc = S.make_scoring({"init": [30000, -20000, -25000, -5000, 0, 0, 0, 0, 0, 0]})
     osc = oracle_scoring_of(sc)
     got = ctx.sw_batch(dna, sc, 250000, max_hits=5)
     for p in range(dna.n_pairs):
         rc, want = O.oracle_sw(osc, dna.seq_a(p), dna.seq_b(p), 250000, 5)
-        assert rc == 0 and got[p] == want, (threads, window, "64-bit keys", p)
+        assert rc == 0 and got[p] == want, (sweep_variant, "large scores", p)
+
+
+def test_sw_sweep_wide_pairs_and_many_hits(ctx):
+    """Rows beyond one wave's registers (600 .. 1 500 columns: column segments of 512, the records of two rows in
+    HBM; 1 200+ columns also take a fill that cannot report the candidates' box) and pairs with hundreds of hits
+    (more than the 64 the sweep ranks itself: ordered by the host) -- against the oracle."""
+    rng = W.Rng(1717)
+
+    def rand(n, alpha=b"ACGT"):
+        return bytes(alpha[i] for i in rng.below(len(alpha), n)) if n else b""
+
+    def planted(la, lb):
+        ref = rand(lb)
+        cut = int(rng.below(max(1, lb - min(la, lb) + 1), 1)[0])
+        return (ref[cut:cut + la] + rand(max(0, la - (lb - cut))))[:la], ref
+
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = oracle_scoring_of(sc)
+    wide = W.from_pairs([planted(la, 70 + la % 90) for la in (600, 1023, 1024, 1500)] +
+                        [(rand(700), rand(90)), (b"ACGT" * 200, b"ACGT" * 30), planted(90, 70)])
+    for thr, max_hits in ((30, 4), (8, 1 << 20)):
+        got = ctx.sw_batch(wide, sc, thr, max_hits=max_hits, hit_cap=100000)
+        for p in range(wide.n_pairs):
+            rc, want = O.oracle_sw(osc, wide.seq_a(p), wide.seq_b(p), thr, max_hits)
+            assert rc == 0 and got[p] == want, ("wide", thr, p)
+    many = W.from_pairs([(rand(300), rand(300)) for _ in range(3)] + [(b"ACGTTGCA" * 30, b"TGCAACGT" * 40)])
+    for max_hits in (70, 1 << 20):
+        got = ctx.sw_batch(many, sc, 4, max_hits=max_hits, hit_cap=400000)
+        for p in range(many.n_pairs):
+            rc, want = O.oracle_sw(osc, many.seq_a(p), many.seq_b(p), 4, max_hits)
+            assert rc == 0 and got[p] == want, ("many hits", max_hits, p)
+        assert max(len(h) for h in got) > 64
 
 
 def test_sw_batch_multi_hit_in_several_chunks(ctx, monkeypatch):
     """seqalign_sw_batch(max_hits > 1) on a batch that does not fit one chunk (tiny chunk budget): the per-chunk
-    scratch (key arenas, direction bytes, class lists) is reused chunk after chunk; hits equal the one-chunk call's."""
+    scratch (hit keys, walker lists, string slots) is reused chunk after chunk; hits equal the one-chunk call's."""
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     batch = W.dna_sw_read_vs_ref(120, seed=73, read_len=80, ref_len=300)
     one = ctx.sw_batch(batch, sc, 16, max_hits=6)
@@ -718,15 +696,11 @@ def test_sw_batch_multi_hit_in_several_chunks(ctx, monkeypatch):
         assert rc == 0 and one[p] == want, p
 
 
-@pytest.mark.parametrize("enum_kernel", ["window", "wave", "lane"])
-def test_sw_enumeration_repeats_and_ties(ctx, enum_kernel, monkeypatch):
+def test_sw_enumeration_repeats_and_ties(ctx, sweep_variant):
     """Device multi-hit enumeration on inputs built to stress its order rules: tandem
     repeats (many equal-score candidates: column-ascending, then index-ascending ties),
-    long walks (longer than the wave kernel's recorded path), many hits per pair and
-    the max_hits cut -- the wave-per-pair kernel (batches of 64 speculative walks) and
-    the lane-per-pair kernel must both reproduce the sequential reference procedure."""
-    if enum_kernel != "window":
-        monkeypatch.setenv("SEQALIGN_SW_ENUM", enum_kernel)
+    long walks, many hits per pair and the max_hits cut must reproduce the sequential
+    reference procedure."""
     rng = W.Rng(77)
 
     def rand(n):
@@ -748,7 +722,7 @@ def test_sw_enumeration_repeats_and_ties(ctx, enum_kernel, monkeypatch):
             got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits)
             for p in range(batch.n_pairs):
                 rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
-                assert rc == 0 and got[p] == want, (enum_kernel, spec, max_hits, p)
+                assert rc == 0 and got[p] == want, (sweep_variant, spec, max_hits, p)
             assert max(len(h) for h in got) == max_hits   # the cut is exercised
 
 
