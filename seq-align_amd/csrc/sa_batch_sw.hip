@@ -102,8 +102,8 @@ static SaKeyLayout key_layout(const seqalign_dev_scoring *sc, uint32_t max_a, ui
   l.score_bits = bits_for((uint64_t)cap);
   return l;
 }
-// the sweep's records hold a key and 4 state bits in 64 bits
-static bool key_layout_fits(const SaKeyLayout &l) { return l.row_bits + l.col_bits + l.score_bits <= 60; }
+// a key is at most 64 bits wide, all ones excluded
+static bool key_layout_fits(const SaKeyLayout &l) { return l.row_bits + l.col_bits + l.score_bits <= 63; }
 
 // SW hits of one chunk, enumerated on the device:
 //   fill (reports the candidates' count and box) -> reverse sweep (sa_sw_sweep.hip: every hit's key, in order)
@@ -117,7 +117,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   const uint64_t n = c.count;
   hipStream_t st = ctx->stream;
   int rc;
-  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_tstat = ctx->e[2], &d_box = ctx->e[3], &d_rows = ctx->e[4],
+  DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_box = ctx->e[3], &d_rows = ctx->e[4],
          &d_rowoff = ctx->e[5], &d_walk = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
          &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10], &d_dst = ctx->e[11];
   StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
@@ -160,9 +160,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     row_off.resize(n);
     uint64_t total = 0;
     for (uint64_t k = 0; k < n; ++k) { row_off[k] = total; total += 2 * ((uint64_t)batch->len_a[c.first + k] + 1); }
-    if ((rc = d_rows.reserve(total * 8 + 16)) || (rc = d_rowoff.reserve(n * 8))) return rc;
+    if ((rc = d_rows.reserve(total * 16 + 16)) || (rc = d_rowoff.reserve(n * 8))) return rc;
     HIP_TRY(hipMemcpyAsync(d_rowoff.p, row_off.data(), n * 8, hipMemcpyHostToDevice, st));
     q.rows = d_rows.as<unsigned long long>(); q.row_off = d_rowoff.as<uint64_t>();
+  }
+  const bool trace = getenv("SEQALIGN_SWEEP_TRACE") != nullptr;   // development aid: per-pair counters on stderr
+  DevBuf &d_trace = ctx->e[12];
+  if (trace) {
+    if ((rc = d_trace.reserve(n * 64))) return rc;
+    HIP_TRY(hipMemsetAsync(d_trace.p, 0, n * 64, st));
+    q.trace = d_trace.as<unsigned long long>();
   }
   if ((e = sa_launch_sw_sweep(q, st)) != hipSuccess) return fail_hip(e, "sw sweep");
   tm.lap("sw: enqueue fill + sweep");
@@ -174,6 +181,18 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   HIP_TRY(hipMemcpyAsync(h_err_key, d_meta.p, n * 16, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
   tm.lap("sw: wait (fill + sweep), counts");
+  if (trace) {
+    std::vector<unsigned long long> t(8 * n);
+    HIP_TRY(hipMemcpy(t.data(), d_trace.p, n * 64, hipMemcpyDeviceToHost));
+    double sum[5] = {0, 0, 0, 0, 0}, hits_total = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      for (int j = 0; j < 5; ++j) sum[j] += (double)t[8 * k + j];
+      hits_total += h_count[k];
+    }
+    fprintf(stderr, "[seqalign sweep trace] pairs %llu  per pair: %.0f cycles (100 MHz ticks x ?), %.1f rows, %.1f active row segments, "
+                    "%.1f rounds, %.0f cycles in active segments, %.2f hits\n",
+            (unsigned long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, hits_total / n);
+  }
 
   std::vector<uint64_t> cell0(n + 1, 0);
   for (uint64_t k = 0; k < n; ++k)
@@ -213,49 +232,50 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   const uint64_t nw = walk_pair.size();
   if (nw > 0xffffffffull) return SEQALIGN_E_TOO_LARGE;
 
-  // ---- one traceback per hit
-  if ((rc = d_walk.reserve(nw * 16 + 16)) || (rc = d_hits.reserve(nw * sizeof(SaDevHit) + 16)) || (rc = d_tstat.reserve(nw * 4 + 16)) ||
+  // ---- one traceback per hit (smith_waterman.c:217-255; the traceback kernels of sa_traceback.hip, one walk per hit)
+  // per walk: head | len | score | status | pos[4]
+  if ((rc = d_walk.reserve(nw * 16 + 16)) || (rc = d_hits.reserve(nw * 32 + 16)) ||
       (rc = ctx->t_out_a.reserve(str_total + 16)) || (rc = ctx->t_out_b.reserve(str_total + 16)) ||
-      (rc = ctx->h_misc.reserve(nw * (sizeof(SaDevHit) + 4) + 16)) || (rc = d_dst.reserve(nw * 8 + 16)))
+      (rc = ctx->h_misc.reserve(nw * 32 + 16)) || (rc = d_dst.reserve(nw * 8 + 16)))
     return rc;
   uint64_t *dv_walk_str = d_walk.as<uint64_t>();
   uint32_t *dv_walk_pair = reinterpret_cast<uint32_t *>(dv_walk_str + nw), *dv_walk_rank = dv_walk_pair + nw;
-  SaDevHit *h_hits = ctx->h_misc.as<SaDevHit>();
-  uint32_t *h_tstat = reinterpret_cast<uint32_t *>(h_hits + nw);
+  uint32_t *dv_meta = d_hits.as<uint32_t>();
+  const uint32_t *h_meta = ctx->h_misc.as<uint32_t>();
   if (nw) {
     HIP_TRY(hipMemcpyAsync(dv_walk_str, walk_str.data(), nw * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dv_walk_pair, walk_pair.data(), nw * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dv_walk_rank, walk_rank.data(), nw * 4, hipMemcpyHostToDevice, st));
-    SaHitTraceParams t;
+    SaTraceParams t;
     memset(&t, 0, sizeof(t));
     t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b;
     t.mat_off = d.mat_off; t.M = d.match_scores; t.A = d.gap_a_scores; t.B = d.gap_b_scores;
-    t.code = sc->d_code; t.table = sc->d_table; t.hit_keys = q.hit_keys;
-    t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.walker_str = dv_walk_str;
-    t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>(); t.hits = d_hits.as<SaDevHit>();
-    t.trace_status = d_tstat.as<uint32_t>();
-    t.n_walkers = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
-    t.flags = q.flags; t.layout = layout;
-    if ((e = sa_launch_sw_hit_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
+    t.code = sc->d_code; t.table = sc->d_table; t.str_off = dv_walk_str;
+    t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
+    t.out_head = dv_meta; t.out_len = dv_meta + nw; t.out_score = reinterpret_cast<int32_t *>(dv_meta + 2 * nw);
+    t.trace_status = dv_meta + 3 * nw; t.out_pos = dv_meta + 4 * nw;
+    t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.layout = layout;
+    t.n_pairs = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
+    t.flags = q.flags;
+    if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
     // ---- round trip 2: the hits (their lengths size the packing)
-    HIP_TRY(hipMemcpyAsync(h_hits, d_hits.p, nw * sizeof(SaDevHit), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_tstat, d_tstat.p, nw * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, dv_meta, nw * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
   tm.lap("sw: hit tracebacks");
   std::vector<uint64_t> dst_off(nw);
   uint64_t gathered = 0;
   for (uint64_t w = 0; w < nw; ++w) {
-    if (h_tstat[w]) return (int)h_tstat[w];
+    if (h_meta[3 * nw + w]) return (int)h_meta[3 * nw + w];
     dst_off[w] = gathered;
-    gathered += h_hits[w].length;
+    gathered += h_meta[nw + w];
   }
   if (nw) {
     if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
         (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
       return rc;
     HIP_TRY(hipMemcpyAsync(d_dst.p, dst_off.data(), nw * 8, hipMemcpyHostToDevice, st));
-    if ((e = sa_launch_gather_hits(ctx->t_out_a.as<char>(), ctx->t_out_b.as<char>(), dv_walk_str, d_hits.as<SaDevHit>(),
+    if ((e = sa_launch_gather_hits(ctx->t_out_a.as<char>(), ctx->t_out_b.as<char>(), dv_walk_str, dv_meta, dv_meta + nw,
                                    d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_b.as<char>(), (uint32_t)nw, st)) != hipSuccess)
       return fail_hip(e, "gather hits");
     HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
@@ -265,15 +285,15 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   tm.lap("sw: gather + strings D2H");
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
   for (uint64_t w = 0; w < nw; ++w) {
-    const SaDevHit &src = h_hits[w];
-    if (*found >= hit_cap || *used_str + src.length + 1 > str_cap) return SEQALIGN_E_NOMEM;
-    memcpy(out_a + *used_str, ha + dst_off[w], src.length);
-    memcpy(out_b + *used_str, hb + dst_off[w], src.length);
-    out_a[*used_str + src.length] = out_b[*used_str + src.length] = '\0';
+    const uint32_t len = h_meta[nw + w], *pos = h_meta + 4 * nw + 4 * w;
+    if (*found >= hit_cap || *used_str + len + 1 > str_cap) return SEQALIGN_E_NOMEM;
+    memcpy(out_a + *used_str, ha + dst_off[w], len);
+    memcpy(out_b + *used_str, hb + dst_off[w], len);
+    out_a[*used_str + len] = out_b[*used_str + len] = '\0';
     seqalign_sw_hit_t &h = hits[(*found)++];
-    h.pair = c.first + walk_pair[w]; h.score = src.score; h.pos_a = src.pos_a; h.pos_b = src.pos_b;
-    h.len_a = src.len_a; h.len_b = src.len_b; h.length = src.length; h.str_off = *used_str;
-    *used_str += src.length + 1;
+    h.pair = c.first + walk_pair[w]; h.score = reinterpret_cast<const int32_t *>(h_meta)[2 * nw + w];
+    h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3]; h.length = len; h.str_off = *used_str;
+    *used_str += len + 1;
   }
   tm.lap("sw: unpack hits");
   return overflow ? SEQALIGN_E_NOMEM : SEQALIGN_OK;

@@ -304,6 +304,7 @@ static int launch_traceback(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *s
   if (b->n_pairs == 0) return SEQALIGN_OK;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   SaTraceParams p;
+  memset(&p, 0, sizeof(p));
   p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
   p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
   p.code = sc->d_code; p.table = sc->d_table; p.str_off = t->str_off; p.out_a = t->out_a; p.out_b = t->out_b;

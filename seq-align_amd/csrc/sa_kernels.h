@@ -59,13 +59,6 @@ struct SaReduceParams {
   uint32_t n_pairs;
 };
 
-/* one SW hit as the enumeration kernel reports it (smith_waterman.c:249-255) */
-struct SaDevHit {
-  int32_t score;
-  uint32_t pos_a, pos_b, len_a, len_b, length;
-  uint32_t str_off;       /* into the pair's string slot */
-};
-
 /* candidate count and bounding box per pair, as the stream fill (SA_STREAM_CAND) or sa_launch_sw_box leaves them */
 struct SaCandBox {
   uint32_t *cand_count;       /* [n]                                                       */
@@ -99,34 +92,11 @@ struct SaSweepParams {
   uint32_t flags;
   uint32_t max_len_a;            /* of the chunk: picks the kernel                                    */
   SaKeyLayout layout;
+  unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (SEQALIGN_SWEEP_TRACE) */
 };
 #define SA_SWEEP_UNSORTED 0x80000000u
 /* columns one wave keeps in registers; wider pairs are swept segment by segment with the records in `rows` */
 #define SA_SWEEP_SEGMENT 512u
-
-/* one traceback per hit: walker w writes hit walker_rank[w] of pair walker_pair[w] right-aligned into its string
- * slot (len_a + len_b chars at walker_str[w]) and fills hits[w] (str_off = first char inside the slot) */
-struct SaHitTraceParams {
-  const uint8_t *arena;
-  const uint64_t *off_a;
-  const uint32_t *len_a;
-  const uint64_t *off_b;
-  const uint32_t *len_b;
-  const uint64_t *mat_off;
-  const int32_t *M, *A, *B;
-  const uint16_t *code;
-  const int32_t *table;
-  const unsigned long long *hit_keys;
-  const uint32_t *walker_pair, *walker_rank;
-  const uint64_t *walker_str;
-  char *out_a, *out_b;
-  SaDevHit *hits;                /* [n_walkers]                                                       */
-  uint32_t *trace_status;        /* [n_walkers] 0 or SEQALIGN_E_*                                      */
-  uint32_t n_walkers, K;
-  int32_t open1, ext, gen_eq, gen_ne;
-  uint32_t flags;
-  SaKeyLayout layout;
-};
 
 struct SaTraceParams {
   const uint8_t *arena;
@@ -145,6 +115,11 @@ struct SaTraceParams {
   uint32_t *trace_status;
   const uint64_t *start_index; /* SW: end cell of the hit per pair; NULL = NW        */
   uint32_t *out_pos;           /* SW: [4*n] pos_a, pos_b, len_a, len_b               */
+  /* SW multi-hit path: n_pairs WALKS, walk w = hit walker_rank[w] of pair walker_pair[w], ending at the cell packed in
+   * hit_keys[mat_off[pair] + rank] (layout); str_off and every out_* array are indexed by the walk */
+  const uint32_t *walker_pair, *walker_rank;
+  const unsigned long long *hit_keys;
+  SaKeyLayout layout;
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
@@ -181,11 +156,11 @@ hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
  * pass over M */
 hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, hipStream_t stream);
 /* SW multi-hit enumeration (sa_sw_sweep.hip): every hit of every pair in one reverse sweep, then one traceback
- * per wanted hit, then the strings packed back to back (walker w's `length` chars from its slot to dst_off[w]) */
+ * per wanted hit (sa_launch_nw_traceback with SaTraceParams::hit_keys), then the strings packed back to back (walk
+ * w's len[w] chars at head[w] of its slot to dst_off[w]) */
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream);
-hipError_t sa_launch_sw_hit_traceback(const SaHitTraceParams &p, hipStream_t stream);
-hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uint64_t *walker_str, const SaDevHit *hits,
-                                 const uint64_t *dst_off, char *dst_a, char *dst_b, uint32_t n_walkers,
+hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uint64_t *walker_str, const uint32_t *head,
+                                 const uint32_t *len, const uint64_t *dst_off, char *dst_a, char *dst_b, uint32_t n_walkers,
                                  hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
 /* three device allocations of `bytes`, spread over HBM and checked (sa_placement.hip);

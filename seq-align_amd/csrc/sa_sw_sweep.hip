@@ -22,14 +22,18 @@
 // candidates, no visited bitmap, no iteration over walks.  (Checked against the sequential procedure by
 // tests/test_gpu_parity.py and tools/fuzz_e2e.py; the argument in full: DESIGN.md 3.6.)
 //
-// One WAVE per pair; lane l owns columns l, l+64, ... (coalesced row loads, 12 B per cell, each row loaded once and
-// kept for the row above it, the next row in flight while this one is worked on).  Per row and column slot the
-// wave carries one 64-bit record: key << 4 | state at the NEXT cell << 2 | state here, of the walk that won the
-// cell and moves on.  Arrivals from the row below are one DPP shift; arrivals along the row (GAP_B moves) make a
-// right-to-left dependency, which is resolved by iterating the row until nothing changes -- walks rarely move
-// sideways for more than a cell or two, so that is one or two rounds.  The predecessor of the winner's state is the
-// traceback's own decision (reverse_move_t; for plain scorings the same three equality tests on 32-bit values).
-// Rows without candidates and without live walks cost their loads and a ballot.
+// One WAVE per pair; lane l owns CPL consecutive columns (the fill kernel's layout: a row is one contiguous run of
+// 64 * CPL cells, loaded with one wide load per lane and matrix; 12 B per cell, each row loaded once and kept for
+// the row above it, the next row in flight while this one is worked on).  Per cell the wave carries the key of the
+// walk that won it and four bits: where that walk goes (up-left / up / left / nowhere) and the state it arrives
+// in.  Arrivals from the row below are register moves (one DPP shift at the lane border).  Arrivals along the row
+// (GAP_B moves) make a right-to-left dependency: each lane resolves its own columns in order, and the lanes
+// iterate until no lane's incoming walk changes -- a sideways run crosses few lane borders, so that is one or two
+// passes (the row's fixed point is unique: the rightmost cell has no such arrival and every cell is a function of
+// the one to its right).  Where a walk goes from a cell is worked out for all three states of every cell of an
+// active row at once: the traceback's own decision (reverse_move_t; for plain scorings the same three equality
+// tests on 32-bit values).  Rows without candidates and without live walks cost their loads and a ballot.
+// Keys are 32 bits wide when row, column and score fit 31 bits, else 64.
 // Pairs wider than SA_SWEEP_SEGMENT columns are swept in column segments, right to left within a row, with the
 // records of the last two rows in HBM (SaSweepParams::rows) and segments nothing can reach skipped.
 //
@@ -41,28 +45,19 @@
 
 namespace sa {
 
-typedef unsigned long long rec_t;
-constexpr rec_t kNone = ~0ull;           // no walk (its state bits read 3: never a valid state)
-
 // lane l <- lane l+1; lane 63 <- `last`.  DPP ctrl 0x130 = wave_shl:1 (GFX9 family)
-__device__ __forceinline__ int wave_shl1(int src, int last) {
-  return __builtin_amdgcn_update_dpp(last, src, 0x130, 0xf, 0xf, false);
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t src, uint32_t last) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)src, 0x130, 0xf, 0xf, false);
 }
-__device__ __forceinline__ rec_t rec_from_right(rec_t v, rec_t last) {
-  const uint32_t lo = (uint32_t)wave_shl1((int)(uint32_t)v, (int)(uint32_t)last);
-  const uint32_t hi = (uint32_t)wave_shl1((int)(uint32_t)(v >> 32), (int)(uint32_t)(last >> 32));
-  return ((rec_t)hi << 32) | lo;
+__device__ __forceinline__ unsigned long long wave_shl1(unsigned long long v, unsigned long long last) {
+  const uint32_t lo = wave_shl1((uint32_t)v, (uint32_t)last), hi = wave_shl1((uint32_t)(v >> 32), (uint32_t)(last >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ rec_t rec_lane(rec_t v, int lane_uniform) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
-  return ((rec_t)hi << 32) | lo;
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane_uniform) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform);
 }
-__device__ __forceinline__ rec_t rec_min(rec_t a, rec_t b) { return a < b ? a : b; }
-// an out record (walk leaving a cell) as the arrival it makes if it left in state `dir`: the key with the state
-// it arrives in, or kNone
-__device__ __forceinline__ rec_t arrival_of(rec_t out, uint32_t dir) {
-  return ((uint32_t)out & 3u) == dir ? ((out & ~0xfull) | (((uint32_t)out >> 2) & 3u)) : kNone;
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long v, int lane_uniform) {
+  return ((unsigned long long)lane_value((uint32_t)(v >> 32), lane_uniform) << 32) | lane_value((uint32_t)v, lane_uniform);
 }
 
 // reverse_move_t's view of the one predecessor cell a decision needs
@@ -73,8 +68,36 @@ struct RegAccess {
   __device__ __forceinline__ void cell(uint32_t, uint32_t, int &m, int &a, int &b) const { m = pm; a = pa; b = pb; }
 };
 
-template <int CPL, bool MULTI>
+// N consecutive ints from a 4-byte aligned address (rows start anywhere: the reference layout has pitch len_a + 1)
+template <int N>
+__device__ __forceinline__ void load_run(const int32_t *src, int (&v)[N], int first = 0) {
+  if constexpr (N == 1) {
+    v[first] = src[0];
+  } else if constexpr (N == 2) {
+    const v2i_u q = *reinterpret_cast<const v2i_u *>(src);
+    v[first] = q.x; v[first + 1] = q.y;
+  } else if constexpr (N == 3) {
+    const v3i_u q = *reinterpret_cast<const v3i_u *>(src);
+    v[first] = q.x; v[first + 1] = q.y; v[first + 2] = q.z;
+  } else {
+    const v4i_u q = *reinterpret_cast<const v4i_u *>(src);
+    v[first] = q.x; v[first + 1] = q.y; v[first + 2] = q.z; v[first + 3] = q.w;
+    if constexpr (N > 4) {
+      int rest[N - 4];
+      load_run<N - 4>(src + 4, rest);
+#pragma unroll
+      for (int k = 0; k < N - 4; ++k) v[first + 4 + k] = rest[k];
+    }
+  }
+}
+
+// what a cell's winner does next, 4 bits: bits 0-1 = where it goes (MAT_MATCH: up-left, MAT_GAP_A: up, MAT_GAP_B:
+// left, kStay: nowhere -- no winner, or the walk ends here), bits 2-3 = the state it arrives in
+constexpr uint32_t kStay = 3u;
+
+template <int CPL, bool MULTI, typename KeyT>
 __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) {
+  constexpr KeyT kNone = ~(KeyT)0;         // no walk
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x;
   if (p.cand_count[pair] == 0) {
@@ -85,11 +108,20 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
   const uint64_t mo = p.mat_off[pair];
   const int32_t *__restrict__ Mg = p.M + mo, *__restrict__ Ag = p.A + mo, *__restrict__ Bg = p.B + mo;
   const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair], *__restrict__ sb_ = p.arena + p.off_b[pair];
-  rec_t *hit_keys = p.hit_keys + mo;
+  unsigned long long *hit_keys = p.hit_keys + mo;
   const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1], cmin = p.cand_box[4ull * pair + 2],
                  cmax = p.cand_box[4ull * pair + 3];
   const int thr = max(p.min_score[pair], 1);
-  const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
+  // the substitution table in LDS (up to SA_LDS_TABLE_MAX_K classes): one lookup per cell and row
+  extern __shared__ int32_t lds_table[];
+  const int32_t *table = p.table;
+  if (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) {
+    for (uint32_t i = lane; i < p.K * p.K; i += kWave) lds_table[i] = p.table[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // one wave: program order; the fence pins the compiler
+    __builtin_amdgcn_s_waitcnt(0);
+    table = lds_table;
+  }
+  const TraceConsts k{p.code, table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
   // plain scorings (no free / forbidden gaps, no sentinel scores): the three decisions of alignment_reverse_move
@@ -101,134 +133,167 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
   const int cap = p.layout.cap;
   constexpr uint32_t kSegW = kWave * CPL;
   const uint32_t seg_hi = MULTI ? cmax / kSegW : 0u, seg_cmin = MULTI ? cmin / kSegW : 0u;
-  rec_t *rows = MULTI ? p.rows + p.row_off[pair] : nullptr;   // [2][W]
+  // wide pairs: [2 rows][W columns][key, what-next] as two uint64 per column
+  unsigned long long *rows = MULTI ? p.rows + 2 * p.row_off[pair] : nullptr;
 
   int m[CPL], a[CPL], b[CPL], pm[CPL], pa[CPL], pb[CPL];   // this segment of row y / of row y - 1
-  rec_t orec[CPL];                                          // walks leaving the cells of row y + 1
+  KeyT wk[CPL];                                             // row y + 1 coming in, row y going out: the cells' winners
+  uint32_t wz[CPL];                                         // and what they do next (kStay | ...: nothing leaves the cell)
   int ca[CPL];                                              // codes of seq_a[x - 1] (one segment: loaded once)
   uint32_t n_hits = 0;                                      // wave-uniform
   uint32_t err = 0;                                         // per lane: error of the lowest walk that met one,
-  rec_t err_key = kNone;                                    // and that walk
+  KeyT err_key = kNone;                                     // and that walk
   int chunk_code = 0;                                       // lane t: code of seq_b[y - 1] for the row t below the chunk's top
+  unsigned long long tr_rows = 0, tr_active = 0, tr_rounds = 0, tr_cycles = 0;   // development aid (p.trace)
+  const unsigned long long t_start = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
   auto load_row = [&](uint32_t y, uint32_t x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL]) __attribute__((always_inline)) {
-    const uint32_t at0 = y * W + x0 + lane;
+    const uint32_t xl = x0 + lane * CPL, at = y * W + xl;
+    if (xl + CPL <= W || (xl < W && y < lb)) {   // (past the row's end is the next row: inside the pair's matrix unless y = len_b)
+      load_run<CPL>(Mg + at, dm); load_run<CPL>(Ag + at, da); load_run<CPL>(Bg + at, db);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const bool in = x0 + c * kWave + lane < W;
-      dm[c] = in ? Mg[at0 + c * kWave] : 0; da[c] = in ? Ag[at0 + c * kWave] : 0; db[c] = in ? Bg[at0 + c * kWave] : 0;
+      for (int c = 0; c < CPL; ++c) dm[c] = xl + c < W ? dm[c] : 0;   // no candidates there
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const bool in = xl + c < W;
+        dm[c] = in ? Mg[at + c] : 0; da[c] = in ? Ag[at + c] : 0; db[c] = in ? Bg[at + c] : 0;
+      }
     }
   };
 
   // One segment of one row.  left[6]: match / gap_a / gap_b of the column left of the segment on row y and on
-  // row y - 1 (wave-uniform); r_prev / r_cur: the records right of the segment on row y + 1 / row y.  orec comes in
-  // as row y + 1's records and leaves as row y's.  Returns whether any walk leaves this segment of the row.
-  auto sweep_segment = [&](uint32_t y, uint32_t x0, const int (&left)[6], rec_t r_prev, rec_t r_cur, int code_b) __attribute__((always_inline)) -> bool {
+  // row y - 1 (wave-uniform); rp_k / rp_z: winner and what-next of the cell right of the segment on row y + 1;
+  // rc_k / rc_z: of the cell right of it on row y.  wk / wz come in as row y + 1's and leave as row y's.
+  // Returns whether any walk leaves this segment of the row.
+  auto sweep_segment = [&](uint32_t y, uint32_t x0, const int (&left)[6], KeyT rp_k, uint32_t rp_z, KeyT rc_k, uint32_t rc_z,
+                           int code_b) __attribute__((always_inline)) -> bool {
+    const uint32_t xl = x0 + lane * CPL;
     // ---- arrivals from below and the cell's own candidacy
-    rec_t base[CPL];
-    unsigned long long any = 0;
+    KeyT bk[CPL];
+    uint32_t bs[CPL];   // state the best arrival from below / the candidate stands in
+    {
+      const KeyT dk_edge = wave_shl1(wk[0], rp_k);          // the cell right of my last column, on row y + 1
+      const uint32_t dz_edge = wave_shl1(wz[0], rp_z);
+      bool any = false;
 #pragma unroll
-    for (int c = CPL - 1; c >= 0; --c) {
-      const uint32_t x = x0 + c * kWave + lane;
-      const rec_t right = (c == CPL - 1) ? r_prev : rec_lane(orec[c + 1 < CPL ? c + 1 : c], 0);
-      const rec_t diag = arrival_of(rec_from_right(orec[c], right), MAT_MATCH);
-      const rec_t vert = arrival_of(orec[c], MAT_GAP_A);
-      const rec_t own = (m[c] >= thr && x < W)
-                            ? ((((rec_t)(uint32_t)(cap - m[c]) << sshift) | ((rec_t)x << cshift) | y) << 4)
-                            : kNone;
-      base[c] = rec_min(own, rec_min(diag, vert));
-      any |= __ballot(base[c] != kNone);
-    }
-    if (any == 0 && r_cur == kNone) {   // nothing arrives in this segment (a walk entering from the right would)
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) orec[c] = kNone;
-      return false;
-    }
-    // neighbours to the left: (x-1, y-1) for MATCH, (x-1, y) for GAP_B
-    int dm_[CPL], da_[CPL], db_[CPL], lm_[CPL], la_[CPL], lb_[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      dm_[c] = wave_shr1(pm[c], c ? read_lane(pm[c ? c - 1 : 0], 63) : left[3]);
-      da_[c] = wave_shr1(pa[c], c ? read_lane(pa[c ? c - 1 : 0], 63) : left[4]);
-      db_[c] = wave_shr1(pb[c], c ? read_lane(pb[c ? c - 1 : 0], 63) : left[5]);
-      lm_[c] = wave_shr1(m[c], c ? read_lane(m[c ? c - 1 : 0], 63) : left[0]);
-      la_[c] = wave_shr1(a[c], c ? read_lane(a[c ? c - 1 : 0], 63) : left[1]);
-      lb_[c] = wave_shr1(b[c], c ? read_lane(b[c ? c - 1 : 0], 63) : left[2]);
-    }
-    // the walk `w` that wins cell c: where does it go?  -> its out record (kNone + term: score 0, a hit)
-    uint32_t term = 0;                      // bit c: the winner of slot c ends here
-    auto decide = [&](int c, rec_t w) __attribute__((always_inline)) -> rec_t {
-      const uint32_t st = (uint32_t)w & 3u, x = x0 + c * kWave + lane;
-      const int s = st == MAT_MATCH ? m[c] : st == MAT_GAP_A ? a[c] : b[c];
-      term &= ~(1u << c);
-      if (s <= 0) { term |= 1u << c; return kNone; }
-      const int qm = st == MAT_MATCH ? dm_[c] : st == MAT_GAP_A ? pm[c] : lm_[c];
-      const int qa = st == MAT_MATCH ? da_[c] : st == MAT_GAP_A ? pa[c] : la_[c];
-      const int qb = st == MAT_MATCH ? db_[c] : st == MAT_GAP_A ? pb[c] : lb_[c];
-      int code_a = 0;
-      if (st == MAT_MATCH) {
-        if constexpr (MULTI) code_a = p.code[sa_[x - 1]];
-        else code_a = ca[c];
+      for (int c = 0; c < CPL; ++c) {
+        const KeyT dk = c + 1 < CPL ? wk[c + 1 < CPL ? c + 1 : c] : dk_edge;
+        const uint32_t dz = c + 1 < CPL ? wz[c + 1 < CPL ? c + 1 : c] : dz_edge;
+        KeyT best = (m[c] >= thr) ? (KeyT)((((unsigned long long)(uint32_t)(cap - m[c]) << sshift) |
+                                            ((unsigned long long)(xl + c) << cshift) | y))
+                                  : kNone;
+        uint32_t st = MAT_MATCH;
+        if ((dz & 3u) == MAT_MATCH && dk < best) { best = dk; st = dz >> 2; }
+        if ((wz[c] & 3u) == MAT_GAP_A && wk[c] < best) { best = wk[c]; st = wz[c] >> 2; }
+        bk[c] = best; bs[c] = st;
+        any |= best != kNone;
       }
-      uint32_t ns;
-      if (plain) {
-        int va = k.open1, vb = k.open1, vm = k.open1;
-        if (st == MAT_MATCH) {
-          va = vb = vm = (k.K <= 1) ? ((code_a & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
-                                    : subst_score<SA_SUBST_GLOBAL>(code_a & 0xff, (code_a >> 8) * k.K, code_b, k.table,
-                                                                   k.gen_eq, k.gen_ne);
-        } else if (st == MAT_GAP_A) va = k.ext;
-        else vb = k.ext;
-        ns = (qa + va == s) ? 1u : (qb + vb == s) ? 2u : 0u;
-        if (ns == 0u && qm + vm != s) { if (!err || w < err_key) { err = 7; err_key = w; } }
-      } else {
-        RegAccess acc{qm, qa, qb, code_a, code_b};
-        uint32_t qx = x, qy = y;
-        int pmx = (int)st, ps = s;
-        const uint32_t e = reverse_move_t(acc, k, la, lb, qx, qy, pmx, ps);
-        if (e && (!err || w < err_key)) { err = e; err_key = w; }
-        ns = (uint32_t)pmx;
+      if (!__any(any) && (rc_z & 3u) != MAT_GAP_B) {   // nothing arrives in this segment
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { wk[c] = kNone; wz[c] = kStay; }
+        return false;
       }
-      return (w & ~0xfull) | (ns << 2) | st;
-    };
-    rec_t w[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      w[c] = base[c];
-      orec[c] = kNone;
-      if (w[c] != kNone) orec[c] = decide(c, w[c]);
     }
-    // ---- arrivals along the row: iterate until the row is stable (its fixed point is unique: the rightmost cell
-    // has no such arrival, and every cell is a function of the one to its right)
-    for (;;) {
-      bool changed = false;
+    const unsigned long long t_seg = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    ++tr_active;
+    // ---- where a walk standing on a cell goes, for each of its three states: 2 bits per state = the predecessor's
+    // matrix, or 3 = this state's score is 0 (the walk ends here: a hit).  For every cell of the segment at once (no
+    // divergence; nearly every row of a candidates' box has walks on it).  bad: bit s = state s has no predecessor
+    // that explains its score (bit 3 + s: its pair of characters has no score).
+    uint32_t dir[CPL], bad[CPL];
+    {
+      const int e_pm = wave_shr1(pm[CPL - 1], left[3]), e_pa = wave_shr1(pa[CPL - 1], left[4]), e_pb = wave_shr1(pb[CPL - 1], left[5]);
+      const int e_m = wave_shr1(m[CPL - 1], left[0]), e_a = wave_shr1(a[CPL - 1], left[1]), e_b = wave_shr1(b[CPL - 1], left[2]);
 #pragma unroll
-      for (int c = CPL - 1; c >= 0; --c) {
-        const rec_t right = (c == CPL - 1) ? r_cur : rec_lane(orec[c + 1 < CPL ? c + 1 : c], 0);
-        const rec_t nw = rec_min(base[c], arrival_of(rec_from_right(orec[c], right), MAT_GAP_B));
-        if (nw != w[c]) {   // (also when a walk that seemed to arrive does not: the cell to the right changed hands)
-          w[c] = nw;
-          term &= ~(1u << c);
-          orec[c] = kNone;
-          if (nw != kNone) orec[c] = decide(c, nw);
-          changed = true;
+      for (int c = 0; c < CPL; ++c) {
+        const int cl = c ? c - 1 : 0;
+        const int s3[3] = {m[c], a[c], b[c]};
+        const int qm[3] = {c ? pm[cl] : e_pm, pm[c], c ? m[cl] : e_m};   // MATCH <- (x-1, y-1), GAP_A <- (x, y-1), GAP_B <- (x-1, y)
+        (void)qm;
+        const int qa[3] = {c ? pa[cl] : e_pa, pa[c], c ? a[cl] : e_a};
+        const int qb[3] = {c ? pb[cl] : e_pb, pb[c], c ? b[cl] : e_b};
+        dir[c] = 0x3fu; bad[c] = 0;
+        if (plain) {
+          const int sub = (k.K <= 1) ? ((ca[c] & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
+                                     : subst_score<SA_SUBST_LDS>(ca[c] & 0xff, (ca[c] >> 8) * k.K, code_b, k.table, k.gen_eq, k.gen_ne);
+          const int va[3] = {sub, k.ext, k.open1}, vb[3] = {sub, k.open1, k.ext};
+#pragma unroll
+          for (int st = 0; st < 3; ++st) {
+            const uint32_t f = (qa[st] + va[st] == s3[st]) ? 1u : (qb[st] + vb[st] == s3[st]) ? 2u : 0u;
+            const bool moves = s3[st] > 0;
+            if (moves) dir[c] = (dir[c] & ~(3u << (2 * st))) | (f << (2 * st));
+            // (f = 0 without qm + vm == s, the "program error" of alignment.c:329-345, cannot happen here: these
+            // are the fill's own values, and a positive plain score IS one of its three candidates)
+          }
+        } else {
+#pragma unroll
+          for (int st = 0; st < 3; ++st) {
+            if (s3[st] > 0) {
+              RegAccess acc{qm[st], qa[st], qb[st], ca[c], code_b};
+              uint32_t qx = xl + c, qy = y;
+              int pmx = st, ps = s3[st];
+              const uint32_t e = reverse_move_t(acc, k, la, lb, qx, qy, pmx, ps);
+              if (e) bad[c] |= (e == 5u ? 8u : 1u) << st;
+              dir[c] = (dir[c] & ~(3u << (2 * st))) | ((uint32_t)pmx << (2 * st));
+            }
+          }
         }
       }
+    }
+    // ---- arrivals along the row: my columns right to left, then again while some lane's incoming walk changes
+    KeyT in_k = kNone;          // the walk entering my last column from the right, and its state
+    uint32_t in_s = 0;
+    uint32_t ws[CPL];           // state the winner stands in
+    for (bool first = true;; first = false) {
+      ++tr_rounds;
+      KeyT hk = in_k;
+      uint32_t hs = in_s;
+#pragma unroll
+      for (int c = CPL - 1; c >= 0; --c) {
+        const bool side = hk < bk[c];
+        const KeyT win = side ? hk : bk[c];
+        const uint32_t st = side ? hs : bs[c];
+        const uint32_t f = (dir[c] >> (2u * st)) & 3u;
+        wk[c] = win; ws[c] = st;
+        const bool leaves = win != kNone && f != 3u;
+        wz[c] = leaves ? ((f << 2) | st) : kStay;
+        hk = (leaves && st == MAT_GAP_B) ? win : kNone;   // what enters the column to the left
+        hs = f;
+      }
+      // my first column's sideways walk is the left lane's incoming one; lane 63 takes the segment's right neighbour
+      const KeyT nk = wave_shl1((wz[0] & 3u) == MAT_GAP_B ? wk[0] : kNone, (rc_z & 3u) == MAT_GAP_B ? rc_k : kNone);
+      const uint32_t ns = wave_shl1(wz[0] >> 2, rc_z >> 2);
+      const bool changed = nk != in_k || (nk != kNone && ns != in_s);
+      in_k = nk; in_s = ns;
+      (void)first;
       if (!__any(changed)) break;
+    }
+    // a winner standing in a state that cannot be explained: the error of alignment_reverse_move (alignment.c:329-345)
+    {
+      bool any_bad = false;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) any_bad |= wk[c] != kNone && ((bad[c] >> ws[c]) & 9u) != 0u;
+      if (__any(any_bad)) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (wk[c] != kNone && ((bad[c] >> ws[c]) & 9u) && (!err || wk[c] < err_key)) { err = ((bad[c] >> ws[c]) & 8u) ? 5u : 7u; err_key = wk[c]; }
+      }
     }
     // ---- hits: winners whose state has score 0
     bool out_live = false;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const bool hit = w[c] != kNone && ((term >> c) & 1u);
+      const bool hit = wk[c] != kNone && ((dir[c] >> (2u * ws[c])) & 3u) == 3u;
       const unsigned long long bal = __ballot(hit);
       if (bal) {
         const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (hit) hit_keys[pos] = w[c] >> 4;
+        if (hit) hit_keys[pos] = (unsigned long long)wk[c];
         n_hits += (uint32_t)__popcll(bal);
       }
-      out_live |= orec[c] != kNone;
+      out_live |= wz[c] != kStay;
     }
+    if (p.trace) tr_cycles += __builtin_amdgcn_s_memtime() - t_seg;
     return __any(out_live);
   };
 
@@ -237,9 +302,9 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
     // ------------------------------------------------------------------ the whole row in one segment
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t x = c * kWave + lane;
+      const uint32_t x = lane * CPL + c;
       ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
-      orec[c] = kNone;
+      wk[c] = kNone; wz[c] = kStay;
     }
     const int none[6] = {0, 0, 0, 0, 0, 0};   // column 0 is a border column: its states never move left
     int nm[CPL], na[CPL], nb[CPL];
@@ -251,7 +316,8 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
       if (q == 0) {   // every 64 rows: lane t fetches seq_b's code for row y - t
         chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
       }
-      const bool live = sweep_segment(y, 0, none, kNone, kNone, read_lane(chunk_code, q));
+      const bool live = sweep_segment(y, 0, none, kNone, kStay, kNone, kStay, read_lane(chunk_code, q));
+      ++tr_rows;
       if (y == 0 || (!live && y <= rmin)) break;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -267,10 +333,12 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
       const int q = (int)((rmax - y) & (kWave - 1));
       if (q == 0) chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
       const int code_b = read_lane(chunk_code, q);
-      rec_t *cur_rows = rows + (size_t)(y & 1u) * W;
-      const rec_t *prev_rows = rows + (size_t)((y + 1u) & 1u) * W;
+      unsigned long long *cur_rows = rows + (size_t)(y & 1u) * 2 * W;
+      const unsigned long long *prev_rows = rows + (size_t)((y + 1u) & 1u) * 2 * W;
       const bool box_row = y >= rmin;     // (y <= rmax always)
-      rec_t r_cur = kNone;
+      KeyT rc_k = kNone;
+      uint32_t rc_z = kStay;
+      ++tr_rows;
       uint32_t lo = seg_hi + 1, live_lo = seg_hi + 1;
       bool row_live = false;
       for (uint32_t s = seg_hi;; --s) {
@@ -286,25 +354,33 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
         const bool have_prev = s >= prev_lo;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const uint32_t x = x0 + c * kWave + lane;
-          orec[c] = (have_prev && x < W) ? __hip_atomic_load(prev_rows + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kNone;
+          const uint32_t x = x0 + lane * CPL + c;
+          ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
+          wk[c] = kNone; wz[c] = kStay;
+          if (have_prev && x < W) {
+            wk[c] = (KeyT)__hip_atomic_load(prev_rows + 2 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wz[c] = (uint32_t)__hip_atomic_load(prev_rows + 2 * x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-        rec_t r_prev = kNone;
-        if (s + 1 >= prev_lo && s + 1 <= seg_hi && x0 + kSegW < W)
-          r_prev = __hip_atomic_load(prev_rows + x0 + kSegW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool live = sweep_segment(y, x0, left, r_prev, r_cur, code_b);
+        KeyT rp_k = kNone;
+        uint32_t rp_z = kStay;
+        if (s + 1 >= prev_lo && s + 1 <= seg_hi && x0 + kSegW < W) {
+          rp_k = (KeyT)__hip_atomic_load(prev_rows + 2 * (x0 + kSegW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rp_z = (uint32_t)__hip_atomic_load(prev_rows + 2 * (x0 + kSegW) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool live = sweep_segment(y, x0, left, rp_k, rp_z, rc_k, rc_z, code_b);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const uint32_t x = x0 + c * kWave + lane;
-          if (x < W) cur_rows[x] = orec[c];
+          const uint32_t x = x0 + lane * CPL + c;
+          if (x < W) { cur_rows[2 * x] = (unsigned long long)wk[c]; cur_rows[2 * x + 1] = wz[c]; }
         }
         lo = s;
         if (live) { live_lo = s; row_live = true; }
-        r_cur = rec_lane(orec[0], 0);
+        rc_k = lane_value(wk[0], 0); rc_z = lane_value(wz[0], 0);
         if (s == 0) break;
         // is anything left of here reachable?  candidates, walks from the row below (a diagonal move crosses one
         // segment border at most), the walk leaving this segment's first column
-        const bool more = (box_row && s - 1 >= seg_cmin) || s >= prev_live_lo || r_cur != kNone;
+        const bool more = (box_row && s - 1 >= seg_cmin) || s >= prev_live_lo || (rc_z & 3u) == MAT_GAP_B;
         if (!more) break;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this row's records are in L2 before the next row reads them
@@ -314,17 +390,20 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
   }
 
   // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
-  rec_t first_err = err ? err_key : kNone;   // the lowest erroring walk of the wave
+  unsigned long long first_err = err ? (unsigned long long)err_key : ~0ull;   // the lowest erroring walk of the wave
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) first_err = rec_min(first_err, (rec_t)__shfl_xor(first_err, o));
-  const unsigned long long err_lanes = __ballot(err != 0 && err_key == first_err);
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(first_err, o);
+    first_err = other < first_err ? other : first_err;
+  }
+  const unsigned long long err_lanes = __ballot(err != 0 && (unsigned long long)err_key == first_err);
   uint32_t status = err_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)err, __builtin_ctzll(err_lanes)) : 0u;
   if (n_hits > 1) {
     if (n_hits <= (uint32_t)kWave) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const rec_t key = lane < (int)n_hits ? __hip_atomic_load(hit_keys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kNone;
+      const unsigned long long key = lane < (int)n_hits ? __hip_atomic_load(hit_keys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < n_hits; ++j) rank += rec_lane(key, (int)j) < key;
+      for (uint32_t j = 0; j < n_hits; ++j) rank += lane_value(key, (int)j) < key;
       if (lane < (int)n_hits) hit_keys[rank] = key;
     } else {
       status |= SA_SWEEP_UNSORTED;
@@ -333,95 +412,67 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
   if (lane == 0) {
     p.hit_count[pair] = n_hits;
     p.status[pair] = status;
-    p.err_key[pair] = first_err >> 4;
+    p.err_key[pair] = first_err;
+    if (p.trace) {
+      unsigned long long *t = p.trace + 8ull * pair;
+      t[0] = __builtin_amdgcn_s_memtime() - t_start; t[1] = tr_rows; t[2] = tr_active; t[3] = tr_rounds; t[4] = tr_cycles;
+    }
   }
-}
-
-// ---- one traceback per wanted hit (smith_waterman.c:217-255).  One LANE per hit: the walk is a chain of dependent
-// loads; the hits of a batch overlap each other's.
-__global__ void __launch_bounds__(kWave) sw_hit_traceback_kernel(const SaHitTraceParams p) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= p.n_walkers) return;
-  const uint32_t pair = p.walker_pair[w];
-  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
-  const uint64_t mo = p.mat_off[pair];
-  const PairView v{p.arena + p.off_a[pair], p.arena + p.off_b[pair], p.M + mo, p.A + mo, p.B + mo, la, lb, W};
-  const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
-                      (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
-                      (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
-  const unsigned long long key = p.hit_keys[mo + p.walker_rank[w]];
-  const uint32_t end_y = (uint32_t)key & ((1u << p.layout.row_bits) - 1u);
-  const uint32_t end_x = (uint32_t)(key >> p.layout.row_bits) & ((1u << p.layout.col_bits) - 1u);
-  const int end_score = p.layout.cap - (int)(uint32_t)(key >> (p.layout.row_bits + p.layout.col_bits));
-  char *oa = p.out_a + p.walker_str[w], *ob = p.out_b + p.walker_str[w];
-  uint32_t x = end_x, y = end_y, head = la + lb, e = 0;
-  int matrix = MAT_MATCH, score = end_score;
-  while (score > 0) {
-    --head;
-    oa[head] = (matrix == MAT_GAP_A) ? '-' : (char)v.seq_a[x - 1];
-    ob[head] = (matrix == MAT_GAP_B) ? '-' : (char)v.seq_b[y - 1];
-    if ((e = reverse_move(v, k, x, y, matrix, score))) break;
-  }
-  SaDevHit h;   // smith_waterman.c:249-255
-  h.score = end_score; h.pos_a = x; h.pos_b = y; h.len_a = end_x - x; h.len_b = end_y - y;
-  h.length = la + lb - head; h.str_off = head;
-  p.hits[w] = h;
-  p.trace_status[w] = e;
 }
 
 // every hit's strings packed back to back for one D2H each: one wave per hit
 __global__ void __launch_bounds__(256) gather_hits_kernel(const char *src_a, const char *src_b, const uint64_t *walker_str,
-                                                          const SaDevHit *hits, const uint64_t *dst_off, char *dst_a,
-                                                          char *dst_b, uint32_t n_walkers) {
+                                                          const uint32_t *head, const uint32_t *len, const uint64_t *dst_off,
+                                                          char *dst_a, char *dst_b, uint32_t n_walkers) {
   const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= n_walkers) return;
   const int lane = threadIdx.x & 63;
-  const uint32_t n = hits[w].length;
-  const char *sa_ = src_a + walker_str[w] + hits[w].str_off, *sb_ = src_b + walker_str[w] + hits[w].str_off;
+  const uint32_t n = len[w];
+  const char *sa_ = src_a + walker_str[w] + head[w], *sb_ = src_b + walker_str[w] + head[w];
   char *da = dst_a + dst_off[w], *db = dst_b + dst_off[w];
   for (uint32_t i = lane; i < n; i += 64) { da[i] = sa_[i]; db[i] = sb_[i]; }
 }
 
-template <int CPL>
+static size_t sweep_lds(const SaSweepParams &p) {
+  return (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) ? (size_t)p.K * p.K * sizeof(int32_t) : 0;
+}
+
+template <int CPL, bool MULTI>
 static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
-  hipLaunchKernelGGL((sw_sweep_kernel<CPL, false>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+  // 32-bit keys when they fit with the all-ones value to spare
+  if (p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31)
+    hipLaunchKernelGGL((sw_sweep_kernel<CPL, MULTI, uint32_t>), dim3(p.n_pairs), dim3(kWave), sweep_lds(p), stream, p);
+  else
+    hipLaunchKernelGGL((sw_sweep_kernel<CPL, MULTI, unsigned long long>), dim3(p.n_pairs), dim3(kWave), sweep_lds(p), stream, p);
 }
 
 }  // namespace sa
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest pair
-  if (const char *env = getenv("SEQALIGN_SWEEP_SEGMENTS")) {       // tests: segments of 64 * v columns for every pair
-    const int v = atoi(env);
-    if ((v == 2 || v == 3) && p.rows) {
-      if (v == 2) hipLaunchKernelGGL((sa::sw_sweep_kernel<2, true>), dim3(p.n_pairs), dim3(sa::kWave), 0, stream, p);
-      else hipLaunchKernelGGL((sa::sw_sweep_kernel<3, true>), dim3(p.n_pairs), dim3(sa::kWave), 0, stream, p);
-      return hipGetLastError();
-    }
+  const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest pair
+  int forced = 0;
+  if (const char *env = getenv("SEQALIGN_SWEEP_SEGMENTS")) forced = atoi(env);   // tests: segments of 64 * v columns for every pair
+  if ((forced == 2 || forced == 3) && p.rows) {
+    if (forced == 2) sa::launch_sweep<2, true>(p, stream);
+    else sa::launch_sweep<3, true>(p, stream);
   }
   // (one column per lane is not instantiated: the compiler keeps its 1-element arrays in scratch)
-  if (need <= 2) sa::launch_sweep<2>(p, stream);
-  else if (need <= 3) sa::launch_sweep<3>(p, stream);
-  else if (need <= 4) sa::launch_sweep<4>(p, stream);
-  else if (need <= 5) sa::launch_sweep<5>(p, stream);
-  else if (need <= 6) sa::launch_sweep<6>(p, stream);
-  else if (need <= SA_SWEEP_SEGMENT / sa::kWave) sa::launch_sweep<SA_SWEEP_SEGMENT / sa::kWave>(p, stream);
-  else hipLaunchKernelGGL((sa::sw_sweep_kernel<SA_SWEEP_SEGMENT / sa::kWave, true>), dim3(p.n_pairs), dim3(sa::kWave), 0, stream, p);
+  else if (need <= 2) sa::launch_sweep<2, false>(p, stream);
+  else if (need <= 3) sa::launch_sweep<3, false>(p, stream);
+  else if (need <= 4) sa::launch_sweep<4, false>(p, stream);
+  else if (need <= 5) sa::launch_sweep<5, false>(p, stream);
+  else if (need <= 6) sa::launch_sweep<6, false>(p, stream);
+  else if (need <= SA_SWEEP_SEGMENT / sa::kWave) sa::launch_sweep<SA_SWEEP_SEGMENT / sa::kWave, false>(p, stream);
+  else sa::launch_sweep<SA_SWEEP_SEGMENT / sa::kWave, true>(p, stream);
   return hipGetLastError();
 }
 
-hipError_t sa_launch_sw_hit_traceback(const SaHitTraceParams &p, hipStream_t stream) {
-  if (p.n_walkers == 0) return hipSuccess;
-  hipLaunchKernelGGL(sa::sw_hit_traceback_kernel, dim3((p.n_walkers + sa::kWave - 1) / sa::kWave), dim3(sa::kWave), 0, stream, p);
-  return hipGetLastError();
-}
-
-hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uint64_t *walker_str, const SaDevHit *hits,
-                                 const uint64_t *dst_off, char *dst_a, char *dst_b, uint32_t n_walkers,
+hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uint64_t *walker_str, const uint32_t *head,
+                                 const uint32_t *len, const uint64_t *dst_off, char *dst_a, char *dst_b, uint32_t n_walkers,
                                  hipStream_t stream) {
   if (n_walkers == 0) return hipSuccess;
-  hipLaunchKernelGGL(sa::gather_hits_kernel, dim3((n_walkers + 3) / 4), dim3(256), 0, stream, src_a, src_b, walker_str, hits,
-                     dst_off, dst_a, dst_b, n_walkers);
+  hipLaunchKernelGGL(sa::gather_hits_kernel, dim3((n_walkers + 3) / 4), dim3(256), 0, stream, src_a, src_b, walker_str, head,
+                     len, dst_off, dst_a, dst_b, n_walkers);
   return hipGetLastError();
 }

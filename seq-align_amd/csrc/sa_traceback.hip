@@ -16,13 +16,27 @@
 
 namespace sa {
 
+// Where SW walk `w` starts: the cell start_index[w], or -- walks of the multi-hit path (sa_sw_sweep.hip) -- the cell
+// packed in hit number walker_rank[w] of its pair's sorted hit keys.
+__device__ __forceinline__ void sw_walk_start(const SaTraceParams &p, uint32_t w, uint64_t mo, uint32_t W, uint32_t &x, uint32_t &y) {
+  if (p.hit_keys) {
+    const unsigned long long key = p.hit_keys[mo + p.walker_rank[w]];
+    y = (uint32_t)key & ((1u << p.layout.row_bits) - 1u);
+    x = (uint32_t)(key >> p.layout.row_bits) & ((1u << p.layout.col_bits) - 1u);
+  } else {
+    const uint32_t end = (uint32_t)p.start_index[w];
+    x = end % W; y = end / W;
+  }
+}
+
 // SW: start_index != nullptr -> local alignment ending at that match_scores cell
 // (smith_waterman.c:165-258 on a fresh mask: the first fetched hit always
 // succeeds), walked until the score reaches 0.
 template <bool SW>
 __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
-  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pair >= p.n_pairs) return;
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;   // the walk: one per pair, or one per SW hit (walker_pair)
+  if (w >= p.n_pairs) return;
+  const uint32_t pair = p.walker_pair ? p.walker_pair[w] : w;
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair];
   const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
@@ -32,8 +46,8 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   const int32_t *__restrict__ Ag = p.A + mo;
   const int32_t *__restrict__ Bg = p.B + mo;
   const uint32_t W = la + 1;
-  char *oa = p.out_a + p.str_off[pair];
-  char *ob = p.out_b + p.str_off[pair];
+  char *oa = p.out_a + p.str_off[w];
+  char *ob = p.out_b + p.str_off[w];
 
   const PairView v{sa_, sb_, Mg, Ag, Bg, la, lb, W};
   const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
@@ -44,9 +58,8 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   int score;
   uint32_t x, y, head = la + lb, err = 0;
   if constexpr (SW) {
-    const uint32_t end = (uint32_t)p.start_index[pair];
-    x = end % W; y = end / W;
-    score = Mg[end];
+    sw_walk_start(p, w, mo, W, x, y);
+    score = Mg[y * W + x];
   } else {
     // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
     const uint32_t corner = W * (lb + 1) - 1;
@@ -55,7 +68,7 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
     { const int b = Bg[corner]; if (b >= score) { matrix = MAT_GAP_B; score = b; } }
     { const int a = Ag[corner]; if (a >= score) { matrix = MAT_GAP_A; score = a; } }
   }
-  p.out_score[pair] = score;
+  p.out_score[w] = score;
   const uint32_t end_x = x, end_y = y;
 
   while (SW ? (score > 0) : (x > 0 && y > 0)) {
@@ -72,15 +85,15 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
     }
   } else {
     // smith_waterman.c:251-255: start position and consumed lengths
-    p.out_pos[4 * pair + 0] = x;
-    p.out_pos[4 * pair + 1] = y;
-    p.out_pos[4 * pair + 2] = end_x - x;
-    p.out_pos[4 * pair + 3] = end_y - y;
+    p.out_pos[4 * w + 0] = x;
+    p.out_pos[4 * w + 1] = y;
+    p.out_pos[4 * w + 2] = end_x - x;
+    p.out_pos[4 * w + 3] = end_y - y;
   }
   (void)end_x; (void)end_y;
-  p.out_head[pair] = head;
-  p.out_len[pair] = la + lb - head;
-  p.trace_status[pair] = err;
+  p.out_head[w] = head;
+  p.out_len[w] = la + lb - head;
+  p.trace_status[w] = err;
 }
 
 // ---------------------------------------------------------------------------
@@ -169,8 +182,9 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
   __shared__ uint16_t tile_codes[kWavesPerBlock][2 * kTile];
   __shared__ uint8_t tile_chars[kWavesPerBlock][2 * kTile];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const uint32_t pair = blockIdx.x * kWavesPerBlock + wave;
-  if (pair >= p.n_pairs) return;
+  const uint32_t w = blockIdx.x * kWavesPerBlock + wave;
+  if (w >= p.n_pairs) return;
+  const uint32_t pair = p.walker_pair ? p.walker_pair[w] : w;
 
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
@@ -178,15 +192,14 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
   const TraceConsts k{p.code, p.table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
-  char *oa = p.out_a + p.str_off[pair];
-  char *ob = p.out_b + p.str_off[pair];
+  char *oa = p.out_a + p.str_off[w];
+  char *ob = p.out_b + p.str_off[w];
   TileAccess t{v, p.code, tile_cells[wave], tile_codes[wave], tile_chars[wave], 0, 0, false, lane};
 
   int matrix = MAT_MATCH, score;
   uint32_t x, y, head = la + lb, err = 0;
   if constexpr (SW) {
-    const uint32_t end = (uint32_t)p.start_index[pair];
-    x = end % W; y = end / W;
+    sw_walk_start(p, w, mo, W, x, y);
     t.refill(x, y);
     int a_, b_;
     t.cell(x, y, score, a_, b_);
@@ -220,15 +233,15 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
       }
     } else {
       // smith_waterman.c:251-255: start position and consumed lengths
-      p.out_pos[4 * pair + 0] = x;
-      p.out_pos[4 * pair + 1] = y;
-      p.out_pos[4 * pair + 2] = end_x - x;
-      p.out_pos[4 * pair + 3] = end_y - y;
+      p.out_pos[4 * w + 0] = x;
+      p.out_pos[4 * w + 1] = y;
+      p.out_pos[4 * w + 2] = end_x - x;
+      p.out_pos[4 * w + 3] = end_y - y;
     }
-    p.out_score[pair] = end_score;
-    p.out_head[pair] = head;
-    p.out_len[pair] = la + lb - head;
-    p.trace_status[pair] = err;
+    p.out_score[w] = end_score;
+    p.out_head[w] = head;
+    p.out_len[w] = la + lb - head;
+    p.trace_status[w] = err;
   }
 }
 
@@ -236,18 +249,21 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  const bool sw = p.start_index || p.hit_keys;
   // Measured (seq-align_amd/tools/long_e2e.py): the tiled wave-per-pair walker wins when there are few pairs
   // (1 x 10 000^2: 9.5 -> 7.4 ms, 16 x 5 000^2: 6.6 -> 4.2 ms of traceback) and loses a little when the lanes of
   // one-lane-per-pair waves are all busy (10 k x 150^2: +0.13 ms).  SEQALIGN_TRACE_KERNEL=lane|wave forces one.
   const char *force = getenv("SEQALIGN_TRACE_KERNEL");
-  const bool lane_kernel = force ? force[0] == 'l' : p.n_pairs >= 2048;
+  // SW walks (a hit is ~the shorter sequence long): the tiled walker also wins with 10 000 walks (C3: 0.58 -> 0.47 ms,
+  // C4: 0.88 -> 0.45 ms)
+  const bool lane_kernel = force ? force[0] == 'l' : (!sw && p.n_pairs >= 2048);
   if (lane_kernel) {
     const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
-    if (p.start_index) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);
+    if (sw) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(sa::traceback_kernel<false>, grid, block, 0, stream, p);
   } else {
     const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock), block(sa::kWave * sa::kWavesPerBlock);
-    if (p.start_index) hipLaunchKernelGGL(sa::traceback_wave_kernel<true>, grid, block, 0, stream, p);
+    if (sw) hipLaunchKernelGGL(sa::traceback_wave_kernel<true>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(sa::traceback_wave_kernel<false>, grid, block, 0, stream, p);
   }
   return hipGetLastError();
