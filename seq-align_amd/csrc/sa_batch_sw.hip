@@ -132,6 +132,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
   SaCandBox cand;
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
+  cand.cand_rows = d_keys.as<uint32_t>();   // the rows' candidate columns: at the end of every pair's part of the key arena
   seqalign_dev_batch_t d;
   bool reported = false;
   if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported))) return rc;
@@ -156,7 +157,10 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_len_a = c.max_a; q.layout = layout;
   std::vector<uint64_t> row_off;   // (function scope: the copy below is asynchronous)
-  if (c.max_a + 1 > SA_SWEEP_SEGMENT || getenv("SEQALIGN_SWEEP_SEGMENTS")) {   // wide pairs: two rows of records per pair
+  const char *rows_env = getenv("SEQALIGN_SWEEP_ROWS");   // "hbm": the records of two rows in HBM for every pair (tests)
+  if (c.max_a + 1 <= SA_SWEEP_LDS_COLUMNS && !(rows_env && rows_env[0] == 'h')) {
+    q.lds_columns = (c.max_a + 2u) & ~1u;
+  } else {   // wide pairs: two rows of records per pair in HBM
     row_off.resize(n);
     uint64_t total = 0;
     for (uint64_t k = 0; k < n; ++k) { row_off[k] = total; total += 2 * ((uint64_t)batch->len_a[c.first + k] + 1); }
@@ -184,14 +188,14 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (trace) {
     std::vector<unsigned long long> t(8 * n);
     HIP_TRY(hipMemcpy(t.data(), d_trace.p, n * 64, hipMemcpyDeviceToHost));
-    double sum[5] = {0, 0, 0, 0, 0}, hits_total = 0;
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hits_total = 0;
     for (uint64_t k = 0; k < n; ++k) {
-      for (int j = 0; j < 5; ++j) sum[j] += (double)t[8 * k + j];
+      for (int j = 0; j < 8; ++j) sum[j] += (double)t[8 * k + j];
       hits_total += h_count[k];
     }
     fprintf(stderr, "[seqalign sweep trace] pairs %llu  per pair: %.0f cycles (100 MHz ticks x ?), %.1f rows, %.1f active row segments, "
-                    "%.1f rounds, %.0f cycles in active segments, %.2f hits\n",
-            (unsigned long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, hits_total / n);
+                    "%.1f rounds, %.0f cycles in active segments, %.2f hits; row phases: prefetch issue %.0f, segments %.0f, fence + rotate %.0f\n",
+            (unsigned long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, hits_total / n, sum[5] / n, sum[6] / n, sum[7] / n);
   }
 
   std::vector<uint64_t> cell0(n + 1, 0);

@@ -159,8 +159,9 @@ constexpr int kBestRowBits = 21;   // packed tie-break: column (11 bits) | row (
 //   SA_STREAM_BEST  the best cell per pair (above) -- seqalign_sw_batch with max_hits = 1
 //   SA_STREAM_CAND  how many cells have score >= cand_min[pair] and their bounding box -- the candidate scan of
 //                   smith_waterman.c:152-156 for the multi-hit path, which then sweeps only the box's rows
-//                   (sa_sw_sweep.hip).  Per row: one ballot per column slot; rows without a candidate cost the
-//                   ballots and one scalar branch.
+//                   (sa_sw_sweep.hip), and within a row only the columns between its lowest and highest candidate
+//                   (cand_rows: two uint32 per row, 64 rows per store).  Per row: one ballot per column slot; rows
+//                   without a candidate cost the ballots and one scalar branch.
 enum { SA_STREAM_PLAIN = 0, SA_STREAM_BEST = 1, SA_STREAM_CAND = 2 };
 
 template <int CPL, int SUBST, bool GENERAL, int R, int FB, int MODE>
@@ -231,7 +232,13 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   // candidate emission: wave-uniform running count and bounding box of the pair's candidates
   uint32_t cand_n = 0, box_rmin = 0xffffffffu, box_rmax = 0, box_cmin = 0xffffffffu, box_cmax = 0;
   int cand_thr = INT32_MAX;
-  if constexpr (CAND) cand_thr = max(p.cand_min[pair], 1);   // candidates need match_scores > 0 (smith_waterman.c:154)
+  uint32_t rr_lo = 0xffffffffu, rr_hi = 0;
+  uint32_t *cand_rows = nullptr;   // [len_b + 1][2]: lowest / highest candidate column of every row (lo > hi: none)
+  if constexpr (CAND) {
+    cand_thr = max(p.cand_min[pair], 1);   // candidates need match_scores > 0 (smith_waterman.c:154)
+    cand_rows = sa_cand_rows(p.cand_rows, mo, W, lb);
+    if (lane == 0) *reinterpret_cast<uint2 *>(cand_rows) = make_uint2(0xffffffffu, 0u);   // row 0: borders only
+  }
   if constexpr (BEST) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { best_s[c] = 0; best_r[c] = 0; }
@@ -263,17 +270,25 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
         bal[c] = __ballot(c < ncol && mv[c] >= cand_thr);
         any |= bal[c];
       }
+      uint32_t row_lo = 0xffffffffu, row_hi = 0;   // this row's candidates: lowest / highest column (wave-uniform)
       if (any) {   // wave-uniform
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           cand_n += (uint32_t)__popcll(bal[c]);
           if (bal[c]) {
-            box_cmin = min(box_cmin, (uint32_t)__builtin_ctzll(bal[c]) * CPL + c);
-            box_cmax = max(box_cmax, (uint32_t)(63 - __builtin_clzll(bal[c])) * CPL + c);
+            row_lo = min(row_lo, (uint32_t)__builtin_ctzll(bal[c]) * CPL + c);
+            row_hi = max(row_hi, (uint32_t)(63 - __builtin_clzll(bal[c])) * CPL + c);
           }
         }
+        box_cmin = min(box_cmin, row_lo);
+        box_cmax = max(box_cmax, row_hi);
         box_rmin = min(box_rmin, j);
         box_rmax = j;
+      }
+      // per-row ranges: lane q keeps row j's, 64 rows leave as one coalesced store
+      if (lane == q) { rr_lo = row_lo; rr_hi = row_hi; }
+      if (q == kWave - 1 || j == lb) {
+        if (lane <= q) *reinterpret_cast<uint2 *>(cand_rows + 2ull * (j - q + lane)) = make_uint2(rr_lo, rr_hi);
       }
     }
   }

@@ -33,7 +33,17 @@ struct SaFillParams {
   const int32_t *cand_min;
   uint32_t *cand_count;
   uint32_t *cand_box;
+  uint32_t *cand_rows;   /* per row of every pair: lowest / highest candidate column (lo > hi: none); see sa_cand_rows */
 };
+
+/* The per-row candidate ranges of pair p (two uint32 per row, rows 0..len_b) live at the END of the pair's region of
+ * the multi-hit path's 8-byte-per-cell arena (SaSweepParams::hit_keys as uint32: cells [mat_off, mat_off + W * (len_b + 1)));
+ * the hits' keys grow from its start.  Both fit: a pair has at most len_a * len_b hits and W * (len_b + 1) cells. */
+#ifdef __HIPCC__
+__host__ __device__ inline uint32_t *sa_cand_rows(uint32_t *arena32, uint64_t mat_off, uint32_t W, uint32_t len_b) {
+  return arena32 + 2ull * (mat_off + (uint64_t)W * (len_b + 1ull)) - 2ull * (len_b + 1ull);
+}
+#endif
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit
  * order (score desc, column asc, then cell index = row asc; smith_waterman.c:71-86):
@@ -63,6 +73,7 @@ struct SaReduceParams {
 struct SaCandBox {
   uint32_t *cand_count;       /* [n]                                                       */
   uint32_t *cand_box;         /* [4n] rmin, rmax, cmin, cmax                               */
+  uint32_t *cand_rows;        /* the 8-byte-per-cell arena, as uint32 (sa_cand_rows)       */
   const int32_t *cand_min;    /* [n] per-pair min_score                                    */
 };
 
@@ -85,8 +96,10 @@ struct SaSweepParams {
   uint32_t *hit_count;           /* [n] every hit of the pair (no max_hits here)                      */
   uint32_t *status;              /* [n] 0, SEQALIGN_E_* of a walk (see err_key), | SA_SWEEP_UNSORTED   */
   unsigned long long *err_key;   /* [n] key of the first (lowest) walk that met the error             */
-  unsigned long long *rows;      /* wide pairs only: two rows of walker records per pair, pair p at row_off[p] */
-  const uint64_t *row_off;
+  uint32_t lds_columns;          /* != 0: the records of two rows live in LDS, sized for this many columns (>= every
+                                    pair's len_a + 1); 0: in `rows`                                                  */
+  unsigned long long *rows;      /* lds_columns == 0: 4 * (len_a + 1) uint64 per pair, pair p at 2 * row_off[p]      */
+  const uint64_t *row_off;       /* [n] prefix of 2 * (len_a + 1)                                                    */
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
@@ -95,8 +108,8 @@ struct SaSweepParams {
   unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (SEQALIGN_SWEEP_TRACE) */
 };
 #define SA_SWEEP_UNSORTED 0x80000000u
-/* columns one wave keeps in registers; wider pairs are swept segment by segment with the records in `rows` */
-#define SA_SWEEP_SEGMENT 512u
+/* widest pair (columns) whose two rows of records fit LDS (12 B per column and row with 64-bit keys) */
+#define SA_SWEEP_LDS_COLUMNS 2048u
 
 struct SaTraceParams {
   const uint8_t *arena;

@@ -124,9 +124,10 @@ sw_reduce_kernel(const SaReduceParams p) {
   }
 }
 
-// The candidates' count and bounding box (SaFillParams::cand_*) from a match_scores matrix that is already in HBM
-// -- for fills that cannot report them while the values are in registers (anything but the stream kernel).  Same
-// streaming loop as above: 4 B per cell read, one wave per pair.
+// The candidates' count, bounding box and per-row column ranges (SaFillParams::cand_*) from a match_scores matrix
+// that is already in HBM -- for fills that cannot report them while the values are in registers (anything but the
+// stream kernel).  Same streaming loop as above: 4 B per cell read, one wave per pair; a candidate updates its row's
+// range with two atomics (the lanes of a step straddle rows).
 __global__ void __launch_bounds__(kWave *kWavesPerBlock)
 sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -135,6 +136,9 @@ sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
   const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1;
   const uint32_t cells = W * H;
   const int32_t *__restrict__ M = p.M + p.mat_off[pair];
+  uint32_t *rows = sa_cand_rows(c.cand_rows, p.mat_off[pair], W, H - 1);
+  for (uint32_t r = lane; r < H; r += kWave) { rows[2 * r] = 0xffffffffu; rows[2 * r + 1] = 0u; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (one wave: the atomics below follow in program order)
   const int thr = max(c.cand_min[pair], 1);
   uint32_t count = 0;                                                    // per lane, reduced at the end
   uint32_t rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;   // per lane, reduced at the end
@@ -156,6 +160,8 @@ sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
         if (v[k] >= thr) {
           ++count;
           rmin = min(rmin, row); rmax = max(rmax, row); cmin = min(cmin, col); cmax = max(cmax, col);
+          atomicMin(&rows[2 * row], col);
+          atomicMax(&rows[2 * row + 1], col);
         }
         if (++col == W) { col = 0; ++row; }
       }

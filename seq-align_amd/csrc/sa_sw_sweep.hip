@@ -22,23 +22,23 @@
 // candidates, no visited bitmap, no iteration over walks.  (Checked against the sequential procedure by
 // tests/test_gpu_parity.py and tools/fuzz_e2e.py; the argument in full: DESIGN.md 3.6.)
 //
-// One WAVE per pair; lane l owns CPL consecutive columns (the fill kernel's layout: a row is one contiguous run of
-// 64 * CPL cells, loaded with one wide load per lane and matrix; 12 B per cell, each row loaded once and kept for
-// the row above it, the next row in flight while this one is worked on).  Per cell the wave carries the key of the
-// walk that won it and four bits: where that walk goes (up-left / up / left / nowhere) and the state it arrives
-// in.  Arrivals from the row below are register moves (one DPP shift at the lane border).  Arrivals along the row
-// (GAP_B moves) make a right-to-left dependency: each lane resolves its own columns in order, and the lanes
-// iterate until no lane's incoming walk changes -- a sideways run crosses few lane borders, so that is one or two
-// passes (the row's fixed point is unique: the rightmost cell has no such arrival and every cell is a function of
-// the one to its right).  Where a walk goes from a cell is worked out for all three states of every cell of an
-// active row at once: the traceback's own decision (reverse_move_t; for plain scorings the same three equality
-// tests on 32-bit values).  Rows without candidates and without live walks cost their loads and a ballot.
-// Keys are 32 bits wide when row, column and score fit 31 bits, else 64.
-// Pairs wider than SA_SWEEP_SEGMENT columns are swept in column segments, right to left within a row, with the
-// records of the last two rows in HBM (SaSweepParams::rows) and segments nothing can reach skipped.
+// One WAVE per pair.  Per cell the wave keeps the key of the walk that won it and four bits: where that walk
+// goes (up-left / up / left / nowhere) and the state it arrives in -- for the last two rows, in LDS, indexed by
+// column (pairs wider than SA_SWEEP_LDS_COLUMNS: in HBM, SaSweepParams::rows).  A row of a candidates' box is
+// mostly empty: the walks live in a band around the hits' diagonals.  The fill reports, per row, the lowest and
+// highest column holding a candidate (SaFillParams::cand_rows); with the columns of the row below that walks left
+// from, that is all a row can have arrivals in, and the wave works on that stretch only, in segments of 64 * CPL
+// columns counted from its right end (usually one): lane l owns CPL consecutive columns of the segment; match /
+// gap_a / gap_b of row y and y - 1 are one wide load per lane and matrix (only the stretch is read, 24 B per cell
+// of it -- the second read of a row hits L2).  Arrivals from the row below are LDS reads and a DPP shift at the lane
+// border.  Arrivals along the row (GAP_B moves) make a right-to-left dependency: each lane resolves its own columns
+// in order, and the lanes iterate until no lane's incoming walk changes (the row's fixed point is unique: the
+// rightmost cell has no such arrival and every cell is a function of the one to its right).  Where a walk goes from
+// a cell is worked out for all three states of every cell of a segment at once: the traceback's own decision
+// (reverse_move_t; for plain scorings the same three equality tests on 32-bit values).  Rows nothing can arrive in
+// cost a scalar test.  Keys are 32 bits wide when row, column and score fit 31 bits, else 64.
 //
-// Bound: HBM reads of the box's rows (12 B per cell) for many pairs; the latency of one row's work x the rows of
-// the box for few pairs.
+// Bound: VALU work per cell of the bands (~100 instructions); HBM traffic is a fraction of the fill's.
 #include <algorithm>
 
 #include "sa_trace_common.hpp"
@@ -95,8 +95,8 @@ __device__ __forceinline__ void load_run(const int32_t *src, int (&v)[N], int fi
 // left, kStay: nowhere -- no winner, or the walk ends here), bits 2-3 = the state it arrives in
 constexpr uint32_t kStay = 3u;
 
-template <int CPL, bool MULTI, typename KeyT>
-__global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) {
+template <int CPL, typename KeyT, bool LDSROWS>
+__global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
   constexpr KeyT kNone = ~(KeyT)0;         // no walk
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x;
@@ -109,18 +109,36 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
   const int32_t *__restrict__ Mg = p.M + mo, *__restrict__ Ag = p.A + mo, *__restrict__ Bg = p.B + mo;
   const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair], *__restrict__ sb_ = p.arena + p.off_b[pair];
   unsigned long long *hit_keys = p.hit_keys + mo;
-  const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1], cmin = p.cand_box[4ull * pair + 2],
-                 cmax = p.cand_box[4ull * pair + 3];
+  const uint32_t *cand_rows = sa_cand_rows(reinterpret_cast<uint32_t *>(p.hit_keys), mo, W, lb);
+  const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1];
   const int thr = max(p.min_score[pair], 1);
-  // the substitution table in LDS (up to SA_LDS_TABLE_MAX_K classes): one lookup per cell and row
-  extern __shared__ int32_t lds_table[];
+  // LDS: the substitution table (up to SA_LDS_TABLE_MAX_K classes: one lookup per cell and row), then the records
+  extern __shared__ __attribute__((aligned(8))) int32_t lds_words[];
   const int32_t *table = p.table;
-  if (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) {
-    for (uint32_t i = lane; i < p.K * p.K; i += kWave) lds_table[i] = p.table[i];
+  if (table_ints) {
+    for (uint32_t i = lane; i < p.K * p.K; i += kWave) lds_words[i] = p.table[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // one wave: program order; the fence pins the compiler
     __builtin_amdgcn_s_waitcnt(0);
-    table = lds_table;
+    table = lds_words;
   }
+  // the codes of seq_a, by column (column x holds seq_a[x - 1]; code_ints = 0: pairs too wide, read from HBM each time)
+  uint16_t *col_code = reinterpret_cast<uint16_t *>(lds_words + table_ints);
+  if (code_ints) {
+    for (uint32_t x = lane; x < W; x += kWave) col_code[x] = x >= 1 ? p.code[sa_[x - 1]] : (uint16_t)0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  // records of two rows: winner's key and what it does next, per column
+  KeyT *rk;
+  uint32_t *rz;
+  if constexpr (LDSROWS) {
+    rk = reinterpret_cast<KeyT *>(lds_words + table_ints + code_ints);
+    rz = reinterpret_cast<uint32_t *>(rk + 2ull * p.lds_columns);
+  } else {
+    rk = reinterpret_cast<KeyT *>(p.rows + 2 * p.row_off[pair]);
+    rz = reinterpret_cast<uint32_t *>(p.rows + 2 * p.row_off[pair] + 2ull * W);
+  }
+  const uint32_t row_pitch = LDSROWS ? p.lds_columns : W;
   const TraceConsts k{p.code, table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
@@ -131,44 +149,53 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
                                   SA_F_HAS_SENTINEL));
   const uint32_t cshift = p.layout.row_bits, sshift = p.layout.row_bits + p.layout.col_bits;
   const int cap = p.layout.cap;
-  constexpr uint32_t kSegW = kWave * CPL;
-  const uint32_t seg_hi = MULTI ? cmax / kSegW : 0u, seg_cmin = MULTI ? cmin / kSegW : 0u;
-  // wide pairs: [2 rows][W columns][key, what-next] as two uint64 per column
-  unsigned long long *rows = MULTI ? p.rows + 2 * p.row_off[pair] : nullptr;
+  constexpr int kSegW = kWave * CPL;
 
   int m[CPL], a[CPL], b[CPL], pm[CPL], pa[CPL], pb[CPL];   // this segment of row y / of row y - 1
   KeyT wk[CPL];                                             // row y + 1 coming in, row y going out: the cells' winners
-  uint32_t wz[CPL];                                         // and what they do next (kStay | ...: nothing leaves the cell)
-  int ca[CPL];                                              // codes of seq_a[x - 1] (one segment: loaded once)
+  uint32_t wz[CPL];                                         // and what they do next (kStay: nothing leaves the cell)
+  int ca[CPL];                                              // codes of seq_a[x - 1]
   uint32_t n_hits = 0;                                      // wave-uniform
   uint32_t err = 0;                                         // per lane: error of the lowest walk that met one,
   KeyT err_key = kNone;                                     // and that walk
   int chunk_code = 0;                                       // lane t: code of seq_b[y - 1] for the row t below the chunk's top
-  unsigned long long tr_rows = 0, tr_active = 0, tr_rounds = 0, tr_cycles = 0;   // development aid (p.trace)
+  uint2 chunk_range = make_uint2(0xffffffffu, 0u);          // lane t: that row's candidate columns
+  int live_lo = INT32_MAX, live_hi = -1;                    // columns of this row a walk leaves (wave-uniform)
+  unsigned long long tr_rows = 0, tr_active = 0, tr_rounds = 0, tr_cycles = 0, tr_a = 0, tr_b = 0, tr_c = 0;   // development aid (p.trace)
   const unsigned long long t_start = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
-  auto load_row = [&](uint32_t y, uint32_t x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL]) __attribute__((always_inline)) {
-    const uint32_t xl = x0 + lane * CPL, at = y * W + xl;
-    if (xl + CPL <= W || (xl < W && y < lb)) {   // (past the row's end is the next row: inside the pair's matrix unless y = len_b)
+  auto load_row = [&](uint32_t y, int x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL]) __attribute__((always_inline)) {
+    const int xl = x0 + lane * CPL;
+    const uint32_t at = y * W + (uint32_t)xl;
+    // (past the row's end is the next row: inside the pair's matrix unless y = len_b)
+    if (xl >= 0 && ((uint32_t)xl + CPL <= W || ((uint32_t)xl < W && y < lb))) {
       load_run<CPL>(Mg + at, dm); load_run<CPL>(Ag + at, da); load_run<CPL>(Bg + at, db);
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) dm[c] = xl + c < W ? dm[c] : 0;   // no candidates there
+      for (int c = 0; c < CPL; ++c) dm[c] = (uint32_t)(xl + c) < W ? dm[c] : 0;   // no candidates there
     } else {
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const bool in = xl + c < W;
+        const bool in = (uint32_t)(xl + c) < W;   // (negative columns wrap to huge values)
         dm[c] = in ? Mg[at + c] : 0; da[c] = in ? Ag[at + c] : 0; db[c] = in ? Bg[at + c] : 0;
       }
     }
   };
+  auto rec_key = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> KeyT {
+    if constexpr (LDSROWS) return rk[row * row_pitch + col];
+    else return __hip_atomic_load(rk + (size_t)row * row_pitch + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto rec_next = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> uint32_t {
+    if constexpr (LDSROWS) return rz[row * row_pitch + col];
+    else return __hip_atomic_load(rz + (size_t)row * row_pitch + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
-  // One segment of one row.  left[6]: match / gap_a / gap_b of the column left of the segment on row y and on
-  // row y - 1 (wave-uniform); rp_k / rp_z: winner and what-next of the cell right of the segment on row y + 1;
-  // rc_k / rc_z: of the cell right of it on row y.  wk / wz come in as row y + 1's and leave as row y's.
-  // Returns whether any walk leaves this segment of the row.
-  auto sweep_segment = [&](uint32_t y, uint32_t x0, const int (&left)[6], KeyT rp_k, uint32_t rp_z, KeyT rc_k, uint32_t rc_z,
-                           int code_b) __attribute__((always_inline)) -> bool {
-    const uint32_t xl = x0 + lane * CPL;
+  // One segment of one row: columns x0 .. x0 + 64 * CPL - 1 (x0 may be negative: those cells do not exist).
+  // left[6]: match / gap_a / gap_b of column x0 - 1 on row y and on row y - 1 (wave-uniform); rp_k / rp_z: winner
+  // and what-next of the cell right of the segment on row y + 1; rc_k / rc_z: of the cell right of it on row y.
+  // wk / wz come in as row y + 1's and leave as row y's; live_lo / live_hi take in the columns a walk leaves.
+  auto sweep_segment = [&](uint32_t y, int x0, const int (&left)[6], KeyT rp_k, uint32_t rp_z, KeyT rc_k, uint32_t rc_z,
+                           int code_b) __attribute__((always_inline)) {
+    const int xl = x0 + lane * CPL;
     // ---- arrivals from below and the cell's own candidacy
     KeyT bk[CPL];
     uint32_t bs[CPL];   // state the best arrival from below / the candidate stands in
@@ -181,7 +208,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
         const KeyT dk = c + 1 < CPL ? wk[c + 1 < CPL ? c + 1 : c] : dk_edge;
         const uint32_t dz = c + 1 < CPL ? wz[c + 1 < CPL ? c + 1 : c] : dz_edge;
         KeyT best = (m[c] >= thr) ? (KeyT)((((unsigned long long)(uint32_t)(cap - m[c]) << sshift) |
-                                            ((unsigned long long)(xl + c) << cshift) | y))
+                                            ((unsigned long long)(uint32_t)(xl + c) << cshift) | y))
                                   : kNone;
         uint32_t st = MAT_MATCH;
         if ((dz & 3u) == MAT_MATCH && dk < best) { best = dk; st = dz >> 2; }
@@ -192,15 +219,15 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
       if (!__any(any) && (rc_z & 3u) != MAT_GAP_B) {   // nothing arrives in this segment
 #pragma unroll
         for (int c = 0; c < CPL; ++c) { wk[c] = kNone; wz[c] = kStay; }
-        return false;
+        return;
       }
     }
     const unsigned long long t_seg = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     ++tr_active;
     // ---- where a walk standing on a cell goes, for each of its three states: 2 bits per state = the predecessor's
     // matrix, or 3 = this state's score is 0 (the walk ends here: a hit).  For every cell of the segment at once (no
-    // divergence; nearly every row of a candidates' box has walks on it).  bad: bit s = state s has no predecessor
-    // that explains its score (bit 3 + s: its pair of characters has no score).
+    // divergence).  bad (scorings that are not plain): bit s = state s has no predecessor that explains its score
+    // (bit 3 + s: its pair of characters has no score).
     uint32_t dir[CPL], bad[CPL];
     {
       const int e_pm = wave_shr1(pm[CPL - 1], left[3]), e_pa = wave_shr1(pa[CPL - 1], left[4]), e_pb = wave_shr1(pb[CPL - 1], left[5]);
@@ -210,9 +237,9 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
         const int cl = c ? c - 1 : 0;
         const int s3[3] = {m[c], a[c], b[c]};
         const int qm[3] = {c ? pm[cl] : e_pm, pm[c], c ? m[cl] : e_m};   // MATCH <- (x-1, y-1), GAP_A <- (x, y-1), GAP_B <- (x-1, y)
-        (void)qm;
         const int qa[3] = {c ? pa[cl] : e_pa, pa[c], c ? a[cl] : e_a};
         const int qb[3] = {c ? pb[cl] : e_pb, pb[c], c ? b[cl] : e_b};
+        (void)qm;
         dir[c] = 0x3fu; bad[c] = 0;
         if (plain) {
           const int sub = (k.K <= 1) ? ((ca[c] & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
@@ -221,9 +248,8 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
 #pragma unroll
           for (int st = 0; st < 3; ++st) {
             const uint32_t f = (qa[st] + va[st] == s3[st]) ? 1u : (qb[st] + vb[st] == s3[st]) ? 2u : 0u;
-            const bool moves = s3[st] > 0;
-            if (moves) dir[c] = (dir[c] & ~(3u << (2 * st))) | (f << (2 * st));
-            // (f = 0 without qm + vm == s, the "program error" of alignment.c:329-345, cannot happen here: these
+            if (s3[st] > 0) dir[c] = (dir[c] & ~(3u << (2 * st))) | (f << (2 * st));
+            // (f = 0 without qm + cost == s, the "program error" of alignment.c:329-345, cannot happen here: these
             // are the fill's own values, and a positive plain score IS one of its three candidates)
           }
         } else {
@@ -231,7 +257,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
           for (int st = 0; st < 3; ++st) {
             if (s3[st] > 0) {
               RegAccess acc{qm[st], qa[st], qb[st], ca[c], code_b};
-              uint32_t qx = xl + c, qy = y;
+              uint32_t qx = (uint32_t)(xl + c), qy = y;
               int pmx = st, ps = s3[st];
               const uint32_t e = reverse_move_t(acc, k, la, lb, qx, qy, pmx, ps);
               if (e) bad[c] |= (e == 5u ? 8u : 1u) << st;
@@ -245,7 +271,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
     KeyT in_k = kNone;          // the walk entering my last column from the right, and its state
     uint32_t in_s = 0;
     uint32_t ws[CPL];           // state the winner stands in
-    for (bool first = true;; first = false) {
+    for (;;) {
       ++tr_rounds;
       KeyT hk = in_k;
       uint32_t hs = in_s;
@@ -266,11 +292,10 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
       const uint32_t ns = wave_shl1(wz[0] >> 2, rc_z >> 2);
       const bool changed = nk != in_k || (nk != kNone && ns != in_s);
       in_k = nk; in_s = ns;
-      (void)first;
       if (!__any(changed)) break;
     }
     // a winner standing in a state that cannot be explained: the error of alignment_reverse_move (alignment.c:329-345)
-    {
+    if (!plain) {
       bool any_bad = false;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) any_bad |= wk[c] != kNone && ((bad[c] >> ws[c]) & 9u) != 0u;
@@ -293,100 +318,121 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
       }
       out_live |= wz[c] != kStay;
     }
+    const unsigned long long live = __ballot(out_live);
+    if (live) {   // (at lane granularity: a superset is fine)
+      live_lo = min(live_lo, x0 + (int)__builtin_ctzll(live) * CPL);
+      live_hi = max(live_hi, x0 + (63 - (int)__builtin_clzll(live)) * CPL + CPL - 1);
+    }
     if (p.trace) tr_cycles += __builtin_amdgcn_s_memtime() - t_seg;
-    return __any(out_live);
   };
 
-  uint32_t y = rmax;
-  if constexpr (!MULTI) {
-    // ------------------------------------------------------------------ the whole row in one segment
+  // the scores a segment needs: rows y and y - 1 at columns x0 .. x0 + 64 * CPL - 1, and the column left of them
+  auto load_segment = [&](uint32_t y, int x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL], int (&dpm)[CPL], int (&dpa)[CPL],
+                          int (&dpb)[CPL], int (&dleft)[6]) __attribute__((always_inline)) {
+    load_row(y, x0, dm, da, db);
+    if (y > 0) load_row(y - 1, x0, dpm, dpa, dpb);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const uint32_t x = lane * CPL + c;
-      ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
-      wk[c] = kNone; wz[c] = kStay;
+    for (int i = 0; i < 6; ++i) dleft[i] = 0;
+    if (x0 > 0) {
+      const uint32_t at = y * W + (uint32_t)x0 - 1;
+      dleft[0] = Mg[at]; dleft[1] = Ag[at]; dleft[2] = Bg[at];
+      if (y > 0) { dleft[3] = Mg[at - W]; dleft[4] = Ag[at - W]; dleft[5] = Bg[at - W]; }
     }
-    const int none[6] = {0, 0, 0, 0, 0, 0};   // column 0 is a border column: its states never move left
-    int nm[CPL], na[CPL], nb[CPL];
-    load_row(y, 0, m, a, b);
-    if (y > 0) load_row(y - 1, 0, pm, pa, pb);
-    for (;; --y) {
-      if (y >= 2) load_row(y - 2, 0, nm, na, nb);   // in flight while this row is worked on
-      const int q = (int)((rmax - y) & (kWave - 1));
-      if (q == 0) {   // every 64 rows: lane t fetches seq_b's code for row y - t
-        chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
-      }
-      const bool live = sweep_segment(y, 0, none, kNone, kStay, kNone, kStay, read_lane(chunk_code, q));
-      ++tr_rows;
-      if (y == 0 || (!live && y <= rmin)) break;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        m[c] = pm[c]; a[c] = pa[c]; b[c] = pb[c];
-        pm[c] = nm[c]; pa[c] = na[c]; pb[c] = nb[c];
-      }
+  };
+  // candidate columns of a row (lo > hi: none), from the chunk of 63 rows the lanes hold
+  uint32_t chunk_top = 0;
+  auto row_range = [&](uint32_t y, int &c_lo, int &c_hi) __attribute__((always_inline)) {
+    const int idx = (int)(chunk_top - y);
+    const uint32_t lo_ = (uint32_t)read_lane((int)chunk_range.x, idx), hi_ = (uint32_t)read_lane((int)chunk_range.y, idx);
+    const bool some = lo_ <= hi_ && y >= rmin;
+    c_lo = some ? (int)lo_ : INT32_MAX; c_hi = some ? (int)hi_ : -1;
+  };
+
+  int prev_w_lo = 1, prev_w_hi = 0;              // columns whose records row y + 1 wrote (none yet)
+  int prev_live_lo = INT32_MAX, prev_live_hi = -1;
+  // The first segment of a row ends at column `top`: the highest column anything can arrive in -- the row's own
+  // candidates, and the columns walks left the row below from.  That is known only when the row below is done, so the
+  // loads go out a row ahead for an upper bound of it (the candidates of this row and of the row below, the walks that
+  // left the row below that one); too far right only costs a little of the segment's width.
+  int top, n_top = -1;
+  int nm[CPL], na[CPL], nb[CPL], npm[CPL], npa[CPL], npb[CPL], nleft[6], left[6];
+  {
+    chunk_top = rmax;
+    chunk_code = (rmax >= 1u + lane) ? (int)p.code[sb_[rmax - lane - 1]] : 0;
+    chunk_range = (rmax >= (uint32_t)lane) ? *reinterpret_cast<const uint2 *>(cand_rows + 2ull * (rmax - lane)) : make_uint2(0xffffffffu, 0u);
+    int c_lo, c_hi;
+    row_range(rmax, c_lo, c_hi);
+    top = min(c_hi, (int)W - 1);
+    load_segment(rmax, top - kSegW + 1, m, a, b, pm, pa, pb, left);
+  }
+  for (uint32_t y = rmax;; --y) {
+    if (chunk_top - y >= (uint32_t)kWave - 1) {   // lane t: seq_b's code and the candidate columns of row y - t (rows y and y - 1 are needed)
+      chunk_top = y;
+      chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
+      chunk_range = (y >= (uint32_t)lane) ? *reinterpret_cast<const uint2 *>(cand_rows + 2ull * (y - lane)) : make_uint2(0xffffffffu, 0u);
     }
-  } else {
-    // ------------------------------------------------------------------ column segments, records in HBM
-    uint32_t prev_lo = seg_hi + 1;        // lowest segment whose records row y + 1 wrote (none yet)
-    uint32_t prev_live_lo = seg_hi + 1;   // lowest segment of row y + 1 with a walk leaving it
-    for (;; --y) {
-      const int q = (int)((rmax - y) & (kWave - 1));
-      if (q == 0) chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
-      const int code_b = read_lane(chunk_code, q);
-      unsigned long long *cur_rows = rows + (size_t)(y & 1u) * 2 * W;
-      const unsigned long long *prev_rows = rows + (size_t)((y + 1u) & 1u) * 2 * W;
-      const bool box_row = y >= rmin;     // (y <= rmax always)
+    const int code_b = read_lane(chunk_code, (int)(chunk_top - y));
+    const unsigned long long tp0 = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    int c_lo, c_hi;
+    row_range(y, c_lo, c_hi);
+    ++tr_rows;
+    if (y > 0) {   // the next row's first segment: loads in flight while this row is worked on
+      int n_lo, n_hi;
+      row_range(y - 1, n_lo, n_hi);
+      n_top = min(max(max(n_hi, c_hi), prev_live_hi), (int)W - 1);
+      if (n_top >= 0) load_segment(y - 1, n_top - kSegW + 1, nm, na, nb, npm, npa, npb, nleft);
+    }
+    const unsigned long long tp1 = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    // the stretch of this row anything can arrive in: its candidates, and up / up-left of where walks left row y + 1
+    const int lo = max(min(c_lo, prev_live_lo == INT32_MAX ? INT32_MAX : prev_live_lo - 1), 0);
+    const uint32_t cur = y & 1u, prv = cur ^ 1u;
+    int w_lo = 1, w_hi = 0;
+    live_lo = INT32_MAX; live_hi = -1;
+    if (top >= 0 && (c_hi >= 0 || prev_live_hi >= 0)) {
+      w_hi = top;
       KeyT rc_k = kNone;
       uint32_t rc_z = kStay;
-      ++tr_rows;
-      uint32_t lo = seg_hi + 1, live_lo = seg_hi + 1;
-      bool row_live = false;
-      for (uint32_t s = seg_hi;; --s) {
-        const uint32_t x0 = s * kSegW;
-        load_row(y, x0, m, a, b);
-        if (y > 0) load_row(y - 1, x0, pm, pa, pb);
-        int left[6] = {0, 0, 0, 0, 0, 0};
-        if (x0 > 0) {
-          const uint32_t at = y * W + x0 - 1;
-          left[0] = Mg[at]; left[1] = Ag[at]; left[2] = Bg[at];
-          if (y > 0) { left[3] = Mg[at - W]; left[4] = Ag[at - W]; left[5] = Bg[at - W]; }
-        }
-        const bool have_prev = s >= prev_lo;
+      for (int x_top = top;;) {
+        const int x0 = x_top - kSegW + 1, xl = x0 + lane * CPL;
+        if (x_top != top) load_segment(y, x0, m, a, b, pm, pa, pb, left);   // (a second segment: the walks spread out)
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const uint32_t x = x0 + lane * CPL + c;
-          ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
-          wk[c] = kNone; wz[c] = kStay;
-          if (have_prev && x < W) {
-            wk[c] = (KeyT)__hip_atomic_load(prev_rows + 2 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wz[c] = (uint32_t)__hip_atomic_load(prev_rows + 2 * x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          const int x = xl + c;
+          ca[c] = (x >= 1 && x <= (int)la) ? (code_ints ? (int)col_code[x] : (int)p.code[sa_[x - 1]]) : 0;
+          const bool have = x >= prev_w_lo && x <= prev_w_hi;
+          wk[c] = have ? rec_key(prv, (uint32_t)x) : kNone;
+          wz[c] = have ? rec_next(prv, (uint32_t)x) : kStay;
         }
         KeyT rp_k = kNone;
         uint32_t rp_z = kStay;
-        if (s + 1 >= prev_lo && s + 1 <= seg_hi && x0 + kSegW < W) {
-          rp_k = (KeyT)__hip_atomic_load(prev_rows + 2 * (x0 + kSegW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          rp_z = (uint32_t)__hip_atomic_load(prev_rows + 2 * (x0 + kSegW) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const bool live = sweep_segment(y, x0, left, rp_k, rp_z, rc_k, rc_z, code_b);
+        if (x_top + 1 >= prev_w_lo && x_top + 1 <= prev_w_hi) { rp_k = rec_key(prv, (uint32_t)x_top + 1); rp_z = rec_next(prv, (uint32_t)x_top + 1); }
+        sweep_segment(y, x0, left, rp_k, rp_z, rc_k, rc_z, code_b);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const uint32_t x = x0 + lane * CPL + c;
-          if (x < W) { cur_rows[2 * x] = (unsigned long long)wk[c]; cur_rows[2 * x + 1] = wz[c]; }
+          const int x = xl + c;
+          if (x >= 0 && x <= x_top) { rk[cur * row_pitch + (uint32_t)x] = wk[c]; rz[cur * row_pitch + (uint32_t)x] = wz[c]; }
         }
-        lo = s;
-        if (live) { live_lo = s; row_live = true; }
+        w_lo = max(x0, 0);
+        if (x0 <= 0) break;
         rc_k = lane_value(wk[0], 0); rc_z = lane_value(wz[0], 0);
-        if (s == 0) break;
-        // is anything left of here reachable?  candidates, walks from the row below (a diagonal move crosses one
-        // segment border at most), the walk leaving this segment's first column
-        const bool more = (box_row && s - 1 >= seg_cmin) || s >= prev_live_lo || (rc_z & 3u) == MAT_GAP_B;
-        if (!more) break;
+        x_top = x0 - 1;
+        // is anything left of here reachable?  candidates and arrivals from below (lo), the walk leaving this
+        // segment's first column sideways
+        if (x_top < lo && (rc_z & 3u) != MAT_GAP_B) break;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this row's records are in L2 before the next row reads them
-      prev_lo = lo; prev_live_lo = live_lo;
-      if (y == 0 || (!row_live && y <= rmin)) break;
     }
+    const unsigned long long tp2 = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+    // this row's records are written before the next row reads them (one wave: LDS in program order; HBM: to L2)
+    if constexpr (LDSROWS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    prev_w_lo = w_lo; prev_w_hi = w_hi; prev_live_lo = live_lo; prev_live_hi = live_hi;
+    if (y == 0 || (live_hi < 0 && y <= rmin)) break;
+    top = n_top;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { m[c] = nm[c]; a[c] = na[c]; b[c] = nb[c]; pm[c] = npm[c]; pa[c] = npa[c]; pb[c] = npb[c]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) left[i] = nleft[i];
+    if (p.trace) { const unsigned long long tp3 = __builtin_amdgcn_s_memtime(); tr_a += tp1 - tp0; tr_b += tp2 - tp1; tr_c += tp3 - tp2; }
   }
 
   // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
@@ -415,7 +461,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p) 
     p.err_key[pair] = first_err;
     if (p.trace) {
       unsigned long long *t = p.trace + 8ull * pair;
-      t[0] = __builtin_amdgcn_s_memtime() - t_start; t[1] = tr_rows; t[2] = tr_active; t[3] = tr_rounds; t[4] = tr_cycles;
+      t[0] = __builtin_amdgcn_s_memtime() - t_start; t[1] = tr_rows; t[2] = tr_active; t[3] = tr_rounds; t[4] = tr_cycles; t[5] = tr_a; t[6] = tr_b; t[7] = tr_c;
     }
   }
 }
@@ -433,38 +479,35 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(const char *src_a, con
   for (uint32_t i = lane; i < n; i += 64) { da[i] = sa_[i]; db[i] = sb_[i]; }
 }
 
-static size_t sweep_lds(const SaSweepParams &p) {
-  return (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) ? (size_t)p.K * p.K * sizeof(int32_t) : 0;
-}
-
-template <int CPL, bool MULTI>
+template <int CPL>
 static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
+  const uint32_t table_ints = (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) ? ((p.K * p.K + 1u) & ~1u) : 0u;
+  const uint32_t code_ints = p.max_len_a + 1 <= 16384u ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;   // uint16 per column
   // 32-bit keys when they fit with the all-ones value to spare
-  if (p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31)
-    hipLaunchKernelGGL((sw_sweep_kernel<CPL, MULTI, uint32_t>), dim3(p.n_pairs), dim3(kWave), sweep_lds(p), stream, p);
-  else
-    hipLaunchKernelGGL((sw_sweep_kernel<CPL, MULTI, unsigned long long>), dim3(p.n_pairs), dim3(kWave), sweep_lds(p), stream, p);
+  const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
+  const dim3 grid(p.n_pairs), block(kWave);
+  const size_t fixed = ((size_t)table_ints + code_ints) * 4;
+  if (p.lds_columns) {
+    const size_t lds = fixed + (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
+    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, true>), grid, block, lds, stream, p, table_ints, code_ints);
+    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, true>), grid, block, lds, stream, p, table_ints, code_ints);
+  } else {
+    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, false>), grid, block, fixed, stream, p, table_ints, code_ints);
+    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, false>), grid, block, fixed, stream, p, table_ints, code_ints);
+  }
 }
 
 }  // namespace sa
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest pair
-  int forced = 0;
-  if (const char *env = getenv("SEQALIGN_SWEEP_SEGMENTS")) forced = atoi(env);   // tests: segments of 64 * v columns for every pair
-  if ((forced == 2 || forced == 3) && p.rows) {
-    if (forced == 2) sa::launch_sweep<2, true>(p, stream);
-    else sa::launch_sweep<3, true>(p, stream);
-  }
-  // (one column per lane is not instantiated: the compiler keeps its 1-element arrays in scratch)
-  else if (need <= 2) sa::launch_sweep<2, false>(p, stream);
-  else if (need <= 3) sa::launch_sweep<3, false>(p, stream);
-  else if (need <= 4) sa::launch_sweep<4, false>(p, stream);
-  else if (need <= 5) sa::launch_sweep<5, false>(p, stream);
-  else if (need <= 6) sa::launch_sweep<6, false>(p, stream);
-  else if (need <= SA_SWEEP_SEGMENT / sa::kWave) sa::launch_sweep<SA_SWEEP_SEGMENT / sa::kWave, false>(p, stream);
-  else sa::launch_sweep<SA_SWEEP_SEGMENT / sa::kWave, true>(p, stream);
+  // columns per lane of a segment: the band of walks around a hit's diagonal is a few dozen cells wide for short
+  // sequences and grows with the scores; one segment should hold it.  SEQALIGN_SWEEP_CPL (tests, experiments)
+  int cpl = p.max_len_a + 1 <= 192 ? 1 : p.max_len_a + 1 <= 640 ? 2 : 4;
+  if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4) cpl = v; }
+  if (cpl == 1) sa::launch_sweep<1>(p, stream);
+  else if (cpl == 2) sa::launch_sweep<2>(p, stream);
+  else sa::launch_sweep<4>(p, stream);
   return hipGetLastError();
 }
 

@@ -594,10 +594,11 @@ def test_arena_allocator(ctx):
 
 
 SWEEP_VARIANTS = {
-    "registers": {},                                  # a pair's row in one wave's registers (up to 512 columns)
-    "segments-128": {"SEQALIGN_SWEEP_SEGMENTS": "2"},   # column segments of 128 / 192 columns, records in HBM
-    "segments-192": {"SEQALIGN_SWEEP_SEGMENTS": "3"},
-    "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box itself
+    "default": {},                                    # segment width by sequence length, records of two rows in LDS
+    "segments-64": {"SEQALIGN_SWEEP_CPL": "1"},       # 64-column segments: several per row where the walks spread out
+    "segments-256": {"SEQALIGN_SWEEP_CPL": "4"},
+    "hbm-rows": {"SEQALIGN_SWEEP_ROWS": "hbm", "SEQALIGN_SWEEP_CPL": "1"},   # the records in HBM (pairs too wide for LDS)
+    "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box and rows itself
 }
 
 
@@ -649,9 +650,9 @@ def test_sw_sweep_enumeration(ctx, sweep_variant):
 
 
 def test_sw_sweep_wide_pairs_and_many_hits(ctx):
-    """Rows beyond one wave's registers (600 .. 1 500 columns: column segments of 512, the records of two rows in
-    HBM; 1 200+ columns also take a fill that cannot report the candidates' box) and pairs with hundreds of hits
-    (more than the 64 the sweep ranks itself: ordered by the host) -- against the oracle."""
+    """Wide rows (600 .. 2 500 columns: 1 200+ take a fill that cannot report the candidates' box and rows itself,
+    2 049+ keep the sweep's records in HBM) and pairs with hundreds of hits (more than the 64 the sweep ranks
+    itself: ordered by the host) -- against the oracle."""
     rng = W.Rng(1717)
 
     def rand(n, alpha=b"ACGT"):
@@ -664,7 +665,7 @@ def test_sw_sweep_wide_pairs_and_many_hits(ctx):
 
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     osc = oracle_scoring_of(sc)
-    wide = W.from_pairs([planted(la, 70 + la % 90) for la in (600, 1023, 1024, 1500)] +
+    wide = W.from_pairs([planted(la, 70 + la % 90) for la in (600, 1023, 1024, 1500, 2500)] +
                         [(rand(700), rand(90)), (b"ACGT" * 200, b"ACGT" * 30), planted(90, 70)])
     for thr, max_hits in ((30, 4), (8, 1 << 20)):
         got = ctx.sw_batch(wide, sc, thr, max_hits=max_hits, hit_cap=100000)
