@@ -95,9 +95,14 @@ __device__ __forceinline__ void load_run(const int32_t *src, int (&v)[N], int fi
 // left, kStay: nowhere -- no winner, or the walk ends here), bits 2-3 = the state it arrives in
 constexpr uint32_t kStay = 3u;
 
-template <int CPL, typename KeyT, bool LDSROWS>
+// ROWS: where the winners of the last two rows live -- SA_ROWS_REG: the segment is the whole row, they stay in
+// registers; SA_ROWS_LDS / SA_ROWS_HBM: by column in LDS / in SaSweepParams::rows, the segments follow the walks
+enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_HBM = 2 };
+
+template <int CPL, typename KeyT, int ROWS>
 __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
   constexpr KeyT kNone = ~(KeyT)0;         // no walk
+  constexpr bool LDSROWS = (ROWS == SA_ROWS_LDS);
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x;
   if (p.cand_count[pair] == 0) {
@@ -123,18 +128,18 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
   }
   // the codes of seq_a, by column (column x holds seq_a[x - 1]; code_ints = 0: pairs too wide, read from HBM each time)
   uint16_t *col_code = reinterpret_cast<uint16_t *>(lds_words + table_ints);
-  if (code_ints) {
+  if (ROWS != SA_ROWS_REG && code_ints) {
     for (uint32_t x = lane; x < W; x += kWave) col_code[x] = x >= 1 ? p.code[sa_[x - 1]] : (uint16_t)0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
   }
   // records of two rows: winner's key and what it does next, per column
-  KeyT *rk;
-  uint32_t *rz;
-  if constexpr (LDSROWS) {
+  KeyT *rk = nullptr;
+  uint32_t *rz = nullptr;
+  if constexpr (ROWS == SA_ROWS_LDS) {
     rk = reinterpret_cast<KeyT *>(lds_words + table_ints + code_ints);
     rz = reinterpret_cast<uint32_t *>(rk + 2ull * p.lds_columns);
-  } else {
+  } else if constexpr (ROWS == SA_ROWS_HBM) {
     rk = reinterpret_cast<KeyT *>(p.rows + 2 * p.row_off[pair]);
     rz = reinterpret_cast<uint32_t *>(p.rows + 2 * p.row_off[pair] + 2ull * W);
   }
@@ -326,6 +331,37 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
     if (p.trace) tr_cycles += __builtin_amdgcn_s_memtime() - t_seg;
   };
 
+  if constexpr (ROWS == SA_ROWS_REG) {
+    // ------------------------------------------------------------------ the whole row in one segment that never
+    // moves: the winners stay in registers, every row is loaded once and kept for the row above it, the next row
+    // is in flight while this one is worked on
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t x = lane * CPL + c;
+      ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
+      wk[c] = kNone; wz[c] = kStay;
+    }
+    const int none[6] = {0, 0, 0, 0, 0, 0};   // column 0 is a border column: its states never move left
+    int nm[CPL], na[CPL], nb[CPL];
+    uint32_t y = rmax;
+    load_row(y, 0, m, a, b);
+    if (y > 0) load_row(y - 1, 0, pm, pa, pb);
+    for (;; --y) {
+      if (y >= 2) load_row(y - 2, 0, nm, na, nb);
+      const int q = (int)((rmax - y) & (kWave - 1));
+      if (q == 0) chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;   // every 64 rows: lane t, row y - t
+      live_hi = -1;
+      sweep_segment(y, 0, none, kNone, kStay, kNone, kStay, read_lane(chunk_code, q));
+      ++tr_rows;
+      if (y == 0 || (live_hi < 0 && y <= rmin)) break;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        m[c] = pm[c]; a[c] = pa[c]; b[c] = pb[c];
+        pm[c] = nm[c]; pa[c] = na[c]; pb[c] = nb[c];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ segments that follow the walks
   // the scores a segment needs: rows y and y - 1 at columns x0 .. x0 + 64 * CPL - 1, and the column left of them
   auto load_segment = [&](uint32_t y, int x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL], int (&dpm)[CPL], int (&dpa)[CPL],
                           int (&dpb)[CPL], int (&dleft)[6]) __attribute__((always_inline)) {
@@ -380,7 +416,22 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
       int n_lo, n_hi;
       row_range(y - 1, n_lo, n_hi);
       n_top = min(max(max(n_hi, c_hi), prev_live_hi), (int)W - 1);
-      if (n_top >= 0) load_segment(y - 1, n_top - kSegW + 1, nm, na, nb, npm, npa, npb, nleft);
+      if (n_top >= 0 && n_top == top) {   // the same columns: row y - 1 is here already, as this row's row above
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { nm[c] = pm[c]; na[c] = pa[c]; nb[c] = pb[c]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { nleft[i] = left[3 + i]; nleft[3 + i] = 0; }
+        if (y > 1) {
+          const int x0 = n_top - kSegW + 1;
+          load_row(y - 2, x0, npm, npa, npb);
+          if (x0 > 0) {
+            const uint32_t at = (y - 2) * W + (uint32_t)x0 - 1;
+            nleft[3] = Mg[at]; nleft[4] = Ag[at]; nleft[5] = Bg[at];
+          }
+        }
+      } else if (n_top >= 0) {
+        load_segment(y - 1, n_top - kSegW + 1, nm, na, nb, npm, npa, npb, nleft);
+      }
     }
     const unsigned long long tp1 = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     // the stretch of this row anything can arrive in: its candidates, and up / up-left of where walks left row y + 1
@@ -435,6 +486,8 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
     if (p.trace) { const unsigned long long tp3 = __builtin_amdgcn_s_memtime(); tr_a += tp1 - tp0; tr_b += tp2 - tp1; tr_c += tp3 - tp2; }
   }
 
+  }
+
   // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
   unsigned long long first_err = err ? (unsigned long long)err_key : ~0ull;   // the lowest erroring walk of the wave
 #pragma unroll
@@ -479,35 +532,52 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(const char *src_a, con
   for (uint32_t i = lane; i < n; i += 64) { da[i] = sa_[i]; db[i] = sb_[i]; }
 }
 
-template <int CPL>
+template <int CPL, int ROWS>
 static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t table_ints = (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) ? ((p.K * p.K + 1u) & ~1u) : 0u;
-  const uint32_t code_ints = p.max_len_a + 1 <= 16384u ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;   // uint16 per column
+  // uint16 per column
+  const uint32_t code_ints = (ROWS != SA_ROWS_REG && p.max_len_a + 1 <= 16384u) ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;
   // 32-bit keys when they fit with the all-ones value to spare
   const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
   const dim3 grid(p.n_pairs), block(kWave);
-  const size_t fixed = ((size_t)table_ints + code_ints) * 4;
-  if (p.lds_columns) {
-    const size_t lds = fixed + (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
-    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, true>), grid, block, lds, stream, p, table_ints, code_ints);
-    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, true>), grid, block, lds, stream, p, table_ints, code_ints);
-  } else {
-    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, false>), grid, block, fixed, stream, p, table_ints, code_ints);
-    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, false>), grid, block, fixed, stream, p, table_ints, code_ints);
-  }
+  size_t lds = ((size_t)table_ints + code_ints) * 4;
+  if (ROWS == SA_ROWS_LDS) lds += (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
+  if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
+  else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
 }
 
 }  // namespace sa
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  // columns per lane of a segment: the band of walks around a hit's diagonal is a few dozen cells wide for short
-  // sequences and grows with the scores; one segment should hold it.  SEQALIGN_SWEEP_CPL (tests, experiments)
-  int cpl = p.max_len_a + 1 <= 192 ? 1 : p.max_len_a + 1 <= 640 ? 2 : 4;
-  if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4) cpl = v; }
-  if (cpl == 1) sa::launch_sweep<1>(p, stream);
-  else if (cpl == 2) sa::launch_sweep<2>(p, stream);
-  else sa::launch_sweep<4>(p, stream);
+  // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks
+  // spread over most of the row anyway).  Beyond that, segments of 256 columns follow the walks, with the winners of
+  // two rows in LDS (up to SA_SWEEP_LDS_COLUMNS columns) or in HBM.  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the second
+  // form with segments of 64 * that many columns (tests, experiments).
+  const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest row
+  int forced = 0;
+  if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) forced = atoi(env);
+  if (forced != 1 && forced != 2 && forced != 4) forced = 0;
+  if (!forced && need <= 8) {
+    // (one column per lane is not instantiated: no pair is that narrow in practice)
+    if (need <= 2) sa::launch_sweep<2, sa::SA_ROWS_REG>(p, stream);
+    else if (need <= 3) sa::launch_sweep<3, sa::SA_ROWS_REG>(p, stream);
+    else if (need <= 4) sa::launch_sweep<4, sa::SA_ROWS_REG>(p, stream);
+    else if (need <= 5) sa::launch_sweep<5, sa::SA_ROWS_REG>(p, stream);
+    else if (need <= 6) sa::launch_sweep<6, sa::SA_ROWS_REG>(p, stream);
+    else sa::launch_sweep<8, sa::SA_ROWS_REG>(p, stream);
+  } else {
+    const int cpl = forced ? forced : 4;
+    if (p.lds_columns) {
+      if (cpl == 1) sa::launch_sweep<1, sa::SA_ROWS_LDS>(p, stream);
+      else if (cpl == 2) sa::launch_sweep<2, sa::SA_ROWS_LDS>(p, stream);
+      else sa::launch_sweep<4, sa::SA_ROWS_LDS>(p, stream);
+    } else {
+      if (cpl == 1) sa::launch_sweep<1, sa::SA_ROWS_HBM>(p, stream);
+      else if (cpl == 2) sa::launch_sweep<2, sa::SA_ROWS_HBM>(p, stream);
+      else sa::launch_sweep<4, sa::SA_ROWS_HBM>(p, stream);
+    }
+  }
   return hipGetLastError();
 }
 
