@@ -224,14 +224,13 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * score >= min_score[p], at most max_hits per pair, into the caller's hit array
  * (hit_cap entries total).
  *   max_hits == 1: GPU fill + GPU reduction + GPU traceback of the best hit.
- *   max_hits >= 2: GPU fill that also emits every cell >= min_score as a sort key
- *       (smith_waterman.c:152-156) -> per-pair key sort (:159-161) -> enumeration
- *       on the device with 16 hit slots per pair: one workgroup per pair, the
- *       predecessor of every state and the visited bits in LDS (pairs whose
- *       candidates do not fit an LDS window: one wave per pair walking the
- *       matrices in HBM).  Only the strings cross PCIe.  A pair that fills all
- *       16 slots while max_hits asks for more is finished on the host from its
- *       matrices and sorted keys (rare: that pair's data only).
+ *   max_hits >= 2: GPU fill that also reports where the cells >= min_score are (count,
+ *       bounding box, columns per row) -> one reverse sweep over each pair's matrices:
+ *       a cell is marked by the lowest-ranked walk (reference order: score desc, column
+ *       asc, index asc) that arrives at it, so the winners -- and with them every hit of
+ *       the pair, in order -- follow from one pass over the rows, bottom to top, without
+ *       the sequential procedure of smith_waterman.c:165-277 being run
+ *       -> one GPU traceback per wanted hit.  Any max_hits; only the strings cross PCIe.
  *   SEQALIGN_TRACEBACK=host: the matrices and the compacted candidates of every
  *       pair are copied back and the hits are enumerated on the host (threaded
  *       over pairs). */
