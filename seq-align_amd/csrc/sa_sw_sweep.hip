@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
   KeyT wk[CPL];                                             // row y + 1 coming in, row y going out: the cells' winners
   uint32_t wz[CPL];                                         // and what they do next (kStay: nothing leaves the cell)
   int ca[CPL];                                              // codes of seq_a[x - 1]
+  int thr_c[CPL];                                           // the pair's min_score; INT_MAX for columns that do not exist
   uint32_t n_hits = 0;                                      // wave-uniform
   uint32_t err = 0;                                         // per lane: error of the lowest walk that met one,
   KeyT err_key = kNone;                                     // and that walk
@@ -172,12 +173,13 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
   auto load_row = [&](uint32_t y, int x0, int (&dm)[CPL], int (&da)[CPL], int (&db)[CPL]) __attribute__((always_inline)) {
     const int xl = x0 + lane * CPL;
     const uint32_t at = y * W + (uint32_t)xl;
-    // (past the row's end is the next row: inside the pair's matrix unless y = len_b)
-    if (xl >= 0 && ((uint32_t)xl + CPL <= W || ((uint32_t)xl < W && y < lb))) {
-      load_run<CPL>(Mg + at, dm); load_run<CPL>(Ag + at, da); load_run<CPL>(Bg + at, db);
+    if (y < lb && x0 >= 0) {   // (wave-uniform) a lane's run may reach past the row's end: that is the next row, still
+                               // inside the pair's matrix
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) dm[c] = (uint32_t)(xl + c) < W ? dm[c] : 0;   // no candidates there
-    } else {
+      for (int c = 0; c < CPL; ++c) { dm[c] = 0; da[c] = 0; db[c] = 0; }
+      // (what a straddling lane reads past the row's end is not used: thr_c below)
+      if ((uint32_t)xl < W) { load_run<CPL>(Mg + at, dm); load_run<CPL>(Ag + at, da); load_run<CPL>(Bg + at, db); }
+    } else {                   // the last row, or a segment that straddles column 0: cell by cell
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const bool in = (uint32_t)(xl + c) < W;   // (negative columns wrap to huge values)
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
       for (int c = 0; c < CPL; ++c) {
         const KeyT dk = c + 1 < CPL ? wk[c + 1 < CPL ? c + 1 : c] : dk_edge;
         const uint32_t dz = c + 1 < CPL ? wz[c + 1 < CPL ? c + 1 : c] : dz_edge;
-        KeyT best = (m[c] >= thr) ? (KeyT)((((unsigned long long)(uint32_t)(cap - m[c]) << sshift) |
+        KeyT best = (m[c] >= thr_c[c]) ? (KeyT)((((unsigned long long)(uint32_t)(cap - m[c]) << sshift) |
                                             ((unsigned long long)(uint32_t)(xl + c) << cshift) | y))
                                   : kNone;
         uint32_t st = MAT_MATCH;
@@ -339,6 +341,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
     for (int c = 0; c < CPL; ++c) {
       const uint32_t x = lane * CPL + c;
       ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
+      thr_c[c] = x < W ? thr : INT32_MAX;
       wk[c] = kNone; wz[c] = kStay;
     }
     const int none[6] = {0, 0, 0, 0, 0, 0};   // column 0 is a border column: its states never move left
@@ -450,6 +453,7 @@ __global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, 
         for (int c = 0; c < CPL; ++c) {
           const int x = xl + c;
           ca[c] = (x >= 1 && x <= (int)la) ? (code_ints ? (int)col_code[x] : (int)p.code[sa_[x - 1]]) : 0;
+          thr_c[c] = (uint32_t)x < W ? thr : INT32_MAX;
           const bool have = x >= prev_w_lo && x <= prev_w_hi;
           wk[c] = have ? rec_key(prv, (uint32_t)x) : kNone;
           wz[c] = have ? rec_next(prv, (uint32_t)x) : kStay;
