@@ -5,7 +5,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for w in C3 C4; do
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
-             "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"; do
+             "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
+             "FETCH_SIZE" \
+             "WRITE_SIZE"; do
     i=$((i+1))
     timeout 300 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/swpmc_$w/p$i -o p -- python $R/seq-align_amd/tools/sw_enum_profile.py $w 4 > $R/gpurun_out/swpmc_$w.p$i.log 2>&1
   done

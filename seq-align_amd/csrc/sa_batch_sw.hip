@@ -288,17 +288,32 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   }
   tm.lap("sw: gather + strings D2H");
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  // where every hit goes in the caller's buffers (a prefix over the lengths), then the copies on the thread pool
+  uint64_t n_out = 0;
+  bool no_room = false;
+  std::vector<uint64_t> out_off(nw);
   for (uint64_t w = 0; w < nw; ++w) {
-    const uint32_t len = h_meta[nw + w], *pos = h_meta + 4 * nw + 4 * w;
-    if (*found >= hit_cap || *used_str + len + 1 > str_cap) return SEQALIGN_E_NOMEM;
-    memcpy(out_a + *used_str, ha + dst_off[w], len);
-    memcpy(out_b + *used_str, hb + dst_off[w], len);
-    out_a[*used_str + len] = out_b[*used_str + len] = '\0';
-    seqalign_sw_hit_t &h = hits[(*found)++];
-    h.pair = c.first + walk_pair[w]; h.score = reinterpret_cast<const int32_t *>(h_meta)[2 * nw + w];
-    h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3]; h.length = len; h.str_off = *used_str;
+    const uint32_t len = h_meta[nw + w];
+    if (*found + n_out >= hit_cap || *used_str + len + 1 > str_cap) { no_room = true; break; }
+    out_off[w] = *used_str;
     *used_str += len + 1;
+    ++n_out;
   }
+  const uint64_t first_hit = *found;
+  constexpr uint64_t kPack = 1024;
+  parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
+    for (uint64_t w = blk * kPack, e2 = std::min(n_out, (blk + 1) * kPack); w < e2; ++w) {
+      const uint32_t len = h_meta[nw + w], *pos = h_meta + 4 * nw + 4 * w;
+      memcpy(out_a + out_off[w], ha + dst_off[w], len);
+      memcpy(out_b + out_off[w], hb + dst_off[w], len);
+      out_a[out_off[w] + len] = out_b[out_off[w] + len] = '\0';
+      seqalign_sw_hit_t &h = hits[first_hit + w];
+      h.pair = c.first + walk_pair[w]; h.score = reinterpret_cast<const int32_t *>(h_meta)[2 * nw + w];
+      h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3]; h.length = len; h.str_off = out_off[w];
+    }
+  });
+  *found += n_out;
+  if (no_room) return SEQALIGN_E_NOMEM;
   tm.lap("sw: unpack hits");
   return overflow ? SEQALIGN_E_NOMEM : SEQALIGN_OK;
 }
@@ -329,10 +344,10 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
   }
   if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
-      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)) ||
-      (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
+      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)))
     return rc;
   hipStream_t st = ctx->stream;
+  StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
   HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
   uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
   seqalign_trace_t t;
@@ -342,20 +357,37 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
   if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
   uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
-  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+  // a hit is much shorter than its slot of len_a + len_b characters: pack the strings on the device, bring back
+  // what was written (C3: 2 x 1.7 MB instead of 2 x 11.5 MB over PCIe)
+  DevBuf &d_dst = ctx->e[11], &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
+  std::vector<uint64_t> dst_off(n);
+  uint64_t gathered = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
+    dst_off[k] = gathered;
+    gathered += h_meta[n + k];
+  }
+  if ((rc = d_dst.reserve(n * 8 + 16)) || (rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
+      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(d_dst.p, dst_off.data(), n * 8, hipMemcpyHostToDevice, st));
+  hipError_t e = sa_launch_gather_hits(ctx->t_out_a.as<char>(), ctx->t_out_b.as<char>(), ctx->t_str_off.as<uint64_t>(), d_meta,
+                                       d_meta + n, d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_b.as<char>(), (uint32_t)n, st);
+  if (e != hipSuccess) return fail_hip(e, "gather hits");
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k;
-    const uint32_t head = h_meta[k], len = h_meta[n + k], status = h_meta[3 * n + k];
+    const uint32_t len = h_meta[n + k];
     const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
-    if (status) return (int)status;
     if (score <= 0 || score < min_score[p]) continue;
     if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
-    memcpy(out_a + used_str, ha + h_off[k] + head, len);
-    memcpy(out_b + used_str, hb + h_off[k] + head, len);
+    memcpy(out_a + used_str, ha + dst_off[k], len);
+    memcpy(out_b + used_str, hb + dst_off[k], len);
     out_a[used_str + len] = out_b[used_str + len] = '\0';
     seqalign_sw_hit_t &h = hits[found++];
     const uint32_t *pos = h_meta + 4 * n + 4 * k;
