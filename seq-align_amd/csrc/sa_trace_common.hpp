@@ -61,10 +61,14 @@ __device__ __forceinline__ uint32_t reverse_move_t(Access &acc, const TraceConst
   acc.cell(nx, ny, mi, ai, bi);
   x = nx; y = ny;
   const long long av = ai, bv = bi, mv = mi, cur = score;
-  if ((!k.no_gaps_a || nx == 0 || nx == la) && av + via_a == cur) { matrix = MAT_GAP_A; score = (int)av; }
-  else if ((!k.no_gaps_b || ny == 0 || ny == lb) && bv + via_b == cur) { matrix = MAT_GAP_B; score = (int)bv; }
-  else if (mv + via_m == cur) { matrix = MAT_MATCH; score = (int)mv; }
-  else return 7;
+  // (all three tests before the priority chain: the three loads behind them go out together instead of one per
+  // branch -- a walker is a chain of dependent round trips as it is)
+  const bool from_a = (!k.no_gaps_a || nx == 0 || nx == la) & (av + via_a == cur);
+  const bool from_b = (!k.no_gaps_b || ny == 0 || ny == lb) & (bv + via_b == cur);
+  const bool from_m = mv + via_m == cur;
+  if (!(from_a | from_b | from_m)) return 7;
+  matrix = from_a ? MAT_GAP_A : from_b ? MAT_GAP_B : MAT_MATCH;
+  score = from_a ? ai : from_b ? bi : mi;
   return 0;
 }
 
