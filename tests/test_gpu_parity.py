@@ -681,6 +681,19 @@ def test_sw_sweep_wide_pairs_and_many_hits(ctx):
         assert max(len(h) for h in got) > 64
 
 
+def test_sw_batch_output_capacity_is_respected(ctx):
+    """seqalign_sw_batch with too few hit slots: SEQALIGN_E_NOMEM, nothing written past the caller's capacity (the
+    hits that fit are delivered, in order)."""
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    batch = W.from_pairs([(b"ACGTTGCA" * 12, b"TGCAACGT" * 30)] * 3)
+    full = ctx.sw_batch(batch, sc, 8, max_hits=6)
+    assert all(len(h) == 6 for h in full)
+    for max_hits in (1, 6):
+        with pytest.raises(S.SeqAlignError) as err:
+            ctx.sw_batch(batch, sc, 8, max_hits=max_hits, hit_cap=2 if max_hits == 1 else 7)
+        assert err.value.code == 4   # SEQALIGN_E_NOMEM
+
+
 def test_sw_batch_multi_hit_in_several_chunks(ctx, monkeypatch):
     """seqalign_sw_batch(max_hits > 1) on a batch that does not fit one chunk (tiny chunk budget): the per-chunk
     scratch (hit keys, walker lists, string slots) is reused chunk after chunk; hits equal the one-chunk call's."""
