@@ -99,8 +99,10 @@ constexpr uint32_t kStay = 3u;
 // registers; SA_ROWS_LDS / SA_ROWS_HBM: by column in LDS / in SaSweepParams::rows, the segments follow the walks
 enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_HBM = 2 };
 
+// (occupancy: the row loop is half latency -- a row's loads, its dependent passes -- so a wave more per SIMD is worth
+// a few spilled registers on the cold paths: C3 2.91 -> 2.39 ms with 5 instead of 4; 6 loses again)
 template <int CPL, typename KeyT, int ROWS>
-__global__ void __launch_bounds__(kWave) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
+__global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : CPL == 3 ? 5 : CPL == 4 ? 4 : CPL == 5 ? 3 : 1) : 1)) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
   constexpr KeyT kNone = ~(KeyT)0;         // no walk
   constexpr bool LDSROWS = (ROWS == SA_ROWS_LDS);
   const int lane = threadIdx.x;
