@@ -193,8 +193,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       for (int j = 0; j < 8; ++j) sum[j] += (double)t[8 * k + j];
       hits_total += h_count[k];
     }
-    fprintf(stderr, "[seqalign sweep trace] pairs %llu  per pair: %.0f cycles (100 MHz ticks x ?), %.1f rows, %.1f active row segments, "
-                    "%.1f rounds, %.0f cycles in active segments, %.2f hits; row phases: prefetch issue %.0f, segments %.0f, fence + rotate %.0f\n",
+    fprintf(stderr, "[seqalign sweep trace] pairs %llu  per pair: %.0f cycles (s_memtime), %.1f rows, %.1f active row segments, "
+                    "%.1f passes, %.0f cycles in active segments, %.2f hits; wide pairs, per row: prefetch issue %.0f, segments %.0f, fence + rotate %.0f cycles\n",
             (unsigned long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, hits_total / n, sum[5] / n, sum[6] / n, sum[7] / n);
   }
 

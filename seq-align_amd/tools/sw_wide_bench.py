@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""seqalign_sw_batch (up to 4 hits per pair) on WIDE pairs -- a long seq_a against short reads: the sweep works in
+segments that follow the walks (sa_sw_sweep.hip), with the winners of two rows in LDS / in HBM.  DESIGN.md 3.6."""
 import sys, time
-sys.path.insert(0, "/root/repo/seq-align_amd/python"); sys.path.insert(0, "/root/repo")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "seq-align_amd" / "python")); sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 import seqalign_amd as S
 from seqalign_amd import workloads as W
