@@ -141,7 +141,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     SaReduceParams r;
     memset(&r, 0, sizeof(r));
     r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores; r.n_pairs = (uint32_t)n;
-    if ((e = sa_launch_sw_box(r, cand, st)) != hipSuccess) return fail_hip(e, "sw candidate box");
+    if ((e = sa_launch_sw_box(r, cand, c.max_b, st)) != hipSuccess) return fail_hip(e, "sw candidate box");
   }
 
   // ---- the sweep: every hit of every pair
@@ -156,17 +156,33 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.open1 = sc->flat.open1; q.ext = sc->flat.ext;
   q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_len_a = c.max_a; q.layout = layout;
+  // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows up to 512 columns in registers,
+  // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
+  // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  SEQALIGN_SWEEP_MODE=strips|pair
+  // forces one (tests, experiments).
   std::vector<uint64_t> row_off;   // (function scope: the copy below is asynchronous)
-  const char *rows_env = getenv("SEQALIGN_SWEEP_ROWS");   // "hbm": the records of two rows in HBM for every pair (tests)
-  if (c.max_a + 1 <= SA_SWEEP_LDS_COLUMNS && !(rows_env && rows_env[0] == 'h')) {
-    q.lds_columns = (c.max_a + 2u) & ~1u;
-  } else {   // wide pairs: two rows of records per pair in HBM
+  const char *mode_env = getenv("SEQALIGN_SWEEP_MODE");
+  const uint32_t w_max = c.max_a + 1;
+  bool strips = w_max > 512 && (w_max > SA_SWEEP_LDS_COLUMNS || n < 1024);
+  if (mode_env && mode_env[0] == 's') strips = true;
+  if (mode_env && mode_env[0] == 'p' && w_max <= SA_SWEEP_LDS_COLUMNS) strips = false;
+  if (w_max <= SA_SWEEP_LDS_COLUMNS) q.lds_columns = (c.max_a + 2u) & ~1u;
+  DevBuf &d_prog = ctx->e[2];
+  if (strips) {
+    const uint32_t spp = sa_sweep_strips_per_pair(c.max_a);
+    const uint64_t blocks = sa_sweep_strip_blocks((uint32_t)n, c.max_a);
     row_off.resize(n);
-    uint64_t total = 0;
-    for (uint64_t k = 0; k < n; ++k) { row_off[k] = total; total += 2 * ((uint64_t)batch->len_a[c.first + k] + 1); }
-    if ((rc = d_rows.reserve(total * 16 + 16)) || (rc = d_rowoff.reserve(n * 8))) return rc;
+    uint64_t rows_total = 0;
+    for (uint64_t k = 0; k < n; ++k) { row_off[k] = rows_total; rows_total += (uint64_t)batch->len_b[c.first + k] + 1; }
+    if ((rc = d_prog.reserve((2 * blocks + 1) * 4 + 16)) || (rc = d_rows.reserve(rows_total * spp * 16 + 16)) ||
+        (rc = d_rowoff.reserve(n * 8)))
+      return rc;
+    HIP_TRY(hipMemsetAsync(d_prog.p, 0, (2 * blocks + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(q.err_key, 0xff, n * 8, st));     // the strips of a pair report into the same words
+    HIP_TRY(hipMemsetAsync(q.hit_count, 0, n * 8, st));      // hit_count | status
     HIP_TRY(hipMemcpyAsync(d_rowoff.p, row_off.data(), n * 8, hipMemcpyHostToDevice, st));
-    q.rows = d_rows.as<unsigned long long>(); q.row_off = d_rowoff.as<uint64_t>();
+    q.strip_progress = d_prog.as<uint32_t>(); q.strips_per_pair = spp;
+    q.bnd = d_rows.as<unsigned long long>(); q.row_off = d_rowoff.as<uint64_t>();
   }
   const bool trace = getenv("SEQALIGN_SWEEP_TRACE") != nullptr;   // development aid: per-pair counters on stderr
   DevBuf &d_trace = ctx->e[12];
@@ -209,7 +225,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   for (uint64_t k = 0; k < n && !overflow; ++k) {
     const uint32_t cnt = h_count[k], take = std::min(cnt, max_hits);
     unsigned long long *dev_keys = d_keys.as<unsigned long long>() + cell0[k];
-    if (h_status[k] & SA_SWEEP_UNSORTED) {   // more than 64 hits in one pair: ordered here (rare; that pair's keys only)
+    if ((h_status[k] & SA_SWEEP_UNSORTED) || (strips && cnt > 1)) {   // more than 64 hits in one pair, or a pair swept
+                                                                       // in strips: ordered here (that pair's keys only)
       big.resize(cnt);
       HIP_TRY(hipMemcpy(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost));
       std::sort(big.begin(), big.end());
@@ -330,11 +347,15 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   const uint64_t n = c.count;
   if (!have_best) {
     if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
-    seqalign_sw_reduce_t r;
+    SaReduceParams r;
     memset(&r, 0, sizeof(r));
-    r.n_pairs = n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.match_scores = d.match_scores;
+    r.n_pairs = (uint32_t)n; r.len_a = d.len_a; r.len_b = d.len_b; r.mat_off = d.mat_off; r.M = d.match_scores;
     r.min_score = 1; r.best_score = ctx->best_score.as<int32_t>(); r.best_index = ctx->best_index.as<uint64_t>();
-    if ((rc = seqalign_sw_reduce_device(ctx, &r, ctx->stream))) return rc;
+    // few long pairs: several waves per pair (a wave streams ~4 GB/s on its own)
+    const uint64_t max_cells = ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1);
+    if (n < 2048) r.slices = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_cells >> 18, 1), 4096);
+    hipError_t e = sa_launch_sw_reduce(r, ctx->stream);
+    if (e != hipSuccess) return fail_hip(e, "sw reduce launch");
   }
   if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 32))) return rc;
   uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();

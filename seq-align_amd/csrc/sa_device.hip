@@ -339,6 +339,7 @@ extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_
   p.cand_count = r->cand_count; p.cand_off = r->cand_off; p.cand_cap = r->cand_cap;
   p.cand_index = r->cand_index; p.cand_score = r->cand_score;
   p.n_pairs = (uint32_t)r->n_pairs;
+  p.slices = 0;
   hipError_t e = sa_launch_sw_reduce(p, st);
   if (e != hipSuccess) return fail_hip(e, "sw reduce launch");
   return SEQALIGN_OK;

@@ -67,6 +67,7 @@ struct SaReduceParams {
   uint32_t *cand_index;
   int32_t *cand_score;
   uint32_t n_pairs;
+  uint32_t slices;   /* > 1 (best cell only, few long pairs): that many waves per pair (sa_reduce.hip) */
 };
 
 /* candidate count and bounding box per pair, as the stream fill (SA_STREAM_CAND) or sa_launch_sw_box leaves them */
@@ -96,10 +97,17 @@ struct SaSweepParams {
   uint32_t *hit_count;           /* [n] every hit of the pair (no max_hits here)                      */
   uint32_t *status;              /* [n] 0, SEQALIGN_E_* of a walk (see err_key), | SA_SWEEP_UNSORTED   */
   unsigned long long *err_key;   /* [n] key of the first (lowest) walk that met the error             */
-  uint32_t lds_columns;          /* != 0: the records of two rows live in LDS, sized for this many columns (>= every
-                                    pair's len_a + 1); 0: in `rows`                                                  */
-  unsigned long long *rows;      /* lds_columns == 0: 4 * (len_a + 1) uint64 per pair, pair p at 2 * row_off[p]      */
-  const uint64_t *row_off;       /* [n] prefix of 2 * (len_a + 1)                                                    */
+                                 /* (strips: the caller zeroes hit_count / status and sets err_key to ~0; the hits are
+                                    never ordered by the kernel)                                       */
+  uint32_t lds_columns;          /* one wave per pair, wide rows: the winners of two rows live in LDS, sized for this
+                                    many columns (>= every pair's len_a + 1)                                         */
+  /* one wave per strip of SA_SWEEP_STRIP_COLUMNS columns (few wide pairs; strip_progress != NULL selects it): */
+  uint32_t *strip_progress;      /* [2 * sa_sweep_strip_blocks() + 1] zeroed: per (pair, strip) rows done | end, then
+                                    the ticket counter                                                               */
+  uint32_t strips_per_pair;      /* sa_sweep_strips_per_pair(max_len_a)                                              */
+  unsigned long long *bnd;       /* per pair, row (counted from the box's last row) and strip: the winner of the strip's
+                                    first column, 2 uint64; pair p at 2 * row_off[p] * strips_per_pair               */
+  const uint64_t *row_off;       /* [n] prefix of len_b + 1                                                          */
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
@@ -110,6 +118,10 @@ struct SaSweepParams {
 #define SA_SWEEP_UNSORTED 0x80000000u
 /* widest pair (columns) whose two rows of records fit LDS (12 B per column and row with 64-bit keys) */
 #define SA_SWEEP_LDS_COLUMNS 2048u
+/* columns per strip when a pair is swept by one wave per strip */
+#define SA_SWEEP_STRIP_COLUMNS 256u
+uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a);
+uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a);
 
 struct SaTraceParams {
   const uint8_t *arena;
@@ -167,7 +179,7 @@ bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, 
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */
-hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, hipStream_t stream);
+hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, uint32_t max_len_b, hipStream_t stream);
 /* SW multi-hit enumeration (sa_sw_sweep.hip): every hit of every pair in one reverse sweep, then one traceback
  * per wanted hit (sa_launch_nw_traceback with SaTraceParams::hit_keys), then the strings packed back to back (walk
  * w's len[w] chars at head[w] of its slot to dst_off[w]) */

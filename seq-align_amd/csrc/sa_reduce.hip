@@ -11,6 +11,8 @@
 //     min_score).
 // One wave per pair: the candidate counter lives in a wave-uniform register, no
 // atomics.  HBM-read bound: 4 B per cell.
+#include <algorithm>
+
 #include "sa_fill_common.hpp"
 
 namespace sa {
@@ -124,26 +126,26 @@ sw_reduce_kernel(const SaReduceParams p) {
   }
 }
 
-// The candidates' count, bounding box and per-row column ranges (SaFillParams::cand_*) from a match_scores matrix
-// that is already in HBM -- for fills that cannot report them while the values are in registers (anything but the
-// stream kernel).  Same streaming loop as above: 4 B per cell read, one wave per pair; a candidate updates its row's
-// range with two atomics (the lanes of a step straddle rows).
-__global__ void __launch_bounds__(kWave *kWavesPerBlock)
-sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t pair = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (pair >= p.n_pairs) return;
-  const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1;
-  const uint32_t cells = W * H;
-  const int32_t *__restrict__ M = p.M + p.mat_off[pair];
-  uint32_t *rows = sa_cand_rows(c.cand_rows, p.mat_off[pair], W, H - 1);
-  for (uint32_t r = lane; r < H; r += kWave) { rows[2 * r] = 0xffffffffu; rows[2 * r + 1] = 0u; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (one wave: the atomics below follow in program order)
-  const int thr = max(c.cand_min[pair], 1);
-  uint32_t count = 0;                                                    // per lane, reduced at the end
-  uint32_t rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;   // per lane, reduced at the end
+// ---- the best cell only, FEW LONG pairs: a pair's cells in slices, one wave per slice.
+// One wave per pair streams a 10 000 x 10 000 pair's 400 MB alone (100 ms); here the waves of a pair merge their best
+// cells with one 64-bit atomicMin on a key whose order is the reference's hit order:
+//     (INT_MAX - score) << 32 | column << row_bits | row        (column and row share 32 bits: cells < 2^31)
+__global__ void __launch_bounds__(256) sw_best_init_kernel(uint64_t *best_index, uint32_t n_pairs) {
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair < n_pairs) best_index[pair] = ~0ull;
+}
+
+__global__ void __launch_bounds__(kWave) sw_best_slices_kernel(const SaReduceParams p, const uint32_t slices) {
+  const int lane = threadIdx.x;
+  const uint32_t pair = blockIdx.x;
+  const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1, cells = W * H;
   constexpr uint32_t kStep = kWave * 4;
-  for (uint32_t base = 0; base < cells; base += kStep) {
+  const uint32_t per = ((cells + slices - 1) / slices + kStep - 1) / kStep * kStep;
+  const uint32_t lo = blockIdx.y * per, hi = min(cells, lo + per);
+  if (lo >= cells) return;
+  const int32_t *__restrict__ M = p.M + p.mat_off[pair];
+  Best best{0, 0};
+  for (uint32_t base = lo; base < hi; base += kStep) {
     const uint32_t i0 = base + lane * 4;
     int v[4];
     if (i0 + 4 <= cells) {
@@ -153,44 +155,127 @@ sw_box_kernel(const SaReduceParams p, const SaCandBox c) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = (i0 + k < cells) ? M[i0 + k] : 0;
     }
-    if (v[0] >= thr || v[1] >= thr || v[2] >= thr || v[3] >= thr) {
-      uint32_t row = i0 / W, col = i0 - row * W;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (v[k] >= thr) {
-          ++count;
-          rmin = min(rmin, row); rmax = max(rmax, row); cmin = min(cmin, col); cmax = max(cmax, col);
-          atomicMin(&rows[2 * row], col);
-          atomicMax(&rows[2 * row + 1], col);
-        }
-        if (++col == W) { col = 0; ++row; }
-      }
+    for (int k = 0; k < 4; ++k) {
+      if (v[k] > best.score) best = Best{v[k], i0 + k};
+      else if (v[k] == best.score && v[k] > 0 && better(v[k], i0 + k, best, W)) best = Best{v[k], i0 + k};
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    count += (uint32_t)__shfl_xor((int)count, o);
-    rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, o)); rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, o));
-    cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, o)); cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o));
+    const Best other{__shfl_xor(best.score, o), (unsigned)__shfl_xor((int)best.idx, o)};
+    if (better(other.score, other.idx, best, W)) best = other;
   }
-  if (lane == 0) {
-    c.cand_count[pair] = count;
+  if (lane == 0 && best.score > 0) {
+    const uint32_t row = best.idx / W, col = best.idx - row * W, row_bits = 32u - (uint32_t)__builtin_clz(H | 1u);
+    const unsigned long long key = ((unsigned long long)(uint32_t)(INT32_MAX - best.score) << 32) | ((unsigned long long)col << row_bits) | row;
+    atomicMin(reinterpret_cast<unsigned long long *>(p.best_index + pair), key);
+  }
+}
+
+__global__ void __launch_bounds__(256) sw_best_finish_kernel(const SaReduceParams p) {
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= p.n_pairs) return;
+  const unsigned long long key = p.best_index[pair];
+  int score = 0;
+  uint64_t index = 0;
+  if (key != ~0ull) {
+    const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1, row_bits = 32u - (uint32_t)__builtin_clz(H | 1u);
+    const uint32_t low = (uint32_t)key, row = low & ((1u << row_bits) - 1u), col = row_bits < 32u ? low >> row_bits : 0u;
+    score = INT32_MAX - (int)(uint32_t)(key >> 32);
+    index = (uint64_t)row * W + col;
+  }
+  p.best_score[pair] = score;
+  p.best_index[pair] = index;
+}
+
+// The candidates' count, bounding box and per-row column ranges (SaFillParams::cand_*) from a match_scores matrix
+// that is already in HBM -- for fills that cannot report them while the values are in registers (anything but the
+// stream kernel: rows over 1 023 columns).  One wave per block of 64 rows of a pair, row by row: 4 B per cell
+// read; a row's lowest / highest candidate column from two ballots; the pair's count and box with a few atomics per
+// wave.
+constexpr uint32_t kBoxRows = 64;
+
+__global__ void __launch_bounds__(256) sw_box_init_kernel(const SaCandBox c, uint32_t n_pairs) {
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= n_pairs) return;
+  c.cand_count[pair] = 0;
+  uint32_t *box = c.cand_box + 4ull * pair;
+  box[0] = 0xffffffffu; box[1] = 0u; box[2] = 0xffffffffu; box[3] = 0u;
+}
+
+__global__ void __launch_bounds__(kWave) sw_box_kernel(const SaReduceParams p, const SaCandBox c, const uint32_t rows_per_block) {
+  const int lane = threadIdx.x;
+  const uint32_t pair = blockIdx.x;
+  const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1;
+  const uint32_t row0 = blockIdx.y * rows_per_block;
+  if (row0 >= H) return;
+  const int32_t *__restrict__ M = p.M + p.mat_off[pair];
+  uint32_t *rows = sa_cand_rows(c.cand_rows, p.mat_off[pair], W, H - 1);
+  const int thr = max(c.cand_min[pair], 1);
+  uint32_t count = 0, rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;   // wave-uniform
+  for (uint32_t r = row0; r < min(row0 + rows_per_block, H); ++r) {
+    const int32_t *row = M + (size_t)r * W;
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (uint32_t base = 0; base < W; base += kWave * 4) {
+      const uint32_t x = base + lane * 4;
+      int v[4] = {0, 0, 0, 0};
+      if (x + 4 <= W) {
+        const v4i_u q = __builtin_nontemporal_load(reinterpret_cast<const v4i_u *>(row + x));
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (x + k < W) ? row[x + k] : 0;
+      }
+      const uint32_t bits = (v[0] >= thr) | ((v[1] >= thr) << 1) | ((v[2] >= thr) << 2) | ((v[3] >= thr) << 3);
+      const unsigned long long any = __ballot(bits != 0);
+      if (any) {   // columns grow with the lane: the row's lowest candidate is in the lowest such lane
+        const int first = __builtin_ctzll(any), last = 63 - __builtin_clzll(any);
+        const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)bits, first), bl = (uint32_t)__builtin_amdgcn_readlane((int)bits, last);
+        lo = min(lo, base + first * 4 + (uint32_t)__builtin_ctz(bf));
+        hi = max(hi, base + last * 4 + (31u - (uint32_t)__builtin_clz(bl)));
+        // (the count: 4 ballots would do; a per-lane popcount and one reduction at the end is cheaper)
+      }
+      count += (uint32_t)__popc(bits);   // per lane here, reduced below
+    }
+    if (lane == 0) { rows[2 * r] = lo; rows[2 * r + 1] = hi; }
+    if (lo <= hi) { rmin = min(rmin, r); rmax = r; cmin = min(cmin, lo); cmax = max(cmax, hi); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) count += (uint32_t)__shfl_xor((int)count, o);
+  if (lane == 0 && count) {
+    atomicAdd(&c.cand_count[pair], count);
     uint32_t *box = c.cand_box + 4ull * pair;
-    box[0] = rmin; box[1] = rmax; box[2] = cmin; box[3] = cmax;
+    atomicMin(&box[0], rmin); atomicMax(&box[1], rmax); atomicMin(&box[2], cmin); atomicMax(&box[3], cmax);
   }
 }
 
 }  // namespace sa
 
-hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, hipStream_t stream) {
+hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, uint32_t max_len_b, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock), block(sa::kWave * sa::kWavesPerBlock);
-  hipLaunchKernelGGL(sa::sw_box_kernel, grid, block, 0, stream, p, c);
+  hipLaunchKernelGGL(sa::sw_box_init_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, stream, c, p.n_pairs);
+  const uint32_t rows_per_block = std::max<uint32_t>(sa::kBoxRows, (max_len_b + 65535u) / 65535u);   // (grid.y limit)
+  const uint32_t row_blocks = (max_len_b + rows_per_block) / rows_per_block;
+  for (uint32_t first = 0; first < p.n_pairs; first += 32768) {   // (grid.x, grid.y limits)
+    SaReduceParams q = p;
+    SaCandBox d = c;
+    const uint32_t cnt = p.n_pairs - first < 32768u ? p.n_pairs - first : 32768u;
+    q.len_a += first; q.len_b += first; q.mat_off += first; q.n_pairs = cnt;
+    d.cand_count += first; d.cand_box += 4ull * first; d.cand_min += first;
+    hipLaunchKernelGGL(sa::sw_box_kernel, dim3(cnt, row_blocks), dim3(sa::kWave), 0, stream, q, d, rows_per_block);
+  }
   return hipGetLastError();
 }
 
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (p.slices > 1 && !p.cand_count && !p.cand_cap && p.n_pairs <= 32768u) {   // few long pairs, best cell only
+    hipLaunchKernelGGL(sa::sw_best_init_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, stream, p.best_index, p.n_pairs);
+    hipLaunchKernelGGL(sa::sw_best_slices_kernel, dim3(p.n_pairs, p.slices), dim3(sa::kWave), 0, stream, p, p.slices);
+    hipLaunchKernelGGL(sa::sw_best_finish_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, stream, p);
+    return hipGetLastError();
+  }
   const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock),
       block(sa::kWave * sa::kWavesPerBlock);
   if (p.cand_cap) hipLaunchKernelGGL(sa::sw_reduce_kernel<true>, grid, block, 0, stream, p);

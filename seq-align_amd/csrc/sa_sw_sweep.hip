@@ -95,21 +95,37 @@ __device__ __forceinline__ void load_run(const int32_t *src, int (&v)[N], int fi
 // left, kStay: nowhere -- no winner, or the walk ends here), bits 2-3 = the state it arrives in
 constexpr uint32_t kStay = 3u;
 
-// ROWS: where the winners of the last two rows live -- SA_ROWS_REG: the segment is the whole row, they stay in
-// registers; SA_ROWS_LDS / SA_ROWS_HBM: by column in LDS / in SaSweepParams::rows, the segments follow the walks
-enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_HBM = 2 };
+// ROWS: how a pair is laid over waves, and where the winners of the row below live --
+//   SA_ROWS_REG    one wave, the segment is the whole row (up to 512 columns): they stay in registers;
+//   SA_ROWS_LDS    one wave, segments that follow the walks: by column in LDS (up to SA_SWEEP_LDS_COLUMNS columns);
+//   SA_ROWS_STRIP  one wave per 256-column strip of the pair, the strips of a pair a pipeline from right to left:
+//                  in registers, with the first column's winners handed to the strip on the left through HBM.
+enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_STRIP = 2 };
 
 // (occupancy: the row loop is half latency -- a row's loads, its dependent passes -- so a wave more per SIMD is worth
 // a few spilled registers on the cold paths: C3 2.91 -> 2.39 ms with 5 instead of 4; 6 loses again)
 template <int CPL, typename KeyT, int ROWS>
 __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : CPL == 3 ? 5 : CPL == 4 ? 4 : CPL == 5 ? 3 : 1) : 1)) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
   constexpr KeyT kNone = ~(KeyT)0;         // no walk
-  constexpr bool LDSROWS = (ROWS == SA_ROWS_LDS);
   const int lane = threadIdx.x;
-  const uint32_t pair = blockIdx.x;
-  if (p.cand_count[pair] == 0) {
-    if (lane == 0) { p.hit_count[pair] = 0; p.status[pair] = 0; }
-    return;
+  uint32_t pair = blockIdx.x, strip = 0;
+  if constexpr (ROWS == SA_ROWS_STRIP) {
+    // A workgroup draws a TICKET when it starts running (sa_fill_strips.hip has the argument in full): ticket =
+    // (group of 8 pairs, strip counted from the RIGHT, pair in group), so the strip a wave waits for always holds a
+    // lower ticket -- it is resident or done, whatever order the hardware dispatches workgroups in.
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(p.strip_progress + 2ull * gridDim.x, 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    const uint32_t gs = ticket >> 3;
+    pair = (gs / p.strips_per_pair) * 8 + (ticket & 7u);
+    strip = p.strips_per_pair - 1 - gs % p.strips_per_pair;
+    if (pair >= p.n_pairs) return;
+    if (p.cand_count[pair] == 0) return;   // (hit_count / status / err_key are initialised by the host)
+  } else {
+    if (p.cand_count[pair] == 0) {
+      if (lane == 0) { p.hit_count[pair] = 0; p.status[pair] = 0; }
+      return;
+    }
   }
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
   const uint64_t mo = p.mat_off[pair];
@@ -130,7 +146,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   }
   // the codes of seq_a, by column (column x holds seq_a[x - 1]; code_ints = 0: pairs too wide, read from HBM each time)
   uint16_t *col_code = reinterpret_cast<uint16_t *>(lds_words + table_ints);
-  if (ROWS != SA_ROWS_REG && code_ints) {
+  if (ROWS == SA_ROWS_LDS && code_ints) {
     for (uint32_t x = lane; x < W; x += kWave) col_code[x] = x >= 1 ? p.code[sa_[x - 1]] : (uint16_t)0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
@@ -141,11 +157,8 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   if constexpr (ROWS == SA_ROWS_LDS) {
     rk = reinterpret_cast<KeyT *>(lds_words + table_ints + code_ints);
     rz = reinterpret_cast<uint32_t *>(rk + 2ull * p.lds_columns);
-  } else if constexpr (ROWS == SA_ROWS_HBM) {
-    rk = reinterpret_cast<KeyT *>(p.rows + 2 * p.row_off[pair]);
-    rz = reinterpret_cast<uint32_t *>(p.rows + 2 * p.row_off[pair] + 2ull * W);
   }
-  const uint32_t row_pitch = LDSROWS ? p.lds_columns : W;
+  const uint32_t row_pitch = p.lds_columns;
   const TraceConsts k{p.code, table, (int)p.K, p.open1, p.ext, p.gen_eq, p.gen_ne,
                       (p.flags & SA_F_NO_START_GAP) != 0, (p.flags & SA_F_NO_END_GAP) != 0,
                       (p.flags & SA_F_NO_GAPS_A) != 0, (p.flags & SA_F_NO_GAPS_B) != 0};
@@ -189,14 +202,8 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
       }
     }
   };
-  auto rec_key = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> KeyT {
-    if constexpr (LDSROWS) return rk[row * row_pitch + col];
-    else return __hip_atomic_load(rk + (size_t)row * row_pitch + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto rec_next = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> uint32_t {
-    if constexpr (LDSROWS) return rz[row * row_pitch + col];
-    else return __hip_atomic_load(rz + (size_t)row * row_pitch + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
+  auto rec_key = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> KeyT { return rk[row * row_pitch + col]; };
+  auto rec_next = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) -> uint32_t { return rz[row * row_pitch + col]; };
 
   // One segment of one row: columns x0 .. x0 + 64 * CPL - 1 (x0 may be negative: those cells do not exist).
   // left[6]: match / gap_a / gap_b of column x0 - 1 on row y and on row y - 1 (wave-uniform); rp_k / rp_z: winner
@@ -321,7 +328,12 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
       const bool hit = wk[c] != kNone && ((dir[c] >> (2u * ws[c])) & 3u) == 3u;
       const unsigned long long bal = __ballot(hit);
       if (bal) {
-        const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        uint32_t first = n_hits;
+        if constexpr (ROWS == SA_ROWS_STRIP) {   // the strips of a pair share its hit list
+          if (lane == 0) first = atomicAdd(p.hit_count + pair, (uint32_t)__popcll(bal));
+          first = __builtin_amdgcn_readfirstlane(first);
+        }
+        const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (hit) hit_keys[pos] = (unsigned long long)wk[c];
         n_hits += (uint32_t)__popcll(bal);
       }
@@ -364,6 +376,100 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
         m[c] = pm[c]; a[c] = pa[c]; b[c] = pb[c];
         pm[c] = nm[c]; pa[c] = na[c]; pb[c] = nb[c];
       }
+    }
+  } else if constexpr (ROWS == SA_ROWS_STRIP) {
+    // ------------------------------------------------------------------ one strip of a wide pair
+    // Strip s works on columns [s * 64 * CPL, (s + 1) * 64 * CPL) of every row, bottom to top, like the one-wave
+    // form above.  All it needs from outside is what enters from the right: the winner of the strip's right
+    // neighbour column on this row and on the row below -- the strip to the right publishes its first column's
+    // winners row by row (16 B per row) and, every 64 rows, how far it has got; this strip waits for that before it
+    // starts a chunk of 64 rows, so it runs 64 rows behind.  A strip ends when nothing is alive in it, no candidate
+    // lies above, and the strip to its right has ended; the ends ripple leftwards.
+    const uint32_t s_hi = p.cand_box[4ull * pair + 3] / (uint32_t)kSegW;   // the strip holding the highest candidate column
+    if (strip > s_hi) return;                                               // nothing ever happens right of it
+    const int x0 = (int)(strip * (uint32_t)kSegW);
+    const uint32_t S = p.strips_per_pair;
+    uint32_t *prog = p.strip_progress + 2ull * ((uint64_t)pair * S);        // [strip][rows done | 1 + rows done at the end]
+    unsigned long long *bnd = p.bnd + 2ull * p.row_off[pair] * S;           // [row counted from rmax][strip][key | what-next]
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t x = (uint32_t)x0 + lane * CPL + c;
+      ca[c] = (x >= 1 && x <= la) ? (int)p.code[sa_[x - 1]] : 0;
+      thr_c[c] = x < W ? thr : INT32_MAX;
+      wk[c] = kNone; wz[c] = kStay;
+    }
+    auto load_left = [&](uint32_t y, int (&d)[3]) __attribute__((always_inline)) {
+      d[0] = d[1] = d[2] = 0;
+      if (x0 > 0) { const uint32_t at = y * W + (uint32_t)x0 - 1; d[0] = Mg[at]; d[1] = Ag[at]; d[2] = Bg[at]; }
+    };
+    int nm[CPL], na[CPL], nb[CPL], lc[3], lp[3], ln[3] = {0, 0, 0};
+    lp[0] = lp[1] = lp[2] = 0;
+    uint32_t y = rmax, r = 0;                   // r: rows done, counted from rmax
+    load_row(y, x0, m, a, b); load_left(y, lc);
+    if (y > 0) { load_row(y - 1, x0, pm, pa, pb); load_left(y - 1, lp); }
+    bool right_over = strip == s_hi;            // nothing (more) will come from the right
+    bool right_ended = strip == s_hi;           // the strip to the right has published its end
+    uint32_t avail = 0;                         // rows the strip to the right has published
+    unsigned long long chunk_k = ~0ull, chunk_z = kStay;   // lane t: its first column's winner on row r0 + t
+    KeyT rp_k = kNone;
+    uint32_t rp_z = kStay;
+    for (;; --y, ++r) {
+      const int q = (int)(r & (kWave - 1));
+      if (q == 0) {
+        chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
+        if (!right_over) {
+          const uint32_t need = min(r + (uint32_t)kWave, rmax + 1u);
+          uint32_t done_rows, ended;
+          // (the strip to my right holds a lower ticket: it is resident or done, see above)
+          for (;;) {
+            done_rows = __hip_atomic_load(prog + 2 * (strip + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ended = __hip_atomic_load(prog + 2 * (strip + 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done_rows >= need || ended) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the loads below see those rows' winners
+          avail = ended ? ended - 1 : done_rows;
+          right_ended = ended != 0;
+          const uint32_t rr = r + (uint32_t)lane;
+          chunk_k = ~0ull; chunk_z = kStay;
+          if (rr < avail) {
+            const unsigned long long *src = bnd + 2ull * ((uint64_t)rr * S + strip + 1);
+            chunk_k = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chunk_z = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (right_ended && avail <= r) right_over = true;
+        }
+      }
+      KeyT rc_k = kNone;
+      uint32_t rc_z = kStay;
+      if (!right_over && r < avail) { rc_k = (KeyT)lane_value(chunk_k, q); rc_z = (uint32_t)lane_value(chunk_z, q); }
+      if (y >= 2) { load_row(y - 2, x0, nm, na, nb); load_left(y - 2, ln); }
+      const int left[6] = {lc[0], lc[1], lc[2], lp[0], lp[1], lp[2]};
+      live_hi = -1;
+      sweep_segment(y, x0, left, rp_k, rp_z, rc_k, rc_z, read_lane(chunk_code, q));
+      ++tr_rows;
+      if (strip > 0 && lane == 0) {   // my first column's winner on this row, for the strip to the left
+        unsigned long long *dst = bnd + 2ull * ((uint64_t)r * S + strip);
+        dst[0] = wk[0] == kNone ? ~0ull : (unsigned long long)wk[0];
+        dst[1] = wz[0];
+      }
+      const bool last = y == 0 || (live_hi < 0 && y <= rmin && (right_over || (right_ended && r + 1 >= avail)));
+      if (strip > 0 && (q == kWave - 1 || last)) {   // publish: rows up to this one are written
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) {
+          __hip_atomic_store(prog + 2 * strip, r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (last) __hip_atomic_store(prog + 2 * strip + 1, r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (last) break;
+      rp_k = rc_k; rp_z = rc_z;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        m[c] = pm[c]; a[c] = pa[c]; b[c] = pb[c];
+        pm[c] = nm[c]; pa[c] = na[c]; pb[c] = nb[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { lc[i] = lp[i]; lp[i] = ln[i]; }
     }
   } else {
     // ------------------------------------------------------------------ segments that follow the walks
@@ -479,9 +585,8 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
       }
     }
     const unsigned long long tp2 = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
-    // this row's records are written before the next row reads them (one wave: LDS in program order; HBM: to L2)
-    if constexpr (LDSROWS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // this row's records are written before the next row reads them (one wave: LDS in program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     prev_w_lo = w_lo; prev_w_hi = w_hi; prev_live_lo = live_lo; prev_live_hi = live_hi;
     if (y == 0 || (live_hi < 0 && y <= rmin)) break;
     top = n_top;
@@ -503,6 +608,13 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   }
   const unsigned long long err_lanes = __ballot(err != 0 && (unsigned long long)err_key == first_err);
   uint32_t status = err_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)err, __builtin_ctzll(err_lanes)) : 0u;
+  if constexpr (ROWS == SA_ROWS_STRIP) {   // the strips of a pair report into the same words; the host orders the hits
+    if (lane == 0 && status) {
+      atomicMin(p.err_key + pair, first_err);
+      atomicMax(p.status + pair, status);
+    }
+    return;
+  }
   if (n_hits > 1) {
     if (n_hits <= (uint32_t)kWave) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -542,10 +654,10 @@ template <int CPL, int ROWS>
 static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t table_ints = (p.K > 1 && p.K <= SA_LDS_TABLE_MAX_K) ? ((p.K * p.K + 1u) & ~1u) : 0u;
   // uint16 per column
-  const uint32_t code_ints = (ROWS != SA_ROWS_REG && p.max_len_a + 1 <= 16384u) ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;
+  const uint32_t code_ints = (ROWS == SA_ROWS_LDS && p.max_len_a + 1 <= 16384u) ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;
   // 32-bit keys when they fit with the all-ones value to spare
   const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
-  const dim3 grid(p.n_pairs), block(kWave);
+  const dim3 grid(ROWS == SA_ROWS_STRIP ? sa_sweep_strip_blocks(p.n_pairs, p.max_len_a) : p.n_pairs), block(kWave);
   size_t lds = ((size_t)table_ints + code_ints) * 4;
   if (ROWS == SA_ROWS_LDS) lds += (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
   if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
@@ -554,17 +666,25 @@ static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
 
 }  // namespace sa
 
+uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a) { return (max_len_a + 1 + SA_SWEEP_STRIP_COLUMNS - 1) / SA_SWEEP_STRIP_COLUMNS; }
+uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a) {
+  return ((n_pairs + 7u) / 8u) * 8u * sa_sweep_strips_per_pair(max_len_a);
+}
+
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks
-  // spread over most of the row anyway).  Beyond that, segments of 256 columns follow the walks, with the winners of
-  // two rows in LDS (up to SA_SWEEP_LDS_COLUMNS columns) or in HBM.  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the second
-  // form with segments of 64 * that many columns (tests, experiments).
+  // spread over most of the row anyway).  Beyond that: many pairs -- one wave per pair, segments of 256 columns that
+  // follow the walks, the winners of two rows in LDS; few pairs, or rows too wide for LDS -- one wave per
+  // 256-column strip (the caller decides: strip_progress != NULL).  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the LDS form
+  // with segments of 64 * that many columns (tests, experiments).
   const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest row
   int forced = 0;
   if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) forced = atoi(env);
   if (forced != 1 && forced != 2 && forced != 4) forced = 0;
-  if (!forced && need <= 8) {
+  if (p.strip_progress) {
+    sa::launch_sweep<SA_SWEEP_STRIP_COLUMNS / sa::kWave, sa::SA_ROWS_STRIP>(p, stream);
+  } else if (!forced && need <= 8) {
     // (one column per lane is not instantiated: no pair is that narrow in practice)
     if (need <= 2) sa::launch_sweep<2, sa::SA_ROWS_REG>(p, stream);
     else if (need <= 3) sa::launch_sweep<3, sa::SA_ROWS_REG>(p, stream);
@@ -574,15 +694,10 @@ hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
     else sa::launch_sweep<8, sa::SA_ROWS_REG>(p, stream);
   } else {
     const int cpl = forced ? forced : 4;
-    if (p.lds_columns) {
-      if (cpl == 1) sa::launch_sweep<1, sa::SA_ROWS_LDS>(p, stream);
-      else if (cpl == 2) sa::launch_sweep<2, sa::SA_ROWS_LDS>(p, stream);
-      else sa::launch_sweep<4, sa::SA_ROWS_LDS>(p, stream);
-    } else {
-      if (cpl == 1) sa::launch_sweep<1, sa::SA_ROWS_HBM>(p, stream);
-      else if (cpl == 2) sa::launch_sweep<2, sa::SA_ROWS_HBM>(p, stream);
-      else sa::launch_sweep<4, sa::SA_ROWS_HBM>(p, stream);
-    }
+    if (!p.lds_columns) return hipErrorInvalidValue;
+    if (cpl == 1) sa::launch_sweep<1, sa::SA_ROWS_LDS>(p, stream);
+    else if (cpl == 2) sa::launch_sweep<2, sa::SA_ROWS_LDS>(p, stream);
+    else sa::launch_sweep<4, sa::SA_ROWS_LDS>(p, stream);
   }
   return hipGetLastError();
 }

@@ -63,15 +63,15 @@ while time.time() < t_end:
         pairs.append((a, b))
     batch = W.from_pairs(pairs)
     os.environ["SEQALIGN_TRACE_KERNEL"] = ("lane", "wave")[int(v[0] >> 7) & 1]
-    # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns, the records of two rows in LDS
-    # or in HBM, or behind a fill that cannot report the candidates' box and rows
-    for key in ("SEQALIGN_SWEEP_CPL", "SEQALIGN_SWEEP_ROWS", "SEQALIGN_KERNEL"):
+    # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
+    # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
+    for key in ("SEQALIGN_SWEEP_CPL", "SEQALIGN_SWEEP_MODE", "SEQALIGN_KERNEL"):
         os.environ.pop(key, None)
     mode = int(v[0] >> 9) % 8
     if mode < 3:
         os.environ["SEQALIGN_SWEEP_CPL"] = ("1", "2", "4")[mode]
     elif mode == 3:
-        os.environ["SEQALIGN_SWEEP_ROWS"] = "hbm"
+        os.environ["SEQALIGN_SWEEP_MODE"] = "strips"
     elif mode == 4:
         os.environ["SEQALIGN_KERNEL"] = "rowscan"
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain

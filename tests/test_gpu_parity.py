@@ -597,7 +597,7 @@ SWEEP_VARIANTS = {
     "default": {},                                    # segment width by sequence length, records of two rows in LDS
     "segments-64": {"SEQALIGN_SWEEP_CPL": "1"},       # 64-column segments: several per row where the walks spread out
     "segments-256": {"SEQALIGN_SWEEP_CPL": "4"},
-    "hbm-rows": {"SEQALIGN_SWEEP_ROWS": "hbm", "SEQALIGN_SWEEP_CPL": "1"},   # the records in HBM (pairs too wide for LDS)
+    "strips": {"SEQALIGN_SWEEP_MODE": "strips"},      # one wave per 256-column strip of a pair (few wide pairs)
     "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box and rows itself
 }
 
@@ -649,10 +649,14 @@ def test_sw_sweep_enumeration(ctx, sweep_variant):
         assert rc == 0 and got[p] == want, (sweep_variant, "large scores", p)
 
 
-def test_sw_sweep_wide_pairs_and_many_hits(ctx):
-    """Wide rows (600 .. 2 500 columns: 1 200+ take a fill that cannot report the candidates' box and rows itself,
-    2 049+ keep the sweep's records in HBM) and pairs with hundreds of hits (more than the 64 the sweep ranks
-    itself: ordered by the host) -- against the oracle."""
+@pytest.mark.parametrize("mode", ["default", "pair", "strips"])
+def test_sw_sweep_wide_pairs_and_many_hits(ctx, mode, monkeypatch):
+    """Wide rows (600 .. 2 500 columns: 1 200+ take a fill that cannot report the candidates' box and rows itself;
+    one wave per pair with the winners of two rows in LDS, or one wave per 256-column strip -- the default for few
+    pairs and beyond 2 048 columns) and pairs with hundreds of hits (more than the 64 the sweep ranks itself: ordered
+    by the host) -- against the oracle."""
+    if mode != "default":
+        monkeypatch.setenv("SEQALIGN_SWEEP_MODE", mode)
     rng = W.Rng(1717)
 
     def rand(n, alpha=b"ACGT"):
@@ -671,13 +675,13 @@ def test_sw_sweep_wide_pairs_and_many_hits(ctx):
         got = ctx.sw_batch(wide, sc, thr, max_hits=max_hits, hit_cap=100000)
         for p in range(wide.n_pairs):
             rc, want = O.oracle_sw(osc, wide.seq_a(p), wide.seq_b(p), thr, max_hits)
-            assert rc == 0 and got[p] == want, ("wide", thr, p)
+            assert rc == 0 and got[p] == want, ("wide", mode, thr, p)
     many = W.from_pairs([(rand(300), rand(300)) for _ in range(3)] + [(b"ACGTTGCA" * 30, b"TGCAACGT" * 40)])
     for max_hits in (70, 1 << 20):
         got = ctx.sw_batch(many, sc, 4, max_hits=max_hits, hit_cap=400000)
         for p in range(many.n_pairs):
             rc, want = O.oracle_sw(osc, many.seq_a(p), many.seq_b(p), 4, max_hits)
-            assert rc == 0 and got[p] == want, ("many hits", max_hits, p)
+            assert rc == 0 and got[p] == want, ("many hits", mode, max_hits, p)
         assert max(len(h) for h in got) > 64
 
 
