@@ -169,8 +169,14 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (w_max <= SA_SWEEP_LDS_COLUMNS) q.lds_columns = (c.max_a + 2u) & ~1u;
   DevBuf &d_prog = ctx->e[2];
   if (strips) {
-    const uint32_t spp = sa_sweep_strips_per_pair(c.max_a);
-    const uint64_t blocks = sa_sweep_strip_blocks((uint32_t)n, c.max_a);
+    // strip width by how many waves that makes: 128-column strips (and progress published every 16 rows instead of
+    // 64) when the pairs are so few that 256-column strips would leave most of the chip idle (2 x 10 000^2: 42.7 ->
+    // 32.8 ms; 64-column strips gain nothing more: a row's dependent passes cost ~2 us whatever its width)
+    uint32_t cols = sa_sweep_strip_blocks((uint32_t)n, c.max_a, 256) < 1024 ? 128 : 256;
+    if (const char *env = getenv("SEQALIGN_SWEEP_STRIP")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) cols = (uint32_t)v; }
+    q.strip_columns = cols; q.strip_interval = cols == 256 ? 64 : 16;
+    const uint32_t spp = sa_sweep_strips_per_pair(c.max_a, cols);
+    const uint64_t blocks = sa_sweep_strip_blocks((uint32_t)n, c.max_a, cols);
     row_off.resize(n);
     uint64_t rows_total = 0;
     for (uint64_t k = 0; k < n; ++k) { row_off[k] = rows_total; rows_total += (uint64_t)batch->len_b[c.first + k] + 1; }

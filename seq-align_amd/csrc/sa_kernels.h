@@ -101,10 +101,12 @@ struct SaSweepParams {
                                     never ordered by the kernel)                                       */
   uint32_t lds_columns;          /* one wave per pair, wide rows: the winners of two rows live in LDS, sized for this
                                     many columns (>= every pair's len_a + 1)                                         */
-  /* one wave per strip of SA_SWEEP_STRIP_COLUMNS columns (few wide pairs; strip_progress != NULL selects it): */
+  /* one wave per strip of strip_columns columns (few wide pairs; strip_progress != NULL selects it): */
   uint32_t *strip_progress;      /* [2 * sa_sweep_strip_blocks() + 1] zeroed: per (pair, strip) rows done | end, then
                                     the ticket counter                                                               */
-  uint32_t strips_per_pair;      /* sa_sweep_strips_per_pair(max_len_a)                                              */
+  uint32_t strip_columns;        /* 64, 128 or 256                                                                   */
+  uint32_t strip_interval;       /* rows between two publications of a strip's progress: 16 or 64                    */
+  uint32_t strips_per_pair;      /* sa_sweep_strips_per_pair(max_len_a, strip_columns)                               */
   unsigned long long *bnd;       /* per pair, row (counted from the box's last row) and strip: the winner of the strip's
                                     first column, 2 uint64; pair p at 2 * row_off[p] * strips_per_pair               */
   const uint64_t *row_off;       /* [n] prefix of len_b + 1                                                          */
@@ -118,10 +120,8 @@ struct SaSweepParams {
 #define SA_SWEEP_UNSORTED 0x80000000u
 /* widest pair (columns) whose two rows of records fit LDS (12 B per column and row with 64-bit keys) */
 #define SA_SWEEP_LDS_COLUMNS 2048u
-/* columns per strip when a pair is swept by one wave per strip */
-#define SA_SWEEP_STRIP_COLUMNS 256u
-uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a);
-uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a);
+uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a, uint32_t strip_columns);
+uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a, uint32_t strip_columns);
 
 struct SaTraceParams {
   const uint8_t *arena;

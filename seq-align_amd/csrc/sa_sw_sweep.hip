@@ -98,7 +98,7 @@ constexpr uint32_t kStay = 3u;
 // ROWS: how a pair is laid over waves, and where the winners of the row below live --
 //   SA_ROWS_REG    one wave, the segment is the whole row (up to 512 columns): they stay in registers;
 //   SA_ROWS_LDS    one wave, segments that follow the walks: by column in LDS (up to SA_SWEEP_LDS_COLUMNS columns);
-//   SA_ROWS_STRIP  one wave per 256-column strip of the pair, the strips of a pair a pipeline from right to left:
+//   SA_ROWS_STRIP  one wave per strip of 64 * CPL columns of the pair, the strips of a pair a pipeline from right to left:
 //                  in registers, with the first column's winners handed to the strip on the left through HBM.
 enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_STRIP = 2 };
 
@@ -382,13 +382,13 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
     // Strip s works on columns [s * 64 * CPL, (s + 1) * 64 * CPL) of every row, bottom to top, like the one-wave
     // form above.  All it needs from outside is what enters from the right: the winner of the strip's right
     // neighbour column on this row and on the row below -- the strip to the right publishes its first column's
-    // winners row by row (16 B per row) and, every 64 rows, how far it has got; this strip waits for that before it
-    // starts a chunk of 64 rows, so it runs 64 rows behind.  A strip ends when nothing is alive in it, no candidate
+    // winners row by row (16 B per row) and, every strip_interval rows, how far it has got; this strip waits for
+    // that before it starts a chunk of as many rows, so it runs that many rows behind.  A strip ends when nothing is alive in it, no candidate
     // lies above, and the strip to its right has ended; the ends ripple leftwards.
     const uint32_t s_hi = p.cand_box[4ull * pair + 3] / (uint32_t)kSegW;   // the strip holding the highest candidate column
     if (strip > s_hi) return;                                               // nothing ever happens right of it
     const int x0 = (int)(strip * (uint32_t)kSegW);
-    const uint32_t S = p.strips_per_pair;
+    const uint32_t S = p.strips_per_pair, ivl = p.strip_interval;   // ivl: rows between two publications (16 or 64)
     uint32_t *prog = p.strip_progress + 2ull * ((uint64_t)pair * S);        // [strip][rows done | 1 + rows done at the end]
     unsigned long long *bnd = p.bnd + 2ull * p.row_off[pair] * S;           // [row counted from rmax][strip][key | what-next]
 #pragma unroll
@@ -415,10 +415,11 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
     uint32_t rp_z = kStay;
     for (;; --y, ++r) {
       const int q = (int)(r & (kWave - 1));
-      if (q == 0) {
-        chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
+      const int qb = (int)(r & (ivl - 1u));    // row inside the chunk of boundary winners
+      if (q == 0) chunk_code = (y >= 1u + lane) ? (int)p.code[sb_[y - lane - 1]] : 0;
+      if (qb == 0) {
         if (!right_over) {
-          const uint32_t need = min(r + (uint32_t)kWave, rmax + 1u);
+          const uint32_t need = min(r + ivl, rmax + 1u);
           uint32_t done_rows, ended;
           // (the strip to my right holds a lower ticket: it is resident or done, see above)
           for (;;) {
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
           right_ended = ended != 0;
           const uint32_t rr = r + (uint32_t)lane;
           chunk_k = ~0ull; chunk_z = kStay;
-          if (rr < avail) {
+          if (rr < avail && (uint32_t)lane < ivl) {
             const unsigned long long *src = bnd + 2ull * ((uint64_t)rr * S + strip + 1);
             chunk_k = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             chunk_z = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
       }
       KeyT rc_k = kNone;
       uint32_t rc_z = kStay;
-      if (!right_over && r < avail) { rc_k = (KeyT)lane_value(chunk_k, q); rc_z = (uint32_t)lane_value(chunk_z, q); }
+      if (!right_over && r < avail) { rc_k = (KeyT)lane_value(chunk_k, qb); rc_z = (uint32_t)lane_value(chunk_z, qb); }
       if (y >= 2) { load_row(y - 2, x0, nm, na, nb); load_left(y - 2, ln); }
       const int left[6] = {lc[0], lc[1], lc[2], lp[0], lp[1], lp[2]};
       live_hi = -1;
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
         dst[1] = wz[0];
       }
       const bool last = y == 0 || (live_hi < 0 && y <= rmin && (right_over || (right_ended && r + 1 >= avail)));
-      if (strip > 0 && (q == kWave - 1 || last)) {   // publish: rows up to this one are written
+      if (strip > 0 && (qb == (int)ivl - 1 || last)) {   // publish: rows up to this one are written
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) {
           __hip_atomic_store(prog + 2 * strip, r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -657,7 +658,7 @@ static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t code_ints = (ROWS == SA_ROWS_LDS && p.max_len_a + 1 <= 16384u) ? (((p.max_len_a + 2u) / 2u + 1u) & ~1u) : 0u;
   // 32-bit keys when they fit with the all-ones value to spare
   const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
-  const dim3 grid(ROWS == SA_ROWS_STRIP ? sa_sweep_strip_blocks(p.n_pairs, p.max_len_a) : p.n_pairs), block(kWave);
+  const dim3 grid(ROWS == SA_ROWS_STRIP ? sa_sweep_strip_blocks(p.n_pairs, p.max_len_a, kWave * CPL) : p.n_pairs), block(kWave);
   size_t lds = ((size_t)table_ints + code_ints) * 4;
   if (ROWS == SA_ROWS_LDS) lds += (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
   if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
@@ -666,24 +667,27 @@ static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
 
 }  // namespace sa
 
-uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a) { return (max_len_a + 1 + SA_SWEEP_STRIP_COLUMNS - 1) / SA_SWEEP_STRIP_COLUMNS; }
-uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a) {
-  return ((n_pairs + 7u) / 8u) * 8u * sa_sweep_strips_per_pair(max_len_a);
+uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a, uint32_t strip_columns) { return (max_len_a + strip_columns) / strip_columns; }
+uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a, uint32_t strip_columns) {
+  return ((n_pairs + 7u) / 8u) * 8u * sa_sweep_strips_per_pair(max_len_a, strip_columns);
 }
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks
   // spread over most of the row anyway).  Beyond that: many pairs -- one wave per pair, segments of 256 columns that
-  // follow the walks, the winners of two rows in LDS; few pairs, or rows too wide for LDS -- one wave per
-  // 256-column strip (the caller decides: strip_progress != NULL).  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the LDS form
+  // follow the walks, the winners of two rows in LDS; few pairs, or rows too wide for LDS -- one wave per strip of
+  // 64 / 128 / 256 columns (the caller decides: strip_progress != NULL, strip_columns).  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the LDS form
   // with segments of 64 * that many columns (tests, experiments).
   const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest row
   int forced = 0;
   if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) forced = atoi(env);
   if (forced != 1 && forced != 2 && forced != 4) forced = 0;
   if (p.strip_progress) {
-    sa::launch_sweep<SA_SWEEP_STRIP_COLUMNS / sa::kWave, sa::SA_ROWS_STRIP>(p, stream);
+    if (p.strip_columns == 64) sa::launch_sweep<1, sa::SA_ROWS_STRIP>(p, stream);
+    else if (p.strip_columns == 128) sa::launch_sweep<2, sa::SA_ROWS_STRIP>(p, stream);
+    else if (p.strip_columns == 256) sa::launch_sweep<4, sa::SA_ROWS_STRIP>(p, stream);
+    else return hipErrorInvalidValue;
   } else if (!forced && need <= 8) {
     // (one column per lane is not instantiated: no pair is that narrow in practice)
     if (need <= 2) sa::launch_sweep<2, sa::SA_ROWS_REG>(p, stream);

@@ -597,7 +597,7 @@ SWEEP_VARIANTS = {
     "default": {},                                    # segment width by sequence length, records of two rows in LDS
     "segments-64": {"SEQALIGN_SWEEP_CPL": "1"},       # 64-column segments: several per row where the walks spread out
     "segments-256": {"SEQALIGN_SWEEP_CPL": "4"},
-    "strips": {"SEQALIGN_SWEEP_MODE": "strips"},      # one wave per 256-column strip of a pair (few wide pairs)
+    "strips": {"SEQALIGN_SWEEP_MODE": "strips", "SEQALIGN_SWEEP_STRIP": "64"},   # one wave per 64-column strip of a pair
     "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box and rows itself
 }
 
