@@ -22,23 +22,26 @@
 // candidates, no visited bitmap, no iteration over walks.  (Checked against the sequential procedure by
 // tests/test_gpu_parity.py and tools/fuzz_e2e.py; the argument in full: DESIGN.md 3.6.)
 //
-// One WAVE per pair.  Per cell the wave keeps the key of the walk that won it and four bits: where that walk
-// goes (up-left / up / left / nowhere) and the state it arrives in -- for the last two rows, in LDS, indexed by
-// column (pairs wider than SA_SWEEP_LDS_COLUMNS: in HBM, SaSweepParams::rows).  A row of a candidates' box is
-// mostly empty: the walks live in a band around the hits' diagonals.  The fill reports, per row, the lowest and
-// highest column holding a candidate (SaFillParams::cand_rows); with the columns of the row below that walks left
-// from, that is all a row can have arrivals in, and the wave works on that stretch only, in segments of 64 * CPL
-// columns counted from its right end (usually one): lane l owns CPL consecutive columns of the segment; match /
-// gap_a / gap_b of row y and y - 1 are one wide load per lane and matrix (only the stretch is read, 24 B per cell
-// of it -- the second read of a row hits L2).  Arrivals from the row below are LDS reads and a DPP shift at the lane
-// border.  Arrivals along the row (GAP_B moves) make a right-to-left dependency: each lane resolves its own columns
-// in order, and the lanes iterate until no lane's incoming walk changes (the row's fixed point is unique: the
-// rightmost cell has no such arrival and every cell is a function of the one to its right).  Where a walk goes from
-// a cell is worked out for all three states of every cell of a segment at once: the traceback's own decision
-// (reverse_move_t; for plain scorings the same three equality tests on 32-bit values).  Rows nothing can arrive in
-// cost a scalar test.  Keys are 32 bits wide when row, column and score fit 31 bits, else 64.
+// Per cell, the key of the walk that won it and four bits: where that walk goes (up-left / up / left / nowhere)
+// and the state it arrives in.  Lane l owns CPL consecutive columns of a SEGMENT of 64 * CPL columns; match / gap_a /
+// gap_b of a row are one wide load per lane and matrix.  Arrivals from the row below are register moves and a DPP
+// shift at the lane border.  Arrivals along the row (GAP_B moves) make a right-to-left dependency: each lane resolves
+// its own columns in order, and the lanes iterate until no lane's incoming walk changes (the row's fixed point is
+// unique: the rightmost cell has no such arrival and every cell is a function of the one to its right).  Where a
+// walk goes from a cell is worked out for all three states of every cell of a segment at once: the traceback's own
+// decision (reverse_move_t; for plain scorings the same three equality tests on 32-bit values).  Keys are 32 bits
+// wide when row, column and score fit 31 bits, else 64.  Three ways to lay a pair over waves:
+//   * rows up to 512 columns: one wave per pair, the segment is the whole row and never moves; the winners stay in
+//     registers, every row is loaded once (12 B per cell), the next row is in flight while this one is worked on;
+//   * wider rows, many pairs: one wave per pair, the winners of two rows in LDS by column, and only the stretch of
+//     a row anything can arrive in is worked on -- the candidate columns the fill reports per row
+//     (SaFillParams::cand_rows) and the columns walks left the row below from -- in segments counted from its right
+//     end (usually one);
+//   * few wide pairs: one wave per 128- or 256-column strip, the strips of a pair a pipeline from right to left
+//     (the first column's winners handed to the strip on the left through HBM).
 //
-// Bound: VALU work per cell of the bands (~100 instructions); HBM traffic is a fraction of the fill's.
+// Bound: VALU work per cell (~100 instructions) when there are enough pairs; the ~2 us of dependent work per row
+// when there are not.
 #include <algorithm>
 
 #include "sa_trace_common.hpp"
