@@ -676,6 +676,17 @@ def test_sw_sweep_wide_pairs_and_many_hits(ctx, mode, monkeypatch):
         for p in range(wide.n_pairs):
             rc, want = O.oracle_sw(osc, wide.seq_a(p), wide.seq_b(p), thr, max_hits)
             assert rc == 0 and got[p] == want, ("wide", mode, thr, p)
+    # two long, closely related sequences: the plume of the one hit covers most of a 1 300 x 1 170 matrix (every
+    # strip and nearly every row has walks on it)
+    a = bytearray(rand(1300))
+    b = bytearray(a[:1170])
+    for i in range(0, len(b), 23):
+        b[i] = b"ACGT"[(b"ACGT".index(b[i]) + 1) % 4]
+    square = W.from_pairs([(bytes(a), bytes(b)), (bytes(b[:700]), bytes(a[100:1200]))])
+    got = ctx.sw_batch(square, sc, 300, max_hits=5, hit_cap=1000)
+    for p in range(square.n_pairs):
+        rc, want = O.oracle_sw(osc, square.seq_a(p), square.seq_b(p), 300, 5)
+        assert rc == 0 and got[p] == want, ("square", mode, p)
     many = W.from_pairs([(rand(300), rand(300)) for _ in range(3)] + [(b"ACGTTGCA" * 30, b"TGCAACGT" * 40)])
     for max_hits in (70, 1 << 20):
         got = ctx.sw_batch(many, sc, 4, max_hits=max_hits, hit_cap=400000)
