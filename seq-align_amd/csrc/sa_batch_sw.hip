@@ -231,8 +231,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   for (uint64_t k = 0; k < n && !overflow; ++k) {
     const uint32_t cnt = h_count[k], take = std::min(cnt, max_hits);
     unsigned long long *dev_keys = d_keys.as<unsigned long long>() + cell0[k];
-    if ((h_status[k] & SA_SWEEP_UNSORTED) || (strips && cnt > 1)) {   // more than 64 hits in one pair, or a pair swept
-                                                                       // in strips: ordered here (that pair's keys only)
+    if (h_status[k] & SA_SWEEP_UNSORTED) {   // more than 64 hits in one pair: ordered here (rare; that pair's keys only)
       big.resize(cnt);
       HIP_TRY(hipMemcpy(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost));
       std::sort(big.begin(), big.end());

@@ -97,8 +97,7 @@ struct SaSweepParams {
   uint32_t *hit_count;           /* [n] every hit of the pair (no max_hits here)                      */
   uint32_t *status;              /* [n] 0, SEQALIGN_E_* of a walk (see err_key), | SA_SWEEP_UNSORTED   */
   unsigned long long *err_key;   /* [n] key of the first (lowest) walk that met the error             */
-                                 /* (strips: the caller zeroes hit_count / status and sets err_key to ~0; the hits are
-                                    never ordered by the kernel)                                       */
+                                 /* (strips: the caller zeroes hit_count / status and sets err_key to ~0)            */
   uint32_t lds_columns;          /* one wave per pair, wide rows: the winners of two rows live in LDS, sized for this
                                     many columns (>= every pair's len_a + 1)                                         */
   /* one wave per strip of strip_columns columns (few wide pairs; strip_progress != NULL selects it): */

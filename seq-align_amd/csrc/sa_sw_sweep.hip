@@ -641,6 +641,23 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   }
 }
 
+// The strips of a pair append to its hit list in no particular order: one wave per pair ranks up to 64 hits
+// afterwards (as the one-wave-per-pair forms do themselves); longer lists are flagged for the host.
+__global__ void __launch_bounds__(kWave) sw_order_hits_kernel(const SaSweepParams p) {
+  const int lane = threadIdx.x;
+  const uint32_t pair = blockIdx.x, n_hits = p.hit_count[pair];
+  if (n_hits <= 1) return;
+  if (n_hits > (uint32_t)kWave) {
+    if (lane == 0) p.status[pair] |= SA_SWEEP_UNSORTED;
+    return;
+  }
+  unsigned long long *hit_keys = p.hit_keys + p.mat_off[pair];
+  const unsigned long long key = lane < (int)n_hits ? hit_keys[lane] : ~0ull;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n_hits; ++j) rank += lane_value(key, (int)j) < key;
+  if (lane < (int)n_hits) hit_keys[rank] = key;
+}
+
 // every hit's strings packed back to back for one D2H each: one wave per hit
 __global__ void __launch_bounds__(256) gather_hits_kernel(const char *src_a, const char *src_b, const uint64_t *walker_str,
                                                           const uint32_t *head, const uint32_t *len, const uint64_t *dst_off,
@@ -691,6 +708,7 @@ hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
     else if (p.strip_columns == 128) sa::launch_sweep<2, sa::SA_ROWS_STRIP>(p, stream);
     else if (p.strip_columns == 256) sa::launch_sweep<4, sa::SA_ROWS_STRIP>(p, stream);
     else return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sa::sw_order_hits_kernel, dim3(p.n_pairs), dim3(sa::kWave), 0, stream, p);
   } else if (!forced && need <= 8) {
     // (one column per lane is not instantiated: no pair is that narrow in practice)
     if (need <= 2) sa::launch_sweep<2, sa::SA_ROWS_REG>(p, stream);
