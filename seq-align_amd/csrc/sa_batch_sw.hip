@@ -83,17 +83,32 @@ static uint32_t bits_for(uint64_t v) {   // bits needed to hold values 0..v
   return b;
 }
 
+// the most one move of an alignment can add to its score (a substitution; a gap only when a gap score is positive --
+// legal, absurd)
+static int64_t best_move(const seqalign_dev_scoring *sc) {
+  const sa_flat_scoring_t &f = sc->flat;
+  int64_t best = std::max<int64_t>(1, std::max(f.gen_eq, f.gen_ne));
+  for (uint64_t k = 0; k < (uint64_t)f.n_classes * f.n_classes; ++k)
+    if (f.table[k] != SA_S_BLOCKED && f.table[k] != SA_S_UNKNOWN) best = std::max<int64_t>(best, f.table[k]);
+  return std::max<int64_t>(best, std::max(f.ext, f.open1));
+}
+
+// uint64 elements of the multi-hit path's scratch arena a pair needs: the candidate columns of its rows, then its
+// hits' keys.  A hit is a walk from a cell with score >= min_score down to score 0, every move takes off at most
+// best_move(), and the cells it stands on are won by it alone: ceil(min_score / best move) + 1 cells per hit.
+static uint64_t hit_arena_elements(uint32_t len_a, uint32_t len_b, int32_t min_score, int64_t best) {
+  const uint64_t cells = ((uint64_t)len_a + 1) * ((uint64_t)len_b + 1);
+  const uint64_t per_hit = (uint64_t)((std::max<int64_t>(min_score, 1) + best - 1) / best) + 1;
+  return (uint64_t)len_b + 1 + cells / per_hit + 1;
+}
+
 // How the sweep packs a cell into a key (SaKeyLayout): row and column fields sized by the longest sequences, the
 // score field by the largest score the scoring can produce on them.
 static SaKeyLayout key_layout(const seqalign_dev_scoring *sc, uint32_t max_a, uint32_t max_b) {
   const sa_flat_scoring_t &f = sc->flat;
-  int64_t best_step = std::max<int64_t>(1, std::max(f.gen_eq, f.gen_ne));
-  for (uint64_t k = 0; k < (uint64_t)f.n_classes * f.n_classes; ++k)
-    if (f.table[k] != SA_S_BLOCKED && f.table[k] != SA_S_UNKNOWN) best_step = std::max<int64_t>(best_step, f.table[k]);
-  // every move adds at most best_step; gaps only add when a gap score is positive (legal, absurd)
+  const int64_t best_step = best_move(sc);
   int64_t cap = (int64_t)std::min(max_a, max_b) * best_step;
-  if (f.ext > 0 || f.open1 > 0)
-    cap = ((int64_t)max_a + max_b) * std::max<int64_t>(best_step, std::max(f.ext, f.open1));
+  if (f.ext > 0 || f.open1 > 0) cap = ((int64_t)max_a + max_b) * best_step;
   cap = std::min<int64_t>(std::max<int64_t>(cap, 1), INT32_MAX);
   SaKeyLayout l;
   l.cap = (int32_t)cap;
@@ -126,13 +141,22 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (!key_layout_fits(layout)) return SEQALIGN_E_TOO_LARGE;   // (seqalign_sw_batch checks the whole batch first)
 
   // ---- fill + candidates' count and box
+  // every pair's part of the scratch arena (its rows' candidate columns, then its hits' keys)
+  std::vector<uint64_t> hit_off(n + 1, 0);
+  {
+    const int64_t best = best_move(sc);
+    for (uint64_t k = 0; k < n; ++k)
+      hit_off[k + 1] = hit_off[k] + hit_arena_elements(batch->len_a[c.first + k], batch->len_b[c.first + k], min_score[c.first + k], best);
+  }
+  DevBuf &d_hitoff = ctx->e[13];
   if ((rc = d_min.reserve(n * 4)) || (rc = ctx->cand_count.reserve(n * 4)) || (rc = d_box.reserve(n * 16)) ||
-      (rc = d_keys.reserve(c.cells * 8 + 16)) || (rc = d_meta.reserve(n * 16 + 16)))
+      (rc = d_keys.reserve(hit_off[n] * 8 + 16)) || (rc = d_meta.reserve(n * 16 + 16)) || (rc = d_hitoff.reserve((n + 1) * 8)))
     return rc;
   HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_hitoff.p, hit_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
   SaCandBox cand;
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
-  cand.cand_rows = d_keys.as<uint32_t>();   // the rows' candidate columns: at the end of every pair's part of the key arena
+  cand.cand_rows = d_keys.as<uint32_t>(); cand.hit_off = d_hitoff.as<uint64_t>();
   seqalign_dev_batch_t d;
   bool reported = false;
   if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported))) return rc;
@@ -150,7 +174,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.arena = d.arena; q.off_a = d.off_a; q.len_a = d.len_a; q.off_b = d.off_b; q.len_b = d.len_b;
   q.mat_off = d.mat_off; q.M = d.match_scores; q.A = d.gap_a_scores; q.B = d.gap_b_scores;
   q.code = sc->d_code; q.table = sc->d_table; q.cand_count = cand.cand_count; q.cand_box = cand.cand_box;
-  q.min_score = d_min.as<int32_t>(); q.hit_keys = d_keys.as<unsigned long long>();
+  q.min_score = d_min.as<int32_t>(); q.hit_keys = d_keys.as<unsigned long long>(); q.hit_off = d_hitoff.as<uint64_t>();
   q.err_key = d_meta.as<unsigned long long>();
   q.hit_count = reinterpret_cast<uint32_t *>(q.err_key + n); q.status = q.hit_count + n;
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.open1 = sc->flat.open1; q.ext = sc->flat.ext;
@@ -230,12 +254,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<unsigned long long> big;
   for (uint64_t k = 0; k < n && !overflow; ++k) {
     const uint32_t cnt = h_count[k], take = std::min(cnt, max_hits);
-    unsigned long long *dev_keys = d_keys.as<unsigned long long>() + cell0[k];
+    unsigned long long *dev_keys = d_keys.as<unsigned long long>() + hit_off[k] + batch->len_b[c.first + k] + 1;
     if (h_status[k] & SA_SWEEP_UNSORTED) {   // more than 64 hits in one pair: ordered here (rare; that pair's keys only)
       big.resize(cnt);
       HIP_TRY(hipMemcpy(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost));
       std::sort(big.begin(), big.end());
       HIP_TRY(hipMemcpy(dev_keys, big.data(), (size_t)cnt * 8, hipMemcpyHostToDevice));
+    }
+    if (h_status[k] & SA_SWEEP_OVERFLOW) {
+      set_last_error("seqalign_sw_batch: internal error: pair " + std::to_string(c.first + k) + " has more hits than its share of the scratch arena");
+      return SEQALIGN_E_HIP;
     }
     if (const uint32_t err = h_status[k] & ~SA_SWEEP_UNSORTED) {
       // a walk met an error.  The reference would have met it too unless it had stopped before: max_hits hits
@@ -280,7 +308,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
     t.out_head = dv_meta; t.out_len = dv_meta + nw; t.out_score = reinterpret_cast<int32_t *>(dv_meta + 2 * nw);
     t.trace_status = dv_meta + 3 * nw; t.out_pos = dv_meta + 4 * nw;
-    t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.layout = layout;
+    t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.hit_off = q.hit_off; t.layout = layout;
     t.n_pairs = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
     t.flags = q.flags;
     if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
@@ -554,8 +582,15 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   for (uint64_t p = 0; p < batch->n_pairs; ++p) { max_a = std::max(max_a, batch->len_a[p]); max_b = std::max(max_b, batch->len_b[p]); }
   // (a key that does not fit the sweep's records -- scores beyond 2^28 on sequences beyond 2^16 -- goes to the host)
   if (!traceback_on_host() && key_layout_fits(key_layout(sc, max_a, max_b))) {
-    // per cell: the three matrices + the hits' keys
-    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 12 + 8)) {
+    // per cell: the three matrices + the scratch arena's share (rows' candidate columns, hits' keys)
+    uint64_t arena = 0, cells = 0;
+    { const int64_t best = best_move(sc);
+      for (uint64_t p = 0; p < batch->n_pairs; ++p) {
+        arena += hit_arena_elements(batch->len_a[p], batch->len_b[p], min_score[p], best);
+        cells += ((uint64_t)batch->len_a[p] + 1) * ((uint64_t)batch->len_b[p] + 1);
+      } }
+    const size_t arena_per_cell = (size_t)((8 * arena + cells - 1) / std::max<uint64_t>(cells, 1)) + 1;
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 12 + arena_per_cell)) {
       if ((rc = sw_chunk_device_enumerate(ctx, batch, c, sc, min_score, max_hits, hits, hit_cap, &found, out_a, out_b,
                                           str_cap, &used_str)))
         break;

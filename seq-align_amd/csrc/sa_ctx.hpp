@@ -193,7 +193,7 @@ struct seqalign_ctx {
   sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
   sa_host::DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   sa_host::DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
-  sa_host::DevBuf e[13];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
+  sa_host::DevBuf e[14];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
   sa_host::DevBuf strip_progress;                        // sa_fill_strips.hip: rows done per (pair, strip)
   sa_host::HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // cached flattened scoring for the legacy single-pair path

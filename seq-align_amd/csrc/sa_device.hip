@@ -182,7 +182,7 @@ static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_
   p.gap_open = s->flat.gap_open; p.open1 = s->flat.open1; p.ext = s->flat.ext; p.floor = s->flat.floor;
   p.gen_eq = s->flat.gen_eq; p.gen_ne = s->flat.gen_ne; p.flags = s->flat.flags;
   p.best_score = nullptr; p.best_index = nullptr;
-  p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr;
+  p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr; p.cand_rows_off = nullptr;
   return p;
 }
 
@@ -249,6 +249,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
   }
   if (which == SEQALIGN_KERNEL_STREAM && cand) {   // candidates' count and box straight from the fill's registers
     p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box; p.cand_rows = cand->cand_rows;
+    p.cand_rows_off = cand->hit_off;
     if (sa_stream_kernel_emits_candidates(p, batch->max_len_a)) { if (cand_done) *cand_done = true; }
     else p.cand_count = nullptr;
   }

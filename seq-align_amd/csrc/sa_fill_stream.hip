@@ -16,7 +16,7 @@ bool sa_stream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, ui
 }
 
 bool sa_stream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a) {
-  return p.cand_count && p.cand_box && p.cand_rows && p.cand_min && (p.flags & SA_F_IS_SW) &&
+  return p.cand_count && p.cand_box && p.cand_rows && p.cand_rows_off && p.cand_min && (p.flags & SA_F_IS_SW) &&
          sa_stream_kernel_applicable(p, max_len_a);
 }
 

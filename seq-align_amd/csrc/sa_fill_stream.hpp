@@ -236,7 +236,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
   uint32_t *cand_rows = nullptr;   // [len_b + 1][2]: lowest / highest candidate column of every row (lo > hi: none)
   if constexpr (CAND) {
     cand_thr = max(p.cand_min[pair], 1);   // candidates need match_scores > 0 (smith_waterman.c:154)
-    cand_rows = sa_cand_rows(p.cand_rows, mo, W, lb);
+    cand_rows = p.cand_rows + 2ull * p.cand_rows_off[pair];
     if (lane == 0) *reinterpret_cast<uint2 *>(cand_rows) = make_uint2(0xffffffffu, 0u);   // row 0: borders only
   }
   if constexpr (BEST) {

@@ -33,22 +33,15 @@ struct SaFillParams {
   const int32_t *cand_min;
   uint32_t *cand_count;
   uint32_t *cand_box;
-  uint32_t *cand_rows;   /* per row of every pair: lowest / highest candidate column (lo > hi: none); see sa_cand_rows */
+  uint32_t *cand_rows;          /* the multi-hit path's scratch arena (SaSweepParams::hit_keys) as uint32: pair p's part starts
+                                    with its rows' candidate columns -- lowest / highest per row, rows 0..len_b (lo > hi: none) */
+  const uint64_t *cand_rows_off; /* [n] where pair p's part starts, in uint64 (SaSweepParams::hit_off)                    */
 };
-
-/* The per-row candidate ranges of pair p (two uint32 per row, rows 0..len_b) live at the END of the pair's region of
- * the multi-hit path's 8-byte-per-cell arena (SaSweepParams::hit_keys as uint32: cells [mat_off, mat_off + W * (len_b + 1)));
- * the hits' keys grow from its start.  Both fit: a pair has at most len_a * len_b hits and W * (len_b + 1) cells. */
-#ifdef __HIPCC__
-__host__ __device__ inline uint32_t *sa_cand_rows(uint32_t *arena32, uint64_t mat_off, uint32_t W, uint32_t len_b) {
-  return arena32 + 2ull * (mat_off + (uint64_t)W * (len_b + 1ull)) - 2ull * (len_b + 1ull);
-}
-#endif
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit
  * order (score desc, column asc, then cell index = row asc; smith_waterman.c:71-86):
  *     key = (cap - score) << (row_bits + col_bits) | column << row_bits | row
- * cap = an upper bound of every score of the chunk; row_bits + col_bits + score_bits <= 60. */
+ * cap = an upper bound of every score of the chunk; row_bits + col_bits + score_bits <= 63. */
 struct SaKeyLayout {
   int32_t cap;
   uint32_t row_bits, col_bits, score_bits;
@@ -74,7 +67,8 @@ struct SaReduceParams {
 struct SaCandBox {
   uint32_t *cand_count;       /* [n]                                                       */
   uint32_t *cand_box;         /* [4n] rmin, rmax, cmin, cmax                               */
-  uint32_t *cand_rows;        /* the 8-byte-per-cell arena, as uint32 (sa_cand_rows)       */
+  uint32_t *cand_rows;        /* the multi-hit path's scratch arena, as uint32 (SaFillParams::cand_rows) */
+  const uint64_t *hit_off;    /* [n + 1] where pair p's part of it starts, in uint64       */
   const int32_t *cand_min;    /* [n] per-pair min_score                                    */
 };
 
@@ -92,8 +86,11 @@ struct SaSweepParams {
   const uint32_t *cand_count;    /* [n]                                                              */
   const uint32_t *cand_box;      /* [4n]                                                             */
   const int32_t *min_score;      /* [n]                                                              */
-  unsigned long long *hit_keys;  /* out: pair p's hits' keys at elements [mat_off[p], + hit_count[p]): ascending when
-                                    hit_count <= 64, else in the order the sweep met them (SA_SWEEP_UNSORTED)     */
+  unsigned long long *hit_keys;  /* scratch arena; pair p's part is elements [hit_off[p], hit_off[p + 1]): first len_b + 1
+                                    elements = its rows' candidate columns (in: the fill / sa_launch_sw_box), then (out) its
+                                    hits' keys: ascending when hit_count <= 64, else in the order the sweep met them
+                                    (SA_SWEEP_UNSORTED)                                                           */
+  const uint64_t *hit_off;       /* [n + 1]; room for hits: a hit owns at least ceil(min_score / best move) + 1 cells  */
   uint32_t *hit_count;           /* [n] every hit of the pair (no max_hits here)                      */
   uint32_t *status;              /* [n] 0, SEQALIGN_E_* of a walk (see err_key), | SA_SWEEP_UNSORTED   */
   unsigned long long *err_key;   /* [n] key of the first (lowest) walk that met the error             */
@@ -117,6 +114,7 @@ struct SaSweepParams {
   unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (SEQALIGN_SWEEP_TRACE) */
 };
 #define SA_SWEEP_UNSORTED 0x80000000u
+#define SA_SWEEP_OVERFLOW 0x40000000u   /* more hits than the pair's part of the arena holds (cannot happen: see hit_off) */
 /* widest pair (columns) whose two rows of records fit LDS (12 B per column and row with 64-bit keys) */
 #define SA_SWEEP_LDS_COLUMNS 2048u
 uint32_t sa_sweep_strips_per_pair(uint32_t max_len_a, uint32_t strip_columns);
@@ -143,6 +141,7 @@ struct SaTraceParams {
    * hit_keys[mat_off[pair] + rank] (layout); str_off and every out_* array are indexed by the walk */
   const uint32_t *walker_pair, *walker_rank;
   const unsigned long long *hit_keys;
+  const uint64_t *hit_off;     /* (SaSweepParams::hit_off: pair p's keys start at hit_off[p] + len_b + 1) */
   SaKeyLayout layout;
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kWave) sw_box_kernel(const SaReduceParams p, c
   const uint32_t row0 = blockIdx.y * rows_per_block;
   if (row0 >= H) return;
   const int32_t *__restrict__ M = p.M + p.mat_off[pair];
-  uint32_t *rows = sa_cand_rows(c.cand_rows, p.mat_off[pair], W, H - 1);
+  uint32_t *rows = c.cand_rows + 2ull * c.hit_off[pair];
   const int thr = max(c.cand_min[pair], 1);
   uint32_t count = 0, rmin = 0xffffffffu, rmax = 0, cmin = 0xffffffffu, cmax = 0;   // wave-uniform
   for (uint32_t r = row0; r < min(row0 + rows_per_block, H); ++r) {
@@ -262,7 +262,7 @@ hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, uint32_
     SaCandBox d = c;
     const uint32_t cnt = p.n_pairs - first < 32768u ? p.n_pairs - first : 32768u;
     q.len_a += first; q.len_b += first; q.mat_off += first; q.n_pairs = cnt;
-    d.cand_count += first; d.cand_box += 4ull * first; d.cand_min += first;
+    d.cand_count += first; d.cand_box += 4ull * first; d.cand_min += first; d.hit_off += first;
     hipLaunchKernelGGL(sa::sw_box_kernel, dim3(cnt, row_blocks), dim3(sa::kWave), 0, stream, q, d, rows_per_block);
   }
   return hipGetLastError();

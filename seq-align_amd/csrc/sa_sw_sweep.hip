@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   const uint64_t mo = p.mat_off[pair];
   const int32_t *__restrict__ Mg = p.M + mo, *__restrict__ Ag = p.A + mo, *__restrict__ Bg = p.B + mo;
   const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair], *__restrict__ sb_ = p.arena + p.off_b[pair];
-  unsigned long long *hit_keys = p.hit_keys + mo;
-  const uint32_t *cand_rows = sa_cand_rows(reinterpret_cast<uint32_t *>(p.hit_keys), mo, W, lb);
+  // the pair's part of the scratch arena: its rows' candidate columns (from the fill), then room for its hits' keys
+  const uint32_t *cand_rows = reinterpret_cast<const uint32_t *>(p.hit_keys + p.hit_off[pair]);
+  unsigned long long *hit_keys = p.hit_keys + p.hit_off[pair] + lb + 1;
+  const uint32_t hit_cap = (uint32_t)min(p.hit_off[pair + 1] - p.hit_off[pair] - (lb + 1), (uint64_t)0xffffffffu);
   const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1];
   const int thr = max(p.min_score[pair], 1);
   // LDS: the substitution table (up to SA_LDS_TABLE_MAX_K classes: one lookup per cell and row), then the records
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   int ca[CPL];                                              // codes of seq_a[x - 1]
   int thr_c[CPL];                                           // the pair's min_score; INT_MAX for columns that do not exist
   uint32_t n_hits = 0;                                      // wave-uniform
+  bool overflow = false;                                    // wave-uniform: the hit list ran out of room
   uint32_t err = 0;                                         // per lane: error of the lowest walk that met one,
   KeyT err_key = kNone;                                     // and that walk
   int chunk_code = 0;                                       // lane t: code of seq_b[y - 1] for the row t below the chunk's top
@@ -337,8 +340,9 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
           first = __builtin_amdgcn_readfirstlane(first);
         }
         const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (hit) hit_keys[pos] = (unsigned long long)wk[c];
+        if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)wk[c];
         n_hits += (uint32_t)__popcll(bal);
+        if (first + (uint32_t)__popcll(bal) > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
       }
       out_live |= wz[c] != kStay;
     }
@@ -612,14 +616,15 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   }
   const unsigned long long err_lanes = __ballot(err != 0 && (unsigned long long)err_key == first_err);
   uint32_t status = err_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)err, __builtin_ctzll(err_lanes)) : 0u;
-  if constexpr (ROWS == SA_ROWS_STRIP) {   // the strips of a pair report into the same words; the host orders the hits
+  if (overflow) status |= SA_SWEEP_OVERFLOW;
+  if constexpr (ROWS == SA_ROWS_STRIP) {   // the strips of a pair report into the same words
     if (lane == 0 && status) {
       atomicMin(p.err_key + pair, first_err);
-      atomicMax(p.status + pair, status);
+      atomicOr(p.status + pair, status);
     }
     return;
   }
-  if (n_hits > 1) {
+  if (n_hits > 1 && !overflow) {
     if (n_hits <= (uint32_t)kWave) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       const unsigned long long key = lane < (int)n_hits ? __hip_atomic_load(hit_keys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
@@ -646,12 +651,12 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
 __global__ void __launch_bounds__(kWave) sw_order_hits_kernel(const SaSweepParams p) {
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x, n_hits = p.hit_count[pair];
-  if (n_hits <= 1) return;
+  if (n_hits <= 1 || (p.status[pair] & SA_SWEEP_OVERFLOW)) return;
   if (n_hits > (uint32_t)kWave) {
     if (lane == 0) p.status[pair] |= SA_SWEEP_UNSORTED;
     return;
   }
-  unsigned long long *hit_keys = p.hit_keys + p.mat_off[pair];
+  unsigned long long *hit_keys = p.hit_keys + p.hit_off[pair] + p.len_b[pair] + 1;
   const unsigned long long key = lane < (int)n_hits ? hit_keys[lane] : ~0ull;
   uint32_t rank = 0;
   for (uint32_t j = 0; j < n_hits; ++j) rank += lane_value(key, (int)j) < key;

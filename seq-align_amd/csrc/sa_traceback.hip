@@ -18,9 +18,9 @@ namespace sa {
 
 // Where SW walk `w` starts: the cell start_index[w], or -- walks of the multi-hit path (sa_sw_sweep.hip) -- the cell
 // packed in hit number walker_rank[w] of its pair's sorted hit keys.
-__device__ __forceinline__ void sw_walk_start(const SaTraceParams &p, uint32_t w, uint64_t mo, uint32_t W, uint32_t &x, uint32_t &y) {
+__device__ __forceinline__ void sw_walk_start(const SaTraceParams &p, uint32_t w, uint32_t pair, uint32_t W, uint32_t &x, uint32_t &y) {
   if (p.hit_keys) {
-    const unsigned long long key = p.hit_keys[mo + p.walker_rank[w]];
+    const unsigned long long key = p.hit_keys[p.hit_off[pair] + p.len_b[pair] + 1 + p.walker_rank[w]];
     y = (uint32_t)key & ((1u << p.layout.row_bits) - 1u);
     x = (uint32_t)(key >> p.layout.row_bits) & ((1u << p.layout.col_bits) - 1u);
   } else {
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
   int score;
   uint32_t x, y, head = la + lb, err = 0;
   if constexpr (SW) {
-    sw_walk_start(p, w, mo, W, x, y);
+    sw_walk_start(p, w, pair, W, x, y);
     score = Mg[y * W + x];
   } else {
     // end cell: ties resolve GAP_A > GAP_B > MATCH (needleman_wunsch.c:53-66)
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
   int matrix = MAT_MATCH, score;
   uint32_t x, y, head = la + lb, err = 0;
   if constexpr (SW) {
-    sw_walk_start(p, w, mo, W, x, y);
+    sw_walk_start(p, w, pair, W, x, y);
     t.refill(x, y);
     int a_, b_;
     t.cell(x, y, score, a_, b_);
