@@ -135,14 +135,17 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_box = ctx->e[3], &d_rows = ctx->e[4],
          &d_rowoff = ctx->e[5], &d_walk = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
          &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10], &d_dst = ctx->e[11];
-  StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
+  // sources of asynchronous H2D copies: declared BEFORE the guard below, so that they are destroyed after its
+  // hipStreamSynchronize on every exit path
+  std::vector<uint64_t> hit_off(n + 1, 0), row_off, walk_str, dst_off;
+  std::vector<uint32_t> walk_pair, walk_rank;
+  StreamSyncOnExit sync_on_exit(st);
   StageTimer tm;
   const SaKeyLayout layout = key_layout(sc, c.max_a, c.max_b);
   if (!key_layout_fits(layout)) return SEQALIGN_E_TOO_LARGE;   // (seqalign_sw_batch checks the whole batch first)
 
   // ---- fill + candidates' count and box
   // every pair's part of the scratch arena (its rows' candidate columns, then its hits' keys)
-  std::vector<uint64_t> hit_off(n + 1, 0);
   {
     const int64_t best = best_move(sc);
     for (uint64_t k = 0; k < n; ++k)
@@ -184,7 +187,6 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
   // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  SEQALIGN_SWEEP_MODE=strips|pair
   // forces one (tests, experiments).
-  std::vector<uint64_t> row_off;   // (function scope: the copy below is asynchronous)
   const char *mode_env = getenv("SEQALIGN_SWEEP_MODE");
   const uint32_t w_max = c.max_a + 1;
   bool strips = w_max > 512 && (w_max > SA_SWEEP_LDS_COLUMNS || n < 1024);
@@ -247,8 +249,6 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint64_t> cell0(n + 1, 0);
   for (uint64_t k = 0; k < n; ++k)
     cell0[k + 1] = cell0[k] + ((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1);
-  std::vector<uint32_t> walk_pair, walk_rank;
-  std::vector<uint64_t> walk_str;
   uint64_t str_total = 0;
   bool overflow = false;
   std::vector<unsigned long long> big;
@@ -317,7 +317,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     HIP_TRY(hipStreamSynchronize(st));
   }
   tm.lap("sw: hit tracebacks");
-  std::vector<uint64_t> dst_off(nw);
+  dst_off.resize(nw);
   uint64_t gathered = 0;
   for (uint64_t w = 0; w < nw; ++w) {
     if (h_meta[3 * nw + w]) return (int)h_meta[3 * nw + w];
@@ -401,7 +401,8 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
       (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 32)))
     return rc;
   hipStream_t st = ctx->stream;
-  StreamSyncOnExit sync_on_exit(st);   // async copies below target function-local vectors
+  std::vector<uint64_t> dst_off(n);    // (source of an asynchronous copy: declared before the guard, destroyed after its sync)
+  StreamSyncOnExit sync_on_exit(st);
   HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
   uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status | pos[4]
   seqalign_trace_t t;
@@ -416,7 +417,6 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   // a hit is much shorter than its slot of len_a + len_b characters: pack the strings on the device, bring back
   // what was written (C3: 2 x 1.7 MB instead of 2 x 11.5 MB over PCIe)
   DevBuf &d_dst = ctx->e[11], &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
-  std::vector<uint64_t> dst_off(n);
   uint64_t gathered = 0;
   for (uint64_t k = 0; k < n; ++k) {
     if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
@@ -465,6 +465,12 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
   // inside a chunk (the CLI default depends only on the lengths, so batches of
   // equal-length pairs need a single launch)
   for (const Chunk &c : plan_chunks(batch, budget)) {
+    // sources / targets of asynchronous copies: declared before the guard, so that they outlive its
+    // hipStreamSynchronize on every way out of this iteration
+    std::vector<uint64_t> c_off;
+    std::vector<uint32_t> c_cap, h_cidx;
+    std::vector<int32_t> h_cscore;
+    StreamSyncOnExit chunk_sync(ctx->stream);
     seqalign_dev_batch_t d;
     if ((rc = run_chunk(ctx, batch, c, sc, &d))) break;
     const uint64_t n = c.count;
@@ -486,8 +492,8 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
     uint32_t *h_count = ctx->h_misc.as<uint32_t>();
     HIP_TRY(hipMemcpyAsync(h_count, ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::vector<uint64_t> c_off(n);
-    std::vector<uint32_t> c_cap(h_count, h_count + n);
+    c_off.resize(n);
+    c_cap.assign(h_count, h_count + n);
     uint64_t total = 0;
     for (uint64_t k = 0; k < n; ++k) { c_off[k] = total; total += c_cap[k]; }
     if ((rc = ctx->cand_index.reserve(total * 4 + 4)) || (rc = ctx->cand_score.reserve(total * 4 + 4))) break;
@@ -499,8 +505,8 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
 
     const size_t bytes = c.cells * 4;
     if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) break;
-    std::vector<uint32_t> h_cidx(total + 1);
-    std::vector<int32_t> h_cscore(total + 1);
+    h_cidx.resize(total + 1);
+    h_cscore.resize(total + 1);
     hipError_t e = hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_A.p, ctx->A.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_B.p, ctx->B.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
