@@ -121,7 +121,8 @@ static SaKeyLayout key_layout(const seqalign_dev_scoring *sc, uint32_t max_a, ui
 static bool key_layout_fits(const SaKeyLayout &l) { return l.row_bits + l.col_bits + l.score_bits <= 63; }
 
 // SW hits of one chunk, enumerated on the device:
-//   fill (reports the candidates' count and box) -> reverse sweep (sa_sw_sweep.hip: every hit's key, in order)
+//   fill (reports the candidates' count, box and columns per row) -> reverse sweep (sa_sw_sweep.hip: every hit's
+//   key, in order)
 //   -> one traceback per wanted hit -> strings packed -> D2H.
 // Host round trips: the hit counts (they size the traceback), the hits' lengths (they size the packing), the strings.
 // Appends to the caller's hit array / string buffers.
@@ -246,9 +247,6 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
             (unsigned long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, hits_total / n, sum[5] / n, sum[6] / n, sum[7] / n);
   }
 
-  std::vector<uint64_t> cell0(n + 1, 0);
-  for (uint64_t k = 0; k < n; ++k)
-    cell0[k + 1] = cell0[k] + ((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1);
   uint64_t str_total = 0;
   bool overflow = false;
   std::vector<unsigned long long> big;
