@@ -220,8 +220,9 @@ struct ScoringGuard {
 
 // the fill on device-resident data; best_score / best_index (optional, SW): filled by the fill itself
 // when the stream kernel runs (*best_done = true), otherwise the caller runs the separate reduction
-// cand (optional, SW): ask the fill for the multi-hit path's candidate keys; *cand_done tells whether the fill
-// kernel emitted them (the stream kernel does), otherwise the caller runs sa_launch_sw_emit over match_scores
+// cand (optional, SW): ask the fill for what the multi-hit path needs to know about the candidates (count, box,
+// columns per row); *cand_done tells whether the fill kernel reported them (the stream kernel does), otherwise
+// the caller runs sa_launch_sw_box over match_scores
 int fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                 int kernel, void *stream, int32_t *best_score, uint64_t *best_index, bool *best_done,
                 const SaCandBox *cand = nullptr, bool *cand_done = nullptr);

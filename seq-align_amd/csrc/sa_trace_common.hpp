@@ -1,5 +1,5 @@
 // sa_trace_common.hpp -- one traceback step on the device, shared by
-// sa_traceback.hip (NW / best SW hit) and sa_sw_enum.hip (SW hit enumeration).
+// sa_traceback.hip (NW / SW hits) and sa_sw_sweep.hip (SW hit enumeration: where a walk goes from a cell).
 // Decision order of alignment_reverse_move (reference src/alignment.c:244-350).
 #pragma once
 
