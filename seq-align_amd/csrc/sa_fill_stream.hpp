@@ -157,7 +157,7 @@ constexpr int kBestRowBits = 21;   // packed tie-break: column (11 bits) | row (
 
 // What else the kernel reports about match_scores while the values are in registers (SW only):
 //   SA_STREAM_BEST  the best cell per pair (above) -- seqalign_sw_batch with max_hits = 1
-//   SA_STREAM_CAND  how many cells have score >= cand_min[pair] and their bounding box -- the candidate scan of
+//   SA_STREAM_CAND  whether any cell has score >= cand_min[pair] (cand_count: 0 / 1) and the cells' bounding box -- the candidate scan of
 //                   smith_waterman.c:152-156 for the multi-hit path, which then sweeps only the box's rows
 //                   (sa_sw_sweep.hip), and within a row only the columns between its lowest and highest candidate
 //                   (cand_rows: two uint32 per row, 64 rows per store).  Per row: one ballot per column slot; rows
@@ -271,15 +271,10 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
         any |= bal[c];
       }
       uint32_t row_lo = 0xffffffffu, row_hi = 0;   // this row's candidates: lowest / highest column (wave-uniform)
-      if (any) {   // wave-uniform
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          cand_n += (uint32_t)__popcll(bal[c]);
-          if (bal[c]) {
-            row_lo = min(row_lo, (uint32_t)__builtin_ctzll(bal[c]) * CPL + c);
-            row_hi = max(row_hi, (uint32_t)(63 - __builtin_clzll(bal[c])) * CPL + c);
-          }
-        }
+      if (any) {   // wave-uniform.  At lane granularity (a lane's CPL columns): the sweep only needs bounds
+        row_lo = (uint32_t)__builtin_ctzll(any) * CPL;
+        row_hi = (uint32_t)(63 - __builtin_clzll(any)) * CPL + (CPL - 1);
+        cand_n = 1;
         box_cmin = min(box_cmin, row_lo);
         box_cmax = max(box_cmax, row_hi);
         box_rmin = min(box_rmin, j);
@@ -288,7 +283,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
       // per-row ranges: lane q keeps row j's, 64 rows leave as one coalesced store
       if (lane == q) { rr_lo = row_lo; rr_hi = row_hi; }
       if (q == kWave - 1 || j == lb) {
-        if (lane <= q) *reinterpret_cast<uint2 *>(cand_rows + 2ull * (j - q + lane)) = make_uint2(rr_lo, rr_hi);
+        if (lane <= q) *reinterpret_cast<uint2 *>(cand_rows + 2ull * (j - q + lane)) = make_uint2(rr_lo, min(rr_hi, W - 1));
       }
     }
   }
@@ -298,7 +293,7 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
     if (lane == 0) {
       p.cand_count[pair] = cand_n;
       uint32_t *box = p.cand_box + 4ull * pair;
-      box[0] = box_rmin; box[1] = box_rmax; box[2] = box_cmin; box[3] = box_cmax;
+      box[0] = box_rmin; box[1] = box_rmax; box[2] = box_cmin; box[3] = min(box_cmax, W - 1);
     }
   }
 

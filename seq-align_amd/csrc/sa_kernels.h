@@ -27,9 +27,9 @@ struct SaFillParams {
   int32_t *best_score;
   uint64_t *best_index;
   /* optional (stream kernel, SW): what the multi-hit path needs to know about match_scores before it sweeps the
-   * matrices backwards (sa_sw_sweep.hip) -- how many cells have score >= max(cand_min[pair], 1) (the candidates of
-   * smith_waterman.c:152-156) and their bounding box: cand_box[4*pair..] = first row, last row, lowest column,
-   * highest column holding a candidate. */
+   * matrices backwards (sa_sw_sweep.hip) -- whether any cell has score >= max(cand_min[pair], 1) (the candidates of
+   * smith_waterman.c:152-156; cand_count != 0) and bounds of where they are: cand_box[4*pair..] = first row, last row,
+   * a column at or below the lowest, a column at or above the highest candidate column. */
   const int32_t *cand_min;
   uint32_t *cand_count;
   uint32_t *cand_box;
