@@ -437,6 +437,60 @@ def test_sw_batch_hit_lists_at_config_size(ctx, name, where, monkeypatch):
                 assert rc == 0 and live == want
 
 
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_sw_batch_full_size_hit_list_properties(ctx, name):
+    """seqalign_sw_batch with up to 4 hits per pair on the FULL config (10 000 x 150x1000 DNA / 4 000 x 300x300
+    BLOSUM62), through properties that do not need the oracle's minutes: (1) hit 0 of every pair is the hit the
+    best-hit path (max_hits = 1: fill's best cell + one traceback) reports; (2) every hit's two strings re-score to
+    its score under the scoring (substitutions + affine gaps) and are the sequences' own characters at pos / len;
+    (3) a pair's hits come in the reference's order (score desc, then end column asc, then end row asc) and never
+    share a cell (smith_waterman.c:187-199: a walk that meets a marked cell is no hit); (4) a strided sample equals
+    the oracle's sequential enumeration."""
+    cfg = FULL[name]
+    sc = S.make_scoring(cfg["scoring"])
+    osc = oracle_scoring_of(sc)
+    batch = cfg["gen"](cfg["n"], **cfg["kwargs"])
+    thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
+    n = batch.n_pairs
+    multi = ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * n + 8)
+    best = ctx.sw_batch(batch, sc, thr, max_hits=1, hit_cap=n + 8)
+    table = np.zeros((128, 128), np.int64)
+    for x in range(32, 127):
+        for y in range(32, 127):
+            s_, m_ = C.c_int(0), C.c_int(0)
+            if O.oracle().orc_scoring_lookup(C.byref(osc), C.c_char(bytes([x])), C.c_char(bytes([y])), C.byref(s_), C.byref(m_)) == 0:
+                table[x, y] = s_.value
+    go, ge = osc.gap_open, osc.gap_extend
+    assert sum(len(h) for h in multi) >= n // 2
+    for p in range(n):
+        assert multi[p][:1] == best[p], (name, p)
+        a, b = batch.seq_a(p), batch.seq_b(p)
+        cells, prev = set(), None
+        for h in multi[p]:
+            sa_, sb_ = h["a"].encode(), h["b"].encode()
+            assert sa_.replace(b"-", b"") == a[h["pos_a"]:h["pos_a"] + h["len_a"]]
+            assert sb_.replace(b"-", b"") == b[h["pos_b"]:h["pos_b"] + h["len_b"]]
+            score, x, y, in_gap = 0, h["pos_a"], h["pos_b"], 0
+            for ca, cb in zip(sa_, sb_):
+                if ca == 45 or cb == 45:
+                    which = 1 if ca == 45 else 2
+                    score += ge + (go if in_gap != which else 0)
+                    in_gap = which
+                    x, y = x + (cb == 45), y + (ca == 45)
+                else:
+                    score += int(table[ca, cb]); in_gap = 0
+                    x, y = x + 1, y + 1
+                assert (x, y) not in cells, (name, p)
+                cells.add((x, y))
+            assert score == h["score"] >= thr, (name, p, score, h["score"])
+            key = (-h["score"], h["pos_a"] + h["len_a"], h["pos_b"] + h["len_b"])
+            assert prev is None or prev < key, (name, p)
+            prev = key
+    for p in range(0, n, max(1, n // 12)):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, 4)
+        assert rc == 0 and multi[p] == want, (name, p)
+
+
 @pytest.mark.parametrize("pad_cells", [32, 1])
 def test_workgroup_stream_kernel_long_rows(ctx, pad_cells):
     """sa_fill_wgstream.hip: rows of 513 .. 4 096 columns split over 4 or 8 waves of one
