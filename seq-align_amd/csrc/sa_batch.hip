@@ -48,22 +48,30 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
     h_mat[k] = cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
   }
-  constexpr uint64_t kPack = 2048;     // bytes: in parallel, 2048 pairs per task
-  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
-    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
-      const uint64_t p = c.first + k;
-      memcpy(h_seq + h_off_a[k], b->arena + b->off_a[p], b->len_a[p]);
-      memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
-    }
-  });
-  tm.lap("run_chunk: pack");
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
   if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
   hipStream_t st = ctx->stream;
-  HIP_TRY(hipMemcpyAsync(ctx->arena.p, h_seq, c.seq_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
+  // the sequences: packed by the thread pool 2048 pairs per task, in slices of ~8 MB -- a slice's DMA runs while the
+  // next one is being packed
+  constexpr uint64_t kPack = 2048, kSliceBytes = 8u << 20;
+  for (uint64_t k0 = 0; k0 < n;) {
+    uint64_t k1 = k0;
+    while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < kSliceBytes)) k1 = std::min(n, k1 + kPack);
+    parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
+      for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
+        const uint64_t p = c.first + k;
+        memcpy(h_seq + h_off_a[k], b->arena + b->off_a[p], b->len_a[p]);
+        memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
+      }
+    });
+    const uint64_t lo = h_off_a[k0], hi = k1 < n ? h_off_a[k1] : c.seq_bytes;
+    if (hi > lo) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + lo, h_seq + lo, hi - lo, hipMemcpyHostToDevice, st));
+    k0 = k1;
+  }
+  tm.lap("run_chunk: pack + H2D");
   uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
   uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
   seqalign_dev_batch_t d;
@@ -83,7 +91,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
   }
   if (rc) return rc;
-  tm.lap("run_chunk: enqueue H2D + fill");
+  tm.lap("run_chunk: enqueue fill");
   if (dev_out) *dev_out = d;
   return SEQALIGN_OK;
 }
