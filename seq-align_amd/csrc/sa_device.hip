@@ -247,10 +247,12 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     if (reports) { if (best_done) *best_done = true; }
     else p.best_score = nullptr, p.best_index = nullptr;
   }
-  if (which == SEQALIGN_KERNEL_STREAM && cand) {   // candidates' count and box straight from the fill's registers
+  if ((which == SEQALIGN_KERNEL_STREAM || which == SEQALIGN_KERNEL_WGSTREAM) && cand) {   // where the candidates are, straight from the fill's registers
     p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box; p.cand_rows = cand->cand_rows;
     p.cand_rows_off = cand->hit_off;
-    if (sa_stream_kernel_emits_candidates(p, batch->max_len_a)) { if (cand_done) *cand_done = true; }
+    const bool reports = which == SEQALIGN_KERNEL_STREAM ? sa_stream_kernel_emits_candidates(p, batch->max_len_a)
+                                                          : sa_wgstream_kernel_emits_candidates(p, batch->max_len_a);
+    if (reports) { if (cand_done) *cand_done = true; }
     else p.cand_count = nullptr;
   }
   switch (which) {

@@ -38,9 +38,12 @@ constexpr int kWgMaxWaves = 8;   // 4 waves up to 2 048 columns, 8 up to 4 096 (
 // TIGHT (8 waves): the ring only holds the backlog plus ONE row (not the extra row of all lanes), so three
 // workgroups fit a CU instead of one: idle lanes do not write, and a second barrier separates the flush of
 // the previous rows from the append of the next.
-template <int CPL, int SUBST, int kWgWaves, bool GENERAL, bool BEST>
+// MODE: 0 = the matrices only; 1 (SW) = also the pair's best cell; 2 (SW) = also where the cells >= cand_min[pair] are
+// (SaFillParams::cand_*: any at all, bounding box, lowest / highest column per row -- for the multi-hit path's sweep)
+template <int CPL, int SUBST, int kWgWaves, bool GENERAL, int MODE>
 __global__ void __launch_bounds__(kWave *kWgWaves)
 fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per matrix */) {
+  constexpr bool BEST = MODE == 1, CAND = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   // LDS: [3 rings of R ints][slots: 2 parities x 4 waves x {z_last, total}][substitution table]
   int32_t *ring = lds;
@@ -69,8 +72,17 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
              no_gaps_b = (p.flags & SA_F_NO_GAPS_B) != 0;
   __shared__ unsigned long long s_err;          // first cell without a score (GENERAL)
   __shared__ unsigned long long s_best;         // BEST: max over the workgroup of score << 32 | ~(column << 21 | row)
-  if (threadIdx.x == 0) { s_err = ~0ull; s_best = 0ull; }
+  __shared__ uint32_t s_row_lo[2], s_row_hi[2]; // CAND: this row's candidate columns over the waves, by row parity
+  if (threadIdx.x == 0) { s_err = ~0ull; s_best = 0ull; s_row_lo[0] = s_row_lo[1] = 0xffffffffu; s_row_hi[0] = s_row_hi[1] = 0u; }
   unsigned long long err = ~0ull;
+  int cand_thr = INT32_MAX;
+  uint32_t *cand_rows = nullptr;
+  uint32_t box_rmin = 0xffffffffu, box_rmax = 0, box_cmin = 0xffffffffu, box_cmax = 0;   // (thread 0)
+  if constexpr (CAND) {
+    cand_thr = max(p.cand_min[pair], 1);
+    cand_rows = p.cand_rows + 2ull * p.cand_rows_off[pair];
+    if (threadIdx.x == 0) *reinterpret_cast<uint2 *>(cand_rows) = make_uint2(0xffffffffu, 0u);   // row 0: borders only
+  }
 
   // stream positions (all wave-uniform, identical in the four waves)
   const uint32_t a0 = (uint32_t)(((uintptr_t)(p.M + mo) >> 2) & 255u);   // arenas are congruent mod 4 KiB
@@ -203,6 +215,18 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
       }
     }
 
+    if constexpr (CAND) {   // my wave's candidate columns of this row (at lane granularity), merged in LDS before the barrier
+      bool mine = false;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) mine |= (g_first + c <= la) && mv[c] >= cand_thr;
+      const unsigned long long any = __ballot(mine);
+      if (any && lane == 0) {
+        const uint32_t base = wave * kWave * CPL;
+        atomicMin(&s_row_lo[j & 1u], base + (uint32_t)__builtin_ctzll(any) * CPL);
+        atomicMax(&s_row_hi[j & 1u], min(base + (uint32_t)(63 - __builtin_clzll(any)) * CPL + (CPL - 1), la));
+      }
+    }
+
     // ---- 2. gap_b: local part of the prefix max
     bool free_row = false, forced = false;              // wave-uniform (reference alignment.c:139-155)
     if constexpr (GENERAL) {
@@ -228,6 +252,14 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
 
     // ---- 3. one barrier, then the carries
     __syncthreads();
+    if constexpr (CAND) {
+      if (threadIdx.x == 0) {   // (the slot of this parity is next written after the NEXT row's barrier)
+        const uint32_t lo = s_row_lo[j & 1u], hi = s_row_hi[j & 1u];
+        s_row_lo[j & 1u] = 0xffffffffu; s_row_hi[j & 1u] = 0u;
+        *reinterpret_cast<uint2 *>(cand_rows + 2ull * j) = make_uint2(lo, hi);
+        if (lo <= hi) { box_rmin = min(box_rmin, j); box_rmax = j; box_cmin = min(box_cmin, lo); box_cmax = max(box_cmax, hi); }
+      }
+    }
     int carry = INT32_MIN;                              // into my wave
     int left_total = INT32_MIN, left_carry = INT32_MIN, left_z = 0;
 #pragma unroll
@@ -271,6 +303,13 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     __syncthreads();
   }
   if (threadIdx.x == 0) p.status[pair] = GENERAL ? s_err : ~0ull;
+  if constexpr (CAND) {
+    if (threadIdx.x == 0) {
+      p.cand_count[pair] = box_rmin <= box_rmax ? 1u : 0u;
+      uint32_t *box = p.cand_box + 4ull * pair;
+      box[0] = box_rmin; box[1] = box_rmax; box[2] = box_cmin; box[3] = box_cmax;
+    }
+  }
   if constexpr (BEST) {
     int b = 0;
     uint32_t tie = 0;   // (column << 21) | row of the best cell; lowest column, then lowest row, wins a tie
@@ -318,10 +357,12 @@ static hipError_t launch_wg(const SaFillParams &p, uint32_t max_len_a, hipStream
   const bool general = needs_general(p);
   // best-cell reporting: SW only, rows / columns that fit the packed tie-break (21 / 11+ bits)
   const bool best = p.best_score && p.best_index && (p.flags & SA_F_IS_SW);
+  const bool cand = p.cand_count && p.cand_box && p.cand_rows && p.cand_rows_off && p.cand_min && (p.flags & SA_F_IS_SW);
 #define SA_WG_LAUNCH(SUBST_, GEN_, LDS_)                                                                              \
   do {                                                                                                                \
-    if (best) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, true>), grid, block, LDS_, stream, p, R); \
-    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, false>), grid, block, LDS_, stream, p, R);     \
+    if (cand) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, 2>), grid, block, LDS_, stream, p, R);    \
+    else if (best) hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, 1>), grid, block, LDS_, stream, p, R); \
+    else hipLaunchKernelGGL((fill_wgstream_kernel<CPL, SUBST_, NW, GEN_, 0>), grid, block, LDS_, stream, p, R);         \
   } while (0)
   if (p.K <= 1) {
     if (general) SA_WG_LAUNCH(SA_SUBST_SIMPLE, true, lds);
@@ -337,6 +378,11 @@ static hipError_t launch_wg(const SaFillParams &p, uint32_t max_len_a, hipStream
   return hipGetLastError();
 }
 }  // namespace sa
+
+bool sa_wgstream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a) {
+  return p.cand_count && p.cand_box && p.cand_rows && p.cand_rows_off && p.cand_min && (p.flags & SA_F_IS_SW) &&
+         sa_wgstream_kernel_applicable(p, max_len_a);
+}
 
 bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b) {
   return p.best_score && p.best_index && (p.flags & SA_F_IS_SW) && sa_wgstream_kernel_applicable(p, max_len_a) &&

@@ -174,6 +174,7 @@ hipError_t sa_launch_fill_strips(const SaFillParams &p, uint32_t max_len_a, uint
 bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream);
 bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
+bool sa_wgstream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */

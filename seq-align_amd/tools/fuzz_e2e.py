@@ -74,6 +74,8 @@ while time.time() < t_end:
         os.environ["SEQALIGN_SWEEP_MODE"] = "strips"
     elif mode == 4:
         os.environ["SEQALIGN_KERNEL"] = "rowscan"
+    elif mode == 5:
+        os.environ["SEQALIGN_KERNEL"] = "wgstream"   # (rows over 512 columns: reports the candidates itself; else falls back)
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
         res = ctx.nw_batch(batch, sc)
         for p, (a, b) in enumerate(pairs):

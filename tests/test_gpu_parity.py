@@ -703,13 +703,16 @@ def test_sw_sweep_enumeration(ctx, sweep_variant):
         assert rc == 0 and got[p] == want, (sweep_variant, "large scores", p)
 
 
-@pytest.mark.parametrize("mode", ["default", "pair", "strips"])
+@pytest.mark.parametrize("mode", ["default", "pair", "strips", "wgstream-fill"])
 def test_sw_sweep_wide_pairs_and_many_hits(ctx, mode, monkeypatch):
     """Wide rows (600 .. 2 500 columns: 1 200+ take a fill that cannot report the candidates' box and rows itself;
     one wave per pair with the winners of two rows in LDS, or one wave per 256-column strip -- the default for few
     pairs and beyond 2 048 columns) and pairs with hundreds of hits (more than the 64 the sweep ranks itself: ordered
     by the host) -- against the oracle."""
-    if mode != "default":
+    if mode == "wgstream-fill":      # the workgroup-per-pair fill reports the candidates' box and rows itself
+        monkeypatch.setenv("SEQALIGN_KERNEL", "wgstream")
+        monkeypatch.setenv("SEQALIGN_SWEEP_MODE", "pair")
+    elif mode != "default":
         monkeypatch.setenv("SEQALIGN_SWEEP_MODE", mode)
     rng = W.Rng(1717)
 
