@@ -349,6 +349,7 @@ def run(args) -> int:
                        "global_pairs": global_pairs, "kernel": S.KERNEL_NAMES[kernel],
                        "parallelism": f"pair-sharded x{world}, no data-path collective; control plane: {backend}",
                        "arena_placement": args.placement, "arena_placement_quality": round(db.placement_quality, 3),
+                       "arena_placement_search": db.placement_info,
                        "cells_per_step_per_gpu": batch.cells(), "ranks_share_devices": folded},
             "bit_exact_vs_oracle": bool(bit_exact),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

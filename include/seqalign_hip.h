@@ -114,11 +114,15 @@ typedef struct {
 /* Which fill kernel family to launch. */
 enum {
   SEQALIGN_KERNEL_AUTO = 0,
-  SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair.
-                                    CORRECTNESS path: exact for any sign of
-                                    gap_extend (a positive one is always served
-                                    by it), 4-5x slower than the row sweeps: each
-                                    lane stores to a different row             */
+  SEQALIGN_KERNEL_WAVEFRONT = 1, /* anti-diagonal wavefront, one wave per pair
+                                    (north_star's literal schedule); 4-5x slower
+                                    than the row sweeps: each lane stores to a
+                                    different row.  Kept as an independently
+                                    scheduled cross-check; never picked by AUTO.
+                                    (Until round 3 every gap_extend > 0 call was
+                                    routed here; the row sweeps now take the
+                                    trend of their gap_b scan from the right end
+                                    for a positive extension, sa_rowsweep.hpp) */
   SEQALIGN_KERNEL_ROWSCAN = 2,   /* row sweep + max-plus prefix scan for gap_b,
                                     rows stored straight from registers        */
   SEQALIGN_KERNEL_STREAM = 3,    /* same sweep, output through an LDS ring as
@@ -274,21 +278,59 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
 /* ---- arena placement ----------------------------------------------------------- */
 /* Three device buffers of bytes_each for seqalign_dev_batch_t's match_scores /
  * gap_a_scores / gap_b_scores (the reference's three malloc'd matrices,
- * src/alignment.c:183-190, for a whole batch), placed far apart in HBM: on MI355X
- * concurrent write streams within the same ~16 GiB of physical address space slow
- * each other down by ~25 %; hipMalloc'ing the three back to back is
- * the worst case.  Any 4 KiB-aligned device memory is accepted by the fill -- this
+ * src/alignment.c:183-190, for a whole batch), PLACED in HBM: on MI355X the fill's
+ * write pattern (thousands of concurrent sequential streams into three arenas) runs
+ * ~25 % slower when all three arenas lie in one "class" of physical memory than when
+ * one of them lies in another; three hipMallocs in a row usually
+ * land in one class.  Any 4 KiB-aligned device memory is accepted by the fill -- this
  * is only the fast way to get it.  The context's own scratch (host-level entry
- * points) is allocated the same way.  The placement is checked with a write
- * probe and re-tried a few times (up to a few seconds the first time; arenas are
- * meant to be kept and reused).  While it searches, the call holds up to 6 arenas + 2
- * spacers of 24..48 GiB -- never more than half of the device memory that is free at
- * that moment (beyond that it allocates plainly); SEQALIGN_ARENA_SPREAD_GIB=0 switches
- * the search off (the command-line tools do).  *quality, if not NULL, receives the probe's
- * 3-stream / 1-stream bandwidth ratio (~0.95 good, ~0.75 arenas disturb each other,
- * < 0 not probed: arenas under 256 MiB or over 12 GiB).  Free with seqalign_arenas_free. */
+ * points) is allocated the same way.
+ * How: the arenas are built with the virtual-memory API (hipMemCreate / hipMemMap)
+ * from uniform 512 MiB physical chunks.  M and A take the first chunks; further
+ * chunks are created (not mapped, not touched: ~10 us each) and every 4 GiB a window
+ * of them is mapped as a candidate third arena and timed with the fill's own store
+ * pattern against one linear stream (ratio ~0.75: the three disturb each other,
+ * >= 1.0: they do not).  The first candidate at or above the option arena_quality
+ * (default 1.0) ends the walk, otherwise the best one is kept; all other chunks go
+ * straight back.  Bounded by the option arena_scan_gib (default 160; 0 = three plain
+ * hipMallocs, what the command-line tools use) and by 60 % of the free device
+ * memory; typically 10-60 GiB are held for ~0.1 s.  Arenas under 256 MiB are
+ * allocated plainly.  *quality, if not NULL, receives the probe ratio of the result
+ * (< 0: not probed); seqalign_arenas_info tells how it was found.  Arenas are meant
+ * to be kept and reused.  Free with seqalign_arenas_free (NOT hipFree). */
 int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);
 int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]);
+
+#define SEQALIGN_ARENA_MAX_TRIES 64
+typedef struct {
+  float quality;        /* probe ratio of the arenas handed out (< 0: not probed)          */
+  float target;         /* the ratio that would have ended the walk (option arena_quality)  */
+  int32_t vmm;          /* 1: built from hipMemCreate chunks, 0: three hipMallocs            */
+  uint32_t chunk_mib;   /* chunk size                                                        */
+  float depth_gib;      /* how far behind the second arena, in allocation order, the third   */
+  float scanned_gib;    /* device memory held at the end of the walk (transient)             */
+  uint32_t tries;       /* candidates timed                                                  */
+  float try_quality[SEQALIGN_ARENA_MAX_TRIES];    /* their ratios, in order                  */
+  float try_depth_gib[SEQALIGN_ARENA_MAX_TRIES];
+} seqalign_arena_info_t;
+/* How the arenas returned by seqalign_arenas_alloc were placed (arenas[0] identifies them). */
+int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_arena_info_t *info);
+
+/* ---- context options ----------------------------------------------------------- */
+/* Everything that steers a context's choices is an option of THAT context.  The defaults are read once, in
+ * seqalign_ctx_create, from the environment (SEQALIGN_<KEY>, upper case); afterwards only this call changes
+ * them -- nothing below seqalign_ctx_create reads the environment.  Keys and values:
+ *   kernel          auto | wavefront | rowscan | stream | strips | wgstream   what SEQALIGN_KERNEL_AUTO means
+ *   traceback       device | host           where seqalign_nw_batch / seqalign_sw_batch walk the matrices
+ *   trace_kernel    auto | lane | wave      the device walker
+ *   sweep_mode      auto | pair | strips    multi-hit SW: one wave per pair / per strip
+ *   sweep_strip     0 | 64 | 128 | 256      columns per strip       sweep_cpl  0 | 1 | 2 | 4
+ *   chunk_bytes     0 | >= 1 MiB            device memory one host-level chunk may use
+ *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
+ *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
+ *   cpl, wpb, lds_pad, sweep_trace, timing  tuning experiments / development aids
+ * Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */
+int seqalign_ctx_set_option(seqalign_ctx_t *ctx, const char *key, const char *value);
 
 /* ---- CIGAR -------------------------------------------------------------------- */
 /* The reference has no CIGAR output (its result is the pair of gapped strings, src/alignment.h:33-40); this

@@ -446,9 +446,9 @@ int main(int argc, char **argv)
   pairs_t ps = {0};
   int f, rc;
   base = base ? base + 1 : argv[0];
-  /* a command-line run is short: skip the seconds the library would spend searching for a good
-     placement of its matrix arenas (seqalign_hip.h, arena placement) unless the user asks for it */
-  setenv("SEQALIGN_ARENA_SPREAD_GIB", "0", 0);
+  /* a command-line run is short: skip the ~0.1-0.2 s the library would spend looking for a good
+     placement of its matrix arenas (seqalign_hip.h, seqalign_arenas_alloc) unless the user asks for it */
+  setenv("SEQALIGN_ARENA_SCAN_GIB", "0", 0);
   memset(&opt, 0, sizeof opt);
   opt.tool = strstr(base, "sw") ? TOOL_SW : TOOL_NW;
 

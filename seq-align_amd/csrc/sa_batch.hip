@@ -32,7 +32,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
                        const SaCandBox *cand, bool *cand_done) {
   const uint64_t n = c.count;
   int rc;
-  StageTimer tm;
+  StageTimer tm(ctx->opt.timing);
   // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
   const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t));
   if ((rc = ctx->h_desc.reserve(desc_bytes))) return rc;
@@ -213,10 +213,7 @@ void sa_host::parallel_memcpy(void *dst, const void *src, size_t bytes) {
 }
 
 
-bool sa_host::traceback_on_host() {
-  const char *env = getenv("SEQALIGN_TRACEBACK");
-  return env && !strcmp(env, "host");
-}
+bool sa_host::traceback_on_host(const seqalign_ctx *ctx) { return ctx->opt.traceback_host; }
 
 // device traceback of one already-filled chunk; strings land in the caller's buffers
 static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
@@ -225,7 +222,7 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
                                      int32_t *out_score) {
   const uint64_t n = c.count;
   int rc;
-  StageTimer tm;
+  StageTimer tm(ctx->opt.timing);
   // per-pair slots of len_a+len_b chars in a compact device arena
   if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 16))) return rc;
   uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
@@ -273,6 +270,152 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
   return SEQALIGN_OK;
 }
 
+// ---- seqalign_nw_batch, device traceback: one chunk as a PIPELINE of sub-batches -------------------------------
+// The stages of a chunk -- host packs the sequences, H2D, fill (HBM-bound), traceback (a chain of dependent loads per
+// pair: latency-bound, few bytes), D2H of the strings, host unpacks -- use different parts of the machine, and run
+// strictly one after the other they cost their sum (C2: 1.3-1.4 ms for a 0.41 ms fill; C5's per-GPU share: 12.2 ms
+// for 5.1).  Cut into sub-batches of consecutive pairs they overlap:
+//   stream F (fill)   :  H2D(s) fill(s) | H2D(s+1) fill(s+1) | ...
+//   stream T (trace)  :        wait fill(s): traceback(s) D2H(s) | ...            (higher priority: its few waves
+//                                                                                   slip in between the fill's)
+//   host              :  pack(s+1) while the GPU works on s; unpack(s-1) as soon as its strings have landed
+// Same kernels, same buffers (a sub-batch is a pair range of the chunk's descriptor arrays and arenas), same results.
+// Per sub-batch the device sends back ONE block of characters (out_a | out_b of its pairs) and one of per-pair words
+// (head, len, score, status interleaved: SaTraceParams::out_meta4; the fill's status is folded in by the walker).
+static uint32_t pick_subbatches(const seqalign_ctx *ctx, const Chunk &c) {
+  if (ctx->opt.subbatches) return (uint32_t)std::min<uint64_t>(ctx->opt.subbatches, std::max<uint64_t>(c.count, 1));
+  // by size: sub-batches of >= 2 048 pairs (the lane walker's domain; below that the chip is not full either way)
+  // and >= 32 M cells (~0.4 GB of matrices, ~60 us of fill), at most 16
+  const uint64_t by_pairs = c.count / 2048, by_cells = c.cells / (32ull << 20);
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(by_pairs, by_cells), 16));
+}
+
+static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c, const seqalign_dev_scoring *sc,
+                              uint32_t n_sub, const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                              int32_t *out_score) {
+  const uint64_t n = c.count;
+  int rc;
+  StageTimer tm(ctx->opt.timing);
+  // pinned descriptor block: off_a, off_b, mat_off, slot offset (u64 x n + 1) then len_a, len_b (u32)
+  const size_t desc_bytes = (4 * n + 1) * sizeof(uint64_t) + 2 * n * sizeof(uint32_t);
+  if ((rc = ctx->h_desc.reserve(desc_bytes)) || (rc = ctx->h_arena.reserve(c.seq_bytes + 16))) return rc;
+  uint64_t *h_off_a = ctx->h_desc.as<uint64_t>(), *h_off_b = h_off_a + n, *h_mat = h_off_b + n, *h_slot = h_mat + n;
+  uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_slot + n + 1), *h_len_b = h_len_a + n;
+  uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
+  uint64_t pos = 0, cell = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t p = c.first + k;
+    h_slot[k] = pos;                       // a pair's string slot is len_a + len_b chars: the same prefix as the sequences'
+    h_off_a[k] = pos; pos += batch->len_a[p];
+    h_off_b[k] = pos; pos += batch->len_b[p];
+    h_len_a[k] = batch->len_a[p]; h_len_b[k] = batch->len_b[p];
+    h_mat[k] = cell; cell += (uint64_t)(batch->len_a[p] + 1ull) * (batch->len_b[p] + 1ull);
+  }
+  h_slot[n] = pos;
+  const uint64_t total = pos;   // == c.seq_bytes
+  if ((rc = ctx->arena.reserve(c.seq_bytes + 16)) || (rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8)) ||
+      (rc = reserve_arenas(ctx, c.cells * 4)) || (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
+      (rc = ctx->h_ta.reserve(2 * total + 16)) || (rc = ctx->h_tmeta.reserve(n * 16)))
+    return rc;
+  if (!ctx->stream2) {   // the traceback stream: higher priority than the fill's
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
+  }
+  hipStream_t sf = ctx->stream, st = ctx->stream2;
+  StreamSyncOnExit sync_f(sf), sync_t(st);   // pinned / device buffers are reused by the next call: never leave work in flight
+  EventList ev;
+  for (uint32_t s = 0; s < 2 * n_sub; ++s) HIP_TRY(ev.add(hipEventDisableTiming));
+  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, sf));
+
+  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
+  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_slot + n + 1), *dv_len_b = dv_len_a + n;
+  char *d_chars = ctx->t_out_a.as<char>();
+  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();
+  char *h_chars = ctx->h_ta.as<char>();
+  const uint32_t *h_meta = ctx->h_tmeta.as<uint32_t>();
+
+  // sub-batch s = pairs [cut[s], cut[s + 1]) of the chunk, cut at equal cells
+  std::vector<uint64_t> cut(n_sub + 1, n);
+  cut[0] = 0;
+  { uint64_t k = 0;
+    for (uint32_t s = 1; s < n_sub; ++s) {
+      const uint64_t want = c.cells / n_sub * s;
+      while (k < n && h_mat[k] < want) ++k;
+      cut[s] = std::max(k, cut[s - 1]);
+    } }
+
+  constexpr uint64_t kPack = 1024;
+  std::atomic<int> first_error{SEQALIGN_OK};
+  auto unpack = [&](uint32_t s) -> int {   // strings of sub-batch s from the pinned block into the caller's buffers
+    HIP_TRY(hipEventSynchronize(ev.ev[2 * s + 1]));
+    const uint64_t k0 = cut[s], k1 = cut[s + 1];
+    if (k1 == k0) return SEQALIGN_OK;
+    const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
+    const char *ha = h_chars + 2 * c0 - c0, *hb = h_chars + 2 * c0 + (c1 - c0) - c0;   // + slot offset
+    parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
+      for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
+        const uint64_t p = c.first + k;
+        const uint32_t head = h_meta[4 * k], len = h_meta[4 * k + 1], status = h_meta[4 * k + 3];
+        if (status) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, (int)status); continue; }
+        memcpy(out_a + str_off[p], ha + h_slot[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
+        memcpy(out_b + str_off[p], hb + h_slot[k] + head, len);
+        out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
+        out_len[p] = len;
+        out_score[p] = (int32_t)h_meta[4 * k + 2];
+      }
+    });
+    return first_error.load();
+  };
+
+  for (uint32_t s = 0; s < n_sub; ++s) {
+    const uint64_t k0 = cut[s], k1 = cut[s + 1];
+    if (k1 > k0) {
+      const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
+      // host: pack this sub-batch's sequences; stream F: ship them, fill
+      parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
+        for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
+          const uint64_t p = c.first + k;
+          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], batch->len_a[p]);
+          memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], batch->len_b[p]);
+        }
+      });
+      if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, sf));
+      seqalign_dev_batch_t d;
+      d.n_pairs = k1 - k0; d.arena = ctx->arena.as<uint8_t>();
+      d.off_a = dv_off_a + k0; d.len_a = dv_len_a + k0; d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
+      d.mat_off = dv_mat + k0;
+      d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+      d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+      if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) return rc;
+      HIP_TRY(hipEventRecord(ev.ev[2 * s], sf));
+      // stream T: walk, then this sub-batch's characters and words in one copy each
+      HIP_TRY(hipStreamWaitEvent(st, ev.ev[2 * s], 0));
+      SaTraceParams t;
+      memset(&t, 0, sizeof(t));
+      t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b; t.mat_off = d.mat_off;
+      t.M = d.match_scores; t.A = d.gap_a_scores; t.B = d.gap_b_scores; t.code = sc->d_code; t.table = sc->d_table;
+      t.str_off = dv_slot + k0;
+      t.out_a = d_chars + 2 * c0 - c0;                  // + slot offset: a-strings at [2 c0, 2 c0 + (c1 - c0))
+      t.out_b = d_chars + 2 * c0 + (c1 - c0) - c0;      //                b-strings right behind them
+      t.out_meta4 = d_meta + 4 * k0; t.fill_status = d.status;
+      t.n_pairs = (uint32_t)(k1 - k0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
+      t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
+      t.tune_walker = ctx->opt.trace_kernel;
+      hipError_t e = sa_launch_nw_traceback(t, st);
+      if (e != hipSuccess) return fail_hip(e, "traceback launch");
+      if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_chars + 2 * c0, d_chars + 2 * c0, 2 * (c1 - c0), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_meta) + 4 * k0, d_meta + 4 * k0, (k1 - k0) * 16, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ev.ev[2 * s + 1], st));
+    if (s >= 1 && (rc = unpack(s - 1))) return rc;   // the GPU has sub-batch s queued behind it
+  }
+  tm.lap("nw pipelined: all sub-batches enqueued");
+  if ((rc = unpack(n_sub - 1))) return rc;
+  tm.lap("nw pipelined: last sub-batch unpacked");
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                  const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
                                  int32_t *out_score) {
@@ -284,11 +427,18 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   ScoringGuard guard(ctx);
   if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &guard.h))) return rc;
   seqalign_dev_scoring *sc = guard.h;
-  const bool on_host = traceback_on_host();
+  const bool on_host = traceback_on_host(ctx);
   // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
   const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;
   for (const Chunk &c : plan_chunks(batch, budget)) {
     seqalign_dev_batch_t d;
+    if (!on_host) {
+      const uint32_t n_sub = pick_subbatches(ctx, c);
+      if (n_sub > 1) {
+        if ((rc = nw_chunk_pipelined(ctx, batch, c, sc, n_sub, str_off, out_a, out_b, out_len, out_score))) return rc;
+        continue;
+      }
+    }
     if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
     if (!on_host) {
       if ((rc = nw_chunk_device_traceback(ctx, batch, c, sc, d, str_off, out_a, out_b, out_len, out_score))) return rc;

@@ -141,7 +141,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint64_t> hit_off(n + 1, 0), row_off, walk_str, dst_off;
   std::vector<uint32_t> walk_pair, walk_rank;
   StreamSyncOnExit sync_on_exit(st);
-  StageTimer tm;
+  StageTimer tm(ctx->opt.timing);
   const SaKeyLayout layout = key_layout(sc, c.max_a, c.max_b);
   if (!key_layout_fits(layout)) return SEQALIGN_E_TOO_LARGE;   // (seqalign_sw_batch checks the whole batch first)
 
@@ -183,16 +183,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.hit_count = reinterpret_cast<uint32_t *>(q.err_key + n); q.status = q.hit_count + n;
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.open1 = sc->flat.open1; q.ext = sc->flat.ext;
   q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
-  q.max_len_a = c.max_a; q.layout = layout;
+  q.max_len_a = c.max_a; q.layout = layout; q.tune_cpl = ctx->opt.sweep_cpl;
   // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows up to 512 columns in registers,
   // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
-  // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  SEQALIGN_SWEEP_MODE=strips|pair
+  // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  The option sweep_mode = strips | pair
   // forces one (tests, experiments).
-  const char *mode_env = getenv("SEQALIGN_SWEEP_MODE");
+  const int mode_opt = ctx->opt.sweep_mode;   // 0 auto, 1 pair, 2 strips
   const uint32_t w_max = c.max_a + 1;
   bool strips = w_max > 512 && (w_max > SA_SWEEP_LDS_COLUMNS || n < 1024);
-  if (mode_env && mode_env[0] == 's') strips = true;
-  if (mode_env && mode_env[0] == 'p' && w_max <= SA_SWEEP_LDS_COLUMNS) strips = false;
+  if (mode_opt == 2) strips = true;
+  if (mode_opt == 1 && w_max <= SA_SWEEP_LDS_COLUMNS) strips = false;
   if (w_max <= SA_SWEEP_LDS_COLUMNS) q.lds_columns = (c.max_a + 2u) & ~1u;
   DevBuf &d_prog = ctx->e[2];
   if (strips) {
@@ -200,7 +200,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     // 64) when the pairs are so few that 256-column strips would leave most of the chip idle (2 x 10 000^2: 42.7 ->
     // 32.8 ms; 64-column strips gain nothing more: a row's dependent passes cost ~2 us whatever its width)
     uint32_t cols = sa_sweep_strip_blocks((uint32_t)n, c.max_a, 256) < 1024 ? 128 : 256;
-    if (const char *env = getenv("SEQALIGN_SWEEP_STRIP")) { const int v = atoi(env); if (v == 64 || v == 128 || v == 256) cols = (uint32_t)v; }
+    if (const uint32_t v = ctx->opt.sweep_strip; v == 64 || v == 128 || v == 256) cols = v;
     q.strip_columns = cols; q.strip_interval = cols == 256 ? 64 : 16;
     const uint32_t spp = sa_sweep_strips_per_pair(c.max_a, cols);
     const uint64_t blocks = sa_sweep_strip_blocks((uint32_t)n, c.max_a, cols);
@@ -217,7 +217,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     q.strip_progress = d_prog.as<uint32_t>(); q.strips_per_pair = spp;
     q.bnd = d_rows.as<unsigned long long>(); q.row_off = d_rowoff.as<uint64_t>();
   }
-  const bool trace = getenv("SEQALIGN_SWEEP_TRACE") != nullptr;   // development aid: per-pair counters on stderr
+  const bool trace = ctx->opt.sweep_trace;   // development aid: per-pair counters on stderr
   DevBuf &d_trace = ctx->e[12];
   if (trace) {
     if ((rc = d_trace.reserve(n * 64))) return rc;
@@ -308,7 +308,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.trace_status = dv_meta + 3 * nw; t.out_pos = dv_meta + 4 * nw;
     t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.hit_off = q.hit_off; t.layout = layout;
     t.n_pairs = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
-    t.flags = q.flags;
+    t.flags = q.flags; t.tune_walker = ctx->opt.trace_kernel;
     if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
     // ---- round trip 2: the hits (their lengths size the packing)
     HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, dv_meta, nw * 32, hipMemcpyDeviceToHost, st));
@@ -574,7 +574,7 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   seqalign_dev_scoring *sc = guard.h;
   uint64_t used_str = 0, found = 0;
   if (max_hits == 0) return SEQALIGN_OK;
-  if (max_hits == 1 && !traceback_on_host()) {   // best hit only: nothing but the strings crosses PCIe
+  if (max_hits == 1 && !traceback_on_host(ctx)) {   // best hit only: nothing but the strings crosses PCIe
     for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget))
       if ((rc = sw_chunk_best_hit(ctx, batch, c, sc, min_score, hits, hit_cap, n_hits, found, out_a, out_b, str_cap,
                                   used_str)))
@@ -585,7 +585,7 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   uint32_t max_a = 0, max_b = 0;
   for (uint64_t p = 0; p < batch->n_pairs; ++p) { max_a = std::max(max_a, batch->len_a[p]); max_b = std::max(max_b, batch->len_b[p]); }
   // (a key that does not fit the sweep's records -- scores beyond 2^28 on sequences beyond 2^16 -- goes to the host)
-  if (!traceback_on_host() && key_layout_fits(key_layout(sc, max_a, max_b))) {
+  if (!traceback_on_host(ctx) && key_layout_fits(key_layout(sc, max_a, max_b))) {
     // per cell: the three matrices + the scratch arena's share (rows' candidate columns, hits' keys)
     uint64_t arena = 0, cells = 0;
     { const int64_t best = best_move(sc);

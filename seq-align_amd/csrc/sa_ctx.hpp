@@ -95,9 +95,10 @@ void parallel_for(uint64_t n, F fn) {
 }
 
 
-// SEQALIGN_TIMING=1: wall-clock of the host-level stages on stderr (development aid)
+// option "timing": wall-clock of the host-level stages on stderr (development aid)
 struct StageTimer {
-  bool on = getenv("SEQALIGN_TIMING") != nullptr;
+  bool on;
+  explicit StageTimer(bool enabled) : on(enabled) {}
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void lap(const char *what) {
     if (!on) return;
@@ -178,6 +179,30 @@ struct HostBuf {  // grow-only pinned staging
 }  // namespace sa_host
 
 
+// Everything that steers a context's choices.  Filled ONCE, in seqalign_ctx_create, from the SEQALIGN_* environment
+// (sa_options_from_env, sa_device.hip); changed afterwards only through seqalign_ctx_set_option(ctx, key, value)
+// with key = the variable's name without the prefix, in lower case ("kernel", "traceback", "sweep_mode", ...).
+// Nothing below seqalign_ctx_create reads the environment: two contexts in one process can differ, and a test
+// steers a kernel choice on ITS context, not on the process.
+struct SaOptions {
+  int kernel = 0;                 // kernel            auto|wavefront|rowscan|stream|strips|wgstream: what KERNEL_AUTO means
+  uint32_t cpl = 0;               // cpl               columns per lane at least (tuning experiments)
+  uint32_t wpb = 0;               // wpb               pairs per workgroup of the stream kernel: 1|2|4|8
+  uint32_t lds_pad = 0;           // lds_pad           extra LDS bytes per workgroup (occupancy experiments)
+  bool traceback_host = false;    // traceback         device|host: where seqalign_nw_batch / sw_batch walk the matrices
+  uint32_t trace_kernel = 0;      // trace_kernel      auto|lane|wave: the device walker
+  int sweep_mode = 0;             // sweep_mode        auto|pair|strips (sa_batch_sw.hip)
+  uint32_t sweep_strip = 0;       // sweep_strip       64|128|256 columns per strip
+  uint32_t sweep_cpl = 0;         // sweep_cpl         1|2|4: the LDS form of the sweep
+  bool sweep_trace = false;       // sweep_trace       per-pair counters of the sweep on stderr
+  bool timing = false;            // timing            stage laps of the host-level calls on stderr
+  size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
+  uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)
+  uint32_t arena_scan_gib = 160;  // arena_scan_gib    how much HBM the arena placement may hold transiently while it looks
+                                  //                   for memory that does not disturb the first two arenas (0: allocate plainly)
+  float arena_quality = 1.0f;     // arena_quality     placement probe ratio that ends the search
+};
+
 struct seqalign_dev_scoring {
   sa_flat_scoring_t flat;   // host copy (table pointer owned)
   uint16_t *d_code = nullptr;
@@ -186,11 +211,15 @@ struct seqalign_dev_scoring {
 
 struct seqalign_ctx {
   int device = 0;
+  SaOptions opt;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream (created on first use): work that overlaps the main stream's kernels
   size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
+  size_t chunk_budget_default = 0;
   // device scratch for the host-level entry points
-  sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, M, A, B, status;
+  sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, status;
+  sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
+  SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
   sa_host::DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   sa_host::DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
   sa_host::DevBuf e[14];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
@@ -243,7 +272,7 @@ int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)
 int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
                         const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B, uint64_t *status);
-bool traceback_on_host();
+bool traceback_on_host(const seqalign_ctx *ctx);
 void parallel_memcpy(void *dst, const void *src, size_t bytes);
 
 }  // namespace sa_host

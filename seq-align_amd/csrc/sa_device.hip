@@ -35,35 +35,61 @@ extern "C" const char *seqalign_strerror(int code) {
 }
 
 // ----------------------------------------------------------------- context ---
+static SaPlacementOpts placement_opts(const seqalign_ctx *ctx) {
+  SaPlacementOpts o;
+  o.scan_bytes = (size_t)ctx->opt.arena_scan_gib << 30;
+  o.quality_stop = ctx->opt.arena_quality;
+  return o;
+}
+
 int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
-  if (bytes <= ctx->M.cap && bytes <= ctx->A.cap && bytes <= ctx->B.cap) return SEQALIGN_OK;
-  ctx->M.release(); ctx->A.release(); ctx->B.release();
+  if (ctx->arena_set && bytes <= ctx->M.cap) return SEQALIGN_OK;
+  if (ctx->arena_set) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    sa_arenas_destroy(sa_arenas_take(ctx->M.p));
+    ctx->arena_set = nullptr;
+  }
+  ctx->M = DevBuf(); ctx->A = DevBuf(); ctx->B = DevBuf();   // views of the set, never freed on their own
   const size_t want = bytes + bytes / 8 + 4096;
-  void *a[3];
-  hipError_t e = sa_alloc_arenas_spread(want, a, ctx->stream, nullptr);
-  if (e != hipSuccess) return fail_hip(e, "hipMalloc (matrix arenas)");
+  SaArenaSet *set = nullptr;
+  hipError_t e = sa_arenas_create(ctx->device, want, ctx->stream, placement_opts(ctx), &set);
+  if (e != hipSuccess) return fail_hip(e, "matrix arenas");
+  ctx->arena_set = set;
+  void *const *a = sa_arenas_base(set);
   ctx->M.p = a[0]; ctx->A.p = a[1]; ctx->B.p = a[2];
-  ctx->M.cap = ctx->A.cap = ctx->B.cap = want;
+  ctx->M.cap = ctx->A.cap = ctx->B.cap = sa_arenas_bytes(set);
   return SEQALIGN_OK;
 }
 
 extern "C" int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality) {
   if (!ctx || !arenas || !bytes_each) return SEQALIGN_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
-  float q = -1.f;
-  hipError_t e = sa_alloc_arenas_spread((size_t)bytes_each, arenas, ctx->stream, &q);
-  if (e != hipSuccess) return fail_hip(e, "hipMalloc (matrix arenas)");
-  if (quality) *quality = q;
+  SaArenaSet *set = nullptr;
+  hipError_t e = sa_arenas_create(ctx->device, (size_t)bytes_each, ctx->stream, placement_opts(ctx), &set);
+  if (e != hipSuccess) return fail_hip(e, "matrix arenas");
+  for (int k = 0; k < 3; ++k) arenas[k] = sa_arenas_base(set)[k];
+  if (quality) *quality = sa_arenas_info(set)->quality;
   return SEQALIGN_OK;
 }
 
 extern "C" int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]) {
   if (!ctx || !arenas) return SEQALIGN_E_ARG;
+  if (!arenas[0]) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  for (int k = 0; k < 3; ++k) {
-    if (arenas[k]) (void)hipFree(arenas[k]);
-    arenas[k] = nullptr;
-  }
+  SaArenaSet *set = sa_arenas_take(arenas[0]);
+  if (!set) { set_last_error("seqalign_arenas_free: not arenas of seqalign_arenas_alloc"); return SEQALIGN_E_ARG; }
+  sa_arenas_destroy(set);
+  arenas[0] = arenas[1] = arenas[2] = nullptr;
+  return SEQALIGN_OK;
+}
+
+static_assert(sizeof(seqalign_arena_info_t) == sizeof(SaArenaInfo), "seqalign_arena_info_t mirrors SaArenaInfo");
+extern "C" int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_arena_info_t *info) {
+  if (!ctx || !arenas || !info) return SEQALIGN_E_ARG;
+  const SaArenaInfo *i = sa_arenas_find_info(arenas[0]);
+  if (!i) return SEQALIGN_E_ARG;
+  memcpy(info, i, sizeof(*info));
   return SEQALIGN_OK;
 }
 
@@ -76,6 +102,70 @@ extern "C" int seqalign_device_count(void) {
     if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
   }
   return ok;
+}
+
+// ----------------------------------------------------------------- options ---
+// key = the environment variable's name without SEQALIGN_, lower case.  Returns false for an unknown key or a
+// value outside the key's range (nothing is changed then).
+static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
+  SaOptions &o = ctx->opt;
+  auto is = [&](const char *k) { return !strcmp(key, k); };
+  auto eq = [&](const char *v) { return !strcmp(val, v); };
+  const long long num = atoll(val);
+  if (is("kernel")) {
+    static const char *names[] = {"auto", "wavefront", "rowscan", "stream", "strips", "wgstream"};
+    for (int k = 0; k < 6; ++k) if (eq(names[k])) { o.kernel = k; return true; }
+    return false;
+  }
+  if (is("cpl")) { if (num < 0 || num > 16) return false; o.cpl = (uint32_t)num; return true; }
+  if (is("wpb")) { if (num != 0 && num != 1 && num != 2 && num != 4 && num != 8) return false; o.wpb = (uint32_t)num; return true; }
+  if (is("lds_pad")) { if (num < 0 || num > 160 * 1024) return false; o.lds_pad = (uint32_t)num; return true; }
+  if (is("traceback")) { if (!eq("host") && !eq("device")) return false; o.traceback_host = eq("host"); return true; }
+  if (is("trace_kernel")) {
+    if (eq("auto")) o.trace_kernel = 0; else if (eq("lane")) o.trace_kernel = 1; else if (eq("wave")) o.trace_kernel = 2; else return false;
+    return true;
+  }
+  if (is("sweep_mode")) {
+    if (eq("auto")) o.sweep_mode = 0; else if (eq("pair")) o.sweep_mode = 1; else if (eq("strips")) o.sweep_mode = 2; else return false;
+    return true;
+  }
+  if (is("sweep_strip")) { if (num != 0 && num != 64 && num != 128 && num != 256) return false; o.sweep_strip = (uint32_t)num; return true; }
+  if (is("sweep_cpl")) { if (num != 0 && num != 1 && num != 2 && num != 4) return false; o.sweep_cpl = (uint32_t)num; return true; }
+  if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
+  if (is("timing")) { o.timing = num != 0; return true; }
+  if (is("chunk_bytes")) {
+    if (num != 0 && num < (1 << 20)) return false;
+    o.chunk_bytes = (size_t)num;
+    if (num) ctx->chunk_budget = (size_t)num; else ctx->chunk_budget = ctx->chunk_budget_default;
+    return true;
+  }
+  if (is("subbatches")) { if (num < 0 || num > 256) return false; o.subbatches = (uint32_t)num; return true; }
+  if (is("arena_scan_gib")) { if (num < 0 || num > 1024) return false; o.arena_scan_gib = (uint32_t)num; return true; }
+  if (is("arena_quality")) { const double q = atof(val); if (!(q > 0.5 && q < 1.5)) return false; o.arena_quality = (float)q; return true; }
+  return false;
+}
+
+// the ONE place the library reads SEQALIGN_* tuning variables (SEQALIGN_DEVICE: sa_default_ctx_or_die;
+// SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
+static void options_from_env(seqalign_ctx *ctx) {
+  static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
+                               "sweep_cpl", "sweep_trace", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+  for (const char *k : keys) {
+    std::string name = "SEQALIGN_";
+    for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
+    if (const char *v = getenv(name.c_str())) {
+      if (!set_option(ctx, k, v)) fprintf(stderr, "seqalign: ignoring %s=%s (not a value of option \"%s\")\n", name.c_str(), v, k);
+    }
+  }
+}
+
+extern "C" int seqalign_ctx_set_option(seqalign_ctx_t *ctx, const char *key, const char *value) {
+  if (!ctx || !key || !value) return SEQALIGN_E_ARG;
+  if (!set_option(ctx, key, value)) {
+    set_last_error(std::string("seqalign_ctx_set_option: no option \"") + key + "\" with value \"" + value + "\"");
+    return SEQALIGN_E_ARG;
+  }
+  return SEQALIGN_OK;
 }
 
 extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
@@ -106,12 +196,10 @@ extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
   // (288 GB HBM3E: ~100 GB per chunk on an empty MI355X), overridable
   ctx->chunk_budget = free_b ? (free_b / 10) * 4 : (size_t)8 << 30;
   // ...but not more than 48 GB: beyond that a chunk only adds allocation time (page
-  // tables for tens of GB) and delays the first results; SEQALIGN_CHUNK_BYTES overrides
+  // tables for tens of GB) and delays the first results; the option chunk_bytes overrides
   ctx->chunk_budget = std::min<size_t>(ctx->chunk_budget, (size_t)48 << 30);
-  if (const char *env = getenv("SEQALIGN_CHUNK_BYTES")) {
-    size_t v = strtoull(env, nullptr, 10);
-    if (v >= (1u << 20)) ctx->chunk_budget = v;
-  }
+  ctx->chunk_budget_default = ctx->chunk_budget;
+  options_from_env(ctx);
   *out = ctx;
   return SEQALIGN_OK;
 }
@@ -121,8 +209,9 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
+  if (ctx->arena_set) sa_arenas_destroy(sa_arenas_take(ctx->M.p));
   for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
-                    &ctx->M, &ctx->A, &ctx->B, &ctx->status, &ctx->best_score, &ctx->best_index,
+                    &ctx->status, &ctx->best_score, &ctx->best_index,
                     &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score,
                     &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
     b->release();
@@ -173,8 +262,9 @@ extern "C" void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scori
 
 
 // --------------------------------------------------------------- hot path ---
-static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_dev_batch_t *b) {
+static SaFillParams make_params(const seqalign_ctx *ctx, const seqalign_dev_scoring_t *s, const seqalign_dev_batch_t *b) {
   SaFillParams p;
+  p.tune_cpl = ctx->opt.cpl; p.tune_wpb = ctx->opt.wpb; p.tune_lds_pad = ctx->opt.lds_pad;
   p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
   p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
   p.status = b->status; p.code = s->d_code; p.table = s->d_table;
@@ -186,15 +276,9 @@ static SaFillParams make_params(const seqalign_dev_scoring_t *s, const seqalign_
   return p;
 }
 
-static int pick_kernel(int kernel) {
+static int pick_kernel(const seqalign_ctx *ctx, int kernel) {
   if (kernel != SEQALIGN_KERNEL_AUTO) return kernel;
-  if (const char *env = getenv("SEQALIGN_KERNEL")) {
-    if (!strcmp(env, "wavefront")) return SEQALIGN_KERNEL_WAVEFRONT;
-    if (!strcmp(env, "rowscan")) return SEQALIGN_KERNEL_ROWSCAN;
-    if (!strcmp(env, "stream")) return SEQALIGN_KERNEL_STREAM;
-    if (!strcmp(env, "strips")) return SEQALIGN_KERNEL_STRIPS;
-    if (!strcmp(env, "wgstream")) return SEQALIGN_KERNEL_WGSTREAM;
-  }
+  if (ctx->opt.kernel != SEQALIGN_KERNEL_AUTO) return ctx->opt.kernel;   // option "kernel": what AUTO means on this context
   return SEQALIGN_KERNEL_STREAM;   // measured fastest (profiles/); falls back when not applicable
 }
 
@@ -210,15 +294,12 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
   if (batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_E_ARG;
   if ((uint64_t)(batch->max_len_a + 1ull) * (batch->max_len_b + 1ull) >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  SaFillParams p = make_params(scoring, batch);
+  SaFillParams p = make_params(ctx, scoring, batch);
   hipError_t e;
   (void)hipGetLastError();   // the launchers report hipGetLastError(): start from a clean slate
-  int which = pick_kernel(kernel);
-  // a positive gap_extend (legal, absurd) breaks the row scan's saturating-add
-  // identity; the wavefront kernel is exact for any sign
-  if (p.ext > 0) which = SEQALIGN_KERNEL_WAVEFRONT;
+  int which = pick_kernel(ctx, kernel);
   const bool stream_ok = sa_stream_kernel_applicable(p, batch->max_len_a);
-  if (kernel == SEQALIGN_KERNEL_AUTO && which == SEQALIGN_KERNEL_STREAM) {
+  if (kernel == SEQALIGN_KERNEL_AUTO && ctx->opt.kernel == SEQALIGN_KERNEL_AUTO) {
     // One wave per pair needs pairs to fill the chip.  Measured (seq-align_amd/tools/long_pairs.py,
     // profiles/r01_long_pairs.txt): 64 x 1000x1000 -- strips 0.49 ms, rowscan 0.86, stream 2.09;
     // 256 x 1000x1000 -- rowscan 0.99, strips 1.23, stream 2.09; 1000 x 1000x1000 -- stream 3.2,
@@ -315,6 +396,7 @@ static int launch_traceback(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *s
   p.start_index = sw ? t->start_index : nullptr; p.out_pos = sw ? t->out_pos : nullptr;
   p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
   p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
+  p.tune_walker = ctx->opt.trace_kernel;
   hipError_t e = sa_launch_nw_traceback(p, st);
   if (e != hipSuccess) return fail_hip(e, "traceback launch");
   return SEQALIGN_OK;

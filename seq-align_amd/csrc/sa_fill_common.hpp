@@ -117,14 +117,11 @@ __device__ __forceinline__ void store_partial(int32_t *dst, const int (&v)[N], i
     if (k < n) dst[k] = v[k];
 }
 
-// columns per lane for a batch whose longest seq_a is max_len_a; SEQALIGN_CPL
-// (tuning experiments) may raise it
-inline uint32_t columns_per_lane(uint32_t max_len_a) {
+// columns per lane for a batch whose longest seq_a is max_len_a; `at_least`
+// (the context's option "cpl", tuning experiments) may raise it
+inline uint32_t columns_per_lane(uint32_t max_len_a, uint32_t at_least = 0) {
   uint32_t need = (max_len_a + kWave - 1) / kWave;
-  if (const char *env = getenv("SEQALIGN_CPL")) {
-    const uint32_t v = (uint32_t)atoi(env);
-    if (v > need && v <= 16) need = v;
-  }
+  if (at_least > need && at_least <= 16) need = at_least;
   return need;
 }
 

@@ -338,11 +338,11 @@ fill_stream_kernel(const SaFillParams p, const uint32_t table_ints) {
 template <int CPL, int R, int FB, int MODE, int WPB = kWavesPerBlock>
 static hipError_t launch_cpl_mode(const SaFillParams &p, hipStream_t stream) {
   const bool general = needs_general(p);
-  int wpb = WPB;   // pairs per workgroup; SEQALIGN_WPB in {1,2,4,8} (tuning experiments)
-  if (const char *env = getenv("SEQALIGN_WPB")) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8) wpb = v; }
+  int wpb = WPB;   // pairs per workgroup; option "wpb" in {1,2,4,8} (tuning experiments)
+  if (p.tune_wpb == 1 || p.tune_wpb == 2 || p.tune_wpb == 4 || p.tune_wpb == 8) wpb = (int)p.tune_wpb;
   const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
   size_t rings = (size_t)wpb * 3 * R * sizeof(int32_t);
-  if (const char *env = getenv("SEQALIGN_LDS_PAD")) rings += (size_t)atoi(env);   // occupancy experiments
+  rings += p.tune_lds_pad;   // option "lds_pad": occupancy experiments
   if (p.K <= 1) {
     if (general) hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, true, R, FB, MODE>), grid, block, rings, stream, p, 0u);
     else hipLaunchKernelGGL((fill_stream_kernel<CPL, SA_SUBST_SIMPLE, false, R, FB, MODE>), grid, block, rings, stream, p, 0u);
@@ -361,7 +361,7 @@ static hipError_t launch_cpl_mode(const SaFillParams &p, hipStream_t stream) {
 // (a 2 KiB flush unit -- <CPL, 1024, 512> -- was measured in round 1: no difference, removed)
 template <int MODE>
 static hipError_t launch_stream_mode(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
-  const uint32_t need = columns_per_lane(max_len_a + 1);
+  const uint32_t need = columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return launch_cpl_mode<1, 512, 256, MODE>(p, stream);
   if (need <= 2) return launch_cpl_mode<2, 512, 256, MODE>(p, stream);
   if (need <= 3) return launch_cpl_mode<3, 512, 256, MODE>(p, stream);

@@ -221,7 +221,7 @@ static hipError_t launch_cpl(const SaFillParams &p, hipStream_t stream) {
 hipError_t sa_launch_fill_wavefront(const SaFillParams &p, uint32_t max_len_a,
                                     hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  const uint32_t need = sa::columns_per_lane(max_len_a);
+  const uint32_t need = sa::columns_per_lane(max_len_a, p.tune_cpl);
   if (need <= 1) return sa::launch_cpl<1>(p, stream);
   if (need <= 2) return sa::launch_cpl<2>(p, stream);
   if (need <= 3) return sa::launch_cpl<3>(p, stream);

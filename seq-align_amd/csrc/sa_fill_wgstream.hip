@@ -65,6 +65,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   const uint64_t mo = p.mat_off[pair];
   const uint32_t W = la + 1;
   const int floor_ = p.floor, open1 = p.open1, ext = p.ext;
+  const int trend0 = ext > 0 ? (int)(kWgWaves * kWave * CPL) * ext : 0;   // gap_extend > 0: trend from the right end (sa_rowsweep.hpp)
   const Border bd{p.floor, p.gap_open, p.ext, (p.flags & SA_F_IS_SW) != 0, (p.flags & SA_F_NO_START_GAP) != 0};
   // GENERAL (reference alignment.c:101-155): no_end_gap / no_gaps_in_a / no_gaps_in_b, sentinels in the
   // substitution scores, gap_open > 0 -- same case analysis as RowSweep<.., GENERAL> in sa_rowsweep.hpp
@@ -105,7 +106,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     X[c] = (g == 0) ? 0 : max(floor_, b0);
     if constexpr (GENERAL) Y[c] = X[c];
     Ap[c] = (g == 0) ? 0 : floor_;
-    const int g_ext = (int)g * ext;
+    const int g_ext = (int)g * ext - trend0;   // -t(g), sa_rowsweep.hpp
     c1[c] = open1 - g_ext; c2[c] = floor_ - g_ext; c3[c] = g_ext;
     wr[c] = (a0 + g) % R;
   }
@@ -268,7 +269,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
         const int zu = slots[par + 2 * u], tu = slots[par + 2 * u + 1];
         // wave u+1's incoming term: z_last[u] + c1(first column of wave u+1)
         const int g_next = (u + 1) * kWave * CPL;
-        const int t_next = free_row ? zu : addw(zu, open1 - g_next * ext);
+        const int t_next = free_row ? zu : addw(zu, open1 - (g_next * ext - trend0));
         if ((uint32_t)u + 1 == wave) { left_total = tu; left_carry = carry; left_z = zu; }
         carry = max(carry, max(tu, t_next));
       }
@@ -285,7 +286,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
     if (wave > 0) {
       const int g_left = (int)(wave * kWave * CPL) - 1;
       const int pm_left = max(left_total, left_carry);
-      const int b_left = forced ? floor_ : (free_row ? pm_left : addw(pm_left, g_left * ext));
+      const int b_left = forced ? floor_ : (free_row ? pm_left : addw(pm_left, g_left * ext - trend0));
       boundX = max(left_z, b_left);
     }
 

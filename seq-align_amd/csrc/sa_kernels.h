@@ -36,6 +36,8 @@ struct SaFillParams {
   uint32_t *cand_rows;          /* the multi-hit path's scratch arena (SaSweepParams::hit_keys) as uint32: pair p's part starts
                                     with its rows' candidate columns -- lowest / highest per row, rows 0..len_b (lo > hi: none) */
   const uint64_t *cand_rows_off; /* [n] where pair p's part starts, in uint64 (SaSweepParams::hit_off)                    */
+  /* launch tuning (host side only; the context's options, sa_ctx.hpp SaOptions): 0 = the launcher's own choice */
+  uint32_t tune_cpl, tune_wpb, tune_lds_pad;
 };
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit
@@ -111,7 +113,8 @@ struct SaSweepParams {
   uint32_t flags;
   uint32_t max_len_a;            /* of the chunk: picks the kernel                                    */
   SaKeyLayout layout;
-  unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (SEQALIGN_SWEEP_TRACE) */
+  unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (option sweep_trace) */
+  uint32_t tune_cpl;             /* host side only: 1, 2, 4 forces the LDS form with segments of 64 * that many columns (option sweep_cpl) */
 };
 #define SA_SWEEP_UNSORTED 0x80000000u
 #define SA_SWEEP_OVERFLOW 0x40000000u   /* more hits than the pair's part of the arena holds (cannot happen: see hit_off) */
@@ -135,6 +138,13 @@ struct SaTraceParams {
   uint32_t *out_head, *out_len;
   int32_t *out_score;
   uint32_t *trace_status;
+  /* pipelined host-level calls (sa_batch.hip): when out_meta4 != NULL the four per-walk words go there instead,
+   * interleaved -- head, len, score, status of walk w at out_meta4[4w..] -- so that one sub-batch's results are ONE
+   * contiguous D2H; fill_status (optional, [n] per pair): a fill status != ~0 (a character pair without a score,
+   * alignment_scoring.c:178-181) becomes the walk's status SEQALIGN_E_UNKNOWN_PAIR, which saves copying the fill's
+   * status words back separately */
+  uint32_t *out_meta4;
+  const uint64_t *fill_status;
   const uint64_t *start_index; /* SW: end cell of the hit per pair; NULL = NW        */
   uint32_t *out_pos;           /* SW: [4*n] pos_a, pos_b, len_a, len_b               */
   /* SW multi-hit path: n_pairs WALKS, walk w = hit walker_rank[w] of pair walker_pair[w], ending at the cell packed in
@@ -146,6 +156,7 @@ struct SaTraceParams {
   uint32_t n_pairs, K;
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
+  uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
 };
 
 /* substitution lookup flavour */
@@ -187,9 +198,28 @@ hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uin
                                  const uint32_t *len, const uint64_t *dst_off, char *dst_a, char *dst_b, uint32_t n_walkers,
                                  hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
-/* three device allocations of `bytes`, spread over HBM and checked (sa_placement.hip);
- * *quality (may be NULL): 3-stream / 1-stream write bandwidth ratio of the result, < 0 if not probed */
-hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream, float *quality);
+/* the three matrix arenas, placed and checked (sa_placement.hip) */
+#define SA_ARENA_MAX_TRIES 64
+struct SaArenaInfo {   /* = seqalign_arena_info_t (include/seqalign_hip.h) */
+  float quality, target;
+  int32_t vmm;
+  uint32_t chunk_mib;
+  float depth_gib, scanned_gib;
+  uint32_t tries;
+  float try_quality[SA_ARENA_MAX_TRIES], try_depth_gib[SA_ARENA_MAX_TRIES];
+};
+struct SaPlacementOpts {
+  size_t scan_bytes;     /* device memory the walk may hold transiently besides the arenas; 0 = allocate plainly */
+  float quality_stop;    /* probe ratio that ends the walk */
+};
+struct SaArenaSet;
+hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out);
+void sa_arenas_destroy(SaArenaSet *s);
+SaArenaSet *sa_arenas_take(void *base0);   /* removes the set from the registry (seqalign_arenas_free); NULL if unknown */
+const SaArenaInfo *sa_arenas_info(const SaArenaSet *s);
+const SaArenaInfo *sa_arenas_find_info(void *base0);
+void *const *sa_arenas_base(const SaArenaSet *s);
+size_t sa_arenas_bytes(const SaArenaSet *s);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */
 hipError_t sa_launch_dpp_probe(int32_t *out64, int32_t fill, hipStream_t stream);
 

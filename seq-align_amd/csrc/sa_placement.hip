@@ -1,30 +1,43 @@
 // sa_placement.hip -- where the three output arenas live in HBM.
 //
-// Replaces nothing in the reference (its three matrices are three malloc()s,
-// src/alignment.c:183-190); this is the MI355X side of "memory laid out for
-// 288 GB of HBM3E".
+// Replaces nothing in the reference (its three matrices are three malloc()s, src/alignment.c:183-190); this is
+// the MI355X side of "memory laid out for 288 GB of HBM3E".
 //
-// Measured (seq-align_amd/tools/placement_scan.py, tools/probes/stream_probe.hip,
-// profiles/r01_placement_*.txt): the fill kernels write M, A and
-// B concurrently, and write streams that sit within the same ~16 GiB granule of
-// PHYSICAL address space slow each other down.  With the arenas allocated back
-// to back (one allocation, or three consecutive ones -- what any allocator does
-// by default) the C2 fill takes 0.52 ms; with one arena >= 24 GB away from the
-// others 0.41 ms, the speed of a plain memset of the same bytes.  The relation
-// repeats with a period of 128 GiB.  A single sequential stream does not care,
-// which is why memset-style microbenchmarks never show it.
+// What is being dodged (tools/probes/{stream,vmm,skew,stripe}_probe.hip; profiles/r01_*placement*, r03_*probe*):
+// the fill kernels write M, A and B concurrently as thousands of sequential streams (one per wave and matrix).
+// That pattern runs at ~5 TB/s while everything it writes lies in ONE class of physical memory, and at the speed
+// of a linear memset (6.6-6.9 TB/s) when one of the three arenas lies in another class.  A class is a property
+// of the physical placement only: no low address bit matters (any skew from 1 KiB to 64 MiB between the arenas,
+// any distance inside one allocation, any virtual address: the same), classes come as blocks of tens of GiB,
+// and a single linear stream never notices -- consistent with bank / rank parallelism (more classes in flight =
+// more open DRAM rows), which user space can neither see nor ask for.
 //
-// Physical addresses are not visible from user space, but the driver hands out
-// VRAM roughly in address order, so: allocate arena, spacer, arena, spacer,
-// arena, then free the spacers (the arenas keep their placement, the spacers
-// cost nothing afterwards; a spacer is a run of arena-sized allocations, see alloc3).  Because that is a heuristic, the result is CHECKED
-// with a 3-stream write probe against a 1-stream baseline on the same memory and
-// re-tried with a different spacing, keeping the best.
+// Round 2 guessed at the placement with spacer hipMallocs, four tries; a fresh box where the guess failed four
+// times ran the headline kernel 18 % slower.  Why it could fail (stripe_probe): the VRAM manager is a buddy
+// allocator -- a request is served from the free lists of the block sizes it decomposes into, so after an arena
+// of 870 MiB the next one lands in the power-of-two remainders next to it no matter how much was allocated "in
+// between", and a big spacer is taken from another list altogether.  Allocation order says little about where
+// memory is unless every request has the SAME power-of-two size.
+//
+// So the arenas are built with the virtual-memory API from uniform power-of-two chunks:
+//   * hipMemCreate hands out physical chunks (512 MiB; one buddy block each) without mapping them: creating
+//     and releasing a chunk costs ~10 us, so holding a hundred GiB of them for a fraction of a second is free;
+//   * M and A take the first chunks; the rest of the pool is walked in allocation order, every `step` chunks a
+//     window of chunks is mapped as a candidate B and the fill's own store pattern is timed on (M, A, candidate)
+//     against one linear stream over the same bytes (quality = 3 t1 / t3: ~0.75 when all three disturb each
+//     other, >= 1.0 when they do not);
+//   * the first candidate at or above `quality_stop` ends the walk, otherwise the best one seen is kept; every
+//     other chunk goes straight back.  The result, the number of candidates tried and their qualities are
+//     reported (seqalign_arenas_info, bench.py prints them): a placement below target is SAID, never silent.
+// The walk is bounded by `scan_bytes` and by 60 % of what is free; an arena set that cannot be placed that way
+// (tiny arenas, no VMM support, no room) is three plain hipMallocs and reports quality -1 / its probe value.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "sa_kernels.h"
@@ -32,17 +45,19 @@
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef hipMemGenericAllocationHandle_t Handle;
 
-// the stream kernel's write pattern without the arithmetic: wave w owns region w
-// of each arena and appends 1 KiB blocks to the three of them in lock step
+// the stream kernel's write pattern without the arithmetic: wave w owns region w of each arena and appends
+// 1 KiB blocks to the three of them in lock step; regions are `stride_kib` apart (>= region_kib), so the probe
+// samples the whole arena when it is larger than n_regions * region_kib
 __global__ void __launch_bounds__(256) probe_three_streams(char *a0, char *a1, char *a2, uint32_t region_kib,
-                                                           uint32_t n_regions) {
+                                                           uint64_t stride_kib, uint32_t n_regions) {
   extern __shared__ int occupancy_pad[];   // 24 KiB per workgroup, like fill_stream_kernel<3,...>
   const int lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (w >= n_regions) return;
   const v4i val = {(int)w, lane, 0, 0};
-  const uint64_t base = (uint64_t)w * region_kib * 1024 + lane * 16;
+  const uint64_t base = (uint64_t)w * stride_kib * 1024 + lane * 16;
   for (uint32_t k = 0; k < region_kib; ++k) {
     __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(a0 + base + (uint64_t)k * 1024));
     __builtin_nontemporal_store(val, reinterpret_cast<v4i *>(a1 + base + (uint64_t)k * 1024));
@@ -50,7 +65,8 @@ __global__ void __launch_bounds__(256) probe_three_streams(char *a0, char *a1, c
   }
 }
 
-// baseline: one sequential stream, short-lived workgroups, 4 KiB each
+// baseline: one sequential stream over as many bytes as ONE arena gets in the probe above, short-lived
+// workgroups, 4 KiB each
 __global__ void __launch_bounds__(256) probe_one_stream(char *a, uint64_t total_kib) {
   const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= total_kib) return;
@@ -59,11 +75,11 @@ __global__ void __launch_bounds__(256) probe_one_stream(char *a, uint64_t total_
 }
 
 template <class F>
-float median_ms(hipStream_t st, F launch) {
+float median_ms(hipStream_t st, int iters, F launch) {
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
   std::vector<float> t;
-  for (int it = 0; it < 5; ++it) {
+  for (int it = 0; it < iters; ++it) {
     (void)hipEventRecord(e0, st);
     launch();
     (void)hipEventRecord(e1, st);
@@ -79,103 +95,277 @@ float median_ms(hipStream_t st, F launch) {
   return t[t.size() / 2];
 }
 
-// bandwidth of the 3-stream pattern relative to one sequential stream over the
-// same memory: ~0.75 when the arenas disturb each other, ~0.95 when they do not
-float placement_quality(void *const a[3], size_t bytes, hipStream_t st) {
-  const uint32_t region_kib = 88;
-  const size_t use = std::min(bytes, (size_t)1 << 30) / 1024;            // KiB per arena
-  const uint32_t n_regions = (uint32_t)(use / region_kib);
-  if (n_regions < 2048) return -1.f;
-  const uint64_t kib = (uint64_t)n_regions * region_kib;
-  const float t3 = median_ms(st, [&] {
-    hipLaunchKernelGGL(probe_three_streams, dim3((n_regions + 3) / 4), dim3(256), 24576, st, (char *)a[0], (char *)a[1],
-                       (char *)a[2], region_kib, n_regions);
+constexpr uint32_t kRegionKib = 88;        // a 150 x 150 pair's matrix is 89 KiB
+constexpr uint32_t kProbeRegions = 10240;  // as many waves as a C2 launch has pairs
+
+struct ProbeShape {
+  uint32_t n_regions = 0;
+  uint64_t stride_kib = 0;
+  bool ok() const { return n_regions >= 2048; }
+};
+ProbeShape probe_shape(size_t bytes) {
+  ProbeShape s;
+  const uint64_t kib = bytes / 1024;
+  s.n_regions = (uint32_t)std::min<uint64_t>(kProbeRegions, kib / kRegionKib);
+  if (s.n_regions) s.stride_kib = std::max<uint64_t>(kRegionKib, kib / s.n_regions);
+  return s;
+}
+float time_three(void *const a[3], const ProbeShape &s, hipStream_t st, int iters) {
+  return median_ms(st, iters, [&] {
+    hipLaunchKernelGGL(probe_three_streams, dim3((s.n_regions + 3) / 4), dim3(256), 24576, st, (char *)a[0], (char *)a[1],
+                       (char *)a[2], kRegionKib, s.stride_kib, s.n_regions);
   });
-  const float t1 = median_ms(st, [&] {
-    hipLaunchKernelGGL(probe_one_stream, dim3((unsigned)((kib + 3) / 4)), dim3(256), 0, st, (char *)a[0], kib);
-  });
+}
+float time_one(void *a, const ProbeShape &s, hipStream_t st) {
+  const uint64_t kib = (uint64_t)s.n_regions * kRegionKib;   // contiguous from the arena's start: fits, stride >= region
+  return median_ms(st, 6, [&] { hipLaunchKernelGGL(probe_one_stream, dim3((unsigned)((kib + 3) / 4)), dim3(256), 0, st, (char *)a, kib); });
+}
+
+// ------------------------------------------------------------------ chunks ---
+struct VmmEnv {
+  hipMemAllocationProp prop;
+  hipMemAccessDesc access;
+  bool ok = false;
+};
+VmmEnv vmm_env(int device) {
+  VmmEnv v;
+  v.prop = {};
+  v.prop.type = hipMemAllocationTypePinned;
+  v.prop.location.type = hipMemLocationTypeDevice;
+  v.prop.location.id = device;
+  v.access.location = v.prop.location;
+  v.access.flags = hipMemAccessFlagsProtReadWrite;
+  int supported = 0;
+  if (hipDeviceGetAttribute(&supported, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess) supported = 0;
+  size_t gran = 0;
+  v.ok = supported && hipMemGetAllocationGranularity(&gran, &v.prop, hipMemAllocationGranularityRecommended) == hipSuccess;
+  (void)hipGetLastError();
+  return v;
+}
+
+// a run of chunks mapped back to back at one virtual address range
+struct Mapping {
+  char *va = nullptr;
+  size_t bytes = 0, chunk = 0, mapped = 0;
+  hipError_t map(const VmmEnv &env, const Handle *hs, size_t n, size_t chunk_bytes) {
+    chunk = chunk_bytes;
+    bytes = n * chunk;
+    void *p = nullptr;
+    hipError_t e = hipMemAddressReserve(&p, bytes, 0, nullptr, 0);
+    if (e != hipSuccess) return e;
+    va = static_cast<char *>(p);
+    for (size_t i = 0; i < n; ++i) {
+      if ((e = hipMemMap(va + i * chunk, chunk, 0, hs[i], 0)) != hipSuccess) { unmap(); return e; }
+      mapped = i + 1;
+    }
+    if ((e = hipMemSetAccess(va, bytes, &env.access, 1)) != hipSuccess) { unmap(); return e; }
+    return hipSuccess;
+  }
+  void unmap() {
+    if (!va) return;
+    for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(va + i * chunk, chunk);
+    (void)hipMemAddressFree(va, bytes);
+    va = nullptr; mapped = 0;
+  }
+};
+
+}  // namespace
+
+// what seqalign_arenas_alloc hands out, and what seqalign_arenas_free needs to take it back
+struct SaArenaSet {
+  void *base[3] = {nullptr, nullptr, nullptr};
+  size_t bytes = 0;                 // usable bytes per arena
+  bool vmm = false;
+  Mapping map[3];
+  std::vector<Handle> handles[3];
+  SaArenaInfo info;
+};
+
+namespace {
+
+std::mutex g_sets_mu;
+std::map<void *, SaArenaSet *> g_sets;   // by base[0]
+
+void register_set(SaArenaSet *s) {
+  std::lock_guard<std::mutex> lk(g_sets_mu);
+  g_sets[s->base[0]] = s;
+}
+SaArenaSet *take_set(void *base0) {
+  std::lock_guard<std::mutex> lk(g_sets_mu);
+  auto it = g_sets.find(base0);
+  if (it == g_sets.end()) return nullptr;
+  SaArenaSet *s = it->second;
+  g_sets.erase(it);
+  return s;
+}
+
+float quality_of(void *const a[3], size_t bytes, hipStream_t st, int iters = 5) {
+  const ProbeShape s = probe_shape(bytes);
+  if (!s.ok()) return -1.f;
+  const float t3 = time_three(a, s, st, iters), t1 = time_one(a[0], s, st);
   if (t3 <= 0 || t1 <= 0) return -1.f;
   return 3.f * t1 / t3;
 }
 
-void free3(void *a[3]) {
-  for (int k = 0; k < 3; ++k) {
-    if (a[k]) (void)hipFree(a[k]);
-    a[k] = nullptr;
-  }
-}
-
-// arena, spacer, arena, spacer, arena; the spacers are freed again.  A spacer is made of allocations of the
-// ARENA's size: the driver's buddy allocator serves a request from the free lists of the block sizes it decomposes
-// into, so one big spacer allocation would leave the fragments next to the previous arena for the next arena
-// to land in; same-sized fillers use exactly those fragments up first.
-hipError_t alloc3(size_t bytes, size_t spacer, void *out[3]) {
-  out[0] = out[1] = out[2] = nullptr;
-  std::vector<void *> fill;
-  const size_t n_fill = spacer ? (spacer + bytes - 1) / bytes : 0;
+hipError_t plain_set(size_t bytes, hipStream_t st, bool probe, SaArenaSet *s) {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
-    for (size_t f = 0; k && f < n_fill; ++f) {
-      void *p = nullptr;
-      if (hipMalloc(&p, bytes) != hipSuccess) {   // no room: carry on with what we have
-        (void)hipGetLastError();
-        break;
-      }
-      fill.push_back(p);
-    }
-    e = hipMalloc(&out[k], bytes);
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc(&s->base[k], bytes);
+  if (e != hipSuccess) {
+    for (int k = 0; k < 3; ++k) { if (s->base[k]) (void)hipFree(s->base[k]); s->base[k] = nullptr; }
+    return e;
   }
-  for (void *p : fill) (void)hipFree(p);
-  if (e != hipSuccess) free3(out);
-  return e;
+  s->bytes = bytes;
+  s->vmm = false;
+  s->info.quality = probe ? quality_of(s->base, bytes, st) : -1.f;
+  return hipSuccess;
 }
 
 }  // namespace
 
-// SEQALIGN_ARENA_SPREAD_GIB: first spacer size (default 24; 0 = plain allocation)
-// SEQALIGN_ARENA_TRIES: placements to try at most (default 4)
-hipError_t sa_alloc_arenas_spread(size_t bytes, void *out[3], hipStream_t stream, float *quality) {
-  size_t gib = 24;
-  int tries = 4;
-  if (const char *env = getenv("SEQALIGN_ARENA_SPREAD_GIB")) gib = (size_t)strtoull(env, nullptr, 10);
-  if (const char *env = getenv("SEQALIGN_ARENA_TRIES")) tries = std::max(1, atoi(env));
-  if (quality) *quality = -1.f;
-  size_t spacer = gib << 30, free_b = 0, total_b = 0;
-  // arenas as large as the granule span several of them anyway; small ones are not bandwidth-bound
-  if (bytes >= spacer / 2 || bytes < ((size_t)256 << 20) || hipMemGetInfo(&free_b, &total_b) != hipSuccess)
-    spacer = 0;
-  if (!spacer) return alloc3(bytes, 0, out);
-
-  void *best[3] = {nullptr, nullptr, nullptr};
-  float best_q = -2.f;
-  hipError_t e = hipSuccess;
-  for (int attempt = 0; attempt < tries; ++attempt) {
-    // the best placement so far stays allocated while the next one is made: different physical memory
-    const size_t sp = spacer + (size_t)attempt * ((size_t)8 << 30);
-    // Transient footprint of an attempt: the three arenas + two spacers (+ the best placement so far, which stays
-    // allocated).  It must fit in HALF of what is free right now, so that another context / process on the same
-    // GPU is never pushed out of memory by a placement search; otherwise allocate plainly.
-    const size_t transient = 3 * bytes + 2 * sp + (best[0] ? 3 * bytes : 0);
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || transient > free_b / 2) {
-      if (best[0]) break;
-      return alloc3(bytes, 0, out);   // not enough room to spread without crowding the device
-    }
-    void *cand[3];
-    e = alloc3(bytes, sp, cand);
-    if (e != hipSuccess) break;
-    const float q = placement_quality(cand, bytes, stream);
-    if (q > best_q) {
-      free3(best);
-      for (int k = 0; k < 3; ++k) best[k] = cand[k];
-      best_q = q;
-    } else {
-      free3(cand);
-    }
-    if (best_q < 0 || best_q >= 0.97f) break;   // probe unavailable, or good enough (0.92-0.96 still costs 5-8 %)
+hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out) {
+  *out = nullptr;
+  SaArenaSet *s = new (std::nothrow) SaArenaSet();
+  if (!s) return hipErrorOutOfMemory;
+  s->info = SaArenaInfo();
+  s->info.quality = -1.f;
+  s->info.target = opt.quality_stop;
+  const size_t chunk = (size_t)512 << 20;
+  size_t free_b = 0, total_b = 0;
+  const VmmEnv env = vmm_env(device);
+  // small arenas are not bandwidth-bound; without the VMM API, or without room to look around, allocate plainly
+  const bool place = opt.scan_bytes && bytes >= ((size_t)256 << 20) && env.ok &&
+                     hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+  const size_t per = (bytes + chunk - 1) / chunk;                       // chunks per arena
+  const size_t budget = place ? std::min<size_t>(opt.scan_bytes + 3 * per * chunk, free_b / 10 * 6) : 0;
+  const size_t pool_max = budget / chunk;
+  if (!place || pool_max < 3 * per) {
+    const hipError_t e = plain_set(bytes, stream, bytes >= ((size_t)256 << 20), s);
+    if (e != hipSuccess) { delete s; return e; }
+    (void)hipGetLastError();
+    register_set(s);
+    *out = s;
+    return hipSuccess;
   }
-  if (!best[0]) return e != hipSuccess ? e : hipErrorOutOfMemory;
-  (void)hipGetLastError();   // a failed later attempt must not surface as the next launch's error
-  for (int k = 0; k < 3; ++k) out[k] = best[k];
-  if (quality) *quality = best_q;
+
+  // ---- the pool: uniform chunks in allocation order; [0, per) = M, [per, 2 per) = A
+  std::vector<Handle> pool;
+  pool.reserve(pool_max);
+  auto grow_to = [&](size_t n) {   // false: the device has no more to give (another tenant): work with what we have
+    while (pool.size() < n) {
+      Handle h;
+      if (hipMemCreate(&h, chunk, &env.prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+      pool.push_back(h);
+    }
+    return true;
+  };
+  auto release_from = [&](size_t keep_first, const std::vector<size_t> &keep_runs) {
+    // release every chunk except [0, keep_first) and the runs [r, r + per) listed
+    for (size_t i = keep_first; i < pool.size(); ++i) {
+      bool keep = false;
+      for (size_t r : keep_runs) keep = keep || (i >= r && i < r + per);
+      if (!keep) (void)hipMemRelease(pool[i]);
+    }
+  };
+  hipError_t e = hipSuccess;
+  if (!grow_to(3 * per)) {
+    release_from(0, {});
+    e = plain_set(bytes, stream, true, s);
+    if (e != hipSuccess) { delete s; return e; }
+    register_set(s);
+    *out = s;
+    return hipSuccess;
+  }
+  Mapping m, a;
+  if ((e = m.map(env, pool.data(), per, chunk)) != hipSuccess || (e = a.map(env, pool.data() + per, per, chunk)) != hipSuccess) {
+    m.unmap(); a.unmap();
+    release_from(0, {});
+    (void)hipGetLastError();
+    e = plain_set(bytes, stream, true, s);
+    if (e != hipSuccess) { delete s; return e; }
+    register_set(s);
+    *out = s;
+    return hipSuccess;
+  }
+  const ProbeShape shape = probe_shape(bytes);
+  const float t1 = time_one(m.va, shape, stream);
+
+  // ---- walk: candidate B = pool[pos, pos + per); the next candidate starts `step` chunks further (8 chunks =
+  // 4 GiB, or right behind this one if the arenas are larger than that)
+  const size_t step = std::max<size_t>(per, 8);
+  Mapping best_map;
+  size_t best_pos = 0;
+  float best_q = -2.f;
+  for (size_t pos = 2 * per; pos + per <= pool_max && s->info.tries < SA_ARENA_MAX_TRIES; pos += step) {
+    if (!grow_to(pos + per)) break;
+    Mapping c;
+    if (c.map(env, pool.data() + pos, per, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+    void *trio[3] = {m.va, a.va, c.va};
+    const float t3 = time_three(trio, shape, stream, 4);
+    const float q = (t3 > 0 && t1 > 0) ? 3.f * t1 / t3 : -1.f;
+    s->info.try_quality[s->info.tries] = q;
+    s->info.try_depth_gib[s->info.tries] = (float)((double)(pos - 2 * per) * chunk / 1073741824.0);
+    s->info.tries++;
+    if (q > best_q) {
+      best_map.unmap();
+      best_map = c; best_pos = pos; best_q = q;
+    } else {
+      c.unmap();
+    }
+    if (q < 0 || q >= opt.quality_stop) break;   // probe unavailable, or good enough
+  }
+  s->info.scanned_gib = (float)((double)pool.size() * chunk / 1073741824.0);
+  if (!best_map.va) {   // not even one candidate: B right behind A
+    if (grow_to(3 * per) && best_map.map(env, pool.data() + 2 * per, per, chunk) == hipSuccess) best_pos = 2 * per;
+  }
+  if (!best_map.va) {
+    m.unmap(); a.unmap();
+    release_from(0, {});
+    (void)hipGetLastError();
+    e = plain_set(bytes, stream, true, s);
+    if (e != hipSuccess) { delete s; return e; }
+    register_set(s);
+    *out = s;
+    return hipSuccess;
+  }
+  release_from(2 * per, {best_pos});
+  (void)hipGetLastError();   // a failed create / map of the walk must not surface as the next launch's error
+  s->vmm = true;
+  s->bytes = per * chunk;
+  s->map[0] = m; s->map[1] = a; s->map[2] = best_map;
+  s->handles[0].assign(pool.begin(), pool.begin() + per);
+  s->handles[1].assign(pool.begin() + per, pool.begin() + 2 * per);
+  s->handles[2].assign(pool.begin() + best_pos, pool.begin() + best_pos + per);
+  for (int k = 0; k < 3; ++k) s->base[k] = s->map[k].va;
+  s->info.vmm = 1;
+  s->info.chunk_mib = (uint32_t)(chunk >> 20);
+  s->info.depth_gib = (float)((double)(best_pos - 2 * per) * chunk / 1073741824.0);
+  // the figure that is reported: measured once more, on the final three, with more repetitions
+  s->info.quality = quality_of(s->base, bytes, stream, 7);
+  if (s->info.quality < 0) s->info.quality = best_q;
+  register_set(s);
+  *out = s;
   return hipSuccess;
+}
+
+void sa_arenas_destroy(SaArenaSet *s) {
+  if (!s) return;
+  if (s->vmm) {
+    for (int k = 0; k < 3; ++k) {
+      s->map[k].unmap();
+      for (Handle h : s->handles[k]) (void)hipMemRelease(h);
+    }
+  } else {
+    for (int k = 0; k < 3; ++k) if (s->base[k]) (void)hipFree(s->base[k]);
+  }
+  delete s;
+}
+
+SaArenaSet *sa_arenas_take(void *base0) { return take_set(base0); }
+const SaArenaInfo *sa_arenas_info(const SaArenaSet *s) { return &s->info; }
+void *const *sa_arenas_base(const SaArenaSet *s) { return s->base; }
+size_t sa_arenas_bytes(const SaArenaSet *s) { return s->bytes; }
+const SaArenaInfo *sa_arenas_find_info(void *base0) {
+  std::lock_guard<std::mutex> lk(g_sets_mu);
+  auto it = g_sets.find(base0);
+  return it == g_sets.end() ? nullptr : &it->second->info;
 }

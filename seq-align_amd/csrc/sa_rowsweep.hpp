@@ -24,6 +24,13 @@
 // can wrap, no saturation is needed, and the result is the serial recurrence's
 // bit for bit.  Every other add is one the reference performs itself (value >=
 // floor plus one penalty >= -|min_penalty|).
+// ext > 0 (legal upstream, a gap that pays): the same argument needs the trend
+// to move cin UP again, so it is taken from the right end instead -- with
+// t(g) = (G - g)*ext >= 0 for a G at or beyond the last column,
+//   B(g) = max_{k<=g} (cin(k) + t(k)) - t(g),
+// c1 = open1 + t(g), c2 = floor + t(g), c3 = -t(g); for ext <= 0, t(g) = -g*ext
+// is the same thing with G = 0.  One constant (`trend0` = t(0)) is all that
+// differs; the row loop is unchanged.
 #pragma once
 
 #include "sa_fill_common.hpp"
@@ -73,12 +80,14 @@ struct RowSweep {
   int Y[GENERAL ? CPL : 1];        // previous row: max(M,B) (GENERAL only, see row())
   int c1[CPL], c2[CPL], c3[CPL];   // gap_b scan constants (header comment)
   int boundX;                      // max3 of (i0, j-1): lane 0's up-left
+  int trend0;                      // t(0) of the header comment: 0 for ext <= 0, G*ext for ext > 0
   unsigned long long err = ~0ull;  // first cell without a score (GENERAL)
 
   // columns col0+1.., previous row = row 0 (reference alignment.c:61-69)
   __device__ __forceinline__ void start_strip(const SaFillParams &p, const SweepConsts &k, const Border &bd,
                                               const uint8_t *__restrict__ seq_a, uint32_t la, uint32_t i0,
                                               uint32_t col0, int lane) {
+    trend0 = k.ext > 0 ? (kWave * CPL) * k.ext : 0;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const uint32_t idx = col0 + c;
@@ -95,7 +104,7 @@ struct RowSweep {
           if constexpr (GENERAL) Y[c] = 0;
         }
       }
-      const int g_ext = (lane * CPL + c) * k.ext;
+      const int g_ext = (lane * CPL + c) * k.ext - trend0;   // -t(g)
       c1[c] = k.open1 - g_ext;
       c2[c] = k.floor_ - g_ext;
       c3[c] = g_ext;
@@ -172,7 +181,7 @@ struct RowSweep {
             w = (lane == 0) ? (free_row ? k.floor_ : c2[0]) : w;   // gap_b of (0, j) is the floor
           } else {
             // lane 0 continues the previous strip: B(left) + ext, de-trended at g = 0
-            const int carry = free_row ? feedB : addw(feedB, k.ext);
+            const int carry = free_row ? feedB : addw(addw(feedB, k.ext), trend0);
             w = (lane == 0) ? max(w, carry) : w;
           }
         }

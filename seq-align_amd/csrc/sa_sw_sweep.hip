@@ -702,11 +702,10 @@ hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks
   // spread over most of the row anyway).  Beyond that: many pairs -- one wave per pair, segments of 256 columns that
   // follow the walks, the winners of two rows in LDS; few pairs, or rows too wide for LDS -- one wave per strip of
-  // 64 / 128 / 256 columns (the caller decides: strip_progress != NULL, strip_columns).  SEQALIGN_SWEEP_CPL = 1, 2, 4 forces the LDS form
+  // 64 / 128 / 256 columns (the caller decides: strip_progress != NULL, strip_columns).  the option sweep_cpl = 1, 2, 4 forces the LDS form
   // with segments of 64 * that many columns (tests, experiments).
   const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest row
-  int forced = 0;
-  if (const char *env = getenv("SEQALIGN_SWEEP_CPL")) forced = atoi(env);
+  int forced = (int)p.tune_cpl;
   if (forced != 1 && forced != 2 && forced != 4) forced = 0;
   if (p.strip_progress) {
     if (p.strip_columns == 64) sa::launch_sweep<1, sa::SA_ROWS_STRIP>(p, stream);

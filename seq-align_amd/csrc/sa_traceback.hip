@@ -29,6 +29,20 @@ __device__ __forceinline__ void sw_walk_start(const SaTraceParams &p, uint32_t w
   }
 }
 
+// where a finished walk leaves head / len / score / status (SaTraceParams::out_meta4)
+__device__ __forceinline__ void write_walk_meta(const SaTraceParams &p, uint32_t w, uint32_t pair, uint32_t head, uint32_t len,
+                                                int score, uint32_t err) {
+  if (p.fill_status && p.fill_status[pair] != ~0ull && !err) err = 5u;   // SEQALIGN_E_UNKNOWN_PAIR
+  if (p.out_meta4) {
+    *reinterpret_cast<uint4 *>(p.out_meta4 + 4ull * w) = make_uint4(head, len, (uint32_t)score, err);
+  } else {
+    p.out_score[w] = score;
+    p.out_head[w] = head;
+    p.out_len[w] = len;
+    p.trace_status[w] = err;
+  }
+}
+
 // SW: start_index != nullptr -> local alignment ending at that match_scores cell
 // (smith_waterman.c:165-258 on a fresh mask: the first fetched hit always
 // succeeds), walked until the score reaches 0.
@@ -68,7 +82,7 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
     { const int b = Bg[corner]; if (b >= score) { matrix = MAT_GAP_B; score = b; } }
     { const int a = Ag[corner]; if (a >= score) { matrix = MAT_GAP_A; score = a; } }
   }
-  p.out_score[w] = score;
+  const int end_score = score;
   const uint32_t end_x = x, end_y = y;
 
   while (SW ? (score > 0) : (x > 0 && y > 0)) {
@@ -91,9 +105,7 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
     p.out_pos[4 * w + 3] = end_y - y;
   }
   (void)end_x; (void)end_y;
-  p.out_head[w] = head;
-  p.out_len[w] = la + lb - head;
-  p.trace_status[w] = err;
+  write_walk_meta(p, w, pair, head, la + lb - head, end_score, err);
 }
 
 // ---------------------------------------------------------------------------
@@ -238,10 +250,7 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
       p.out_pos[4 * w + 2] = end_x - x;
       p.out_pos[4 * w + 3] = end_y - y;
     }
-    p.out_score[w] = end_score;
-    p.out_head[w] = head;
-    p.out_len[w] = la + lb - head;
-    p.trace_status[w] = err;
+    write_walk_meta(p, w, pair, head, la + lb - head, end_score, err);
   }
 }
 
@@ -252,11 +261,10 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   const bool sw = p.start_index || p.hit_keys;
   // Measured (seq-align_amd/tools/long_e2e.py): the tiled wave-per-pair walker wins when there are few pairs
   // (1 x 10 000^2: 9.5 -> 7.4 ms, 16 x 5 000^2: 6.6 -> 4.2 ms of traceback) and loses a little when the lanes of
-  // one-lane-per-pair waves are all busy (10 k x 150^2: +0.13 ms).  SEQALIGN_TRACE_KERNEL=lane|wave forces one.
-  const char *force = getenv("SEQALIGN_TRACE_KERNEL");
+  // one-lane-per-pair waves are all busy (10 k x 150^2: +0.13 ms).  The option trace_kernel = lane | wave forces one.
   // SW walks (a hit is ~the shorter sequence long): the tiled walker also wins with 10 000 walks (C3: 0.58 -> 0.47 ms,
   // C4: 0.88 -> 0.45 ms)
-  const bool lane_kernel = force ? force[0] == 'l' : (!sw && p.n_pairs >= 2048);
+  const bool lane_kernel = p.tune_walker ? p.tune_walker == 1 : (!sw && p.n_pairs >= 2048);
   if (lane_kernel) {
     const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
     if (sw) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);

@@ -149,6 +149,25 @@ def batch_desc(batch: "workloads.Batch") -> BatchDesc:
                      batch.off_b.ctypes.data, batch.len_b.ctypes.data)
 
 
+OPTION_DEFAULTS = {"kernel": "auto", "cpl": 0, "wpb": 0, "lds_pad": 0, "traceback": "device", "trace_kernel": "auto",
+                   "sweep_mode": "auto", "sweep_strip": 0, "sweep_cpl": 0, "sweep_trace": 0, "timing": 0, "chunk_bytes": 0,
+                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.0}
+
+
+class ArenaInfo(C.Structure):
+    _fields_ = [("quality", C.c_float), ("target", C.c_float), ("vmm", C.c_int32), ("chunk_mib", C.c_uint32),
+                ("depth_gib", C.c_float), ("scanned_gib", C.c_float), ("tries", C.c_uint32),
+                ("try_quality", C.c_float * 64), ("try_depth_gib", C.c_float * 64)]
+
+    def as_dict(self):
+        n = int(self.tries)
+        return {"quality": round(float(self.quality), 3), "target": round(float(self.target), 3), "vmm": bool(self.vmm),
+                "chunk_mib": int(self.chunk_mib), "depth_gib": round(float(self.depth_gib), 1),
+                "scanned_gib": round(float(self.scanned_gib), 1), "tries": n,
+                "try_quality": [round(float(self.try_quality[i]), 3) for i in range(n)],
+                "try_depth_gib": [round(float(self.try_depth_gib[i]), 1) for i in range(n)]}
+
+
 class Context:
     """seqalign_ctx_t* for one device."""
 
@@ -167,6 +186,26 @@ class Context:
 
     def __exit__(self, *exc):
         self.close()
+
+    # ---- options (seqalign_ctx_set_option: key = SEQALIGN_<KEY> in lower case) -----------------
+    def set_option(self, key: str, value) -> None:
+        _check(lib().seqalign_ctx_set_option(self._h, key.encode(), str(value).encode()), f"seqalign_ctx_set_option({key}={value})")
+
+    def options(self, **kv):
+        """Context manager: set options on THIS context, put the given defaults back on exit.
+        `with ctx.options(traceback="host"): ...`; the values restored are OPTION_DEFAULTS'."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                for k, v in kv.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_inner, *exc):
+                for k in kv:
+                    ctx.set_option(k, OPTION_DEFAULTS[k])
+        return _Scope()
 
     # ---- scoring -----------------------------------------------------------
     def upload_scoring(self, scoring: Scoring, is_sw: int) -> C.c_void_p:
@@ -327,6 +366,7 @@ class DeviceBatch:
         self.mat_off = t(self.mat_off_host)
         stride = (self.total_cells + 1023) // 1024 * 1024
         self.placement_quality = -1.0
+        self.placement_info = None
         if placement == "packed":
             # one allocation, three 4 KiB-aligned arenas back to back (the stream kernel
             # wants the arenas congruent mod 4 KiB; torch's allocator only promises 512 B)
@@ -345,6 +385,9 @@ class DeviceBatch:
                    "seqalign_arenas_alloc")
             self._arena_ptrs = ptrs
             self.placement_quality = float(q.value)
+            info = ArenaInfo()
+            _check(lib().seqalign_arenas_info(self._ctx._h, ptrs, C.byref(info)), "seqalign_arenas_info")
+            self.placement_info = info.as_dict()
             self.M, self.A, self.B = (torch.as_tensor(_RawDeviceInts(ptrs[k], self.total_cells), device=dev)
                                       for k in range(3))
         self.status = torch.zeros(batch.n_pairs, dtype=torch.int64, device=dev)
@@ -450,6 +493,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
+    "seqalign_arenas_info", "seqalign_ctx_set_option",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",

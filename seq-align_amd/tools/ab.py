@@ -65,14 +65,13 @@ for v in args.variants:
 res = {v: [] for v, _, _ in parsed}
 for r in range(args.rounds + 1):
     for v, kid, env in parsed:
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
+        # variant options: SEQALIGN_<KEY>=value or key=value, set on the context for this variant's launches
+        keys = {k: (k[len("SEQALIGN_"):].lower() if k.startswith("SEQALIGN_") else k) for k in env}
+        for k, v_ in env.items():
+            ctx.set_option(keys[k], v_)
         ms = time_memset(args.launches) if kid < 0 else db.time_fill_ms(ctx, h, kid, args.launches)
-        for k, o in old.items():
-            if o is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = o
+        for k in env:
+            ctx.set_option(keys[k], S.OPTION_DEFAULTS[keys[k]])
         if r:   # round 0 = warm-up
             res[v].append(float(np.median(ms)))
 alg = db.algorithmic_bytes()

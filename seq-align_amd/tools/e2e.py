@@ -22,7 +22,7 @@ with S.Context(0) as ctx:
     batch = getattr(W, gen)(n, **kwargs)
     sc = S.make_scoring(spec)
     for mode in ("device", "host"):
-        os.environ["SEQALIGN_TRACEBACK"] = mode
+        ctx.set_option("traceback", mode)
         ctx.nw_batch(batch, sc, raw=True)             # warm-up (allocations, pinned staging)
         ts = []
         for _ in range(3):   # raw=True: time the C entry point, not Python tuple building
@@ -36,7 +36,7 @@ with S.Context(0) as ctx:
     out["fill_batch_C2_matrices_to_host"] = dict(seconds=min(ts), gcups=batch.cells() / min(ts) / 1e9,
                                                  GBps=12 * float(batch.matrix_cells().sum()) / min(ts) / 1e9)
     del M, A, B
-    os.environ["SEQALIGN_TRACEBACK"] = "device"
+    ctx.set_option("traceback", "device")
     for name in ("C3", "C4"):
         gen, kwargs, n, is_sw, spec, _ = WORKLOADS[name]
         sc = S.make_scoring(spec)
@@ -57,10 +57,10 @@ with S.Context(0) as ctx:
             ts.append(time.perf_counter() - t0)
         out[f"sw_batch_{name}_4hits_device"] = dict(seconds=min(ts), gcups=batch.cells() / min(ts) / 1e9, hits=nh)
         # the same through the host path (candidates + matrices over PCIe), a tenth of the config
-        os.environ["SEQALIGN_TRACEBACK"] = "host"
+        ctx.set_option("traceback", "host")
         batch = getattr(W, gen)(n // 10, **kwargs)
         ctx.sw_batch(batch, sc, thr, max_hits=4, raw=True)
         t0 = time.perf_counter(); nh = ctx.sw_batch(batch, sc, thr, max_hits=4, raw=True)[0]; t1 = time.perf_counter()
         out[f"sw_batch_{name}_tenth_4hits_host"] = dict(seconds=t1 - t0, gcups=batch.cells() / (t1 - t0) / 1e9, hits=nh)
-        os.environ["SEQALIGN_TRACEBACK"] = "device"
+        ctx.set_option("traceback", "device")
 print(json.dumps(out, indent=1))

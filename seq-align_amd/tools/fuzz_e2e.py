@@ -62,20 +62,21 @@ while time.time() < t_end:
             a = a[:len(a) // 2] + b"N" + a[len(a) // 2:]
         pairs.append((a, b))
     batch = W.from_pairs(pairs)
-    os.environ["SEQALIGN_TRACE_KERNEL"] = ("lane", "wave")[int(v[0] >> 7) & 1]
+    ctx.set_option("trace_kernel", ("lane", "wave")[int(v[0] >> 7) & 1])
     # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
     # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
-    for key in ("SEQALIGN_SWEEP_CPL", "SEQALIGN_SWEEP_MODE", "SEQALIGN_KERNEL"):
-        os.environ.pop(key, None)
+    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches"):
+        ctx.set_option(key, S.OPTION_DEFAULTS[key])
     mode = int(v[0] >> 9) % 8
     if mode < 3:
-        os.environ["SEQALIGN_SWEEP_CPL"] = ("1", "2", "4")[mode]
+        ctx.set_option("sweep_cpl", (1, 2, 4)[mode])
     elif mode == 3:
-        os.environ["SEQALIGN_SWEEP_MODE"] = "strips"
+        ctx.set_option("sweep_mode", "strips")
     elif mode == 4:
-        os.environ["SEQALIGN_KERNEL"] = "rowscan"
+        ctx.set_option("kernel", "rowscan")
     elif mode == 5:
-        os.environ["SEQALIGN_KERNEL"] = "wgstream"   # (rows over 512 columns: reports the candidates itself; else falls back)
+        ctx.set_option("kernel", "wgstream")   # (rows over 512 columns: reports the candidates itself; else falls back)
+    ctx.set_option("subbatches", (0, 1, 2, 5)[int(v[0] >> 12) % 4])   # seqalign_nw_batch: pipelined sub-batches
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
         res = ctx.nw_batch(batch, sc)
         for p, (a, b) in enumerate(pairs):

@@ -33,6 +33,21 @@ def ctx():
         yield c
 
 
+@pytest.fixture
+def opts(ctx):
+    """Set options on the module's context for ONE test (seqalign_ctx_set_option: a context's choices are its
+    own options, not process environment); the defaults come back afterwards."""
+    changed = []
+
+    def set_(**kv):
+        for k, v in kv.items():
+            ctx.set_option(k, v)
+            changed.append(k)
+    yield set_
+    for k in changed:
+        ctx.set_option(k, S.OPTION_DEFAULTS[k])
+
+
 def oracle_scoring_of(sc: S.Scoring) -> O.Scoring:
     return O.Scoring.from_buffer_copy(bytes(sc))
 
@@ -277,10 +292,10 @@ def test_full_size_config_properties(ctx, name):
 
 @pytest.mark.parametrize("kernel", [S.KERNEL_AUTO] + KERNELS, ids=KID)
 def test_positive_gap_extend(ctx, kernel):
-    """gap_extend > 0 (legal upstream: scoring_init takes any int, alignment_scoring.c:21-55).  The row-scan
-    kernels' de-trended prefix max assumes ext <= 0, so EVERY kernel request -- AUTO and explicit ones alike --
-    is served by the anti-diagonal kernel (sa_device.hip: fill_device); the matrices must still be the
-    reference recurrence's, and so must the alignments built from them."""
+    """gap_extend > 0 (legal upstream: scoring_init takes any int, alignment_scoring.c:21-55).  The row sweeps'
+    gap_b scan takes its trend from the right end for a positive extension (sa_rowsweep.hpp: t(g) = (G - g) ext),
+    so every kernel serves the request itself (until round 3 all of them were routed to the anti-diagonal kernel);
+    the matrices must be the reference recurrence's, and so must the alignments built from them."""
     for spec in ({"init": [1, -2, -4, 1, 0, 0, 0, 0, 0, 0]}, {"init": [2, -3, -6, 2, 0, 1, 0, 0, 0, 0]},
                  {"init": [1, -1, 0, 3, 1, 0, 0, 0, 0, 1]}):
         sc = S.make_scoring(spec)
@@ -331,20 +346,17 @@ def test_host_level_fill_batch_and_chunking(ctx):
         o, n = int(off[p]), oM.size
         assert np.array_equal(M[o:o + n], oM) and np.array_equal(A[o:o + n], oA) and np.array_equal(B[o:o + n], oB)
     # tiny chunk budget -> many chunks, same bytes
-    os.environ["SEQALIGN_CHUNK_BYTES"] = str(1 << 20)
-    try:
-        with S.Context(0) as small:
-            M2, A2, B2, _, _ = small.fill_batch(batch, sc, 0)
-    finally:
-        del os.environ["SEQALIGN_CHUNK_BYTES"]
+    with S.Context(0) as small:
+        small.set_option("chunk_bytes", 1 << 20)
+        M2, A2, B2, _, _ = small.fill_batch(batch, sc, 0)
     assert np.array_equal(M, M2) and np.array_equal(A, A2) and np.array_equal(B, B2)
 
 
 @pytest.mark.parametrize("where", ["device", "host"])
-def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
+def test_nw_batch_strings_match_oracle_and_golden(ctx, where, opts):
     """End-to-end NW: GPU fill + traceback on the device (default) or on the host
-    from the copied-back matrices (SEQALIGN_TRACEBACK=host); identical strings."""
-    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
+    from the copied-back matrices (option traceback=host); identical strings."""
+    opts(traceback=where)
     cfg = load("configs.json")["C2_related"]
     sc = S.make_scoring(cfg["scoring"])
     batch = W.make(cfg["gen"], cfg["n"], cfg["kwargs"])
@@ -364,11 +376,63 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, monkeypatch):
             assert rc == 0 and res[p] == (s, ra, rb)
 
 
+@pytest.mark.parametrize("n_sub", [2, 5, 16])
+def test_nw_batch_pipelined_subbatches(ctx, opts, n_sub):
+    """seqalign_nw_batch with a chunk cut into sub-batches that overlap fill / traceback / copies on two streams
+    (sa_batch.hip: nw_chunk_pipelined; by default only for large chunks, forced here): same strings and scores as
+    the reference's needleman_wunsch_align (src/needleman_wunsch.c:53-145) -- golden C2 pairs, a ragged batch with
+    empty sequences and sub-batch cuts inside runs of tiny pairs -- and an unknown character pair inside one
+    sub-batch is still reported (alignment_scoring.c:178-181)."""
+    opts(subbatches=n_sub)
+    cfg = load("configs.json")["C2_related"]
+    sc = S.make_scoring(cfg["scoring"])
+    res = ctx.nw_batch(W.make(cfg["gen"], cfg["n"], cfg["kwargs"]), sc)
+    for p, g in enumerate(cfg["pairs"]):
+        assert res[p] == (g["score"], g["result_a"].encode(), g["result_b"].encode())
+    osc = oracle_scoring_of(sc)
+    r = W.ragged(400, seed=300 + n_sub, max_len=180, lower_frac=0.1)
+    pairs = [(b"", b""), (b"A", b""), (b"", b"C")] * 5 + [(r.seq_a(p), r.seq_b(p)) for p in range(r.n_pairs)] + [(b"G", b"G")] * 7
+    batch = W.from_pairs(pairs)
+    res = ctx.nw_batch(batch, sc)
+    for p in range(batch.n_pairs):
+        rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+        assert rc == 0 and res[p] == (s_, ra, rb), (n_sub, p)
+    hyb = S.make_scoring({"preset": "DNA_hybridization"})
+    bad = W.from_pairs([(b"ACGT", b"ACGT")] * 40 + [(b"ACGT", b"AXGT")] + [(b"ACGT", b"ACGT")] * 40)
+    with pytest.raises(S.SeqAlignError) as err:
+        ctx.nw_batch(bad, hyb)
+    assert err.value.code == S.E_UNKNOWN_PAIR
+
+
+def test_context_options(ctx):
+    """seqalign_ctx_set_option: unknown keys and out-of-range values are refused (nothing changes), options are
+    per context, and the environment is read once, when a context is created."""
+    with pytest.raises(S.SeqAlignError) as err:
+        ctx.set_option("no_such_option", 1)
+    assert err.value.code == S.E_ARG
+    for key, val in (("kernel", "fastest"), ("traceback", "nowhere"), ("sweep_strip", 100), ("wpb", 3), ("chunk_bytes", 17)):
+        with pytest.raises(S.SeqAlignError):
+            ctx.set_option(key, val)
+    sc = S.make_scoring({"preset": "default"})
+    batch = W.dna_nw_150(64, seed=3, related=True)
+    want = ctx.nw_batch(batch, sc)
+    os.environ["SEQALIGN_TRACEBACK"] = "host"
+    try:
+        with S.Context(0) as other:          # picks "host" up at creation ...
+            os.environ["SEQALIGN_TRACEBACK"] = "nonsense"   # ... and never looks again
+            assert other.nw_batch(batch, sc) == want
+            assert ctx.nw_batch(batch, sc) == want
+    finally:
+        del os.environ["SEQALIGN_TRACEBACK"]
+    for k, v in S.OPTION_DEFAULTS.items():   # every documented key is accepted with its default
+        ctx.set_option(k, v)
+
+
 @pytest.mark.parametrize("walker", ["lane", "wave"])
-def test_device_traceback_walkers_agree_with_oracle(ctx, walker, monkeypatch):
+def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     """Both device walkers (one lane per pair from HBM; one wave per pair from 16x16 LDS tiles)
     on pairs that cross many tiles, hug the borders and end in long gap runs."""
-    monkeypatch.setenv("SEQALIGN_TRACE_KERNEL", walker)
+    opts(trace_kernel=walker)
     pairs = [(b"ACGT" * 40, b"ACGT" * 40), (b"A" * 100, b"A" * 17), (b"C" * 5, b"G" * 90), (b"ACGTTGCA" * 9, b"TTTT" + b"ACGTTGCA" * 7),
              (b"G", b"G"), (b"", b"ACGT"), (b"ACGT", b"")]
     r = W.ragged(40, seed=91, max_len=260, lower_frac=0.1)
@@ -393,11 +457,11 @@ def test_device_traceback_walkers_agree_with_oracle(ctx, walker, monkeypatch):
 
 @pytest.mark.parametrize("max_hits,where", [(5, "device"), (16, "device"), (1, "device"), (1, "host"), (5, "host"),
                                             (40, "device")])
-def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
+def test_sw_batch_hits_match_oracle(ctx, max_hits, where, opts):
     """max_hits=1: fill + reduction + traceback of the best hit on the device;
     max_hits<=16: candidates sorted and enumerated on the device (one lane per pair);
-    larger / SEQALIGN_TRACEBACK=host: candidates + matrices go back, host enumerates."""
-    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
+    larger / option traceback=host: candidates + matrices go back, host enumerates."""
+    opts(traceback=where)
     for spec, gen, kw, thr in (
             ({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, W.dna_sw_read_vs_ref, dict(seed=21, read_len=60, ref_len=300), 24),
             ({"preset": "BLOSUM62"}, W.protein_sw_300, dict(seed=22, length=120), 24),
@@ -416,12 +480,12 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, monkeypatch):
 
 @pytest.mark.parametrize("name", ["C3", "C4"])
 @pytest.mark.parametrize("where", ["device", "host"])
-def test_sw_batch_hit_lists_at_config_size(ctx, name, where, monkeypatch):
+def test_sw_batch_hit_lists_at_config_size(ctx, name, where, opts):
     """seqalign_sw_batch at the BASELINE dimensions (150x1000 DNA / 300x300 BLOSUM62, --minscore 60): the ordered
     hit lists of 64 seeded pairs, max_hits 1 and unlimited, against the committed ORACLE-DERIVED lists
     (tests/golden/sw_hits_oracle.json -- the reference's smith_waterman.c cannot be built here) and a live
     oracle run.  Reference: src/smith_waterman.c:137-277."""
-    monkeypatch.setenv("SEQALIGN_TRACEBACK", where)
+    opts(traceback=where)
     g = load("sw_hits_oracle.json")[name]
     sc = S.make_scoring({"preset": "BLOSUM62"} if g["scoring"] == "BLOSUM62" else g["scoring"])
     osc = oracle_scoring_of(sc)
@@ -621,18 +685,49 @@ def test_multi_context_calls_equal_single_context(ctx):
 
 
 def test_arena_allocator(ctx):
-    """seqalign_arenas_alloc: three 4 KiB-aligned device buffers the fill accepts; small
-    requests are not probed (quality < 0), large ones report the write-probe ratio."""
+    """seqalign_arenas_alloc: three 4 KiB-aligned device buffers the fill accepts; small requests are plain
+    allocations and not probed (quality < 0); large ones are built from hipMemCreate chunks, the third arena
+    chosen by the write probe -- the walk is reported (seqalign_arenas_info) and ends at the target or takes the
+    best candidate; with arena_scan_gib = 0 they are three hipMallocs.  Every byte of a placed arena is writable
+    and readable (chunks mapped back to back), and the memory comes back on free."""
     import torch
     lib = S.lib()
-    for nbytes, probed in ((1 << 20, False), (300 << 20, True)):
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for nbytes, placed in ((1 << 20, False), (300 << 20, True), ((1 << 30) + 12345 * 4096, True)):
         ptrs = (C.c_void_p * 3)()
         q = C.c_float(0.0)
         assert lib.seqalign_arenas_alloc(ctx._h, C.c_uint64(nbytes), ptrs, C.byref(q)) == 0
         assert all(p and p % 4096 == 0 for p in ptrs) and len({int(p) for p in ptrs}) == 3
-        assert (q.value > 0.3) if probed else (q.value < 0)
+        info = S.ArenaInfo()
+        assert lib.seqalign_arenas_info(ctx._h, ptrs, C.byref(info)) == 0
+        d = info.as_dict()
+        assert (q.value > 0.3) if placed else (q.value < 0)
+        assert d["vmm"] == placed and abs(d["quality"] - q.value) < 1e-3
+        if placed:
+            assert 1 <= d["tries"] <= 64 and d["chunk_mib"] == 512 and len(d["try_quality"]) == d["tries"]
+            assert d["quality"] >= d["target"] - 0.05 or d["tries"] > 1      # below target only after looking further
+            assert max(d["try_quality"]) >= d["quality"] - 0.08               # the kept candidate is (about) the best seen
+            n = nbytes // 4
+            for k, p_ in enumerate(ptrs):   # first / last words and every chunk seam
+                t = torch.as_tensor(S._RawDeviceInts(p_, n), device="cuda:0")
+                t.fill_(k + 1)
+                idx = torch.tensor([0, n - 1] + [j for j in range((512 << 20) // 4 - 1, n, (512 << 20) // 4) for j in (j, min(j + 1, n - 1))],
+                                   device="cuda:0")
+                assert int(t.sum().item()) == (k + 1) * n and bool((t[idx] == k + 1).all())
+                del t
         assert lib.seqalign_arenas_free(ctx._h, ptrs) == 0
         assert not any(ptrs)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)      # spacer chunks and arenas all returned
+    with S.Context(0) as plain:
+        plain.set_option("arena_scan_gib", 0)
+        ptrs = (C.c_void_p * 3)()
+        assert lib.seqalign_arenas_alloc(plain._h, C.c_uint64(300 << 20), ptrs, None) == 0
+        info = S.ArenaInfo()
+        assert lib.seqalign_arenas_info(plain._h, ptrs, C.byref(info)) == 0 and not info.vmm and info.tries == 0
+        assert lib.seqalign_arenas_free(plain._h, ptrs) == 0
+        bogus = (C.c_void_p * 3)(4096, 8192, 12288)
+        assert lib.seqalign_arenas_free(plain._h, bogus) == S.E_ARG
     # a batch on library-placed arenas and one on a packed allocation give the same bytes
     sc = S.make_scoring({"preset": "default"})
     batch = W.dna_nw_150(3000, seed=5)
@@ -649,17 +744,16 @@ def test_arena_allocator(ctx):
 
 SWEEP_VARIANTS = {
     "default": {},                                    # segment width by sequence length, records of two rows in LDS
-    "segments-64": {"SEQALIGN_SWEEP_CPL": "1"},       # 64-column segments: several per row where the walks spread out
-    "segments-256": {"SEQALIGN_SWEEP_CPL": "4"},
-    "strips": {"SEQALIGN_SWEEP_MODE": "strips", "SEQALIGN_SWEEP_STRIP": "64"},   # one wave per 64-column strip of a pair
-    "box-pass": {"SEQALIGN_KERNEL": "rowscan"},       # a fill that cannot report the candidates' box and rows itself
+    "segments-64": {"sweep_cpl": 1},                  # 64-column segments: several per row where the walks spread out
+    "segments-256": {"sweep_cpl": 4},
+    "strips": {"sweep_mode": "strips", "sweep_strip": 64},   # one wave per 64-column strip of a pair
+    "box-pass": {"kernel": "rowscan"},                # a fill that cannot report the candidates' box and rows itself
 }
 
 
 @pytest.fixture(params=list(SWEEP_VARIANTS))
-def sweep_variant(request, monkeypatch):
-    for k, v in SWEEP_VARIANTS[request.param].items():
-        monkeypatch.setenv(k, v)
+def sweep_variant(request, opts):
+    opts(**SWEEP_VARIANTS[request.param])
     return request.param
 
 
@@ -704,16 +798,15 @@ def test_sw_sweep_enumeration(ctx, sweep_variant):
 
 
 @pytest.mark.parametrize("mode", ["default", "pair", "strips", "wgstream-fill"])
-def test_sw_sweep_wide_pairs_and_many_hits(ctx, mode, monkeypatch):
+def test_sw_sweep_wide_pairs_and_many_hits(ctx, mode, opts):
     """Wide rows (600 .. 2 500 columns: 1 200+ take a fill that cannot report the candidates' box and rows itself;
     one wave per pair with the winners of two rows in LDS, or one wave per 256-column strip -- the default for few
     pairs and beyond 2 048 columns) and pairs with hundreds of hits (more than the 64 the sweep ranks itself: ordered
     by the host) -- against the oracle."""
     if mode == "wgstream-fill":      # the workgroup-per-pair fill reports the candidates' box and rows itself
-        monkeypatch.setenv("SEQALIGN_KERNEL", "wgstream")
-        monkeypatch.setenv("SEQALIGN_SWEEP_MODE", "pair")
+        opts(kernel="wgstream", sweep_mode="pair")
     elif mode != "default":
-        monkeypatch.setenv("SEQALIGN_SWEEP_MODE", mode)
+        opts(sweep_mode=mode)
     rng = W.Rng(1717)
 
     def rand(n, alpha=b"ACGT"):
@@ -766,14 +859,14 @@ def test_sw_batch_output_capacity_is_respected(ctx):
         assert err.value.code == 4   # SEQALIGN_E_NOMEM
 
 
-def test_sw_batch_multi_hit_in_several_chunks(ctx, monkeypatch):
+def test_sw_batch_multi_hit_in_several_chunks(ctx):
     """seqalign_sw_batch(max_hits > 1) on a batch that does not fit one chunk (tiny chunk budget): the per-chunk
     scratch (hit keys, walker lists, string slots) is reused chunk after chunk; hits equal the one-chunk call's."""
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     batch = W.dna_sw_read_vs_ref(120, seed=73, read_len=80, ref_len=300)
     one = ctx.sw_batch(batch, sc, 16, max_hits=6)
-    monkeypatch.setenv("SEQALIGN_CHUNK_BYTES", str(6 << 20))     # ~30 pairs per chunk
     with S.Context(0) as small:
+        small.set_option("chunk_bytes", 6 << 20)     # ~30 pairs per chunk
         many = small.sw_batch(batch, sc, 16, max_hits=6)
     assert one == many
     osc = oracle_scoring_of(sc)
