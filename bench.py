@@ -12,8 +12,12 @@ synthetic batch that is already resident in HBM.
           `scaling` is "weak"; at N = 8 the job is exactly C5.  `--scaling strong`
           shards the whole 1 M pairs over N ranks instead (N >= 2: a shard must fit HBM).
           Pairs are independent: NO collective on the data path.  The control plane
-          (barrier, MAX of the elapsed time, SUM of the cells) is two scalars over
-          torch.distributed "gloo" -- no RCCL needed (SEQALIGN_DIST_BACKEND=nccl uses it).
+          (barrier, MAX of the elapsed time, SUM of the cells, per-rank figures for the report) is a
+          handful of scalars over a key-value store (torch.distributed.TCPStore: the launcher's own
+          when run under torch.distributed.run) -- no process group, no RCCL
+          (SEQALIGN_DIST_BACKEND=gloo|nccl switches to torch.distributed collectives).
+          Each rank pins itself (and the library's host worker threads, which inherit the mask) to its
+          share of the CPUs of its GPU's NUMA node.
 
     python bench.py --gpus 1 --steps 1000 --warmup 10
     python bench.py --gpus 8                     # launches its 8 ranks itself
@@ -100,6 +104,60 @@ def launch_ranks(n: int, argv: list[str]) -> int:
         if p.poll() is None:
             p.kill()
     return rc
+
+
+def _cpulist(text: str) -> list[int]:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_cpus(device: int, sysfs: Path = Path("/sys")):
+    """(numa node, its CPUs) of HIP device `device`, from the PCI address torch reports; (None, []) if unknown."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        dev = sysfs / "bus" / "pci" / "devices" / bdf
+        node = int((dev / "numa_node").read_text())
+        cpus = _cpulist((dev / "local_cpulist").read_text())
+        if node < 0:
+            return None, []
+        return node, cpus
+    except Exception:
+        return None, []
+
+
+def pin_rank(node, cpus, local_rank: int, local_world: int, nodes_of_ranks: list) -> dict:
+    """Pin this process to its share of its GPU's NUMA node: the node's CPUs are dealt out evenly among the local
+    ranks whose GPUs hang off the same node, in rank order (hyper-thread siblings -- cpu c and c + n/2 on this
+    platform -- end up in the same share because the list is cut into contiguous runs of physical ids).
+    The library's worker pool is created later and inherits the mask (its size = CPUs in the mask, <= 32)."""
+    if node is None or not cpus or not hasattr(os, "sched_setaffinity"):
+        return {"numa_node": node, "cpus": None}
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    peers = [r for r in range(local_world) if nodes_of_ranks[r] == node]
+    if not allowed or local_rank not in peers:
+        return {"numa_node": node, "cpus": None}
+    k, m = peers.index(local_rank), len(peers)
+    half = len(allowed) // 2
+    if half and all(b - a == 1 for a, b in zip(allowed[:half], allowed[1:half])) and len(allowed) % 2 == 0 and len(allowed) >= 2 * m:
+        # two runs (first threads, then their siblings): take the same slice of both
+        a, b = allowed[:half], allowed[half:]
+        per = half // m
+        mine = a[k * per:(k + 1) * per] + b[k * per:(k + 1) * per]
+    else:
+        per = max(1, len(allowed) // m)
+        mine = allowed[k * per:(k + 1) * per] or allowed
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {"numa_node": node, "cpus": None}
+    return {"numa_node": node, "cpus": len(mine), "first_cpu": mine[0]}
 
 
 def make_shard(name: str, rank: int, world: int, pairs: int, scaling: str):
@@ -226,9 +284,9 @@ def run(args) -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     workload = args.workload or ("C2" if world == 1 else "C5")
     args.workload = workload
-    backend = os.environ.get("SEQALIGN_DIST_BACKEND", "gloo")
+    backend = os.environ.get("SEQALIGN_DIST_BACKEND", "store")
     if args.plumbing_test:
-        return plumbing_test(args, rank, world, Group("gloo"))
+        return plumbing_test(args, rank, world, Group(backend if backend != "nccl" else "store"))
 
     import torch
     import seqalign_amd as S
@@ -239,6 +297,12 @@ def run(args) -> int:
     local = local % n_dev
     torch.cuda.set_device(local)
     grp = Group(backend, torch.device("cuda", local) if backend == "nccl" else None)
+    # NUMA: this rank and the library's host threads onto the CPUs next to this rank's GPU
+    node, node_cpus = gpu_numa_cpus(local)
+    pin = {"numa_node": node, "cpus": None}
+    if world > 1 and not args.no_pin:
+        nodes = grp.gather_objects(node)
+        pin = pin_rank(node, node_cpus, rank, world, nodes)
 
     gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
     batch, global_pairs, first_pair = make_shard(workload, rank, world, args.pairs, args.scaling)
@@ -309,9 +373,11 @@ def run(args) -> int:
             t1 = time.perf_counter()
             fn()
             walls.append(time.perf_counter() - t1)
-        wall = grp.max_float(float(np.median(walls)))
+        wall_mine = float(np.median(walls))
+        wall = grp.max_float(wall_mine)
         e2e = {"call": call, "ms": wall * 1e3, "value": total_cells / wall / 1e9, "unit": "GCUPS",
-               "includes": "host pack, H2D, fill, device traceback, D2H of the strings, host unpack"}
+               "includes": "host pack, H2D, fill, device traceback, D2H of the strings, host unpack",
+               "ms_this_rank": wall_mine * 1e3}
         if is_sw:   # the multi-hit path: reverse sweep + one traceback per hit
             fn4 = lambda: ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * batch.n_pairs + 8, raw=True)
             fn4()
@@ -325,6 +391,11 @@ def run(args) -> int:
             e2e["up_to_4_hits"] = {"call": "seqalign_sw_batch(max_hits=4)", "ms": wall4 * 1e3,
                                    "value": total_cells / wall4 / 1e9, "unit": "GCUPS"}
 
+    # per-rank figures for the report: a slow rank (placement, NUMA, a busy neighbour) must be visible, not averaged away
+    per_rank = grp.gather_objects({"rank": rank, "device": local, "kernel_ms": round(kern_ms, 4),
+                                   "arena_placement_quality": round(db.placement_quality, 3),
+                                   "arena_placement_tries": (db.placement_info or {}).get("tries"),
+                                   "e2e_ms": round(e2e["ms_this_rank"], 3) if e2e else None, **pin})
     if rank == 0:
         alg_bytes = db.algorithmic_bytes()
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -358,7 +429,14 @@ def run(args) -> int:
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if e2e:
+            e2e.pop("ms_this_rank", None)
             out["e2e"] = e2e
+        out["per_rank"] = per_rank
+        worst_q = min((r["arena_placement_quality"] for r in per_rank if r["arena_placement_quality"] is not None
+                       and r["arena_placement_quality"] >= 0), default=None)
+        if worst_q is not None and db.placement_info and worst_q < db.placement_info["target"] - 0.03:
+            out["config"]["arena_placement_note"] = (f"placement below target on at least one rank (worst {worst_q}): "
+                                                     "the walk ran out of candidates; see per_rank / arena_placement_search")
         if is_sw:
             # the SW local-maxima reduction as a separate kernel (4 B/cell read)
             thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
@@ -399,6 +477,7 @@ def main() -> int:
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to its GPU's NUMA node")
     ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
                     help="output arenas: the library's spread allocator (seqalign_arenas_alloc) or one packed allocation")
     ap.add_argument("--plumbing-test", action="store_true",

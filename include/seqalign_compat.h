@@ -140,9 +140,10 @@ extern const char align_col_mismatch[], align_col_indel[], align_col_context[], 
  *     and for scoring_init(..., no_gaps_in_a = no_gaps_in_b = 1) with gap penalties below
  *     the mismatch score (upstream leaves them out of min_penalty, alignment_scoring.c:49-54,
  *     but still applies them in the last row and column, alignment.c:128,146).
- * All calls of the legacy API share one device context behind a mutex: an aligner_t per
- * thread stays correct, but the fills run one after the other -- batches belong in
- * seqalign_hip.h. */
+ * Every thread that calls the legacy API gets its own device context (stream, scratch, cached
+ * scoring) on first use: one aligner_t per thread runs in parallel, as with the reference
+ * (src/alignment.c:170-202 mutates only its own aligner_t).  A call still costs a launch and two
+ * PCIe round trips (~0.1 ms) whatever the pair's size -- batches belong in seqalign_hip.h. */
 void aligner_align(aligner_t *aligner, const char *seq_a, const char *seq_b,
                    size_t len_a, size_t len_b, const scoring_t *scoring, char is_sw);
 void aligner_destroy(aligner_t *aligner);

@@ -165,9 +165,9 @@ extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  ScoringGuard guard(ctx);
-  if ((rc = seqalign_scoring_upload(ctx, scoring, is_sw, &guard.h))) return rc;
-  return fill_batch_uploaded(ctx, batch, guard.h, mat_off, M, A, B, status);
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = cached_scoring(ctx, scoring, is_sw, &sc))) return rc;
+  return fill_batch_uploaded(ctx, batch, sc, mat_off, M, A, B, status);
 }
 
 int sa_host::fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,
@@ -271,23 +271,33 @@ static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *
 }
 
 // ---- seqalign_nw_batch, device traceback: one chunk as a PIPELINE of sub-batches -------------------------------
-// The stages of a chunk -- host packs the sequences, H2D, fill (HBM-bound), traceback (a chain of dependent loads per
-// pair: latency-bound, few bytes), D2H of the strings, host unpacks -- use different parts of the machine, and run
-// strictly one after the other they cost their sum (C2: 1.3-1.4 ms for a 0.41 ms fill; C5's per-GPU share: 12.2 ms
-// for 5.1).  Cut into sub-batches of consecutive pairs they overlap:
-//   stream F (fill)   :  H2D(s) fill(s) | H2D(s+1) fill(s+1) | ...
-//   stream T (trace)  :        wait fill(s): traceback(s) D2H(s) | ...            (higher priority: its few waves
-//                                                                                   slip in between the fill's)
-//   host              :  pack(s+1) while the GPU works on s; unpack(s-1) as soon as its strings have landed
+// The stages of a chunk -- host packs the sequences, H2D, fill (HBM-bound), traceback, D2H of the strings, host
+// unpacks -- run strictly one after the other cost their sum (C2: 1.3-1.4 ms for a 0.41 ms fill; C5's per-GPU share:
+// 12.2 ms for 5.1).  What CAN overlap, measured (profiles/r03/r03_nw_pipeline.md):
+//   * the copies and the host work with the kernels: yes -- they use PCIe and the CPU;
+//   * the traceback of one sub-batch with the fill of the next (two streams, the walkers at high priority): NO.
+//     The walkers are not latency-bound at these sizes, they are bound by scattered 64-byte sectors (3 per step: one
+//     cell of each matrix; 10 k pairs: 0.29 ms = 2 TB/s of sector traffic, 125 k pairs: 3.6 ms = the same rate), so
+//     next to a fill that saturates HBM both simply slow down (walks 0.29 -> 0.5 ms per sub-batch, fills +50 %),
+//     and a walk over few pairs takes its ~0.3 ms however few they are -- 16 sub-batch walks cost more than one.
+// So: sub-batches of consecutive pairs for upload + fill, tracebacks over GROUPS of sub-batches (>= 32 k pairs, or
+// the whole chunk) in the SAME stream as the fills, downloads and unpacking per group:
+//   stream U (upload)   :  H2D(0) H2D(1) H2D(2) ...
+//   stream F (kernels)  :  fill(0) fill(1) .. walk(group 0) fill(..) .. walk(group 1) ...       fill(s) waits for H2D(s)
+//   stream D (download) :                        strings + words of group 0 | group 1 ...       waits for walk(g)
+//   host                :  packs every sub-batch, enqueues as it goes (the GPU starts on the first at once), then
+//                          unpacks the groups in order as they land
 // Same kernels, same buffers (a sub-batch is a pair range of the chunk's descriptor arrays and arenas), same results.
-// Per sub-batch the device sends back ONE block of characters (out_a | out_b of its pairs) and one of per-pair words
+// Per group the device sends back ONE block of characters (out_a | out_b of its pairs) and one of per-pair words
 // (head, len, score, status interleaved: SaTraceParams::out_meta4; the fill's status is folded in by the walker).
 static uint32_t pick_subbatches(const seqalign_ctx *ctx, const Chunk &c) {
   if (ctx->opt.subbatches) return (uint32_t)std::min<uint64_t>(ctx->opt.subbatches, std::max<uint64_t>(c.count, 1));
-  // by size: sub-batches of >= 2 048 pairs (the lane walker's domain; below that the chip is not full either way)
-  // and >= 32 M cells (~0.4 GB of matrices, ~60 us of fill), at most 16
-  const uint64_t by_pairs = c.count / 2048, by_cells = c.cells / (32ull << 20);
-  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(by_pairs, by_cells), 16));
+  // by size, measured (profiles/r03/r03_nw_pipeline.md): C2 (10 k pairs) gains nothing from 2 or 4 sub-batches (1.28 ->
+  // 1.34 ms: its walk must stay one launch, and two half fills are slower than one), C5's share (125 k pairs) 12.6 ->
+  // 11.4 (4) -> 10.2 (8) -> 10.8 ms (16).  So: sub-batches of >= 12 288 pairs and >= 256 M cells (3 GB of matrices),
+  // at most 8.
+  const uint64_t by_pairs = c.count / 12288, by_cells = c.cells / (256ull << 20);
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(by_pairs, by_cells), 8));
 }
 
 static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c, const seqalign_dev_scoring *sc,
@@ -317,25 +327,13 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       (rc = reserve_arenas(ctx, c.cells * 4)) || (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
       (rc = ctx->h_ta.reserve(2 * total + 16)) || (rc = ctx->h_tmeta.reserve(n * 16)))
     return rc;
-  if (!ctx->stream2) {   // the traceback stream: higher priority than the fill's
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIP_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
-  }
-  hipStream_t sf = ctx->stream, st = ctx->stream2;
-  StreamSyncOnExit sync_f(sf), sync_t(st);   // pinned / device buffers are reused by the next call: never leave work in flight
-  EventList ev;
-  for (uint32_t s = 0; s < 2 * n_sub; ++s) HIP_TRY(ev.add(hipEventDisableTiming));
-  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, sf));
+  for (int k = 0; k < 2; ++k)
+    if (!ctx->copy_streams[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[k], hipStreamNonBlocking));
+  hipStream_t sf = ctx->stream, su = ctx->copy_streams[0], sd = ctx->copy_streams[1];
+  // pinned / device buffers are reused by the next call: never leave work in flight
+  StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd);
 
-  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
-  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_slot + n + 1), *dv_len_b = dv_len_a + n;
-  char *d_chars = ctx->t_out_a.as<char>();
-  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();
-  char *h_chars = ctx->h_ta.as<char>();
-  const uint32_t *h_meta = ctx->h_tmeta.as<uint32_t>();
-
-  // sub-batch s = pairs [cut[s], cut[s + 1]) of the chunk, cut at equal cells
+  // sub-batch s = pairs [cut[s], cut[s + 1]) of the chunk, cut at equal cells; group g = sub-batches [gcut[g], gcut[g + 1])
   std::vector<uint64_t> cut(n_sub + 1, n);
   cut[0] = 0;
   { uint64_t k = 0;
@@ -344,13 +342,88 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       while (k < n && h_mat[k] < want) ++k;
       cut[s] = std::max(k, cut[s - 1]);
     } }
+  constexpr uint64_t kGroupPairs = 32768;
+  std::vector<uint32_t> gcut{0};
+  for (uint32_t s = 1; s < n_sub; ++s)
+    if (cut[s] - cut[gcut.back()] >= kGroupPairs && n - cut[s] >= kGroupPairs / 2) gcut.push_back(s);
+  gcut.push_back(n_sub);
+  const uint32_t n_grp = (uint32_t)gcut.size() - 1;
+
+  EventList ev;   // [0, n_sub): upload of s done; [n_sub, n_sub + n_grp): walk of g done; then: download of g done
+  for (uint32_t k = 0; k < n_sub + 2 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
+  HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, su));
+
+  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
+  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_slot + n + 1), *dv_len_b = dv_len_a + n;
+  char *d_chars = ctx->t_out_a.as<char>();
+  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();
+  char *h_chars = ctx->h_ta.as<char>();
+  uint32_t *h_meta = ctx->h_tmeta.as<uint32_t>();
+  auto dev_range = [&](uint64_t k0, uint64_t k1) {
+    seqalign_dev_batch_t d;
+    d.n_pairs = k1 - k0; d.arena = ctx->arena.as<uint8_t>();
+    d.off_a = dv_off_a + k0; d.len_a = dv_len_a + k0; d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
+    d.mat_off = dv_mat + k0;
+    d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+    d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+    return d;
+  };
 
   constexpr uint64_t kPack = 1024;
-  std::atomic<int> first_error{SEQALIGN_OK};
-  auto unpack = [&](uint32_t s) -> int {   // strings of sub-batch s from the pinned block into the caller's buffers
-    HIP_TRY(hipEventSynchronize(ev.ev[2 * s + 1]));
+  uint32_t g = 0;
+  for (uint32_t s = 0; s < n_sub; ++s) {
     const uint64_t k0 = cut[s], k1 = cut[s + 1];
-    if (k1 == k0) return SEQALIGN_OK;
+    if (k1 > k0) {
+      const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
+      parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {   // host: this sub-batch's sequences
+        for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
+          const uint64_t p = c.first + k;
+          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], batch->len_a[p]);
+          memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], batch->len_b[p]);
+        }
+      });
+      if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, su));
+    }
+    HIP_TRY(hipEventRecord(ev.ev[s], su));
+    HIP_TRY(hipStreamWaitEvent(sf, ev.ev[s], 0));
+    if (k1 > k0) {
+      const seqalign_dev_batch_t d = dev_range(k0, k1);
+      if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) return rc;
+    }
+    if (s + 1 == gcut[g + 1]) {   // the group is filled: walk it, send it home
+      const uint64_t g0 = cut[gcut[g]], g1 = cut[s + 1];
+      if (g1 > g0) {
+        const uint64_t c0 = h_slot[g0], c1 = h_slot[g1];
+        const seqalign_dev_batch_t d = dev_range(g0, g1);
+        SaTraceParams t;
+        memset(&t, 0, sizeof(t));
+        t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b; t.mat_off = d.mat_off;
+        t.M = d.match_scores; t.A = d.gap_a_scores; t.B = d.gap_b_scores; t.code = sc->d_code; t.table = sc->d_table;
+        t.str_off = dv_slot + g0;
+        t.out_a = d_chars + 2 * c0 - c0;                  // + slot offset: a-strings at [2 c0, 2 c0 + (c1 - c0))
+        t.out_b = d_chars + 2 * c0 + (c1 - c0) - c0;      //                b-strings right behind them
+        t.out_meta4 = d_meta + 4 * g0; t.fill_status = d.status;
+        t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
+        t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
+        t.tune_walker = ctx->opt.trace_kernel;
+        hipError_t e = sa_launch_nw_traceback(t, sf);
+        if (e != hipSuccess) return fail_hip(e, "traceback launch");
+        HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sf));
+        HIP_TRY(hipStreamWaitEvent(sd, ev.ev[n_sub + g], 0));
+        if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_chars + 2 * c0, d_chars + 2 * c0, 2 * (c1 - c0), hipMemcpyDeviceToHost, sd));
+        HIP_TRY(hipMemcpyAsync(h_meta + 4 * g0, d_meta + 4 * g0, (g1 - g0) * 16, hipMemcpyDeviceToHost, sd));
+      }
+      HIP_TRY(hipEventRecord(ev.ev[n_sub + n_grp + g], sd));
+      ++g;
+    }
+  }
+  tm.lap("nw pipelined: all sub-batches packed + enqueued");
+
+  std::atomic<int> first_error{SEQALIGN_OK};
+  for (g = 0; g < n_grp; ++g) {   // strings of group g from the pinned block into the caller's buffers
+    HIP_TRY(hipEventSynchronize(ev.ev[n_sub + n_grp + g]));
+    const uint64_t k0 = cut[gcut[g]], k1 = cut[gcut[g + 1]];
+    if (k1 == k0) continue;
     const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
     const char *ha = h_chars + 2 * c0 - c0, *hb = h_chars + 2 * c0 + (c1 - c0) - c0;   // + slot offset
     parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
@@ -365,54 +438,9 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         out_score[p] = (int32_t)h_meta[4 * k + 2];
       }
     });
-    return first_error.load();
-  };
-
-  for (uint32_t s = 0; s < n_sub; ++s) {
-    const uint64_t k0 = cut[s], k1 = cut[s + 1];
-    if (k1 > k0) {
-      const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
-      // host: pack this sub-batch's sequences; stream F: ship them, fill
-      parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
-        for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
-          const uint64_t p = c.first + k;
-          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], batch->len_a[p]);
-          memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], batch->len_b[p]);
-        }
-      });
-      if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, sf));
-      seqalign_dev_batch_t d;
-      d.n_pairs = k1 - k0; d.arena = ctx->arena.as<uint8_t>();
-      d.off_a = dv_off_a + k0; d.len_a = dv_len_a + k0; d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
-      d.mat_off = dv_mat + k0;
-      d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
-      d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
-      if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) return rc;
-      HIP_TRY(hipEventRecord(ev.ev[2 * s], sf));
-      // stream T: walk, then this sub-batch's characters and words in one copy each
-      HIP_TRY(hipStreamWaitEvent(st, ev.ev[2 * s], 0));
-      SaTraceParams t;
-      memset(&t, 0, sizeof(t));
-      t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b; t.mat_off = d.mat_off;
-      t.M = d.match_scores; t.A = d.gap_a_scores; t.B = d.gap_b_scores; t.code = sc->d_code; t.table = sc->d_table;
-      t.str_off = dv_slot + k0;
-      t.out_a = d_chars + 2 * c0 - c0;                  // + slot offset: a-strings at [2 c0, 2 c0 + (c1 - c0))
-      t.out_b = d_chars + 2 * c0 + (c1 - c0) - c0;      //                b-strings right behind them
-      t.out_meta4 = d_meta + 4 * k0; t.fill_status = d.status;
-      t.n_pairs = (uint32_t)(k1 - k0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
-      t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
-      t.tune_walker = ctx->opt.trace_kernel;
-      hipError_t e = sa_launch_nw_traceback(t, st);
-      if (e != hipSuccess) return fail_hip(e, "traceback launch");
-      if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_chars + 2 * c0, d_chars + 2 * c0, 2 * (c1 - c0), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(h_meta) + 4 * k0, d_meta + 4 * k0, (k1 - k0) * 16, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipEventRecord(ev.ev[2 * s + 1], st));
-    if (s >= 1 && (rc = unpack(s - 1))) return rc;   // the GPU has sub-batch s queued behind it
+    if ((rc = first_error.load())) return rc;
   }
-  tm.lap("nw pipelined: all sub-batches enqueued");
-  if ((rc = unpack(n_sub - 1))) return rc;
-  tm.lap("nw pipelined: last sub-batch unpacked");
+  tm.lap("nw pipelined: all groups unpacked");
   return SEQALIGN_OK;
 }
 
@@ -424,9 +452,8 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  ScoringGuard guard(ctx);
-  if ((rc = seqalign_scoring_upload(ctx, scoring, 0, &guard.h))) return rc;
-  seqalign_dev_scoring *sc = guard.h;
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = cached_scoring(ctx, scoring, 0, &sc))) return rc;
   const bool on_host = traceback_on_host(ctx);
   // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
   const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;

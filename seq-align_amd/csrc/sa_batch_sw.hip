@@ -569,9 +569,8 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  ScoringGuard guard(ctx);
-  if ((rc = seqalign_scoring_upload(ctx, scoring, 1, &guard.h))) return rc;
-  seqalign_dev_scoring *sc = guard.h;
+  seqalign_dev_scoring *sc = nullptr;
+  if ((rc = cached_scoring(ctx, scoring, 1, &sc))) return rc;
   uint64_t used_str = 0, found = 0;
   if (max_hits == 0) return SEQALIGN_OK;
   if (max_hits == 1 && !traceback_on_host(ctx)) {   // best hit only: nothing but the strings crosses PCIe

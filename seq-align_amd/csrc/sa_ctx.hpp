@@ -8,6 +8,7 @@
 //   sa_multi.hip      the same calls over several contexts (GPUs) from one process
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -33,7 +34,9 @@ namespace sa_host {
 
 // Persistent host worker pool: run fn(0..n-1) over the workers + the caller.
 // Pairs / memcpy pieces are independent.  SEQALIGN_HOST_THREADS overrides the
-// worker count (default min(hardware threads, 32)).  One job at a time.
+// worker count (default min(CPUs this process may run on, 32): a rank pinned to its
+// GPU's NUMA node gets a pool of that size, on those CPUs -- the workers inherit
+// the creating thread's affinity mask).  One job at a time.
 class HostPool {
  public:
   static HostPool &get() { static HostPool pool; return pool; }
@@ -55,6 +58,8 @@ class HostPool {
  private:
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t mask;
+    if (sched_getaffinity(0, sizeof(mask), &mask) == 0 && CPU_COUNT(&mask) > 0) hw = (unsigned)CPU_COUNT(&mask);
     unsigned want = hw ? std::min(hw, 32u) : 4u;
     if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
     for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
@@ -214,6 +219,7 @@ struct seqalign_ctx {
   SaOptions opt;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream (created on first use): work that overlaps the main stream's kernels
+  hipStream_t copy_streams[2] = {nullptr, nullptr};   // seqalign_nw_batch's pipeline (sa_batch.hip): upload, download; created on first use
   size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
   size_t chunk_budget_default = 0;
   // device scratch for the host-level entry points
@@ -225,10 +231,9 @@ struct seqalign_ctx {
   sa_host::DevBuf e[14];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
   sa_host::DevBuf strip_progress;                        // sa_fill_strips.hip: rows done per (pair, strip)
   sa_host::HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
-  // cached flattened scoring for the legacy single-pair path
-  seqalign_dev_scoring *cached = nullptr;
-  uint64_t cached_fp = 0;
-  int cached_is_sw = -1;
+  // the last scorings uploaded through cached_scoring (host-level entry points, legacy single-pair path): [is_sw]
+  seqalign_dev_scoring *cached[2] = {nullptr, nullptr};
+  uint64_t cached_fp[2] = {0, 0};
 };
 
 
@@ -237,15 +242,11 @@ namespace sa_host {
 // grow the context's three matrix arenas together (spread placement, sa_placement.hip)
 int reserve_arenas(seqalign_ctx *ctx, size_t bytes);
 
-// releases an uploaded scoring on every exit path of the host-level entry points
-struct ScoringGuard {
-  seqalign_ctx *ctx;
-  seqalign_dev_scoring *h = nullptr;
-  explicit ScoringGuard(seqalign_ctx *c) : ctx(c) {}
-  ~ScoringGuard() { if (h) seqalign_scoring_release(ctx, h); }
-  ScoringGuard(const ScoringGuard &) = delete;
-  ScoringGuard &operator=(const ScoringGuard &) = delete;
-};
+// The uploaded form of `scoring` for the host-level entry points: the context keeps the last one it flattened and
+// uploaded (per NW / SW), keyed by a fingerprint of everything scoring_lookup can see, so that a caller who aligns
+// batch after batch with one scoring_t pays for the flatten + two hipMallocs + two synchronous copies once, not per
+// call (C2: ~0.1 ms of a 1.3 ms call).  Owned by the context; valid until the next call with a different scoring.
+int cached_scoring(seqalign_ctx *ctx, const scoring_t *scoring, int is_sw, seqalign_dev_scoring **out);
 
 // the fill on device-resident data; best_score / best_index (optional, SW): filled by the fill itself
 // when the stream kernel runs (*best_done = true), otherwise the caller runs the separate reduction

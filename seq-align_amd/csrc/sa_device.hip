@@ -5,6 +5,9 @@
 // the runtime or a device is missing every entry point reports it.
 #include "sa_ctx.hpp"
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 using namespace sa_host;
 
 // ------------------------------------------------------------------ errors ---
@@ -47,6 +50,7 @@ int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
   if (ctx->arena_set) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (hipStream_t t : ctx->copy_streams) if (t) (void)hipStreamSynchronize(t);
     sa_arenas_destroy(sa_arenas_take(ctx->M.p));
     ctx->arena_set = nullptr;
   }
@@ -208,7 +212,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
+  for (int k = 0; k < 2; ++k) if (ctx->cached[k]) seqalign_scoring_release(ctx, ctx->cached[k]);
   if (ctx->arena_set) sa_arenas_destroy(sa_arenas_take(ctx->M.p));
   for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
                     &ctx->status, &ctx->best_score, &ctx->best_index,
@@ -221,6 +225,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
                      &ctx->h_tb, &ctx->h_tmeta})
     b->release();
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  for (hipStream_t t : ctx->copy_streams) if (t) (void)hipStreamDestroy(t);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -256,7 +261,7 @@ extern "C" void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scori
   if (h->d_code) (void)hipFree(h->d_code);
   if (h->d_table) (void)hipFree(h->d_table);
   sa_flat_scoring_free(&h->flat);
-  if (ctx && ctx->cached == h) { ctx->cached = nullptr; ctx->cached_is_sw = -1; }
+  if (ctx) for (int k = 0; k < 2; ++k) if (ctx->cached[k] == h) ctx->cached[k] = nullptr;
   delete h;
 }
 
@@ -431,23 +436,38 @@ extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_
 }
 
 // ------------------------------------------- legacy single-pair entry point ---
-static std::once_flag g_default_once;
-static seqalign_ctx *g_default_ctx = nullptr;
-static std::mutex g_default_mu;
+// The reference's aligner_align (src/alignment.c:170-193) touches nothing but its own aligner_t, so one aligner per
+// thread runs in parallel (SURVEY 8b "Threading").  aligner_t is a public 72-byte struct with no room for a handle,
+// so the device side of that promise hangs off the calling THREAD instead: every thread that uses the legacy API gets
+// its own context -- stream, scratch, cached scoring -- on first use, and keeps it until it exits.  No lock is shared
+// between callers (rounds 1-2: one context behind one mutex; 8 threads ran at the speed of one).
+namespace {
+struct ThreadContext {
+  seqalign_ctx *ctx = nullptr;
+  bool main_thread = false;
+  ~ThreadContext() {
+    // a worker thread's context goes with the thread; the main thread's is left to process exit (the HIP runtime
+    // may already be shutting down when the main thread's thread_locals are destroyed)
+    if (ctx && !main_thread) seqalign_ctx_destroy(ctx);
+  }
+};
+thread_local ThreadContext tl_legacy;
+}  // namespace
 
 extern "C" seqalign_ctx_t *sa_default_ctx_or_die(void) {
-  std::call_once(g_default_once, [] {
+  if (!tl_legacy.ctx) {
     int dev = 0;
     if (const char *env = getenv("SEQALIGN_DEVICE")) dev = atoi(env);
-    int rc = seqalign_ctx_create(dev, &g_default_ctx);
+    int rc = seqalign_ctx_create(dev, &tl_legacy.ctx);
     if (rc != SEQALIGN_OK) {
       fprintf(stderr, "seqalign: cannot open GPU %d: %s (%s)\n"
                       "seqalign: this library has no CPU path; an MI355X (gfx950) is required\n",
               dev, seqalign_strerror(rc), seqalign_last_error());
       exit(EXIT_FAILURE);
     }
-  });
-  return g_default_ctx;
+    tl_legacy.main_thread = (getpid() == (pid_t)syscall(SYS_gettid));
+  }
+  return tl_legacy.ctx;
 }
 
 // FNV-1a over everything scoring_lookup can see (header fields, wildcard and swap
@@ -479,20 +499,29 @@ static uint64_t scoring_fingerprint(const scoring_t *sc, int is_sw) {
   return h;
 }
 
+int sa_host::cached_scoring(seqalign_ctx *ctx, const scoring_t *sc, int is_sw, seqalign_dev_scoring **out) {
+  const int k = is_sw ? 1 : 0;
+  const uint64_t fp = scoring_fingerprint(sc, is_sw);
+  if (!ctx->cached[k] || ctx->cached_fp[k] != fp) {
+    if (ctx->cached[k]) {
+      (void)hipStreamSynchronize(ctx->stream);   // nothing of an earlier call may still be reading the old tables
+      seqalign_scoring_release(ctx, ctx->cached[k]);
+    }
+    ctx->cached[k] = nullptr;
+    int rc = seqalign_scoring_upload(ctx, sc, is_sw, &ctx->cached[k]);
+    if (rc) return rc;
+    ctx->cached_fp[k] = fp;
+  }
+  *out = ctx->cached[k];
+  return SEQALIGN_OK;
+}
+
 extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is_sw, const char *a, size_t len_a,
                                 const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
   if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
-  std::lock_guard<std::mutex> lock(g_default_mu);   // the default context is shared
   HIP_TRY(hipSetDevice(ctx->device));
-  const uint64_t fp = scoring_fingerprint(sc, is_sw);
-  if (!ctx->cached || ctx->cached_fp != fp || ctx->cached_is_sw != is_sw) {
-    if (ctx->cached) seqalign_scoring_release(ctx, ctx->cached);
-    ctx->cached = nullptr;
-    int rc = seqalign_scoring_upload(ctx, sc, is_sw, &ctx->cached);
-    if (rc) return rc;
-    ctx->cached_fp = fp;
-    ctx->cached_is_sw = is_sw;
-  }
+  seqalign_dev_scoring *dsc = nullptr;
+  { int rc = cached_scoring(ctx, sc, is_sw, &dsc); if (rc) return rc; }
   // one arena: a then b
   std::vector<char> arena(len_a + len_b + 1);
   if (len_a) memcpy(arena.data(), a, len_a);
@@ -504,7 +533,7 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
   batch.off_a = &off_a; batch.len_a = &la; batch.off_b = &off_b; batch.len_b = &lb;
   int rc = check_batch(&batch);
   if (rc) return rc;
-  return fill_batch_uploaded(ctx, &batch, ctx->cached, &mat_off, M, A, B, status);
+  return fill_batch_uploaded(ctx, &batch, dsc, &mat_off, M, A, B, status);
 }
 
 // ------------------------------------------------------------------- probes ---

@@ -75,6 +75,7 @@ fill_wgstream_kernel(const SaFillParams p, const uint32_t R /* ring ints per mat
   __shared__ unsigned long long s_best;         // BEST: max over the workgroup of score << 32 | ~(column << 21 | row)
   __shared__ uint32_t s_row_lo[2], s_row_hi[2]; // CAND: this row's candidate columns over the waves, by row parity
   if (threadIdx.x == 0) { s_err = ~0ull; s_best = 0ull; s_row_lo[0] = s_row_lo[1] = 0xffffffffu; s_row_hi[0] = s_row_hi[1] = 0u; }
+  __syncthreads();   // the other waves' first atomics on these words (row 1, before the row's own barrier) come after the init
   unsigned long long err = ~0ull;
   int cand_thr = INT32_MAX;
   uint32_t *cand_rows = nullptr;

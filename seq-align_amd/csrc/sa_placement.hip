@@ -31,11 +31,22 @@
 //     reported (seqalign_arenas_info, bench.py prints them): a placement below target is SAID, never silent.
 // The walk is bounded by `scan_bytes` and by 60 % of what is free; an arena set that cannot be placed that way
 // (tiny arenas, no VMM support, no room) is three plain hipMallocs and reports quality -1 / its probe value.
+//
+// A VIRTUAL ADDRESS IS NEVER MAPPED TWICE.  On this stack (ROCm 7.2, gfx950) hipMemUnmap does not invalidate the
+// GPU's translations: after unmap -> map of other chunks at the same address, kernels kept reading and writing the
+// OLD physical memory -- already released, possibly somebody else's (tools/probes/vmm_reuse_probe.hip: 7 of 8
+// re-mapped ranges held the wrong data; with every mapping at a never-used address, 0 of 8; a hipMalloc + hipFree
+// between unmap and map also cured it, i.e. the classic path flushes and the VMM path does not).  So every
+// mapping made here gets its own address reservation, and reservations are never given back to the driver
+// (hipMemAddressFree would let it hand the range out again): address space is the one resource a 64-bit process
+// has plenty of -- a C2-sized walk uses <= 42 GiB of it, a context allocates its arenas a few times in its life --
+// and past 32 TiB of retired ranges the allocator simply stops placing and allocates plainly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -143,7 +154,10 @@ VmmEnv vmm_env(int device) {
   return v;
 }
 
-// a run of chunks mapped back to back at one virtual address range
+std::atomic<unsigned long long> g_retired_va{0};   // address space of mappings taken down (never handed back, see header)
+constexpr unsigned long long kRetiredVaLimit = 32ull << 40;
+
+// a run of chunks mapped back to back at one virtual address range that is used for this and nothing else, ever
 struct Mapping {
   char *va = nullptr;
   size_t bytes = 0, chunk = 0, mapped = 0;
@@ -164,7 +178,7 @@ struct Mapping {
   void unmap() {
     if (!va) return;
     for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(va + i * chunk, chunk);
-    (void)hipMemAddressFree(va, bytes);
+    g_retired_va += bytes;   // NOT hipMemAddressFree: this range must never be mapped again (header)
     va = nullptr; mapped = 0;
   }
 };
@@ -233,7 +247,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   size_t free_b = 0, total_b = 0;
   const VmmEnv env = vmm_env(device);
   // small arenas are not bandwidth-bound; without the VMM API, or without room to look around, allocate plainly
-  const bool place = opt.scan_bytes && bytes >= ((size_t)256 << 20) && env.ok &&
+  const bool place = opt.scan_bytes && bytes >= ((size_t)256 << 20) && env.ok && g_retired_va.load() < kRetiredVaLimit &&
                      hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   const size_t per = (bytes + chunk - 1) / chunk;                       // chunks per arena
   const size_t budget = place ? std::min<size_t>(opt.scan_bytes + 3 * per * chunk, free_b / 10 * 6) : 0;

@@ -6,6 +6,7 @@ Run on an MI355X:  python -m pytest tests -m gpu -x -q
 import ctypes as C
 import itertools
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -957,6 +958,51 @@ def test_legacy_sw_fetch_matches_oracle_hit_lists(ctx):
                                                          h["len_b"], h["a"], h["b"])
     lib.smith_waterman_free(sw)
     lib.alignment_free(res)
+
+
+def test_legacy_api_one_aligner_per_thread_runs_in_parallel(ctx):
+    """The reference's aligner_align mutates only its own aligner_t (src/alignment.c:170-202), so one aligner per thread
+    runs in parallel (SURVEY 8b "Threading").  Here every calling thread gets its own device context: 8 threads x own
+    nw_aligner_t must give the single-thread answers and more than 4x the single-thread pairs per second (rounds 1-2:
+    one context behind one mutex, 1x)."""
+    import threading
+    import time
+    lib = S.lib()
+    sc = S.make_scoring({"preset": "default"})
+    osc = oracle_scoring_of(sc)
+    batch = W.dna_nw_150(48, seed=77, length=120, related=True)
+    pairs = [(batch.seq_a(p), batch.seq_b(p)) for p in range(batch.n_pairs)]
+    want = [O.oracle_nw(osc, a, b)[1:] for a, b in pairs]
+
+    def worker(rounds, out, idx):
+        nw = C.c_void_p(lib.needleman_wunsch_new())
+        res = C.c_void_p(lib.alignment_create(C.c_size_t(512)))
+        ok = True
+        for _ in range(rounds):
+            for (a, b), w in zip(pairs, want):
+                lib.needleman_wunsch_align2(a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), nw, res)
+                r = O.Alignment.from_address(res.value)
+                ok &= (r.score, C.string_at(r.result_a), C.string_at(r.result_b)) == w
+        lib.alignment_free(res)
+        lib.needleman_wunsch_free(nw)
+        out[idx] = ok
+
+    def rate(n_threads, rounds):
+        out = [None] * n_threads
+        ts = [threading.Thread(target=worker, args=(rounds, out, i)) for i in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        assert all(out), out
+        return n_threads * rounds * len(pairs) / dt
+
+    rate(8, 1)                     # every thread's context and scratch exist (first use allocates)
+    one = max(rate(1, 4) for _ in range(2))
+    eight = max(rate(8, 4) for _ in range(2))
+    assert eight > 4.0 * one, (one, eight)
 
 
 def test_legacy_api_sees_scoring_edits_between_calls(ctx):
