@@ -107,7 +107,9 @@ enum { SA_ROWS_REG = 0, SA_ROWS_LDS = 1, SA_ROWS_STRIP = 2 };
 
 // (occupancy: the row loop is half latency -- a row's loads, its dependent passes -- so a wave more per SIMD is worth
 // a few spilled registers on the cold paths: C3 2.91 -> 2.39 ms with 5 instead of 4; 6 loses again)
-template <int CPL, typename KeyT, int ROWS>
+// PLAIN: the scoring has no free / forbidden gaps and no sentinel scores (the launcher decides): only the 32-bit
+// decision code is compiled in, which is what every BASELINE config runs
+template <int CPL, typename KeyT, int ROWS, bool PLAIN>
 __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : CPL == 3 ? 5 : CPL == 4 ? 4 : CPL == 5 ? 3 : 1) : 1)) sw_sweep_kernel(const SaSweepParams p, const uint32_t table_ints, const uint32_t code_ints) {
   constexpr KeyT kNone = ~(KeyT)0;         // no walk
   const int lane = threadIdx.x;
@@ -170,8 +172,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   // plain scorings (no free / forbidden gaps, no sentinel scores): the three decisions of alignment_reverse_move
   // (alignment.c:311-327: GAP_A, then GAP_B, then MATCH) on 32-bit values -- SW scores are >= 0 and far from the
   // int range, so this is the 64-bit code's result; everything else goes through reverse_move_t
-  const bool plain = !(p.flags & (SA_F_NO_START_GAP | SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_NO_MISMATCH |
-                                  SA_F_HAS_SENTINEL));
+  constexpr bool plain = PLAIN;
   const uint32_t cshift = p.layout.row_bits, sshift = p.layout.row_bits + p.layout.col_bits;
   const int cap = p.layout.cap;
   constexpr int kSegW = kWave * CPL;
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
         const int qb[3] = {c ? pb[cl] : e_pb, pb[c], c ? b[cl] : e_b};
         (void)qm;
         dir[c] = 0x3fu; bad[c] = 0;
-        if (plain) {
+        if constexpr (plain) {
           const int sub = (k.K <= 1) ? ((ca[c] & 0xff) == (code_b & 0xff) ? k.gen_eq : k.gen_ne)
                                      : subst_score<SA_SUBST_LDS>(ca[c] & 0xff, (ca[c] >> 8) * k.K, code_b, k.table, k.gen_eq, k.gen_ne);
           const int va[3] = {sub, k.ext, k.open1}, vb[3] = {sub, k.open1, k.ext};
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
       if (!__any(changed)) break;
     }
     // a winner standing in a state that cannot be explained: the error of alignment_reverse_move (alignment.c:329-345)
-    if (!plain) {
+    if constexpr (!plain) {
       bool any_bad = false;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) any_bad |= wk[c] != kNone && ((bad[c] >> ws[c]) & 9u) != 0u;
@@ -686,8 +687,15 @@ static void launch_sweep(const SaSweepParams &p, hipStream_t stream) {
   const dim3 grid(ROWS == SA_ROWS_STRIP ? sa_sweep_strip_blocks(p.n_pairs, p.max_len_a, kWave * CPL) : p.n_pairs), block(kWave);
   size_t lds = ((size_t)table_ints + code_ints) * 4;
   if (ROWS == SA_ROWS_LDS) lds += (size_t)2 * p.lds_columns * ((key32 ? 4 : 8) + 4);
-  if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
-  else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, ROWS>), grid, block, lds, stream, p, table_ints, code_ints);
+  const bool plain = !(p.flags & (SA_F_NO_START_GAP | SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_NO_MISMATCH |
+                                  SA_F_HAS_SENTINEL));
+  if (plain) {
+    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS, true>), grid, block, lds, stream, p, table_ints, code_ints);
+    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, ROWS, true>), grid, block, lds, stream, p, table_ints, code_ints);
+  } else {
+    if (key32) hipLaunchKernelGGL((sw_sweep_kernel<CPL, uint32_t, ROWS, false>), grid, block, lds, stream, p, table_ints, code_ints);
+    else hipLaunchKernelGGL((sw_sweep_kernel<CPL, unsigned long long, ROWS, false>), grid, block, lds, stream, p, table_ints, code_ints);
+  }
 }
 
 }  // namespace sa

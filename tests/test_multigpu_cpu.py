@@ -116,22 +116,81 @@ def test_cell_balanced_shards_on_a_ragged_batch():
     assert b"".join(p.seq_a(i) for p in parts for i in range(p.n_pairs)) == b"".join(b.seq_a(i) for i in range(50))
 
 
-def test_bench_launches_its_own_ranks_and_shards_c5():
-    """`python bench.py --gpus 2` outside any launcher starts two ranks itself (no torchrun, gloo control
-    plane, no RCCL) and shards BASELINE config 5's pair stream by contiguous index.  CPU box: --plumbing-test
-    makes the oracle fill a handful of pairs; what is checked is launcher + sharding + MAX/SUM reductions."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--plumbing-test", "--pairs", "5"],
-                         env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                 # ONE JSON line, from rank 0
-    res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["global_pairs"] == 10 and res["elapsed_max"] == 2.0
-    full = W.dna_nw_indexed(0, 10, seed=5)                 # C5's stream: pair p is the same in every shard size
+def _c5_digests(n):
+    full = W.dna_nw_indexed(0, n, seed=5)                  # C5's stream: pair p is the same in every shard size
     sc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
     want = []
-    for p in range(10):
+    for p in range(n):
         rc, M, A, B = O.oracle_fill(sc, full.seq_a(p), full.seq_b(p), 0)
         want.append([p, O.fnv(M), O.fnv(A), O.fnv(B)])
-    assert res["digests"] == want and res["cells_sum"] == full.cells()
+    return want, full.cells()
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR",
+                                                            "TORCHELASTIC_USE_AGENT_STORE", "SEQALIGN_DIST_BACKEND")}
+    env.update(extra)
+    return env
+
+
+def test_bench_launches_its_own_ranks_and_shards_c5():
+    """`python bench.py --gpus 8` outside any launcher starts eight ranks itself (no torchrun; the control plane is a
+    key-value store, no process group, no RCCL) and shards BASELINE config 5's pair stream by contiguous index.  CPU
+    box: --plumbing-test makes the oracle fill a handful of pairs; what is checked is launcher + sharding + MAX/SUM
+    reductions -- and that rank 0's stdout is EXACTLY one line (the driver parses it)."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--plumbing-test", "--pairs", "3"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[:400]      # ONE line, nothing else on stdout
+    res = json.loads(lines[0])
+    want, cells = _c5_digests(24)
+    assert res["n_gpus"] == 8 and res["global_pairs"] == 24 and res["elapsed_max"] == 8.0
+    assert res["digests"] == want and res["cells_sum"] == cells
+
+
+def test_bench_under_torch_distributed_run_prints_one_line():
+    """The driver's launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N.  The ranks talk through the launcher's own store; stdout of the whole job is the
+    one JSON line -- with the store control plane and with a gloo process group (whose C++ banner must go to stderr)."""
+    for backend in ("store", "gloo"):
+        port = free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--plumbing-test", "--pairs", "4"]
+        out = subprocess.run(cmd, env=_clean_env(SEQALIGN_DIST_BACKEND=backend, OMP_NUM_THREADS="1"), capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, (backend, out.stderr[-2000:])
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), (backend, out.stdout[:600])
+        res = json.loads(lines[0])
+        want, cells = _c5_digests(8)
+        assert res["n_gpus"] == 2 and res["digests"] == want and res["cells_sum"] == cells and res["elapsed_max"] == 2.0
+
+
+def test_rank_pinning_deals_out_a_numa_node():
+    """bench.py pins each rank (and so the library's worker pool) to its share of the CPUs of its GPU's NUMA node:
+    ranks on the same node get disjoint, equal shares that keep hyper-thread siblings together."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    if not hasattr(os, "sched_setaffinity"):
+        return
+    before = os.sched_getaffinity(0)
+    try:
+        allowed = sorted(before)
+        nodes = [0, 0, 1, 1]                      # ranks 0, 1 on node 0; 2, 3 on node 1
+        seen = []
+        for rank in (0, 1):
+            os.sched_setaffinity(0, before)
+            info = bench.pin_rank(0, allowed, rank, 4, nodes)
+            mine = sorted(os.sched_getaffinity(0))
+            seen.append(mine)
+            if len(allowed) >= 2:
+                assert info["cpus"] == len(mine) and 1 <= len(mine) <= max(1, len(allowed) // 2) + 1
+        if len(allowed) >= 2:
+            assert not set(seen[0]) & set(seen[1])
+        os.sched_setaffinity(0, before)
+        assert bench.pin_rank(None, [], 0, 4, nodes)["cpus"] is None      # unknown node: left alone
+        assert sorted(os.sched_getaffinity(0)) == allowed
+    finally:
+        os.sched_setaffinity(0, before)
