@@ -161,6 +161,13 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   SaCandBox cand;
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
   cand.cand_rows = d_keys.as<uint32_t>(); cand.hit_off = d_hitoff.as<uint64_t>();
+  // plain scorings, rows up to 512 columns: the fill writes match_scores + one byte of directions per cell instead of the
+  // three matrices (sa_fill_dirs.hip); the directions go where gap_a_scores would have gone
+  bool dirs_used = false;
+  if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
+  // (only when the sweep will run in its rows-in-registers form: not with the strip / LDS forms forced by an option)
+  const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0;
+  cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
   seqalign_dev_batch_t d;
   bool reported = false;
   if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported))) return rc;
@@ -184,6 +191,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.open1 = sc->flat.open1; q.ext = sc->flat.ext;
   q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
   q.max_len_a = c.max_a; q.layout = layout; q.tune_cpl = ctx->opt.sweep_cpl;
+  q.dirs = dirs_used ? cand.dirs : nullptr;
   // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows up to 512 columns in registers,
   // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
   // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  The option sweep_mode = strips | pair
@@ -308,7 +316,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.trace_status = dv_meta + 3 * nw; t.out_pos = dv_meta + 4 * nw;
     t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.hit_off = q.hit_off; t.layout = layout;
     t.n_pairs = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
-    t.flags = q.flags; t.tune_walker = ctx->opt.trace_kernel;
+    t.flags = q.flags; t.tune_walker = ctx->opt.trace_kernel; t.dirs = q.dirs;
     if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
     // ---- round trip 2: the hits (their lengths size the packing)
     HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, dv_meta, nw * 32, hipMemcpyDeviceToHost, st));

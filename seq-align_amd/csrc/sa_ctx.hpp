@@ -200,6 +200,8 @@ struct SaOptions {
   uint32_t sweep_strip = 0;       // sweep_strip       64|128|256 columns per strip
   uint32_t sweep_cpl = 0;         // sweep_cpl         1|2|4: the LDS form of the sweep
   bool sweep_trace = false;       // sweep_trace       per-pair counters of the sweep on stderr
+  bool sweep_dirs = true;         // sweep_dirs        0|1: the multi-hit path fills match_scores + direction bytes (sa_fill_dirs.hip)
+                                  //                   where it applies, instead of the three matrices
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)

@@ -136,6 +136,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_strip")) { if (num != 0 && num != 64 && num != 128 && num != 256) return false; o.sweep_strip = (uint32_t)num; return true; }
   if (is("sweep_cpl")) { if (num != 0 && num != 1 && num != 2 && num != 4) return false; o.sweep_cpl = (uint32_t)num; return true; }
   if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
+  if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {
     if (num != 0 && num < (1 << 20)) return false;
@@ -153,7 +154,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -332,6 +333,21 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
                              : sa_wgstream_kernel_reports_best(p, batch->max_len_a, batch->max_len_b);
     if (reports) { if (best_done) *best_done = true; }
     else p.best_score = nullptr, p.best_index = nullptr;
+  }
+  if (cand && cand->dirs_used) *cand->dirs_used = false;
+  if (cand && cand->dirs && cand->dirs_used && ctx->opt.sweep_dirs && kernel == SEQALIGN_KERNEL_AUTO &&
+      ctx->opt.kernel == SEQALIGN_KERNEL_AUTO) {
+    // the SW multi-hit path's own fill: match_scores + a byte of directions per cell (sa_fill_dirs.hip)
+    p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box; p.cand_rows = cand->cand_rows;
+    p.cand_rows_off = cand->hit_off;
+    if (sa_dirs_fill_applicable(p, batch->max_len_a, cand->dirs)) {
+      e = sa_launch_fill_dirs(p, batch->max_len_a, cand->dirs, st);
+      if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
+      *cand->dirs_used = true;
+      if (cand_done) *cand_done = true;
+      return SEQALIGN_OK;
+    }
+    p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr; p.cand_rows_off = nullptr;
   }
   if ((which == SEQALIGN_KERNEL_STREAM || which == SEQALIGN_KERNEL_WGSTREAM) && cand) {   // where the candidates are, straight from the fill's registers
     p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box; p.cand_rows = cand->cand_rows;

@@ -72,6 +72,10 @@ struct SaCandBox {
   uint32_t *cand_rows;        /* the multi-hit path's scratch arena, as uint32 (SaFillParams::cand_rows) */
   const uint64_t *hit_off;    /* [n + 1] where pair p's part of it starts, in uint64       */
   const int32_t *cand_min;    /* [n] per-pair min_score                                    */
+  uint8_t *dirs;              /* optional: room for one byte per cell (same cell offsets as the matrices).  If the batch is in
+                                 sa_fill_dirs.hip's domain the fill writes match_scores + directions there INSTEAD of the three
+                                 matrices and sets *dirs_used (gap_a / gap_b are then not written at all)                     */
+  bool *dirs_used;
 };
 
 /* SW multi-hit enumeration: the reverse sweep (sa_sw_sweep.hip) */
@@ -115,6 +119,8 @@ struct SaSweepParams {
   SaKeyLayout layout;
   unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (option sweep_trace) */
   uint32_t tune_cpl;             /* host side only: 1, 2, 4 forces the LDS form with segments of 64 * that many columns (option sweep_cpl) */
+  const uint8_t *dirs;           /* != NULL: the matrices were filled by sa_fill_dirs.hip -- M holds match_scores, dirs one byte
+                                    of directions per cell (same cell offsets), A / B are not used                           */
 };
 #define SA_SWEEP_UNSORTED 0x80000000u
 #define SA_SWEEP_OVERFLOW 0x40000000u   /* more hits than the pair's part of the arena holds (cannot happen: see hit_off) */
@@ -157,6 +163,7 @@ struct SaTraceParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
+  const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
 };
 
 /* substitution lookup flavour */
@@ -186,6 +193,10 @@ bool sa_wgstream_kernel_applicable(const SaFillParams &p, uint32_t max_len_a);
 hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream);
 bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 bool sa_wgstream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a);
+/* the SW multi-hit path's own fill (sa_fill_dirs.hip): match_scores + one byte of directions per cell into `dirs`
+ * (same cell offsets as the matrices), candidates reported as by the stream kernel; plain SW scorings, rows <= 512 columns */
+bool sa_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
+hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */

@@ -647,6 +647,156 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same sweep over what sa_fill_dirs.hip leaves behind: match_scores (candidacy, keys) and one byte of directions
+// per cell -- where a walk goes from a cell in each of its three states was decided by the fill, with the operands
+// still in its registers.  What is left here is the part that IS the sweep: arrivals from the row below, the row's
+// right-to-left passes, hits.  5 B per cell loaded instead of 12, two row registers per column instead of nine,
+// no decision code at all.  Rows up to 512 columns (the whole row in one segment, winners in registers), plain
+// scorings; one wave per pair.
+template <int CPL, typename KeyT>
+__global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6 ? 5 : 4)) sw_sweep_dirs_kernel(const SaSweepParams p) {
+  constexpr KeyT kNone = ~(KeyT)0;
+  const int lane = threadIdx.x;
+  const uint32_t pair = blockIdx.x;
+  if (p.cand_count[pair] == 0) {
+    if (lane == 0) { p.hit_count[pair] = 0; p.status[pair] = 0; p.err_key[pair] = ~0ull; }
+    return;
+  }
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint64_t mo = p.mat_off[pair];
+  const int32_t *__restrict__ Mg = p.M + mo;
+  const uint8_t *__restrict__ Dg = p.dirs + mo;
+  unsigned long long *hit_keys = p.hit_keys + p.hit_off[pair] + lb + 1;
+  const uint32_t hit_cap = (uint32_t)min(p.hit_off[pair + 1] - p.hit_off[pair] - (lb + 1), (uint64_t)0xffffffffu);
+  const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1];
+  const int thr = max(p.min_score[pair], 1);
+  const uint32_t cshift = p.layout.row_bits, sshift = p.layout.row_bits + p.layout.col_bits;
+  const int cap = p.layout.cap;
+
+  int m[CPL], nm[CPL], thr_c[CPL];
+  uint32_t d[CPL], nd[CPL];
+  KeyT wk[CPL];
+  uint32_t wz[CPL];
+  uint32_t n_hits = 0;
+  bool overflow = false;
+  const int xl = lane * CPL;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    thr_c[c] = (uint32_t)(xl + c) < W ? thr : INT32_MAX;
+    wk[c] = kNone; wz[c] = kStay;
+  }
+  auto load_row = [&](uint32_t y, int (&dm)[CPL], uint32_t (&dd)[CPL]) __attribute__((always_inline)) {
+    const uint32_t at = y * W + (uint32_t)xl;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { dm[c] = 0; dd[c] = 0x3fu; }
+    if (y < lb) {   // a lane's run may reach past the row's end: that is the next row, still inside the pair's matrix
+      if ((uint32_t)xl < W) {
+        load_run<CPL>(Mg + at, dm);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dd[c] = Dg[at + c];
+      }
+    } else {        // the last row: cell by cell
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if ((uint32_t)(xl + c) < W) { dm[c] = Mg[at + c]; dd[c] = Dg[at + c]; }
+    }
+  };
+
+  uint32_t y = rmax;
+  load_row(y, m, d);
+  for (;; --y) {
+    if (y >= 1) load_row(y - 1, nm, nd);
+    bool live = false;
+    // ---- arrivals from below and the cell's own candidacy (sw_sweep_kernel::sweep_segment, same rules)
+    KeyT bk[CPL];
+    uint32_t bs[CPL];
+    bool any = false;
+    {
+      const KeyT dk_edge = wave_shl1(wk[0], kNone);
+      const uint32_t dz_edge = wave_shl1(wz[0], kStay);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const KeyT dk = c + 1 < CPL ? wk[c + 1 < CPL ? c + 1 : c] : dk_edge;
+        const uint32_t dz = c + 1 < CPL ? wz[c + 1 < CPL ? c + 1 : c] : dz_edge;
+        KeyT best = (m[c] >= thr_c[c]) ? (KeyT)((((unsigned long long)(uint32_t)(cap - m[c]) << sshift) |
+                                            ((unsigned long long)(uint32_t)(xl + c) << cshift) | y))
+                                  : kNone;
+        uint32_t st = MAT_MATCH;
+        if ((dz & 3u) == MAT_MATCH && dk < best) { best = dk; st = dz >> 2; }
+        if ((wz[c] & 3u) == MAT_GAP_A && wk[c] < best) { best = wk[c]; st = wz[c] >> 2; }
+        bk[c] = best; bs[c] = st;
+        any |= best != kNone;
+      }
+    }
+    if (!__any(any)) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { wk[c] = kNone; wz[c] = kStay; }
+    } else {
+      // ---- arrivals along the row: my columns right to left, then again while some lane's incoming walk changes
+      KeyT in_k = kNone;
+      uint32_t in_s = 0;
+      uint32_t ws[CPL];
+      for (;;) {
+        KeyT hk = in_k;
+        uint32_t hs = in_s;
+#pragma unroll
+        for (int c = CPL - 1; c >= 0; --c) {
+          const bool side = hk < bk[c];
+          const KeyT win = side ? hk : bk[c];
+          const uint32_t st = side ? hs : bs[c];
+          const uint32_t f = (d[c] >> (2u * st)) & 3u;
+          wk[c] = win; ws[c] = st;
+          const bool leaves = win != kNone && f != 3u;
+          wz[c] = leaves ? ((f << 2) | st) : kStay;
+          hk = (leaves && st == MAT_GAP_B) ? win : kNone;
+          hs = f;
+        }
+        const KeyT nk = wave_shl1((wz[0] & 3u) == MAT_GAP_B ? wk[0] : kNone, kNone);
+        const uint32_t ns = wave_shl1(wz[0] >> 2, 0u);
+        const bool changed = nk != in_k || (nk != kNone && ns != in_s);
+        in_k = nk; in_s = ns;
+        if (!__any(changed)) break;
+      }
+      // ---- hits: winners whose state has score 0
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const bool hit = wk[c] != kNone && ((d[c] >> (2u * ws[c])) & 3u) == 3u;
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+          const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)wk[c];
+          n_hits += (uint32_t)__popcll(bal);
+          if (n_hits > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
+        }
+        live |= wz[c] != kStay;
+      }
+    }
+    if (y == 0 || (!__any(live) && y <= rmin)) break;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { m[c] = nm[c]; d[c] = nd[c]; }
+  }
+
+  // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
+  uint32_t status = overflow ? SA_SWEEP_OVERFLOW : 0u;
+  if (n_hits > 1 && !overflow) {
+    if (n_hits <= (uint32_t)kWave) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned long long key = lane < (int)n_hits ? __hip_atomic_load(hit_keys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n_hits; ++j) rank += lane_value(key, (int)j) < key;
+      if (lane < (int)n_hits) hit_keys[rank] = key;
+    } else {
+      status |= SA_SWEEP_UNSORTED;
+    }
+  }
+  if (lane == 0) {
+    p.hit_count[pair] = n_hits;
+    p.status[pair] = status;
+    p.err_key[pair] = ~0ull;
+  }
+}
+
 // The strips of a pair append to its hit list in no particular order: one wave per pair ranks up to 64 hits
 // afterwards (as the one-wave-per-pair forms do themselves); longer lists are flagged for the host.
 __global__ void __launch_bounds__(kWave) sw_order_hits_kernel(const SaSweepParams p) {
@@ -705,8 +855,28 @@ uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a, uint32_t st
   return ((n_pairs + 7u) / 8u) * 8u * sa_sweep_strips_per_pair(max_len_a, strip_columns);
 }
 
+namespace sa {
+template <int CPL>
+static void launch_sweep_dirs(const SaSweepParams &p, hipStream_t stream) {
+  const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
+  if (key32) hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+  else hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+}
+}  // namespace sa
+
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (p.dirs) {   // behind sa_fill_dirs.hip: match_scores + a byte of directions per cell (rows up to 512 columns)
+    const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;
+    if (need > 8 || p.strip_progress) return hipErrorInvalidValue;
+    if (need <= 2) sa::launch_sweep_dirs<2>(p, stream);
+    else if (need <= 3) sa::launch_sweep_dirs<3>(p, stream);
+    else if (need <= 4) sa::launch_sweep_dirs<4>(p, stream);
+    else if (need <= 5) sa::launch_sweep_dirs<5>(p, stream);
+    else if (need <= 6) sa::launch_sweep_dirs<6>(p, stream);
+    else sa::launch_sweep_dirs<8>(p, stream);
+    return hipGetLastError();
+  }
   // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks
   // spread over most of the row anyway).  Beyond that: many pairs -- one wave per pair, segments of 256 columns that
   // follow the walks, the winners of two rows in LDS; few pairs, or rows too wide for LDS -- one wave per strip of

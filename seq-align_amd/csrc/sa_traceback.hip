@@ -109,6 +109,44 @@ __global__ void __launch_bounds__(64) traceback_kernel(const SaTraceParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// SW hits behind sa_fill_dirs.hip: the fill left one byte of directions per cell (where a walk goes from the cell in
+// each of its three states, 3 = that state's score is 0), so a walk is a chain of ONE byte load per step instead of
+// three ints, and there is nothing to decide.  Same loop as traceback_kernel<true> (smith_waterman.c:187-255):
+// while the state's score is positive, emit the column, step back.  One lane per walk.
+__global__ void __launch_bounds__(64) traceback_dirs_kernel(const SaTraceParams p) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.n_pairs) return;
+  const uint32_t pair = p.walker_pair ? p.walker_pair[w] : w;
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
+  const uint8_t *__restrict__ sb_ = p.arena + p.off_b[pair];
+  const uint64_t mo = p.mat_off[pair];
+  const uint8_t *__restrict__ Dg = p.dirs + mo;
+  char *oa = p.out_a + p.str_off[w];
+  char *ob = p.out_b + p.str_off[w];
+  uint32_t x, y, head = la + lb;
+  sw_walk_start(p, w, pair, W, x, y);
+  const int score = p.M[mo + (uint64_t)y * W + x];
+  const uint32_t end_x = x, end_y = y;
+  uint32_t st = MAT_MATCH;
+  for (;;) {
+    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    if (f == 3u) break;                               // this state's score is 0: the hit starts here
+    --head;
+    oa[head] = (st == MAT_GAP_A) ? '-' : (char)sa_[x - 1];
+    ob[head] = (st == MAT_GAP_B) ? '-' : (char)sb_[y - 1];
+    x -= (st != MAT_GAP_A);                           // MATCH: up-left, GAP_A: up, GAP_B: left (alignment.c:274-296)
+    y -= (st != MAT_GAP_B);
+    st = f;
+  }
+  p.out_pos[4 * w + 0] = x;
+  p.out_pos[4 * w + 1] = y;
+  p.out_pos[4 * w + 2] = end_x - x;
+  p.out_pos[4 * w + 3] = end_y - y;
+  write_walk_meta(p, w, pair, head, la + lb - head, score, 0u);
+}
+
+// ---------------------------------------------------------------------------
 // One WAVE per pair, the walk's neighbourhood staged in LDS.
 //
 // A step needs the three matrices at ONE predecessor cell and the two sequence
@@ -258,6 +296,11 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (p.dirs) {   // SW hits behind sa_fill_dirs.hip
+    if (!p.hit_keys || !p.out_pos) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+  }
   const bool sw = p.start_index || p.hit_keys;
   // Measured (seq-align_amd/tools/long_e2e.py): the tiled wave-per-pair walker wins when there are few pairs
   // (1 x 10 000^2: 9.5 -> 7.4 ms, 16 x 5 000^2: 6.6 -> 4.2 ms of traceback) and loses a little when the lanes of

@@ -480,13 +480,17 @@ def test_sw_batch_hits_match_oracle(ctx, max_hits, where, opts):
 
 
 @pytest.mark.parametrize("name", ["C3", "C4"])
-@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("where", ["device", "host", "device-three-matrices"])
 def test_sw_batch_hit_lists_at_config_size(ctx, name, where, opts):
     """seqalign_sw_batch at the BASELINE dimensions (150x1000 DNA / 300x300 BLOSUM62, --minscore 60): the ordered
     hit lists of 64 seeded pairs, max_hits 1 and unlimited, against the committed ORACLE-DERIVED lists
     (tests/golden/sw_hits_oracle.json -- the reference's smith_waterman.c cannot be built here) and a live
-    oracle run.  Reference: src/smith_waterman.c:137-277."""
-    opts(traceback=where)
+    oracle run.  "device" takes the direction-byte path (sa_fill_dirs.hip: both configs are in its domain),
+    "device-three-matrices" round 2's.  Reference: src/smith_waterman.c:137-277."""
+    if where == "device-three-matrices":
+        opts(sweep_dirs=0)
+    else:
+        opts(traceback=where)
     g = load("sw_hits_oracle.json")[name]
     sc = S.make_scoring({"preset": "BLOSUM62"} if g["scoring"] == "BLOSUM62" else g["scoring"])
     osc = oracle_scoring_of(sc)
@@ -744,7 +748,9 @@ def test_arena_allocator(ctx):
 
 
 SWEEP_VARIANTS = {
-    "default": {},                                    # segment width by sequence length, records of two rows in LDS
+    "default": {},                                    # plain scorings, rows <= 512 columns: match_scores + direction bytes
+                                                      # (sa_fill_dirs.hip); else three matrices, form by sequence length
+    "three-matrices": {"sweep_dirs": 0},              # the three-matrix path everywhere (round 2's)
     "segments-64": {"sweep_cpl": 1},                  # 64-column segments: several per row where the walks spread out
     "segments-256": {"sweep_cpl": 4},
     "strips": {"sweep_mode": "strips", "sweep_strip": 64},   # one wave per 64-column strip of a pair
