@@ -215,61 +215,6 @@ void sa_host::parallel_memcpy(void *dst, const void *src, size_t bytes) {
 
 bool sa_host::traceback_on_host(const seqalign_ctx *ctx) { return ctx->opt.traceback_host; }
 
-// device traceback of one already-filled chunk; strings land in the caller's buffers
-static int nw_chunk_device_traceback(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c,
-                                     const seqalign_dev_scoring *sc, const seqalign_dev_batch_t &d,
-                                     const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
-                                     int32_t *out_score) {
-  const uint64_t n = c.count;
-  int rc;
-  StageTimer tm(ctx->opt.timing);
-  // per-pair slots of len_a+len_b chars in a compact device arena
-  if ((rc = ctx->h_tmeta.reserve(n * 8 + n * 16))) return rc;
-  uint64_t *h_off = ctx->h_tmeta.as<uint64_t>();
-  uint64_t total = 0;
-  for (uint64_t k = 0; k < n; ++k) {
-    h_off[k] = total;
-    total += (uint64_t)batch->len_a[c.first + k] + batch->len_b[c.first + k];
-  }
-  if ((rc = ctx->t_str_off.reserve(n * 8)) || (rc = ctx->t_out_a.reserve(total + 16)) ||
-      (rc = ctx->t_out_b.reserve(total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
-      (rc = ctx->h_ta.reserve(total + 16)) || (rc = ctx->h_tb.reserve(total + 16)))
-    return rc;
-  hipStream_t st = ctx->stream;
-  HIP_TRY(hipMemcpyAsync(ctx->t_str_off.p, h_off, n * 8, hipMemcpyHostToDevice, st));
-  uint32_t *d_meta = ctx->t_meta.as<uint32_t>();   // head | len | score | status, n each
-  seqalign_trace_t t;
-  memset(&t, 0, sizeof(t));
-  t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
-  t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
-  t.status = d_meta + 3 * n;
-  if ((rc = seqalign_nw_traceback_device(ctx, sc, &d, &t, st))) return rc;
-  uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
-  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, ctx->t_out_a.p, total, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, ctx->t_out_b.p, total, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 16, hipMemcpyDeviceToHost, st));
-  tm.lap("nw: enqueue traceback + D2H");
-  if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // fill status; synchronises the stream
-  tm.lap("nw: wait for the GPU");
-  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
-  for (uint64_t k = 0; k < n; ++k)
-    if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
-  constexpr uint64_t kPack = 2048;
-  parallel_for((n + kPack - 1) / kPack, [&](uint64_t blk) {
-    for (uint64_t k = blk * kPack, e = std::min(n, (blk + 1) * kPack); k < e; ++k) {
-      const uint64_t p = c.first + k;
-      const uint32_t head = h_meta[k], len = h_meta[n + k];
-      memcpy(out_a + str_off[p], ha + h_off[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
-      memcpy(out_b + str_off[p], hb + h_off[k] + head, len);
-      out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
-      out_len[p] = len;
-      out_score[p] = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
-    }
-  });
-  tm.lap("nw: unpack strings");
-  return SEQALIGN_OK;
-}
-
 // ---- seqalign_nw_batch, device traceback: one chunk as a PIPELINE of sub-batches -------------------------------
 // The stages of a chunk -- host packs the sequences, H2D, fill (HBM-bound), traceback, D2H of the strings, host
 // unpacks -- run strictly one after the other cost their sum (C2: 1.3-1.4 ms for a 0.41 ms fill; C5's per-GPU share:
@@ -323,10 +268,18 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   }
   h_slot[n] = pos;
   const uint64_t total = pos;   // == c.seq_bytes
+  // Plain scorings, rows up to 512 columns: the fill writes ONE byte of directions per cell and nothing else
+  // (sa_fill_dirs.hip) -- the three matrices are never needed, so they are not even allocated.
+  const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a);
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16)) || (rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8)) ||
-      (rc = reserve_arenas(ctx, c.cells * 4)) || (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
+      (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
       (rc = ctx->h_ta.reserve(2 * total + 16)) || (rc = ctx->h_tmeta.reserve(n * 16)))
     return rc;
+  if (use_dirs) {
+    if ((rc = ctx->dirs.reserve(c.cells + 4096)) || (rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+  } else if ((rc = reserve_arenas(ctx, c.cells * 4))) {
+    return rc;
+  }
   for (int k = 0; k < 2; ++k)
     if (!ctx->copy_streams[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[k], hipStreamNonBlocking));
   hipStream_t sf = ctx->stream, su = ctx->copy_streams[0], sd = ctx->copy_streams[1];
@@ -388,7 +341,15 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     HIP_TRY(hipStreamWaitEvent(sf, ev.ev[s], 0));
     if (k1 > k0) {
       const seqalign_dev_batch_t d = dev_range(k0, k1);
-      if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) return rc;
+      if (use_dirs) {
+        bool used = false;
+        if ((rc = nw_dirs_fill(ctx, sc, &d, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>() + k0,
+                               ctx->best_index.as<uint64_t>() + k0, sf, &used)))
+          return rc;
+        if (!used) { set_last_error("seqalign_nw_batch: internal error: directions-only fill refused a batch it had accepted"); return SEQALIGN_E_HIP; }
+      } else if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) {
+        return rc;
+      }
     }
     if (s + 1 == gcut[g + 1]) {   // the group is filled: walk it, send it home
       const uint64_t g0 = cut[gcut[g]], g1 = cut[s + 1];
@@ -403,6 +364,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         t.out_a = d_chars + 2 * c0 - c0;                  // + slot offset: a-strings at [2 c0, 2 c0 + (c1 - c0))
         t.out_b = d_chars + 2 * c0 + (c1 - c0) - c0;      //                b-strings right behind them
         t.out_meta4 = d_meta + 4 * g0; t.fill_status = d.status;
+        if (use_dirs) { t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0; }
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel;
@@ -460,17 +422,11 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   for (const Chunk &c : plan_chunks(batch, budget)) {
     seqalign_dev_batch_t d;
     if (!on_host) {
-      const uint32_t n_sub = pick_subbatches(ctx, c);
-      if (n_sub > 1) {
-        if ((rc = nw_chunk_pipelined(ctx, batch, c, sc, n_sub, str_off, out_a, out_b, out_len, out_score))) return rc;
-        continue;
-      }
-    }
-    if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
-    if (!on_host) {
-      if ((rc = nw_chunk_device_traceback(ctx, batch, c, sc, d, str_off, out_a, out_b, out_len, out_score))) return rc;
+      // (one sub-batch = the plain sequence upload, fill, walk, download on the same code path)
+      if ((rc = nw_chunk_pipelined(ctx, batch, c, sc, pick_subbatches(ctx, c), str_off, out_a, out_b, out_len, out_score))) return rc;
       continue;
     }
+    if ((rc = run_chunk(ctx, batch, c, sc, &d))) return rc;
     const size_t bytes = c.cells * 4;
     if ((rc = ctx->h_M.reserve(bytes)) || (rc = ctx->h_A.reserve(bytes)) || (rc = ctx->h_B.reserve(bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->h_M.p, ctx->M.p, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -200,6 +200,8 @@ struct SaOptions {
   uint32_t sweep_strip = 0;       // sweep_strip       64|128|256 columns per strip
   uint32_t sweep_cpl = 0;         // sweep_cpl         1|2|4: the LDS form of the sweep
   bool sweep_trace = false;       // sweep_trace       per-pair counters of the sweep on stderr
+  bool nw_dirs = true;            // nw_dirs           0|1: seqalign_nw_batch fills ONLY a byte of directions per cell (sa_fill_dirs.hip) where
+                                  //                   it applies (plain scorings, rows <= 512 columns), instead of the three matrices
   bool sweep_dirs = true;         // sweep_dirs        0|1: the multi-hit path fills match_scores + direction bytes (sa_fill_dirs.hip)
                                   //                   where it applies, instead of the three matrices
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
@@ -228,6 +230,7 @@ struct seqalign_ctx {
   sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, status;
   sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
   SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
+  sa_host::DevBuf dirs;              // seqalign_nw_batch: one byte of directions per cell (sa_fill_dirs.hip)
   sa_host::DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   sa_host::DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
   sa_host::DevBuf e[14];                                 // device SW enumeration scratch (see sw_chunk_device_enumerate)
@@ -271,6 +274,9 @@ int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, cons
               seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
               bool *cand_done = nullptr);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
+int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
+                 int32_t *end_score, uint64_t *end_state, void *stream, bool *used);
+bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a);
 int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)
 int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,

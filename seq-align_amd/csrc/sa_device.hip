@@ -137,6 +137,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_cpl")) { if (num != 0 && num != 1 && num != 2 && num != 4) return false; o.sweep_cpl = (uint32_t)num; return true; }
   if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
   if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
+  if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {
     if (num != 0 && num < (1 << 20)) return false;
@@ -154,7 +155,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -216,7 +217,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   for (int k = 0; k < 2; ++k) if (ctx->cached[k]) seqalign_scoring_release(ctx, ctx->cached[k]);
   if (ctx->arena_set) sa_arenas_destroy(sa_arenas_take(ctx->M.p));
   for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
-                    &ctx->status, &ctx->best_score, &ctx->best_index,
+                    &ctx->status, &ctx->best_score, &ctx->best_index, &ctx->dirs,
                     &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score,
                     &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
     b->release();
@@ -375,6 +376,32 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
   }
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   return SEQALIGN_OK;
+}
+
+// seqalign_nw_batch's own fill (sa_fill_dirs.hip): directions only + the end cell's score / state per pair.  *used = false
+// (and nothing launched) when the scoring or the batch is outside that kernel's domain, or the option nw_dirs is off.
+int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
+                          uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, bool *used) {
+  *used = false;
+  if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || batch->n_pairs == 0 || batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_OK;
+  SaFillParams p = make_params(ctx, scoring, batch);
+  p.best_score = end_score; p.best_index = end_state;
+  if (!sa_nw_dirs_fill_applicable(p, batch->max_len_a, dirs)) return SEQALIGN_OK;
+  (void)hipGetLastError();
+  hipError_t e = sa_launch_fill_nw_dirs(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream);
+  if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
+  *used = true;
+  return SEQALIGN_OK;
+}
+// whether nw_dirs_fill would take this batch (decided before any buffer is reserved)
+bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a) {
+  if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO) return false;
+  seqalign_dev_batch_t b;
+  memset(&b, 0, sizeof(b));
+  SaFillParams p = make_params(ctx, scoring, &b);
+  int32_t s = 0; uint64_t t = 0;
+  p.best_score = &s; p.best_index = &t;
+  return sa_nw_dirs_fill_applicable(p, max_len_a, reinterpret_cast<const uint8_t *>((uintptr_t)256));
 }
 
 extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,

@@ -225,6 +225,183 @@ fill_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Needleman-Wunsch for seqalign_nw_batch: the SAME idea one step further.  The host-level call returns strings and
+// scores, never matrices, and its traceback (needleman_wunsch.c:53-145) needs from the three matrices exactly what
+// the byte above holds -- so for plain scorings this kernel writes ONLY the direction byte per cell (1 B instead of
+// 12) plus, per pair, the end cell's score and state (needleman_wunsch.c:53-66: GAP_A >= GAP_B >= MATCH on ties).
+// The walk then costs one byte load per step instead of three ints in three arenas.
+// Borders (alignment.c:46-81): (0,0) = 0; row 0: M = A = floor, B = gap_open + i*ext; column 0: M = B = floor,
+// A = gap_open + j*ext.  No state ever "ends" (code 3 is not used): the walk stops at x == 0 or y == 0.
+// Cells whose score is the floor by clamping carry a meaningless direction, like the reference's traceback (which
+// exits on them, alignment.c:328-349) they are never stood on inside the parity domain.
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t waves = blockDim.x >> 6;
+  const int32_t *table = p.table;
+  if constexpr (SUBST == SA_SUBST_LDS) {
+    int32_t *tbl = lds + (waves * R) / 4;
+    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) tbl[k] = p.table[k];
+    __syncthreads();
+    table = tbl;
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t pair = blockIdx.x * waves + wave;
+  if (pair >= p.n_pairs) return;
+
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
+  const uint8_t *__restrict__ sb_ = p.arena + p.off_b[pair];
+  const uint64_t mo = p.mat_off[pair];
+  const int open1 = p.open1, ext = p.ext, K = (int)p.K, gen_eq = p.gen_eq, gen_ne = p.gen_ne, floor_ = p.floor;
+  const Border bd{p.floor, p.gap_open, p.ext, false, false};
+
+  uint8_t *ring_d = reinterpret_cast<uint8_t *>(lds) + wave * R;
+  const uint32_t a0 = (uint32_t)((uintptr_t)(dirs_arena + mo) & 255u);
+  uint8_t *const gd = dirs_arena + mo - a0;
+  const uint32_t vend = a0 + W * (lb + 1);
+  uint32_t wv = a0, rv = 0;
+  auto flush_block = [&]() __attribute__((always_inline)) {
+    const uint32_t d4 = *reinterpret_cast<const uint32_t *>(ring_d + (rv & (R - 1)) + 4 * lane);
+    if (rv >= a0 && rv + 256 <= vend) {
+      __builtin_nontemporal_store(d4, reinterpret_cast<uint32_t *>(gd + rv + 4 * lane));
+    } else {
+      const uint32_t e = rv + 4 * lane;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (e + t >= a0 && e + t < vend) gd[e + t] = (uint8_t)(d4 >> (8 * t));
+    }
+    rv += 256;
+  };
+  auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
+    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ring_d[(wv + lane * CPL + c) & (R - 1)] = (uint8_t)dv[c];
+    wv += W;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (wv - rv >= 256u) flush_block();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+
+  int fa[CPL], arow[CPL], X[CPL], Yp[CPL], Ap[CPL], c1[CPL], c2[CPL], c3[CPL];
+  uint32_t T[CPL], TY[CPL];
+  int mv[CPL], av[CPL], bv[CPL];   // the row just computed (after the loop: the last row, for the end cell)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const uint32_t g = lane * CPL + c;
+    const int code = (g >= 1 && g <= la) ? (int)p.code[sa_[g - 1]] : 0;
+    fa[c] = code & 0xff;
+    arow[c] = (code >> 8) * K;
+    // row 0 (alignment.c:46-69)
+    mv[c] = av[c] = g ? floor_ : 0;
+    bv[c] = g ? bd.edge_gap(g) : 0;
+    X[c] = max3i(mv[c], av[c], bv[c]); Yp[c] = max(mv[c], bv[c]); Ap[c] = av[c];
+    T[c] = (av[c] == X[c]) ? 1u : (bv[c] == X[c]) ? 2u : 0u;
+    TY[c] = (bv[c] >= mv[c]) ? 2u : 0u;
+    const int g_ext = (int)g * ext;                         // (ext <= 0 in this kernel's domain)
+    c1[c] = open1 - g_ext; c2[c] = floor_ - g_ext; c3[c] = g_ext;
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  {
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dv[c] = 0;   // row 0 is never stood on with a move to make
+    append_row(dv);
+  }
+
+  int chunk_code = 0;
+  for (uint32_t j = 1; j <= lb; ++j) {
+    const int q = (j - 1) & (kWave - 1);
+    if (q == 0) {
+      const uint32_t r = j + lane;
+      if (r <= lb) chunk_code = p.code[sb_[r - 1]];
+      __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    }
+    const int code_b = read_lane(chunk_code, q);
+    const int x_ul = wave_shr1(X[CPL - 1], floor_);
+    const uint32_t t_ul = (uint32_t)wave_shr1((int)T[CPL - 1], 0);
+    const int edge_a = bd.edge_gap(j);   // gap_a of the border cell (0, j) (alignment.c:72-80)
+    int z[CPL];
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int s = subst_score<SUBST>(fa[c], arow[c], code_b, table, gen_eq, gen_ne);
+      const int xd = c ? X[c - (c ? 1 : 0)] : x_ul;
+      const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
+      int m = max(addw(xd, s), floor_);                                                   // alignment.c:101-116
+      const int ae = addw(Ap[c], ext);
+      int a = max3i(addw(Yp[c], open1), ae, floor_);                                      // alignment.c:128-135
+      if (c == 0) { m = lane == 0 ? floor_ : m; a = lane == 0 ? edge_a : a; }             // the border column
+      const uint32_t dA = (ae == a) ? 1u : TY[c];
+      mv[c] = m; av[c] = a; z[c] = max(m, a);
+      dv[c] = td | (dA << 2);
+    }
+    {
+      const int zin = wave_shr1(z[CPL - 1], z[CPL - 1]);
+      int P[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int zl = (c == 0) ? zin : z[c - 1];
+        int w = max(addw(zl, c1[c]), c2[c]);
+        if (c == 0) w = (lane == 0) ? c2[0] : w;     // gap_b of (0, j) is the floor
+        P[c] = (c == 0) ? w : max(P[c - 1], w);
+      }
+      const int incl = wave_scan_max(P[CPL - 1]);
+      const int e = wave_shr1(incl, INT32_MIN);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) bv[c] = addw(max(P[c], e), c3[c]);
+    }
+    {
+      const int al = wave_shr1(av[CPL - 1], 0), bl = wave_shr1(bv[CPL - 1], 0);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int aL = c ? av[c - (c ? 1 : 0)] : al, bL = c ? bv[c - (c ? 1 : 0)] : bl;
+        const int b = bv[c];
+        const uint32_t dB = (addw(aL, open1) == b) ? 1u : (addw(bL, ext) == b) ? 2u : 0u;
+        dv[c] |= dB << 4;
+        const int xn = max(z[c], b);
+        X[c] = xn; Yp[c] = max(mv[c], b); Ap[c] = av[c];
+        T[c] = (av[c] == xn) ? 1u : (b == xn) ? 2u : 0u;
+        TY[c] = (b >= mv[c]) ? 2u : 0u;
+      }
+    }
+    append_row(dv);
+  }
+  while (rv < wv) flush_block();
+
+  // the end cell (la, lb): score and matrix the walk starts in (needleman_wunsch.c:53-66)
+  const int owner = (int)(la / CPL), oc = (int)(la % CPL);
+  int em = 0, ea = 0, eb = 0;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { if (c == oc) { em = mv[c]; ea = av[c]; eb = bv[c]; } }
+  if (lane == owner) {
+    int score = em;
+    uint32_t st = 0;                                  // MATCH
+    if (eb >= score) { st = 2; score = eb; }          // GAP_B
+    if (ea >= score) { st = 1; score = ea; }          // GAP_A
+    p.best_score[pair] = score;
+    p.best_index[pair] = st;
+    p.status[pair] = ~0ull;
+  }
+}
+
+template <int CPL, int R>
+static hipError_t launch_nw_dirs_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  const int wpb = 4;
+  const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
+  const size_t rings = (size_t)wpb * R;
+  if (p.K <= 1) {
+    hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, rings, stream, p, dirs);
+  } else {
+    const size_t lds = rings + (((size_t)p.K * p.K + 3u) & ~(size_t)3u) * sizeof(int32_t);
+    hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_LDS, R>), grid, block, lds, stream, p, dirs);
+  }
+  return hipGetLastError();
+}
+
 template <int CPL, int R>
 static hipError_t launch_dirs_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
   const int wpb = 4;
@@ -260,4 +437,25 @@ hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_
   if (need <= 5) return sa::launch_dirs_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_dirs_cpl<6, 1024>(p, dirs, stream);
   return sa::launch_dirs_cpl<8, 1024>(p, dirs, stream);
+}
+
+// ---- Needleman-Wunsch: directions only (seqalign_nw_batch)
+bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs) {
+  // plain scorings only: no flag at all, no sentinel scores, gap_open <= 0, gap_extend <= 0
+  if ((p.flags & ~SA_F_HAS_SENTINEL) != 0 || (p.flags & SA_F_HAS_SENTINEL) || sa::needs_general(p)) return false;
+  if (p.K > SA_LDS_TABLE_MAX_K || p.ext > 0) return false;
+  if (max_len_a + 1 > 8 * sa::kWave) return false;
+  return dirs && p.best_score && p.best_index && ((uintptr_t)dirs & 255) == 0;
+}
+
+hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
+  if (p.n_pairs == 0) return hipSuccess;
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  if (need <= 1) return sa::launch_nw_dirs_cpl<1, 512>(p, dirs, stream);
+  if (need <= 2) return sa::launch_nw_dirs_cpl<2, 512>(p, dirs, stream);
+  if (need <= 3) return sa::launch_nw_dirs_cpl<3, 512>(p, dirs, stream);
+  if (need <= 4) return sa::launch_nw_dirs_cpl<4, 512>(p, dirs, stream);
+  if (need <= 5) return sa::launch_nw_dirs_cpl<5, 1024>(p, dirs, stream);
+  if (need <= 6) return sa::launch_nw_dirs_cpl<6, 1024>(p, dirs, stream);
+  return sa::launch_nw_dirs_cpl<8, 1024>(p, dirs, stream);
 }

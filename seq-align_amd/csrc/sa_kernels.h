@@ -164,6 +164,8 @@ struct SaTraceParams {
   uint32_t flags;
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
+  const int32_t *nw_score;     /* NW behind the directions-only fill (dirs != NULL): per pair the end cell's score ...            */
+  const uint64_t *nw_state;    /* ... and the matrix the walk starts in (0 MATCH, 1 GAP_A, 2 GAP_B)                                */
 };
 
 /* substitution lookup flavour */
@@ -197,6 +199,10 @@ bool sa_wgstream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len
  * (same cell offsets as the matrices), candidates reported as by the stream kernel; plain SW scorings, rows <= 512 columns */
 bool sa_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
 hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
+/* seqalign_nw_batch's own fill: ONLY the directions (1 B per cell) + per pair the end cell's score (p.best_score) and state
+ * (p.best_index); plain NW scorings (no flag), rows <= 512 columns */
+bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
+hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */

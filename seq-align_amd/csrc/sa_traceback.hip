@@ -146,6 +146,32 @@ __global__ void __launch_bounds__(64) traceback_dirs_kernel(const SaTraceParams 
   write_walk_meta(p, w, pair, head, la + lb - head, score, 0u);
 }
 
+// Needleman-Wunsch behind sa_fill_dirs.hip's directions-only fill (seqalign_nw_batch): the end cell's score and matrix
+// come from the fill (nw_score / nw_state), every step is one byte load.  needleman_wunsch.c:53-145.
+__global__ void __launch_bounds__(64) traceback_nw_dirs_kernel(const SaTraceParams p) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.n_pairs) return;
+  const uint32_t la = p.len_a[w], lb = p.len_b[w], W = la + 1;
+  const uint8_t *__restrict__ sa_ = p.arena + p.off_a[w];
+  const uint8_t *__restrict__ sb_ = p.arena + p.off_b[w];
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[w];
+  char *oa = p.out_a + p.str_off[w];
+  char *ob = p.out_b + p.str_off[w];
+  uint32_t x = la, y = lb, head = la + lb, st = (uint32_t)p.nw_state[w];
+  while (x > 0 && y > 0) {
+    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    --head;
+    oa[head] = (st == MAT_GAP_A) ? '-' : (char)sa_[x - 1];
+    ob[head] = (st == MAT_GAP_B) ? '-' : (char)sb_[y - 1];
+    x -= (st != MAT_GAP_A);
+    y -= (st != MAT_GAP_B);
+    st = f;
+  }
+  for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)sb_[y - 1]; }   // needleman_wunsch.c:117-123
+  for (; x > 0; --x) { --head; oa[head] = (char)sa_[x - 1]; ob[head] = '-'; }   // :126-132
+  write_walk_meta(p, w, w, head, la + lb - head, p.nw_score[w], 0u);
+}
+
 // ---------------------------------------------------------------------------
 // One WAVE per pair, the walk's neighbourhood staged in LDS.
 //
@@ -296,6 +322,11 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (p.dirs && p.nw_state) {   // NW behind the directions-only fill
+    if (!p.nw_score) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+  }
   if (p.dirs) {   // SW hits behind sa_fill_dirs.hip
     if (!p.hit_keys || !p.out_pos) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);

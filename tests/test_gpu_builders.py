@@ -32,7 +32,11 @@ def test_builders_equal_oracle_builders():
 def test_gpu_parity_tests_use_a_scoring_equal_to_the_checkers_own():
     """What test_gpu_parity.py relies on: for the specs it uses, the product's scoring_t bytes ARE what the checker
     would have built from the spec itself."""
-    specs = [{"preset": "default"}, {"preset": "BLOSUM62"}, {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]},
+    # (presets are table data, pinned by test_presets_equal_reference above; "default" is scoring_init 1/-2/-4/-1,
+    # alignment_scoring.c:380-392)
+    default = O.Scoring.from_buffer_copy(bytes(S.make_scoring({"preset": "default"})))
+    assert O.scoring_defined_bytes(default) == O.scoring_defined_bytes(O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle"))
+    specs = [{"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]},
              {"init": [1, -2, -4, 1, 0, 0, 0, 0, 0, 0]}, {"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0], "mutations": [["a", "c", -2], ["c", "a", -1]]}]
     for flags in itertools.product([0, 1], repeat=5):
         specs.append({"init": [1, -2, -4, -1, *flags, 0], "wildcards": [["N", -1]]})

@@ -353,11 +353,15 @@ def test_host_level_fill_batch_and_chunking(ctx):
     assert np.array_equal(M, M2) and np.array_equal(A, A2) and np.array_equal(B, B2)
 
 
-@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("where", ["device", "host", "device-three-matrices"])
 def test_nw_batch_strings_match_oracle_and_golden(ctx, where, opts):
-    """End-to-end NW: GPU fill + traceback on the device (default) or on the host
-    from the copied-back matrices (option traceback=host); identical strings."""
-    opts(traceback=where)
+    """End-to-end NW: GPU fill + traceback on the device (default: for plain scorings the fill writes only a byte of
+    directions per cell, sa_fill_dirs.hip; "device-three-matrices": the three matrices and the walkers that re-derive
+    every step from them) or on the host from the copied-back matrices (option traceback=host); identical strings."""
+    if where == "device-three-matrices":
+        opts(nw_dirs=0)
+    else:
+        opts(traceback=where)
     cfg = load("configs.json")["C2_related"]
     sc = S.make_scoring(cfg["scoring"])
     batch = W.make(cfg["gen"], cfg["n"], cfg["kwargs"])
@@ -377,14 +381,15 @@ def test_nw_batch_strings_match_oracle_and_golden(ctx, where, opts):
             assert rc == 0 and res[p] == (s, ra, rb)
 
 
+@pytest.mark.parametrize("dirs", [1, 0], ids=["directions", "three-matrices"])
 @pytest.mark.parametrize("n_sub", [2, 5, 16])
-def test_nw_batch_pipelined_subbatches(ctx, opts, n_sub):
+def test_nw_batch_pipelined_subbatches(ctx, opts, n_sub, dirs):
     """seqalign_nw_batch with a chunk cut into sub-batches that overlap fill / traceback / copies on two streams
     (sa_batch.hip: nw_chunk_pipelined; by default only for large chunks, forced here): same strings and scores as
     the reference's needleman_wunsch_align (src/needleman_wunsch.c:53-145) -- golden C2 pairs, a ragged batch with
     empty sequences and sub-batch cuts inside runs of tiny pairs -- and an unknown character pair inside one
     sub-batch is still reported (alignment_scoring.c:178-181)."""
-    opts(subbatches=n_sub)
+    opts(subbatches=n_sub, nw_dirs=dirs)
     cfg = load("configs.json")["C2_related"]
     sc = S.make_scoring(cfg["scoring"])
     res = ctx.nw_batch(W.make(cfg["gen"], cfg["n"], cfg["kwargs"]), sc)
@@ -429,11 +434,15 @@ def test_context_options(ctx):
         ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("walker", ["lane", "wave"])
+@pytest.mark.parametrize("walker", ["lane", "wave", "directions"])
 def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
-    """Both device walkers (one lane per pair from HBM; one wave per pair from 16x16 LDS tiles)
-    on pairs that cross many tiles, hug the borders and end in long gap runs."""
-    opts(trace_kernel=walker)
+    """The device walkers -- one lane per pair from the three matrices in HBM, one wave per pair from 16x16 LDS tiles
+    of them, and the ones that follow the fill's direction bytes (sa_fill_dirs.hip; plain scorings, rows <= 512
+    columns, everything else falls back) -- on pairs that cross many tiles, hug the borders and end in long gap runs."""
+    if walker == "directions":
+        opts(nw_dirs=1, sweep_dirs=1)
+    else:
+        opts(trace_kernel=walker, nw_dirs=0, sweep_dirs=0)
     pairs = [(b"ACGT" * 40, b"ACGT" * 40), (b"A" * 100, b"A" * 17), (b"C" * 5, b"G" * 90), (b"ACGTTGCA" * 9, b"TTTT" + b"ACGTTGCA" * 7),
              (b"G", b"G"), (b"", b"ACGT"), (b"ACGT", b"")]
     r = W.ragged(40, seed=91, max_len=260, lower_frac=0.1)
