@@ -27,7 +27,8 @@ Prints ONE JSON line (rank 0).  `value` = all ranks' cells / max-rank seconds.
 `roofline`    : algorithmic bytes per launch / mean kernel duration (HIP events on
                 the launch stream, recorded inside the timed region) vs 8 TB/s.
 `e2e`         : wall clock of the host-level call on the same batch (host buffers in ->
-                H2D -> fill -> device traceback -> strings out), PCIe inclusive; never `value`.
+                H2D -> fill -> device traceback -> strings out), PCIe inclusive, median of 5 calls
+                after 2 warm-up calls; never `value`.
 `cpu_baseline`: the reference itself (oracle/_ref, built from /root/reference in the
                 authoring container) or, if absent, our C restatement (oracle/), timed
                 on this box's host cores by a pthread harness (oracle/cpu_bench.c) on a
@@ -367,8 +368,9 @@ def run(args) -> int:
         else:
             call, fn = "seqalign_nw_batch", lambda: ctx.nw_batch(batch, sc, raw=True)
         fn()                                         # sizes the context's scratch buffers
+        fn()                                         # (and once more: the worker pool and the pinned staging are warm)
         walls = []
-        for _ in range(3):
+        for _ in range(5):
             grp.barrier()
             t1 = time.perf_counter()
             fn()
@@ -381,8 +383,9 @@ def run(args) -> int:
         if is_sw:   # the multi-hit path: reverse sweep + one traceback per hit
             fn4 = lambda: ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * batch.n_pairs + 8, raw=True)
             fn4()
+            fn4()
             walls = []
-            for _ in range(3):
+            for _ in range(5):
                 grp.barrier()
                 t1 = time.perf_counter()
                 fn4()

@@ -213,9 +213,16 @@ int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
 
 /* Global NW over a host batch: GPU fill + traceback (the reference's consumer,
  * src/needleman_wunsch.c:53-145, fresh code).  By default the traceback also runs
- * on the device and only the strings cross PCIe; SEQALIGN_TRACEBACK=host copies
+ * on the device and only the strings cross PCIe; the option traceback=host copies
  * the matrices back and walks them on the host (north_star's literal split --
- * identical results, PCIe-bound).  Results:
+ * identical results, PCIe-bound).  For plain scorings (no free / forbidden gaps, no
+ * sentinel scores, gap_open <= 0, gap_extend <= 0) and rows up to 512 columns the
+ * device path does not write the matrices at all: the fill leaves one byte of
+ * directions per cell -- the answers to alignment_reverse_move's equality tests,
+ * src/alignment.c:311-327, taken while the operands are in registers -- and the
+ * walk follows them (option nw_dirs=0: three matrices everywhere).
+ * Large chunks run as a pipeline of sub-batches (upload / kernels / download on
+ * three streams; option subbatches).  Results:
  * score[p], and the two alignment strings of pair p written NUL-terminated at
  * out_a + str_off[p], out_b + str_off[p] (capacity len_a+len_b+1 each). */
 int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
@@ -235,7 +242,10 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  *       the pair, in order -- follow from one pass over the rows, bottom to top, without
  *       the sequential procedure of smith_waterman.c:165-277 being run
  *       -> one GPU traceback per wanted hit.  Any max_hits; only the strings cross PCIe.
- *   SEQALIGN_TRACEBACK=host: the matrices and the compacted candidates of every
+ *       Plain scorings, rows up to 512 columns: the fill writes match_scores + one byte of
+ *       directions per cell instead of the three matrices, the sweep and the walks read
+ *       those (option sweep_dirs=0: three matrices everywhere).
+ *   option traceback=host: the matrices and the compacted candidates of every
  *       pair are copied back and the hits are enumerated on the host (threaded
  *       over pairs). */
 typedef struct {
@@ -327,6 +337,7 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *   sweep_strip     0 | 64 | 128 | 256      columns per strip       sweep_cpl  0 | 1 | 2 | 4
  *   chunk_bytes     0 | >= 1 MiB            device memory one host-level chunk may use
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
+ *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
  *   cpl, wpb, lds_pad, sweep_trace, timing  tuning experiments / development aids
  * Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */

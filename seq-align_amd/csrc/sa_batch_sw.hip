@@ -244,7 +244,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   tm.lap("sw: wait (fill + sweep), counts");
   if (trace) {
     std::vector<unsigned long long> t(8 * n);
-    HIP_TRY(hipMemcpy(t.data(), d_trace.p, n * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(t.data(), d_trace.p, n * 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hits_total = 0;
     for (uint64_t k = 0; k < n; ++k) {
       for (int j = 0; j < 8; ++j) sum[j] += (double)t[8 * k + j];
@@ -262,10 +263,14 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     const uint32_t cnt = h_count[k], take = std::min(cnt, max_hits);
     unsigned long long *dev_keys = d_keys.as<unsigned long long>() + hit_off[k] + batch->len_b[c.first + k] + 1;
     if (h_status[k] & SA_SWEEP_UNSORTED) {   // more than 64 hits in one pair: ordered here (rare; that pair's keys only)
+      // (on the context's stream, waited for both ways: the kernels that wrote the keys and the walkers that read them
+      // run on that stream, and it is a non-blocking one -- a null-stream hipMemcpy would not be ordered with it)
       big.resize(cnt);
-      HIP_TRY(hipMemcpy(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpyAsync(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
       std::sort(big.begin(), big.end());
-      HIP_TRY(hipMemcpy(dev_keys, big.data(), (size_t)cnt * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(dev_keys, big.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
     }
     if (h_status[k] & SA_SWEEP_OVERFLOW) {
       set_last_error("seqalign_sw_batch: internal error: pair " + std::to_string(c.first + k) + " has more hits than its share of the scratch arena");
@@ -277,7 +282,8 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       bool moot = false;
       if (cnt >= max_hits) {
         unsigned long long last;
-        HIP_TRY(hipMemcpy(&last, dev_keys + (max_hits - 1), 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&last, dev_keys + (max_hits - 1), 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         moot = last < h_err_key[k];
       }
       if (!moot) return (int)err;

@@ -36,8 +36,12 @@ trials = pairs_checked = 0
 while time.time() < t_end:
     v = rng.below(1 << 20, 14).astype(int)
     flags = [int(v[0] >> k) & 1 for k in range(5)]
+    if v[13] % 3 == 0:
+        flags = [0, 0, 0, 0, 0]                   # plain scorings: a third of the draws, not 1 in 32
     match, mismatch = int(v[1] % 6), -int(v[2] % 7)
     go, ge = -int(v[3] % 12), -int(v[4] % 4)
+    if v[13] % 7 == 0:
+        ge = int(1 + v[13] % 2)                   # gap_extend > 0 (legal upstream): the row sweeps' trend from the right end
     if v[11] % 9 == 0:
         go = int(v[11] % 4)                       # gap_open >= 0: the GENERAL path of the row-sweep kernels
     if flags[2] and flags[3]:

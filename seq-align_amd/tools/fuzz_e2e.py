@@ -37,6 +37,8 @@ def rand(n, alpha=b"ACGT"):
 while time.time() < t_end:
     v = rng.below(1 << 20, 16).astype(int)
     flags = [int(v[0] >> k) & 1 for k in range(5)]
+    if v[15] % 5 < 3:
+        flags = [0, 0, 0, 0, 0]                   # plain scorings (the direction-byte fills' domain): 3 draws in 5
     match, mismatch = int(1 + v[1] % 4), -int(v[2] % 5)
     go, ge = -int(v[3] % 8), -int(v[4] % 3)
     if flags[2] and flags[3]:
@@ -65,7 +67,7 @@ while time.time() < t_end:
     ctx.set_option("trace_kernel", ("lane", "wave")[int(v[0] >> 7) & 1])
     # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
     # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
-    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches"):
+    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs"):
         ctx.set_option(key, S.OPTION_DEFAULTS[key])
     mode = int(v[0] >> 9) % 8
     if mode < 3:
@@ -77,6 +79,9 @@ while time.time() < t_end:
     elif mode == 5:
         ctx.set_option("kernel", "wgstream")   # (rows over 512 columns: reports the candidates itself; else falls back)
     ctx.set_option("subbatches", (0, 1, 2, 5)[int(v[0] >> 12) % 4])   # seqalign_nw_batch: pipelined sub-batches
+    if int(v[0] >> 14) % 4 == 0:                  # a quarter of the draws through the three-matrix paths whatever the scoring
+        ctx.set_option("nw_dirs", 0)
+        ctx.set_option("sweep_dirs", 0)
     if min(osc.gap_open + osc.gap_extend, osc.gap_extend) >= -abs(osc.min_penalty):   # NW parity domain
         res = ctx.nw_batch(batch, sc)
         for p, (a, b) in enumerate(pairs):
