@@ -142,8 +142,8 @@ extern const char align_col_mismatch[], align_col_indel[], align_col_context[], 
  *     but still applies them in the last row and column, alignment.c:128,146).
  * Every thread that calls the legacy API gets its own device context (stream, scratch, cached
  * scoring) on first use: one aligner_t per thread runs in parallel, as with the reference
- * (src/alignment.c:170-202 mutates only its own aligner_t).  A call still costs a launch and two
- * PCIe round trips (~0.1 ms) whatever the pair's size -- batches belong in seqalign_hip.h. */
+ * (src/alignment.c:170-202 mutates only its own aligner_t).  A call still costs a launch and a
+ * PCIe round trip (~40 us for a tiny pair, ~0.12 ms for 150 x 150) -- batches belong in seqalign_hip.h. */
 void aligner_align(aligner_t *aligner, const char *seq_a, const char *seq_b,
                    size_t len_a, size_t len_b, const scoring_t *scoring, char is_sw);
 void aligner_destroy(aligner_t *aligner);

@@ -176,6 +176,33 @@ int sa_host::fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   int worst = SEQALIGN_OK;
   for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget)) {
     if ((rc = run_chunk(ctx, batch, c, sc, nullptr))) break;
+    // Small chunks -- the legacy one-pair-per-call API above all -- in ONE round trip: the three matrices and the status
+    // words into pinned staging behind each other, one synchronisation, then plain memcpys.  (One pair used to cost
+    // four: three pageable copies, each waited for, and the status.)
+    const size_t small = c.cells * 4;
+    if (3 * small <= ((size_t)4 << 20)) {
+      if ((rc = ctx->h_M.reserve(3 * small + c.count * 8 + 64))) break;
+      char *pin = ctx->h_M.as<char>();
+      hipStream_t st = ctx->stream;
+      StreamSyncOnExit sync(st);
+      HIP_TRY(hipMemcpyAsync(pin, ctx->M.p, small, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(pin + small, ctx->A.p, small, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(pin + 2 * small, ctx->B.p, small, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(pin + 3 * small, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      uint64_t dev_cell = 0;
+      const uint64_t *h_status = reinterpret_cast<const uint64_t *>(pin + 3 * small);
+      for (uint64_t k = 0; k < c.count; ++k) {
+        const uint64_t p = c.first + k, cells = (uint64_t)(batch->len_a[p] + 1ull) * (batch->len_b[p] + 1ull);
+        memcpy(M + mat_off[p], pin + dev_cell * 4, cells * 4);
+        memcpy(A + mat_off[p], pin + small + dev_cell * 4, cells * 4);
+        memcpy(B + mat_off[p], pin + 2 * small + dev_cell * 4, cells * 4);
+        dev_cell += cells;
+        if (status) status[p] = h_status[k];
+        if (h_status[k] != ~0ull) worst = SEQALIGN_E_UNKNOWN_PAIR;
+      }
+      continue;
+    }
     // copy back: runs of pairs that are contiguous in the caller's arenas go in one piece
     uint64_t k = 0, dev_cell = 0;
     while (k < c.count) {
