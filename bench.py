@@ -379,6 +379,9 @@ def run(args) -> int:
         wall = grp.max_float(wall_mine)
         e2e = {"call": call, "ms": wall * 1e3, "value": total_cells / wall / 1e9, "unit": "GCUPS",
                "includes": "host pack, H2D, fill, device traceback, D2H of the strings, host unpack",
+               "path": ("plain scoring: the fill writes one byte of directions per cell (NW) / match_scores + that byte (SW, "
+                        "max_hits > 1) instead of the three matrices, the walks follow the bytes (DESIGN.md 3.5b); "
+                        "`value` / `roofline` above are the three-matrix fill, the BASELINE metric"),
                "ms_this_rank": wall_mine * 1e3}
         if is_sw:   # the multi-hit path: reverse sweep + one traceback per hit
             fn4 = lambda: ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * batch.n_pairs + 8, raw=True)

@@ -8,13 +8,16 @@ using namespace sa_host;
 // ------------------------------------------------- host-level: chunked fill ---
 
 // split the batch into chunks whose matrices (12 B/cell, plus whatever else the caller keeps per cell) fit the budget
-std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell) {
+std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell, const uint64_t *extra_bytes) {
   std::vector<Chunk> out;
   Chunk c;
-  const uint64_t max_cells = std::max<uint64_t>(budget / std::max<size_t>(bytes_per_cell, 12), 1);
+  const uint64_t per_cell = std::max<size_t>(bytes_per_cell, 12);
+  uint64_t used = 0;   // device bytes of the chunk being built: its cells + what each of its pairs needs besides (extra_bytes[p])
   for (uint64_t p = 0; p < b->n_pairs; ++p) {
     const uint64_t cells = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
-    if (c.count && c.cells + cells > max_cells) { out.push_back(c); c = Chunk(); c.first = p; }
+    const uint64_t need = cells * per_cell + (extra_bytes ? extra_bytes[p] : 0);
+    if (c.count && used + need > budget) { out.push_back(c); c = Chunk(); c.first = p; used = 0; }
+    used += need;
     c.count++; c.cells += cells; c.seq_bytes += (uint64_t)b->len_a[p] + b->len_b[p];
     c.max_a = std::max(c.max_a, b->len_a[p]); c.max_b = std::max(c.max_b, b->len_b[p]);
   }

@@ -599,15 +599,14 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   for (uint64_t p = 0; p < batch->n_pairs; ++p) { max_a = std::max(max_a, batch->len_a[p]); max_b = std::max(max_b, batch->len_b[p]); }
   // (a key that does not fit the sweep's records -- scores beyond 2^28 on sequences beyond 2^16 -- goes to the host)
   if (!traceback_on_host(ctx) && key_layout_fits(key_layout(sc, max_a, max_b))) {
-    // per cell: the three matrices + the scratch arena's share (rows' candidate columns, hits' keys)
-    uint64_t arena = 0, cells = 0;
+    // a chunk holds its pairs' three matrices + each pair's OWN part of the scratch arena (rows' candidate columns, hits'
+    // keys: a pair with a low min_score needs more of it than the batch's average, so it is counted per pair)
+    std::vector<uint64_t> extra(batch->n_pairs);
     { const int64_t best = best_move(sc);
-      for (uint64_t p = 0; p < batch->n_pairs; ++p) {
-        arena += hit_arena_elements(batch->len_a[p], batch->len_b[p], min_score[p], best);
-        cells += ((uint64_t)batch->len_a[p] + 1) * ((uint64_t)batch->len_b[p] + 1);
-      } }
-    const size_t arena_per_cell = (size_t)((8 * arena + cells - 1) / std::max<uint64_t>(cells, 1)) + 1;
-    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 12 + arena_per_cell)) {
+      for (uint64_t p = 0; p < batch->n_pairs; ++p)
+        extra[p] = 8 * hit_arena_elements(batch->len_a[p], batch->len_b[p], min_score[p], best) + 64;
+    }
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 12, extra.data())) {
       if ((rc = sw_chunk_device_enumerate(ctx, batch, c, sc, min_score, max_hits, hits, hit_cap, &found, out_a, out_b,
                                           str_cap, &used_str)))
         break;

@@ -230,6 +230,8 @@ struct seqalign_ctx {
   sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, status;
   sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
   SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
+  sa_host::HostBuf h_one;            // the legacy single-pair call: descriptor + sequences + three matrices + status of ONE pair,
+  void *one_dev = nullptr;           // pinned, read and written in place by the GPU (sa_fill_one_pair); its device address
   sa_host::DevBuf dirs;              // seqalign_nw_batch: one byte of directions per cell (sa_fill_dirs.hip)
   sa_host::DevBuf best_score, best_index, cand_count, cand_off, cand_cap, cand_index, cand_score;
   sa_host::DevBuf t_str_off, t_out_a, t_out_b, t_meta;   // device traceback outputs
@@ -269,7 +271,9 @@ struct Chunk {
   uint32_t max_a = 0, max_b = 0;
 };
 
-std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell = 12);
+// extra_bytes (optional, [n_pairs]): device bytes pair p needs besides its cells (the SW multi-hit path's scratch arena: a pair
+// with a low min_score needs more of it than the batch's average)
+std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell = 12, const uint64_t *extra_bytes = nullptr);
 int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, const seqalign_dev_scoring *sc,
               seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
               bool *cand_done = nullptr);

@@ -223,7 +223,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
     b->release();
   for (DevBuf &b : ctx->e) b.release();
   ctx->strip_progress.release();
-  for (HostBuf *b : {&ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
+  for (HostBuf *b : {&ctx->h_one, &ctx->h_desc, &ctx->h_arena, &ctx->h_M, &ctx->h_A, &ctx->h_B, &ctx->h_misc, &ctx->h_ta,
                      &ctx->h_tb, &ctx->h_tmeta})
     b->release();
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -565,6 +565,50 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
   HIP_TRY(hipSetDevice(ctx->device));
   seqalign_dev_scoring *dsc = nullptr;
   { int rc = cached_scoring(ctx, sc, is_sw, &dsc); if (rc) return rc; }
+  const uint64_t cells = ((uint64_t)len_a + 1) * ((uint64_t)len_b + 1);
+  if (cells >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
+  if (cells * 12 + len_a + len_b <= ((uint64_t)2 << 20)) {
+    // A small pair -- what this entry point is for -- in TWO runtime calls: a launch and a wait.  Everything the pair
+    // needs lives in ONE block of pinned host memory that the GPU reads and writes in place over PCIe,
+    //     [off_a off_b mat_off | len_a len_b | seq_a seq_b ... | M | A | B | status]      (M, A, B 4 KiB aligned)
+    // -- a few hundred bytes of sequence read, the matrices written as the fill's usual aligned 1 KiB blocks (a
+    // 150 x 150 pair's 270 KB take ~7 us of a ~50 us kernel).  No staging copies, so no copy engine latency either.
+    // The batch machinery costs eight runtime calls per pair, an upload / download pair through device memory four;
+    // with several threads in here at once (one context each) it is the runtime's own serialisation of those calls
+    // that bounds the pairs per second (8 threads: 3.4x one thread with four calls).
+    const size_t S = (size_t)((cells * 4 + 4095) & ~4095ull), seq_at = 64, m_at = (seq_at + len_a + len_b + 4095) & ~(size_t)4095;
+    const size_t total = m_at + 3 * S + 64;
+    int rc;
+    if (total > ctx->h_one.cap) {
+      if ((rc = ctx->h_one.reserve(total))) return rc;
+      ctx->one_dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&ctx->one_dev, ctx->h_one.p, 0));
+    }
+    char *h = ctx->h_one.as<char>(), *d = static_cast<char *>(ctx->one_dev);
+    uint64_t *hq = reinterpret_cast<uint64_t *>(h);
+    hq[0] = 0; hq[1] = len_a; hq[2] = 0;                       // off_a, off_b, mat_off
+    uint32_t *hl = reinterpret_cast<uint32_t *>(h + 24);
+    hl[0] = (uint32_t)len_a; hl[1] = (uint32_t)len_b;
+    if (len_a) memcpy(h + seq_at, a, len_a);
+    if (len_b) memcpy(h + seq_at + len_a, b, len_b);
+    hipStream_t st = ctx->stream;
+    StreamSyncOnExit sync(st);
+    seqalign_dev_batch_t db;
+    db.n_pairs = 1; db.arena = reinterpret_cast<const uint8_t *>(d + seq_at);
+    db.off_a = reinterpret_cast<const uint64_t *>(d); db.off_b = db.off_a + 1; db.mat_off = db.off_a + 2;
+    db.len_a = reinterpret_cast<const uint32_t *>(d + 24); db.len_b = db.len_a + 1;
+    db.match_scores = reinterpret_cast<int32_t *>(d + m_at); db.gap_a_scores = reinterpret_cast<int32_t *>(d + m_at + S);
+    db.gap_b_scores = reinterpret_cast<int32_t *>(d + m_at + 2 * S); db.status = reinterpret_cast<uint64_t *>(d + m_at + 3 * S);
+    db.max_len_a = (uint32_t)len_a; db.max_len_b = (uint32_t)len_b;
+    if ((rc = fill_device(ctx, dsc, &db, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));   // kernel end + wait: the GPU's writes to the (coherent) pinned block are visible
+    memcpy(M, h + m_at, cells * 4);
+    memcpy(A, h + m_at + S, cells * 4);
+    memcpy(B, h + m_at + 2 * S, cells * 4);
+    const uint64_t stw = *reinterpret_cast<const uint64_t *>(h + m_at + 3 * S);
+    if (status) *status = stw;
+    return stw == ~0ull ? SEQALIGN_OK : SEQALIGN_E_UNKNOWN_PAIR;
+  }
   // one arena: a then b
   std::vector<char> arena(len_a + len_b + 1);
   if (len_a) memcpy(arena.data(), a, len_a);

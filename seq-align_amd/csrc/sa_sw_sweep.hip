@@ -619,10 +619,11 @@ __global__ void __launch_bounds__(kWave, (ROWS == SA_ROWS_REG ? (CPL <= 2 ? 6 : 
   uint32_t status = err_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)err, __builtin_ctzll(err_lanes)) : 0u;
   if (overflow) status |= SA_SWEEP_OVERFLOW;
   if constexpr (ROWS == SA_ROWS_STRIP) {   // the strips of a pair report into the same words
-    if (lane == 0 && status) {
-      atomicMin(p.err_key + pair, first_err);
-      atomicOr(p.status + pair, status);
-    }
+    // the error of the LOWEST-ranked erroring walk over all strips (what the reference would have met first): key and
+    // code travel in one word -- key << 1 | (code == 7) -- through one atomicMin (keys are at most 63 bits wide);
+    // sw_order_hits_kernel takes them apart again
+    if (lane == 0 && err_lanes) atomicMin(p.err_key + pair, (first_err << 1) | ((status & 7u) == 7u ? 1ull : 0ull));
+    if (lane == 0 && overflow) atomicOr(p.status + pair, SA_SWEEP_OVERFLOW);
     return;
   }
   if (n_hits > 1 && !overflow) {
@@ -802,6 +803,13 @@ __global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6
 __global__ void __launch_bounds__(kWave) sw_order_hits_kernel(const SaSweepParams p) {
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x, n_hits = p.hit_count[pair];
+  {  // the strips' merged error: key << 1 | (code == 7) -> err_key, status
+    const unsigned long long ek = p.err_key[pair];
+    if (ek != ~0ull && lane == 0) {
+      p.status[pair] |= (ek & 1ull) ? 7u : 5u;
+      p.err_key[pair] = ek >> 1;
+    }
+  }
   if (n_hits <= 1 || (p.status[pair] & SA_SWEEP_OVERFLOW)) return;
   if (n_hits > (uint32_t)kWave) {
     if (lane == 0) p.status[pair] |= SA_SWEEP_UNSORTED;
