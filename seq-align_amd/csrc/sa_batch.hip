@@ -57,12 +57,55 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
-  // the sequences: packed by the thread pool 2048 pairs per task, in slices of ~8 MB -- a slice's DMA runs while the
-  // next one is being packed
-  constexpr uint64_t kPack = 2048, kSliceBytes = 8u << 20;
+  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
+  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
+  if (best_done && ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)))) return rc;
+  // the fill of pairs [k0, k1) of the chunk (the whole chunk: 0, n) with whatever the caller asked the fill to report
+  auto range_desc = [&](uint64_t k0, uint64_t k1) {
+    seqalign_dev_batch_t d;
+    d.n_pairs = k1 - k0; d.arena = ctx->arena.as<uint8_t>();
+    d.off_a = dv_off_a + k0; d.len_a = dv_len_a + k0;
+    d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
+    d.mat_off = dv_mat + k0;
+    d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+    d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+    return d;
+  };
+  auto fill_range = [&](uint64_t k0, uint64_t k1, bool *bd, bool *cd, bool *du) -> int {
+    const seqalign_dev_batch_t d = range_desc(k0, k1);
+    if (best_done)
+      return fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>() + k0, ctx->best_index.as<uint64_t>() + k0, bd);
+    if (cand) {
+      SaCandBox sub = *cand;   // per-pair arrays move with the range; hit_off holds absolute offsets into the scratch arena
+      sub.cand_count += k0; sub.cand_box += 4 * k0; sub.cand_min += k0; sub.hit_off += k0;
+      bool used = false;
+      sub.dirs_used = cand->dirs_used ? &used : nullptr;
+      const int r = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr, &sub, cd);
+      if (du) *du = used;
+      return r;
+    }
+    return seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
+  };
+  // The sequences: packed by the thread pool 2048 pairs per task, uploaded in slices on the context's upload stream;
+  // with many pairs the fill is launched slice by slice behind them (the first quarter of the pairs is being filled
+  // while the rest is still being packed and shipped: C3's 11.5 MB of sequences cost 0.35 ms before the fill could
+  // start), otherwise once, behind the last slice.
+  constexpr uint64_t kPack = 2048;
+  const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20)) ? 4 : 1;
+  const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)8 << 20);
+  if (!ctx->copy_streams[0]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[0], hipStreamNonBlocking));
+  hipStream_t su = ctx->copy_streams[0];
+  StreamSyncOnExit sync_u(su);
+  EventList ev;
+  HIP_TRY(ev.add(hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev.ev[0], st));          // the descriptors are on their way on st: uploads go after them
+  HIP_TRY(hipStreamWaitEvent(su, ev.ev[0], 0));
+  bool first = true, consistent = true, bd0 = false, cd0 = false, du0 = false;
+  uint64_t filled_to = 0;
   for (uint64_t k0 = 0; k0 < n;) {
     uint64_t k1 = k0;
-    while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < kSliceBytes)) k1 = std::min(n, k1 + kPack);
+    while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < slice_bytes)) k1 = std::min(n, k1 + kPack);
+    if (n - k1 < kPack) k1 = n;   // no crumb at the end
     parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
       for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
         const uint64_t p = c.first + k;
@@ -71,27 +114,34 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
       }
     });
     const uint64_t lo = h_off_a[k0], hi = k1 < n ? h_off_a[k1] : c.seq_bytes;
-    if (hi > lo) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + lo, h_seq + lo, hi - lo, hipMemcpyHostToDevice, st));
+    if (hi > lo) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + lo, h_seq + lo, hi - lo, hipMemcpyHostToDevice, su));
+    HIP_TRY(ev.add(hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev.ev.back(), su));
+    HIP_TRY(hipStreamWaitEvent(st, ev.ev.back(), 0));
+    if (n_sub > 1 && consistent) {
+      bool bd = false, cd = false, du = false;
+      if ((rc = fill_range(k0, k1, &bd, &cd, &du))) return rc;
+      if (first) { bd0 = bd; cd0 = cd; du0 = du; first = false; }
+      else if (bd != bd0 || cd != cd0 || du != du0) consistent = false;   // (cannot happen with >= 2 048 pairs per slice; see below)
+      filled_to = k1;
+    }
     k0 = k1;
   }
   tm.lap("run_chunk: pack + H2D");
-  uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
-  uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
-  seqalign_dev_batch_t d;
-  d.n_pairs = n; d.arena = ctx->arena.as<uint8_t>();
-  d.off_a = dv_off_a; d.len_a = dv_len_a;
-  d.off_b = dv_off_b; d.len_b = dv_len_b;
-  d.mat_off = dv_mat;
-  d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
-  d.status = ctx->status.as<uint64_t>(); d.max_len_a = c.max_a; d.max_len_b = c.max_b;
-  if (best_done) {
-    if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
-    rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>(),
-                     ctx->best_index.as<uint64_t>(), best_done);
-  } else if (cand) {
-    rc = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr, cand, cand_done);
+  const seqalign_dev_batch_t d = range_desc(0, n);
+  if (n_sub > 1 && consistent && filled_to == n) {
+    if (best_done) *best_done = bd0;
+    if (cand_done) *cand_done = cd0;
+    if (cand && cand->dirs_used) *cand->dirs_used = du0;
+    rc = SEQALIGN_OK;
   } else {
-    rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st);
+    // one launch over the whole chunk (also the way out if the slices' fills had chosen differently: a refill is
+    // idempotent)
+    bool bd = false, cd = false, du = false;
+    rc = fill_range(0, n, &bd, &cd, &du);
+    if (best_done) *best_done = bd;
+    if (cand_done) *cand_done = cd;
+    if (cand && cand->dirs_used) *cand->dirs_used = du;
   }
   if (rc) return rc;
   tm.lap("run_chunk: enqueue fill");
