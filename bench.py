@@ -326,39 +326,10 @@ def run(args) -> int:
     else:
         kernel = {v: k for k, v in S.KERNEL_NAMES.items()}[args.kernel]
 
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        db.fill(ctx, h, kernel, order_after_current=False)
-    torch.cuda.synchronize()
-    grp.barrier()
-
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record(db.stream)  # the stream the kernel is launched on
-        db.fill(ctx, h, kernel, order_after_current=False)
-        ends[i].record(db.stream)
-    torch.cuda.synchronize()
-    grp.barrier()
-    elapsed = time.perf_counter() - t0
-
-    elapsed = grp.max_float(elapsed)               # MAX over ranks
     total_cells = grp.sum_int(batch.cells())       # whole-job cells per step
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
-    kern_ms_max = grp.max_float(kern_ms)
-
-    # parity spot check outside the timed region (checker = oracle): bit-exact int32
-    import orclib as O
-    osc = O.Scoring.from_buffer_copy(bytes(sc))
-    bit_exact = True
-    for p in range(0, batch.n_pairs, max(1, batch.n_pairs // 16)):
-        rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
-        gM, gA, gB = db.pair_matrices(p)
-        bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
-    bit_exact = grp.sum_int(0 if bit_exact else 1) == 0
-
+    # (measured BEFORE the timed loop of the headline: right after a second of back-to-back HBM-bound launches the same
+    # call measures 25 % slower -- C2 1.18 instead of 0.93 ms -- which says something about the GPU's clocks under
+    # sustained load, not about the call)
     # end to end through the host-level entry point on the same batch (never `value`)
     e2e = None
     if not args.no_e2e:
@@ -396,6 +367,38 @@ def run(args) -> int:
             wall4 = grp.max_float(float(np.median(walls)))
             e2e["up_to_4_hits"] = {"call": "seqalign_sw_batch(max_hits=4)", "ms": wall4 * 1e3,
                                    "value": total_cells / wall4 / 1e9, "unit": "GCUPS"}
+
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        db.fill(ctx, h, kernel, order_after_current=False)
+    torch.cuda.synchronize()
+    grp.barrier()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(db.stream)  # the stream the kernel is launched on
+        db.fill(ctx, h, kernel, order_after_current=False)
+        ends[i].record(db.stream)
+    torch.cuda.synchronize()
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
+
+    elapsed = grp.max_float(elapsed)               # MAX over ranks
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    kern_ms_max = grp.max_float(kern_ms)
+
+    # parity spot check outside the timed region (checker = oracle): bit-exact int32
+    import orclib as O
+    osc = O.Scoring.from_buffer_copy(bytes(sc))
+    bit_exact = True
+    for p in range(0, batch.n_pairs, max(1, batch.n_pairs // 16)):
+        rc, M, A, B = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), is_sw)
+        gM, gA, gB = db.pair_matrices(p)
+        bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
+    bit_exact = grp.sum_int(0 if bit_exact else 1) == 0
 
     # per-rank figures for the report: a slow rank (placement, NUMA, a busy neighbour) must be visible, not averaged away
     per_rank = grp.gather_objects({"rank": rank, "device": local, "kernel_ms": round(kern_ms, 4),
