@@ -301,7 +301,7 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
  * of them is mapped as a candidate third arena and timed with the fill's own store
  * pattern against one linear stream (ratio ~0.75: the three disturb each other,
  * 0.98-1.02: one arena in another class, 1.04-1.05: the best there is; the probe repeats to
- * +-2 %).  The first candidate at or above the option arena_quality (default 1.03) ends the walk, otherwise the best one is kept; all other chunks go
+ * +-2 %).  The first candidate at or above the option arena_quality (default 1.045) ends the walk, otherwise the best one is kept; all other chunks go
  * straight back.  Bounded by the option arena_scan_gib (default 160; 0 = three plain
  * hipMallocs, what the command-line tools use) and by 60 % of the free device
  * memory; typically 10-60 GiB are held for ~0.1 s.  Arenas under 256 MiB are

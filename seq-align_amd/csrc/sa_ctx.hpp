@@ -209,7 +209,7 @@ struct SaOptions {
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)
   uint32_t arena_scan_gib = 160;  // arena_scan_gib    how much HBM the arena placement may hold transiently while it looks
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
-  float arena_quality = 1.03f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
+  float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
 };
 
 struct seqalign_dev_scoring {
