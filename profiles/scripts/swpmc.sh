@@ -18,7 +18,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
     con = sqlite3.connect(f)
     for name, cname, val in con.execute("select kernel_name, counter_name, value from counters_collection"):
-        for k in ("sw_sweep_kernel", "sw_hit_traceback_kernel", "fill_stream_kernel"):
+        for k in ("sw_sweep_kernel", "sw_sweep_dirs_kernel", "fill_dirs_kernel", "traceback_dirs_kernel", "fill_stream_kernel"):
             if k in name:
                 acc[name.split("(")[0][-70:]][cname].append(float(val))
 out = {"workload": sys.argv[2], "command": "seq-align_amd/tools/sw_enum_profile.py %s 4 (3 calls)" % sys.argv[2], "per_launch": {}}

@@ -91,9 +91,9 @@ extern "C" int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]) {
 static_assert(sizeof(seqalign_arena_info_t) == sizeof(SaArenaInfo), "seqalign_arena_info_t mirrors SaArenaInfo");
 extern "C" int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_arena_info_t *info) {
   if (!ctx || !arenas || !info) return SEQALIGN_E_ARG;
-  const SaArenaInfo *i = sa_arenas_find_info(arenas[0]);
-  if (!i) return SEQALIGN_E_ARG;
-  memcpy(info, i, sizeof(*info));
+  SaArenaInfo i;
+  if (!sa_arenas_copy_info(arenas[0], &i)) return SEQALIGN_E_ARG;
+  memcpy(info, &i, sizeof(*info));
   return SEQALIGN_OK;
 }
 

@@ -234,7 +234,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
 void sa_arenas_destroy(SaArenaSet *s);
 SaArenaSet *sa_arenas_take(void *base0);   /* removes the set from the registry (seqalign_arenas_free); NULL if unknown */
 const SaArenaInfo *sa_arenas_info(const SaArenaSet *s);
-const SaArenaInfo *sa_arenas_find_info(void *base0);
+bool sa_arenas_copy_info(void *base0, SaArenaInfo *out);   /* false: not arenas of sa_arenas_create */
 void *const *sa_arenas_base(const SaArenaSet *s);
 size_t sa_arenas_bytes(const SaArenaSet *s);
 /* DPP self-test: out[l] = value shifted in from lane l-1 (lane 0 gets `fill`) */

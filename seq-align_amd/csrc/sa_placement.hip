@@ -254,14 +254,16 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   const size_t per = (bytes + chunk - 1) / chunk;                       // chunks per arena
   const size_t budget = place ? std::min<size_t>(opt.scan_bytes + 3 * per * chunk, free_b / 10 * 6) : 0;
   const size_t pool_max = budget / chunk;
-  if (!place || pool_max < 3 * per) {
-    const hipError_t e = plain_set(bytes, stream, bytes >= ((size_t)256 << 20), s);
-    if (e != hipSuccess) { delete s; return e; }
+  // the way out whenever placing is not possible (any more): three plain allocations, probed if large enough to matter
+  auto plain = [&]() -> hipError_t {
     (void)hipGetLastError();
+    const hipError_t pe = plain_set(bytes, stream, bytes >= ((size_t)256 << 20), s);
+    if (pe != hipSuccess) { delete s; return pe; }
     register_set(s);
     *out = s;
     return hipSuccess;
-  }
+  };
+  if (!place || pool_max < 3 * per) return plain();
 
   // ---- the pool: uniform chunks in allocation order; [0, per) = M, [per, 2 per) = A
   std::vector<Handle> pool;
@@ -282,25 +284,15 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
       if (!keep) (void)hipMemRelease(pool[i]);
     }
   };
-  hipError_t e = hipSuccess;
   if (!grow_to(3 * per)) {
     release_from(0, {});
-    e = plain_set(bytes, stream, true, s);
-    if (e != hipSuccess) { delete s; return e; }
-    register_set(s);
-    *out = s;
-    return hipSuccess;
+    return plain();
   }
   Mapping m, a;
-  if ((e = m.map(env, pool.data(), per, chunk)) != hipSuccess || (e = a.map(env, pool.data() + per, per, chunk)) != hipSuccess) {
+  if (m.map(env, pool.data(), per, chunk) != hipSuccess || a.map(env, pool.data() + per, per, chunk) != hipSuccess) {
     m.unmap(); a.unmap();
     release_from(0, {});
-    (void)hipGetLastError();
-    e = plain_set(bytes, stream, true, s);
-    if (e != hipSuccess) { delete s; return e; }
-    register_set(s);
-    *out = s;
-    return hipSuccess;
+    return plain();
   }
   const ProbeShape shape = probe_shape(bytes);
   const float t1 = time_one(m.va, shape, stream);
@@ -340,12 +332,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   if (!best_map.va) {
     m.unmap(); a.unmap();
     release_from(0, {});
-    (void)hipGetLastError();
-    e = plain_set(bytes, stream, true, s);
-    if (e != hipSuccess) { delete s; return e; }
-    register_set(s);
-    *out = s;
-    return hipSuccess;
+    return plain();
   }
   release_from(2 * per, {best_pos});
   (void)hipGetLastError();   // a failed create / map of the walk must not surface as the next launch's error
@@ -384,8 +371,10 @@ SaArenaSet *sa_arenas_take(void *base0) { return take_set(base0); }
 const SaArenaInfo *sa_arenas_info(const SaArenaSet *s) { return &s->info; }
 void *const *sa_arenas_base(const SaArenaSet *s) { return s->base; }
 size_t sa_arenas_bytes(const SaArenaSet *s) { return s->bytes; }
-const SaArenaInfo *sa_arenas_find_info(void *base0) {
+bool sa_arenas_copy_info(void *base0, SaArenaInfo *out) {   // (copied under the registry's lock: the set may be freed by another thread)
   std::lock_guard<std::mutex> lk(g_sets_mu);
   auto it = g_sets.find(base0);
-  return it == g_sets.end() ? nullptr : &it->second->info;
+  if (it == g_sets.end()) return false;
+  *out = it->second->info;
+  return true;
 }

@@ -446,6 +446,26 @@ def test_direction_byte_paths_every_width(ctx, max_len):
                 assert rc == 0 and got[p] == want, (max_len, spec, "sw", max_hits, p)
 
 
+@pytest.mark.parametrize("dirs", [1, 0], ids=["directions", "three-matrices"])
+def test_nw_batch_in_several_chunks(ctx, dirs):
+    """seqalign_nw_batch on a batch that does not fit one chunk (tiny chunk budget): per-chunk scratch (descriptor block,
+    direction bytes or matrices, string slots, pinned staging) is reused chunk after chunk; results equal the one-chunk
+    call's and the oracle's."""
+    sc = S.make_scoring({"preset": "default"})
+    batch = W.dna_nw_150(150, seed=83, length=140, related=True)
+    one = ctx.nw_batch(batch, sc)
+    with S.Context(0) as small:
+        small.set_option("chunk_bytes", 6 << 20)     # ~25 pairs per chunk
+        small.set_option("nw_dirs", dirs)
+        small.set_option("subbatches", 3)
+        many = small.nw_batch(batch, sc)
+    assert one == many
+    osc = oracle_scoring_of(sc)
+    for p in range(0, batch.n_pairs, 11):
+        rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+        assert rc == 0 and one[p] == (s_, ra, rb), p
+
+
 def test_context_options(ctx):
     """seqalign_ctx_set_option: unknown keys and out-of-range values are refused (nothing changes), options are
     per context, and the environment is read once, when a context is created."""
