@@ -173,6 +173,86 @@ __global__ void __launch_bounds__(64) traceback_nw_dirs_kernel(const SaTracePara
 }
 
 // ---------------------------------------------------------------------------
+// The same two walks, one WAVE per walk, from 64 x 64-byte tiles of the directions staged in LDS.  With one lane per
+// walk a step is one dependent byte load from HBM (~1 us), and 4 000 or 10 000 walks are only 63 or 157 waves: the chip
+// idles while every lane waits (C4: 0.34 ms for 4 001 hits).  Here the wave loads the 64 rows x 64 columns that end at
+// the current cell -- lane r one row: 64 contiguous bytes -- plus the sequences' characters of those rows and columns,
+// and walks out of LDS until it steps outside (at least 64 steps per tile, a 300-step walk needs 5-9 tiles).  All
+// lanes walk redundantly (uniform control flow), lane 0 writes the characters.  Bound by instruction issue (~15 per
+// step and wave), so it is the choice while the walks do not fill the chip several times over (the launcher decides).
+template <bool NW>
+__global__ void __launch_bounds__(64) traceback_dirs_tile_kernel(const SaTraceParams p) {
+  constexpr int kT = 64;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
+  __shared__ uint8_t ca[kT], cb[kT];   // seq_a[ox + c - 1], seq_b[oy + r - 1]
+  const int lane = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  const uint32_t pair = NW ? w : (p.walker_pair ? p.walker_pair[w] : w);
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint8_t *__restrict__ sa_ = p.arena + p.off_a[pair];
+  const uint8_t *__restrict__ sb_ = p.arena + p.off_b[pair];
+  const uint64_t mo = p.mat_off[pair];
+  const uint8_t *__restrict__ Dg = p.dirs + mo;
+  char *oa = p.out_a + p.str_off[w];
+  char *ob = p.out_b + p.str_off[w];
+  uint32_t x, y, head = la + lb, st;
+  int score;
+  if constexpr (NW) {
+    x = la; y = lb; st = (uint32_t)p.nw_state[w]; score = p.nw_score[w];
+  } else {
+    sw_walk_start(p, w, pair, W, x, y);
+    st = MAT_MATCH; score = p.M[mo + (uint64_t)y * W + x];
+  }
+  const uint32_t end_x = x, end_y = y;
+  uint32_t ox = 0, oy = 0;
+  bool loaded = false;
+  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  for (;;) {
+    if constexpr (NW) { if (x == 0 || y == 0) break; }
+    if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
+      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
+      oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tile
+      const uint32_t r = oy + lane;
+      if (r <= lb) {
+        // 64 bytes of row r from column ox on; past the row's end that is the next row (or, behind the last pair, the
+        // slack every directions buffer has) -- never used: the walk only reads columns <= x
+        const uint8_t *src = Dg + (uint64_t)r * W + ox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+      }
+      { const uint32_t i = ox + lane; ca[lane] = (i >= 1 && i <= la) ? sa_[i - 1] : (uint8_t)0; }
+      { const uint32_t j = oy + lane; cb[lane] = (j >= 1 && j <= lb) ? sb_[j - 1] : (uint8_t)0; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);   // the tile is in LDS before anyone reads it (one wave: program order)
+      loaded = true;
+    }
+    const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
+    if constexpr (!NW) { if (f == 3u) break; }   // this state's score is 0: the hit starts here
+    --head;
+    if (lane == 0) {
+      oa[head] = (st == MAT_GAP_A) ? '-' : (char)ca[x - ox];
+      ob[head] = (st == MAT_GAP_B) ? '-' : (char)cb[y - oy];
+    }
+    x -= (st != MAT_GAP_A);
+    y -= (st != MAT_GAP_B);
+    st = f;
+  }
+  if (lane != 0) return;
+  if constexpr (NW) {
+    for (; y > 0; --y) { --head; oa[head] = '-'; ob[head] = (char)sb_[y - 1]; }   // needleman_wunsch.c:117-123
+    for (; x > 0; --x) { --head; oa[head] = (char)sa_[x - 1]; ob[head] = '-'; }   // :126-132
+  } else {
+    p.out_pos[4 * w + 0] = x;
+    p.out_pos[4 * w + 1] = y;
+    p.out_pos[4 * w + 2] = end_x - x;
+    p.out_pos[4 * w + 3] = end_y - y;
+  }
+  write_walk_meta(p, w, pair, head, la + lb - head, score, 0u);
+}
+
+// ---------------------------------------------------------------------------
 // One WAVE per pair, the walk's neighbourhood staged in LDS.
 //
 // A step needs the three matrices at ONE predecessor cell and the two sequence
@@ -322,14 +402,20 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  if (p.dirs && p.nw_state) {   // NW behind the directions-only fill
-    if (!p.nw_score) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
-    return hipGetLastError();
-  }
-  if (p.dirs) {   // SW hits behind sa_fill_dirs.hip
-    if (!p.hit_keys || !p.out_pos) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+  if (p.dirs) {
+    // walks on direction bytes: one wave per walk from LDS tiles while the walks do not fill the chip several times over
+    // (issue-bound: ~9 us of instructions per 300-step walk and wave), one lane per walk beyond (bound by scattered
+    // sectors; 125 k walks: 0.42 ms per 40 k).  The option trace_kernel = lane | wave forces one.
+    const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < 32768;
+    if (p.nw_state) {   // NW behind the directions-only fill
+      if (!p.nw_score) return hipErrorInvalidValue;
+      if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
+      else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+    } else {            // SW hits behind sa_fill_dirs.hip
+      if (!p.hit_keys || !p.out_pos) return hipErrorInvalidValue;
+      if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<false>, dim3(p.n_pairs), dim3(64), 0, stream, p);
+      else hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+    }
     return hipGetLastError();
   }
   const bool sw = p.start_index || p.hit_keys;

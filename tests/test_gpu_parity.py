@@ -490,13 +490,15 @@ def test_context_options(ctx):
         ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("walker", ["lane", "wave", "directions"])
+@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave"])
 def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     """The device walkers -- one lane per pair from the three matrices in HBM, one wave per pair from 16x16 LDS tiles
     of them, and the ones that follow the fill's direction bytes (sa_fill_dirs.hip; plain scorings, rows <= 512
     columns, everything else falls back) -- on pairs that cross many tiles, hug the borders and end in long gap runs."""
     if walker == "directions":
         opts(nw_dirs=1, sweep_dirs=1)
+    elif walker.startswith("directions-"):      # one lane per walk from HBM / one wave per walk from 64 x 64-byte LDS tiles
+        opts(nw_dirs=1, sweep_dirs=1, trace_kernel=walker.split("-")[1])
     else:
         opts(trace_kernel=walker, nw_dirs=0, sweep_dirs=0)
     pairs = [(b"ACGT" * 40, b"ACGT" * 40), (b"A" * 100, b"A" * 17), (b"C" * 5, b"G" * 90), (b"ACGTTGCA" * 9, b"TTTT" + b"ACGTTGCA" * 7),
