@@ -299,7 +299,9 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
  * from uniform 512 MiB physical chunks.  M and A take the first chunks; further
  * chunks are created (not mapped, not touched: ~10 us each) and every 4 GiB a window
  * of them is mapped as a candidate third arena and timed with the fill's own store
- * pattern against one linear stream (ratio ~0.75: the three disturb each other,
+ * pattern against one linear stream; if no candidate reaches the target a second walk
+ * moves the SECOND arena the same way (three arenas in three classes are the best there
+ * is: the headline kernel at the speed of a memset) (ratio ~0.75: the three disturb each other,
  * 0.98-1.02: one arena in another class, 1.04-1.05: the best there is; the probe repeats to
  * +-2 %).  The first candidate at or above the option arena_quality (default 1.045) ends the walk, otherwise the best one is kept; all other chunks go
  * straight back.  Bounded by the option arena_scan_gib (default 160; 0 = three plain
@@ -311,15 +313,18 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
 int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, void *arenas[3], float *quality);
 int seqalign_arenas_free(seqalign_ctx_t *ctx, void *arenas[3]);
 
-#define SEQALIGN_ARENA_MAX_TRIES 64
+#define SEQALIGN_ARENA_MAX_TRIES 96
 typedef struct {
   float quality;        /* probe ratio of the arenas handed out (< 0: not probed)          */
   float target;         /* the ratio that would have ended the walk (option arena_quality)  */
   int32_t vmm;          /* 1: built from hipMemCreate chunks, 0: three hipMallocs            */
   uint32_t chunk_mib;   /* chunk size                                                        */
   float depth_gib;      /* how far behind the second arena, in allocation order, the third   */
-  float scanned_gib;    /* device memory held at the end of the walk (transient)             */
-  uint32_t tries;       /* candidates timed                                                  */
+  float scanned_gib;    /* device memory held at the end of the walks (transient)            */
+  float depth_a_gib;    /* where the second walk moved the SECOND arena to (< 0: it stayed    */
+                        /* right behind the first)                                           */
+  uint32_t tries;       /* candidates timed, both walks                                      */
+  uint32_t second_walk_from; /* try_*[second_walk_from ..] belong to the second walk         */
   float try_quality[SEQALIGN_ARENA_MAX_TRIES];    /* their ratios, in order                  */
   float try_depth_gib[SEQALIGN_ARENA_MAX_TRIES];
 } seqalign_arena_info_t;

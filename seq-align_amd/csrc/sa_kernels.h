@@ -216,13 +216,13 @@ hipError_t sa_launch_gather_hits(const char *src_a, const char *src_b, const uin
                                  hipStream_t stream);
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream);
 /* the three matrix arenas, placed and checked (sa_placement.hip) */
-#define SA_ARENA_MAX_TRIES 64
+#define SA_ARENA_MAX_TRIES 96
 struct SaArenaInfo {   /* = seqalign_arena_info_t (include/seqalign_hip.h) */
   float quality, target;
   int32_t vmm;
   uint32_t chunk_mib;
-  float depth_gib, scanned_gib;
-  uint32_t tries;
+  float depth_gib, scanned_gib, depth_a_gib;
+  uint32_t tries, second_walk_from;
   float try_quality[SA_ARENA_MAX_TRIES], try_depth_gib[SA_ARENA_MAX_TRIES];
 };
 struct SaPlacementOpts {

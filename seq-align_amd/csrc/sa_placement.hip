@@ -244,6 +244,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   if (!s) return hipErrorOutOfMemory;
   s->info = SaArenaInfo();
   s->info.quality = -1.f;
+  s->info.depth_a_gib = -1.f;
   s->info.target = opt.quality_stop;
   const size_t chunk = (size_t)512 << 20;
   size_t free_b = 0, total_b = 0;
@@ -297,33 +298,46 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   const ProbeShape shape = probe_shape(bytes);
   const float t1 = time_one(m.va, shape, stream);
 
-  // ---- walk: candidate B = pool[pos, pos + per); the next candidate starts `step` chunks further (8 chunks =
-  // 4 GiB, or right behind this one if the arenas are larger than that)
+  // ---- two walks over the pool, candidates `step` chunks apart (8 chunks = 4 GiB, or back to back if the arenas are
+  // larger than that):
+  //   walk 1: B = pool[pos, pos + per) with A right behind M -- finds memory of another class than M's;
+  //   walk 2: A = pool[pos, pos + per) with that B -- finds a THIRD class.  tools/probes/grade_probe.hip times the whole
+  //           (A, B) grid: one class 0.52 ms, two classes 0.403-0.416, three classes 0.387-0.395 -- the "best grade",
+  //           what a memset of the same bytes takes (profiles/r03/r03_grade_probe.txt).
+  // Either walk ends early at `quality_stop` (a three-class placement; walk 2 is skipped when walk 1 already got there).
   const size_t step = std::max<size_t>(per, 8);
-  Mapping best_map;
-  size_t best_pos = 0;
-  float best_q = -2.f;
-  for (size_t pos = 2 * per; pos + per <= pool_max && s->info.tries < SA_ARENA_MAX_TRIES; pos += step) {
-    if (!grow_to(pos + per)) break;
-    Mapping c;
-    if (c.map(env, pool.data() + pos, per, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
-    void *trio[3] = {m.va, a.va, c.va};
+  auto probe = [&](void *x0, void *x1, void *x2) {
+    void *trio[3] = {x0, x1, x2};
     float t3 = time_three(trio, shape, stream, 4);
     float q = (t3 > 0 && t1 > 0) ? 3.f * t1 / t3 : -1.f;
-    if (q >= 1.02f) {   // a contender: once more with more repetitions (what separates "good" from "the best there is" is 3 %)
+    if (q >= 1.02f) {   // a contender: once more with more repetitions (what separates the grades is 3 %)
       t3 = time_three(trio, shape, stream, 9);
       if (t3 > 0) q = 3.f * t1 / t3;
     }
+    return q;
+  };
+  auto record = [&](float q, size_t pos) {
+    if (s->info.tries >= SA_ARENA_MAX_TRIES) return;
     s->info.try_quality[s->info.tries] = q;
     s->info.try_depth_gib[s->info.tries] = (float)((double)(pos - 2 * per) * chunk / 1073741824.0);
     s->info.tries++;
+  };
+  Mapping best_map;
+  size_t best_pos = 0;
+  float best_q = -2.f;
+  for (size_t pos = 2 * per; pos + per <= pool_max && s->info.tries < SA_ARENA_MAX_TRIES / 2; pos += step) {
+    if (!grow_to(pos + per)) break;
+    Mapping c;
+    if (c.map(env, pool.data() + pos, per, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+    const float q = probe(m.va, a.va, c.va);
+    record(q, pos);
     if (q > best_q) {
       best_map.unmap();
       best_map = c; best_pos = pos; best_q = q;
     } else {
       c.unmap();
     }
-    if (q < 0 || q >= opt.quality_stop) break;   // probe unavailable, or good enough
+    if (q < 0 || q >= opt.quality_stop) break;   // probe unavailable, or as good as it gets
   }
   s->info.scanned_gib = (float)((double)pool.size() * chunk / 1073741824.0);
   if (!best_map.va) {   // not even one candidate: B right behind A
@@ -334,14 +348,35 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
     release_from(0, {});
     return plain();
   }
-  release_from(2 * per, {best_pos});
-  (void)hipGetLastError();   // a failed create / map of the walk must not surface as the next launch's error
+  size_t a_pos = per;   // where A's chunks are in the pool
+  s->info.second_walk_from = s->info.tries;
+  if (best_q >= 0 && best_q < opt.quality_stop) {
+    float best_qa = best_q;
+    for (size_t pos = 2 * per; pos + per <= pool.size() && s->info.tries < SA_ARENA_MAX_TRIES; pos += step) {
+      if (pos + per > best_pos && pos < best_pos + per) continue;   // B's own chunks
+      Mapping c;
+      if (c.map(env, pool.data() + pos, per, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+      const float q = probe(m.va, c.va, best_map.va);
+      record(q, pos);
+      if (q > best_qa + 0.01f) {   // (worth moving for: more than the probe's noise)
+        a.unmap();
+        a = c; a_pos = pos; best_qa = q;
+      } else {
+        c.unmap();
+      }
+      if (q < 0 || q >= opt.quality_stop) break;
+    }
+    best_q = best_qa;
+  }
+  release_from(per, {a_pos, best_pos});
+  (void)hipGetLastError();   // a failed create / map of the walks must not surface as the next launch's error
   s->vmm = true;
   s->bytes = per * chunk;
   s->map[0] = m; s->map[1] = a; s->map[2] = best_map;
   s->handles[0].assign(pool.begin(), pool.begin() + per);
-  s->handles[1].assign(pool.begin() + per, pool.begin() + 2 * per);
+  s->handles[1].assign(pool.begin() + a_pos, pool.begin() + a_pos + per);
   s->handles[2].assign(pool.begin() + best_pos, pool.begin() + best_pos + per);
+  s->info.depth_a_gib = a_pos == per ? -1.f : (float)((double)(a_pos - 2 * per) * chunk / 1073741824.0);
   for (int k = 0; k < 3; ++k) s->base[k] = s->map[k].va;
   s->info.vmm = 1;
   s->info.chunk_mib = (uint32_t)(chunk >> 20);

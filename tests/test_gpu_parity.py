@@ -776,7 +776,7 @@ def test_arena_allocator(ctx):
         assert (q.value > 0.3) if placed else (q.value < 0)
         assert d["vmm"] == placed and abs(d["quality"] - q.value) < 1e-3
         if placed:
-            assert 1 <= d["tries"] <= 64 and d["chunk_mib"] == 512 and len(d["try_quality"]) == d["tries"]
+            assert 1 <= d["tries"] <= 96 and d["second_walk_from"] <= d["tries"] and d["chunk_mib"] == 512 and len(d["try_quality"]) == d["tries"]
             assert d["quality"] >= d["target"] - 0.05 or d["tries"] > 1      # below target only after looking further
             assert max(d["try_quality"]) >= d["quality"] - 0.08               # the kept candidate is (about) the best seen
             n = nbytes // 4
