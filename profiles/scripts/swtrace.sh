@@ -1,0 +1,26 @@
+# Timeline of the last seqalign_sw_batch(max_hits = 4) call on C3 and C4: kernels and copies in time order.
+# Run ON THE GPU BOX from the repo root: bash profiles/scripts/swtrace.sh -> gpurun_out/swtrace_<cfg>/
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for w in C3 C4; do
+  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/swtrace_$w -o t -- python $R/seq-align_amd/tools/sw_enum_profile.py $w 4 > $R/gpurun_out/swtrace_$w.log 2>&1
+  grep max_hits $R/gpurun_out/swtrace_$w.log
+  python - $R/gpurun_out/swtrace_$w <<'PY'
+import csv, glob, sys
+ev = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-48:]))
+for f in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r["Direction"] + " " + r.get("Bytes", r.get("Size", "?"))))
+ev.sort()
+# the last call = everything after the last fill launch
+last_fill = max(i for i, e in enumerate(ev) if "fill" in e[2])
+i0 = last_fill
+while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 300000 and "probe" not in ev[i0 - 1][2]: i0 -= 1
+t0 = ev[i0][0]
+for s, e, n in ev[i0:]:
+    print("%9.3f %9.3f  %8.1f us  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e3, n))
+PY
+done

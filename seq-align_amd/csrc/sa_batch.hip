@@ -338,6 +338,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_slot + n + 1), *h_len_b = h_len_a + n;
   uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
   uint64_t pos = 0, cell = 0;
+  bool same_shape = true;
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k;
     h_slot[k] = pos;                       // a pair's string slot is len_a + len_b chars: the same prefix as the sequences'
@@ -345,18 +346,27 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     h_off_b[k] = pos; pos += batch->len_b[p];
     h_len_a[k] = batch->len_a[p]; h_len_b[k] = batch->len_b[p];
     h_mat[k] = cell; cell += (uint64_t)(batch->len_a[p] + 1ull) * (batch->len_b[p] + 1ull);
+    same_shape = same_shape && h_len_a[k] == h_len_a[0] && h_len_b[k] == h_len_b[0];
   }
   h_slot[n] = pos;
   const uint64_t total = pos;   // == c.seq_bytes
   // Plain scorings, rows up to 512 columns: the fill writes ONE byte of directions per cell and nothing else
   // (sa_fill_dirs.hip) -- the three matrices are never needed, so they are not even allocated.
   const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a);
+  // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
+  // (sa_fill_dirs_x2.hip); each pair's bytes then start on a 256-byte boundary
+  uint64_t stride = 0, mat_total = c.cells;
+  if (use_dirs && same_shape && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
+    stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+    for (uint64_t k = 0; k < n; ++k) h_mat[k] = k * stride;
+    mat_total = n * stride;
+  }
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16)) || (rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8)) ||
       (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
       (rc = ctx->h_ta.reserve(2 * total + 16)) || (rc = ctx->h_tmeta.reserve(n * 16)))
     return rc;
   if (use_dirs) {
-    if ((rc = ctx->dirs.reserve(c.cells + 4096)) || (rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
+    if ((rc = ctx->dirs.reserve(mat_total + 4096)) || (rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
   } else if ((rc = reserve_arenas(ctx, c.cells * 4))) {
     return rc;
   }
@@ -371,7 +381,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   cut[0] = 0;
   { uint64_t k = 0;
     for (uint32_t s = 1; s < n_sub; ++s) {
-      const uint64_t want = c.cells / n_sub * s;
+      const uint64_t want = mat_total / n_sub * s;
       while (k < n && h_mat[k] < want) ++k;
       cut[s] = std::max(k, cut[s - 1]);
     } }
@@ -424,7 +434,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       if (use_dirs) {
         bool used = false;
         if ((rc = nw_dirs_fill(ctx, sc, &d, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>() + k0,
-                               ctx->best_index.as<uint64_t>() + k0, sf, &used)))
+                               ctx->best_index.as<uint64_t>() + k0, sf, &used, stride)))
           return rc;
         if (!used) { set_last_error("seqalign_nw_batch: internal error: directions-only fill refused a batch it had accepted"); return SEQALIGN_E_HIP; }
       } else if ((rc = seqalign_fill_batch_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, sf))) {

@@ -204,6 +204,8 @@ struct SaOptions {
                                   //                   it applies (plain scorings, rows <= 512 columns), instead of the three matrices
   bool sweep_dirs = true;         // sweep_dirs        0|1: the multi-hit path fills match_scores + direction bytes (sa_fill_dirs.hip)
                                   //                   where it applies, instead of the three matrices
+  bool pack16 = true;             // pack16            0|1: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)
+                                  //                   where they apply (every pair of the chunk the same shape, match / mismatch scoring)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)
@@ -279,8 +281,11 @@ int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, cons
               bool *cand_done = nullptr);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
-                 int32_t *end_score, uint64_t *end_state, void *stream, bool *used);
+                 int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0);
 bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a);
+// whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
+// cells start on a multiple of 256)
+bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)
 int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,

@@ -138,6 +138,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
   if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
   if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
+  if (is("pack16")) { o.pack16 = num != 0; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {
     if (num != 0 && num < (1 << 20)) return false;
@@ -155,7 +156,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -280,6 +281,7 @@ static SaFillParams make_params(const seqalign_ctx *ctx, const seqalign_dev_scor
   p.gen_eq = s->flat.gen_eq; p.gen_ne = s->flat.gen_ne; p.flags = s->flat.flags;
   p.best_score = nullptr; p.best_index = nullptr;
   p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr; p.cand_rows_off = nullptr;
+  p.uniform_stride = 0;
   return p;
 }
 
@@ -381,14 +383,18 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
 // seqalign_nw_batch's own fill (sa_fill_dirs.hip): directions only + the end cell's score / state per pair.  *used = false
 // (and nothing launched) when the scoring or the batch is outside that kernel's domain, or the option nw_dirs is off.
 int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
-                          uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, bool *used) {
+                          uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, bool *used,
+                          uint64_t uniform_stride) {
   *used = false;
   if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || batch->n_pairs == 0 || batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_OK;
   SaFillParams p = make_params(ctx, scoring, batch);
   p.best_score = end_score; p.best_index = end_state;
   if (!sa_nw_dirs_fill_applicable(p, batch->max_len_a, dirs)) return SEQALIGN_OK;
   (void)hipGetLastError();
-  hipError_t e = sa_launch_fill_nw_dirs(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream);
+  p.uniform_stride = ctx->opt.pack16 ? uniform_stride : 0;
+  hipError_t e = sa_nw_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, dirs)
+                     ? sa_launch_fill_nw_dirs_x2(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream)
+                     : sa_launch_fill_nw_dirs(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream);
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   *used = true;
   return SEQALIGN_OK;
@@ -402,6 +408,17 @@ bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_s
   int32_t s = 0; uint64_t t = 0;
   p.best_score = &s; p.best_index = &t;
   return sa_nw_dirs_fill_applicable(p, max_len_a, reinterpret_cast<const uint8_t *>((uintptr_t)256));
+}
+
+bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
+  if (!ctx->opt.pack16 || !nw_dirs_applicable(ctx, scoring, len_a)) return false;
+  seqalign_dev_batch_t b;
+  memset(&b, 0, sizeof(b));
+  SaFillParams p = make_params(ctx, scoring, &b);
+  int32_t s = 0; uint64_t t = 0;
+  p.best_score = &s; p.best_index = &t;
+  p.uniform_stride = 256;
+  return sa_nw_dirs_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)256));
 }
 
 extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,

@@ -1,0 +1,291 @@
+// sa_fill_dirs_x2.hip -- the directions-only fills (sa_fill_dirs.hip) with TWO pairs per wave in packed int16.
+//
+// Why: with one byte per cell instead of twelve, the directions-only fills are no longer bound by HBM but by VALU
+// issue -- ~135 vector instructions per 151-cell row (profiles/r03: C2 0.318 ms where the bytes alone would take
+// 0.03 ms).  Every one of those instructions is lane-wise 32-bit arithmetic on scores that, for read-sized pairs,
+// fit 16 bits.  CDNA's packed-math VALU (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_i16 with the `clamp` modifier =
+// saturation / v_pk_ashrrev_i16) works on two int16 per lane per instruction, and the bitwise ops are packed by
+// nature.  So one wave takes TWO pairs of the same shape: pair 2u in the low halves, pair 2u + 1 in the high halves
+// of every register -- no instruction ever mixes the halves, the DPP lane shifts and the prefix-max scan move both
+// at once, and the instruction count per row serves two pairs.
+//
+// Same recurrence and the same direction byte as sa_fill_dirs.hip (reference src/alignment.c:89-167 for the scores,
+// :311-327 for the decisions; sa_rowsweep.hpp for the de-trended prefix max).  What differs:
+//   * int16 with saturating adds.  The NW floor (alignment.c:41) becomes -32768 = the bottom of the type: `max(x,
+//     floor)` is the identity and floor + penalty saturates back to the floor, which is what the reference's clamp
+//     does.  Every comparison that decides a direction is then between the same numbers as in 32 bits as long as
+//     no real score leaves the type: the launcher admits a batch only if
+//     (len_a + len_b + 2) * max|penalty| + (len_a + 1) * |gap_extend| <= 30000  (sa_x2_scores_fit).
+//   * comparisons are sign bits: x < y  <=>  (x -sat y) >> 15 = 0xFFFF per half; selections are v_bfi_b32.
+//   * both pairs' rows have the same length, so ONE set of stream positions serves both rings; the caller lays the
+//     direction bytes out with every pair starting on a 256-byte boundary (SaFillParams::uniform_stride), so every
+//     global store is a whole aligned 256 B block and the last one may run into the pair's own padding.
+// Domain: what sa_fill_dirs.hip takes, AND every pair of the launch has the same len_a and len_b, AND match /
+// mismatch scoring (K <= 1), AND the score bound above.  Anything else takes the one-pair-per-wave kernels.
+#include <algorithm>
+
+#include "sa_rowsweep.hpp"
+
+namespace sa {
+
+typedef short pk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ pk16 pk_splat(int v) { return pk16{(short)v, (short)v}; }
+__device__ __forceinline__ pk16 pk_adds(pk16 a, pk16 b) { return __builtin_elementwise_add_sat(a, b); }   // v_pk_add_i16 clamp
+__device__ __forceinline__ pk16 pk_subs(pk16 a, pk16 b) { return __builtin_elementwise_sub_sat(a, b); }   // v_pk_sub_i16 clamp
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }        // v_pk_max_i16
+// 0xFFFF in every half where x < y
+__device__ __forceinline__ uint32_t pk_lt(pk16 x, pk16 y) { return pk_bits(pk_subs(x, y) >> 15); }
+// mask ? a : b, bit by bit (v_bfi_b32)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ pk16 pk_shr1(pk16 src, pk16 lane0) {
+  return pk_from((uint32_t)wave_shr1((int)pk_bits(src), (int)pk_bits(lane0)));
+}
+// DPP move with bound_ctrl: lanes without a source read 0 -- no `old` register to set up
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ pk16 pk_shr1_zero(pk16 src) { return pk_from(dpp_mov0<0x138>(pk_bits(src))); }   // lane 0 gets 0
+// packed ops the compiler does not pick by itself
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ pk16 pk_mad(uint32_t a, pk16 b, pk16 c) {   // a * b + c per half (wrapping)
+  uint32_t r;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(pk_bits(b)), "v"(pk_bits(c)));
+  return pk_from(r);
+}
+// Exclusive max scan over the 64 lanes, both halves at once: lane l gets the max of lanes < l, lane 0 the bottom of
+// the type.  VOP3P has no DPP form, so each step is a DPP move and a max; done on BIASED values (x ^ 0x8000: signed
+// order = unsigned order) so that 0 -- what bound_ctrl gives a lane without a source -- is the identity, and with
+// full row masks: a max may take the same element twice, so rows 2 and 3 may also see row 1 through row_bcast:15.
+__device__ __forceinline__ pk16 pk_wave_scan_max_excl(pk16 v) {
+  uint32_t u = pk_bits(v) ^ 0x80008000u;
+  u = pk_max_u16(u, dpp_mov0<0x111>(u));   // row_shr:1
+  u = pk_max_u16(u, dpp_mov0<0x112>(u));   // row_shr:2
+  u = pk_max_u16(u, dpp_mov0<0x114>(u));   // row_shr:4
+  u = pk_max_u16(u, dpp_mov0<0x118>(u));   // row_shr:8
+  u = pk_max_u16(u, dpp_mov0<0x142>(u));   // row_bcast:15
+  u = pk_max_u16(u, dpp_mov0<0x143>(u));   // row_bcast:31
+  return pk_from(dpp_mov0<0x138>(u) ^ 0x80008000u);   // wave_shr:1
+}
+
+constexpr uint32_t kBoth = 0x00010001u;   // a 1 in each half
+
+// ---- Needleman-Wunsch, directions only (the packed form of fill_nw_dirs_kernel)
+template <int CPL, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint32_t pair0 = 2 * unit;
+  if (pair0 >= p.n_pairs) return;
+  const bool two = pair0 + 1 < p.n_pairs;          // an odd launch: the last wave's high halves shadow its low ones
+  const uint32_t pair1 = two ? pair0 + 1 : pair0;
+
+  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;   // (the same for every pair: the launcher checked)
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
+  uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
+  const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
+  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  const Border bd{p.floor, p.gap_open, p.ext, false, false};
+  const uint32_t ones = kBoth;
+
+  uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
+  uint32_t wv = 0, rv = 0;   // stream positions = cell indices: written up to wv, flushed up to rv
+  auto flush_block = [&]() __attribute__((always_inline)) {
+    const uint32_t o = (rv & (R - 1)) + 4 * lane;
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
+    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
+    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
+    if (two) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    rv += 256;
+  };
+  auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
+    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      ring0[o] = (uint8_t)dv[c];             // ds_write_b8
+      ring1[o] = (uint8_t)(dv[c] >> 16);     // ds_write_b8_d16_hi
+    }
+    wv += W;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (wv - rv >= 256u) flush_block();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+
+  uint32_t fa[CPL];                       // my columns' folded characters of seq_a, one pair per half
+  pk16 X[CPL], Yp[CPL], Ap[CPL];          // previous row: max3(M,A,B), max(M,B), A
+  pk16 c1[CPL], c3[CPL];                  // gap_b scan constants (sa_rowsweep.hpp): open1 - g*ext, g*ext
+  uint32_t T[CPL], TY4[CPL];              // previous row: which of M/A/B is the max3 (bits 0-1), B >= M ? 2 : 0 (at bits 2-3)
+  pk16 mv[CPL], av[CPL], bv[CPL];         // the row just computed (after the loop: the last row, for the end cell)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const uint32_t g = lane * CPL + c;
+    const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
+    const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
+    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    // row 0 (alignment.c:46-69): the same in both halves
+    const int m0 = g ? -32768 : 0, a0 = m0, b0 = g ? bd.edge_gap(g) : 0;
+    const int x0 = max3i(m0, a0, b0);
+    mv[c] = pk_splat(m0); av[c] = pk_splat(a0); bv[c] = pk_splat(b0);
+    X[c] = pk_splat(x0); Yp[c] = pk_splat(max(m0, b0)); Ap[c] = pk_splat(a0);
+    T[c] = ((a0 == x0) ? 1u : (b0 == x0) ? 2u : 0u) * kBoth;
+    TY4[c] = ((b0 >= m0) ? 8u : 0u) * kBoth;
+    const int g_ext = (int)g * p.ext;
+    c1[c] = pk_splat(p.open1 - g_ext); c3[c] = pk_splat(g_ext);
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  {
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dv[c] = 0;   // row 0 is never stood on with a move to make
+    append_row(dv);
+  }
+
+  uint32_t chunk_code = 0;
+  for (uint32_t j = 1; j <= lb; ++j) {
+    const int q = (j - 1) & (kWave - 1);
+    if (q == 0) {
+      const uint32_t r = j + lane;
+      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    }
+    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);   // this row's folded characters of seq_b (uniform)
+    const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (lane 0: the border column, overridden below)
+    const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
+    const pk16 edge_a = pk_splat(bd.edge_gap(j));   // gap_a of the border cell (0, j) (alignment.c:72-80)
+    pk16 z[CPL];
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      // substitution: equal characters -> gen_eq, else gen_ne = gen_eq + min(fa ^ fb, 1) * (gen_ne - gen_eq)
+      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
+      const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
+      pk16 m = pk_adds(xd, s);                                                             // alignment.c:101-116
+      const pk16 ae = pk_adds(Ap[c], ext);
+      pk16 a = pk_max(pk_adds(Yp[c], open1), ae);                                          // alignment.c:128-135
+      if (c == 0) { m = lane == 0 ? floor_ : m; a = lane == 0 ? edge_a : a; }              // the border column
+      const uint32_t opened = pk_lt(ae, a);                                                // gap_a + ext is NOT the max
+      const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);                                 // GAP_A (1) first, else B >= M ? 2 : 0
+      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
+      dv[c] = td | dA;
+    }
+    pk16 Pm[CPL];                         // de-trended gap_b: prefix max up to and including my column
+    pk16 e;                               //                   prefix max of the lanes to my left
+    {
+      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      pk16 P[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 zl = (c == 0) ? zin : z[c - 1];
+        pk16 w = pk_adds(zl, c1[c]);
+        if (c == 0) w = (lane == 0) ? floor_ : w;     // gap_b of (0, j) is the floor
+        P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
+      }
+      e = pk_wave_scan_max_excl(P[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
+    }
+    {
+      const pk16 al = pk_shr1_zero(av[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
+        const pk16 b = bv[c];
+        // alignment.c:311-327 for GAP_B: the left cell's gap_a + open1 first, then its gap_b + ext, else match.
+        // gap_b(left) + ext == b  <=>  the prefix max did not grow at my column (de-trended: Pm(left) == Pm(mine))
+        const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
+        const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
+        const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
+        dv[c] |= dB;
+        const pk16 yn = pk_max(mv[c], b);
+        const uint32_t m_wins = pk_lt(b, mv[c]);      // B < M
+        const uint32_t a_loses = pk_lt(av[c], yn);    // A < max(M, B)
+        const uint32_t ty4 = bfi(m_wins, 0u, 8u * kBoth);
+        X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
+        T[c] = bfi(a_loses, ty4 >> 2, kBoth);         // GAP_A first, then GAP_B, then MATCH
+        TY4[c] = ty4;
+      }
+    }
+    // the border cell (0, j): never stood on with a move to make, but byte for byte what fill_nw_dirs_kernel stores
+    // there -- GAP_A continues down the column (its first step only if gap_open is 0), else max(M, B) = B
+    dv[0] = lane == 0 ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
+    append_row(dv);
+  }
+  while (rv < wv) flush_block();
+
+  // the end cell (la, lb): score and matrix the walk starts in (needleman_wunsch.c:53-66)
+  const int owner = (int)(la / CPL), oc = (int)(la % CPL);
+  pk16 em = pk_splat(0), ea = em, eb = em;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { if (c == oc) { em = mv[c]; ea = av[c]; eb = bv[c]; } }
+  if (lane == owner) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !two) break;
+      const int m = h ? em.y : em.x, a = h ? ea.y : ea.x, b = h ? eb.y : eb.x;
+      int score = m;
+      uint32_t st = 0;                                // MATCH
+      if (b >= score) { st = 2; score = b; }          // GAP_B
+      if (a >= score) { st = 1; score = a; }          // GAP_A
+      const uint32_t pr = h ? pair1 : pair0;
+      p.best_score[pr] = score;
+      p.best_index[pr] = st;
+      p.status[pr] = ~0ull;
+    }
+  }
+}
+
+template <int CPL, int R>
+static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  const int wpb = 4;
+  const uint32_t units = (p.n_pairs + 1) / 2;
+  const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
+  hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  return hipGetLastError();
+}
+
+}  // namespace sa
+
+// every score the recurrence can produce for pairs up to max_len_a x max_len_b, de-trended or not, stays inside int16
+bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b) {
+  auto mag = [](int64_t v) { return v < 0 ? -v : v; };
+  int64_t pen = std::max(mag(p.gen_eq), mag(p.gen_ne));
+  pen = std::max(pen, std::max(mag(p.open1), mag(p.ext)));
+  pen = std::max(pen, mag(p.gap_open) + mag(p.ext));
+  return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(p.ext) <= 30000;
+}
+
+bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
+  if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs)) return false;
+  if (p.K > 1 || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
+  return sa_x2_scores_fit(p, max_len_a, max_len_b);
+}
+
+hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
+  if (p.n_pairs == 0) return hipSuccess;
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  if (need <= 1) return sa::launch_nw_dirs_x2_cpl<1, 512>(p, dirs, stream);
+  if (need <= 2) return sa::launch_nw_dirs_x2_cpl<2, 512>(p, dirs, stream);
+  if (need <= 3) return sa::launch_nw_dirs_x2_cpl<3, 512>(p, dirs, stream);
+  if (need <= 4) return sa::launch_nw_dirs_x2_cpl<4, 512>(p, dirs, stream);
+  if (need <= 5) return sa::launch_nw_dirs_x2_cpl<5, 1024>(p, dirs, stream);
+  if (need <= 6) return sa::launch_nw_dirs_x2_cpl<6, 1024>(p, dirs, stream);
+  return sa::launch_nw_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+}

@@ -38,6 +38,9 @@ struct SaFillParams {
   const uint64_t *cand_rows_off; /* [n] where pair p's part starts, in uint64 (SaSweepParams::hit_off)                    */
   /* launch tuning (host side only; the context's options, sa_ctx.hpp SaOptions): 0 = the launcher's own choice */
   uint32_t tune_cpl, tune_wpb, tune_lds_pad;
+  /* != 0: every pair of the launch has the same len_a and len_b and pair k's cells start at mat_off[0] + k * uniform_stride
+   * (>= its cell count); the packed two-pairs-per-wave fills (sa_fill_dirs_x2.hip) need a multiple of 256 */
+  uint64_t uniform_stride;
 };
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit
@@ -203,6 +206,11 @@ hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_
  * (p.best_index); plain NW scorings (no flag), rows <= 512 columns */
 bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
 hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
+/* the same fills with two pairs per wave in packed int16 (sa_fill_dirs_x2.hip): uniform batches, match / mismatch scorings,
+ * scores inside int16 */
+bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
+bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
+hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */

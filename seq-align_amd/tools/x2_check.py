@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""The packed two-pairs-per-wave direction fills (sa_fill_dirs_x2.hip, option pack16) against the one-pair kernels
+(pack16 = 0) and the oracle on uniform batches, then their timing on C2 and C5's share.
+
+    python seq-align_amd/tools/x2_check.py [seconds]
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "seq-align_amd" / "python"))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402,F401
+
+import orclib as O  # noqa: E402
+import seqalign_amd as S  # noqa: E402
+from seqalign_amd import workloads as W  # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = W.Rng(77)
+ctx = S.Context(0)
+DNA = np.frombuffer(b"ACGT", np.uint8)
+
+
+def uniform_batch(n, la, lb, related):
+    a = DNA[rng.below(4, n * la).astype(np.int64)].reshape(n, la)
+    if related and la == lb:
+        b = W._mutate(a, lb, DNA, rng, 0.08, 0.03)
+    elif related:
+        b = DNA[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+        k = min(la, lb)
+        b[:, :k] = a[:, :k]
+        flip = rng.unit(n * k).reshape(n, k) < 0.1
+        b[:, :k] = np.where(flip, DNA[rng.below(4, n * k).astype(np.int64)].reshape(n, k), b[:, :k])
+    else:
+        b = DNA[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+    return W._fixed_batch(a, b)
+
+
+def same(r0, r1):
+    return all(np.array_equal(x, y) for x, y in zip(r0, r1))
+
+
+t_end = time.time() + seconds
+trials = pairs = oracle_pairs = 0
+shapes = [(1, 1), (1, 7), (7, 1), (3, 5), (63, 64), (64, 64), (64, 10), (127, 130), (128, 128), (150, 150), (151, 149), (191, 40),
+          (192, 33), (200, 37), (255, 256), (300, 100), (383, 20), (400, 60), (511, 70)]
+while time.time() < t_end:
+    v = rng.below(1 << 20, 12).astype(int)
+    la, lb = shapes[trials % len(shapes)] if trials < 3 * len(shapes) else (int(1 + v[0] % 511), int(1 + v[1] % 300))
+    n = int(1 + v[2] % 700)
+    match, mismatch = int(1 + v[3] % 5), -int(v[4] % 6)
+    go, ge = -int(v[5] % 12), -int(v[6] % 4)
+    spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+    sc = S.make_scoring(spec)
+    batch = uniform_batch(n, la, lb, bool(v[8] & 1))
+    ctx.set_option("pack16", 0)
+    r0 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
+    ctx._nw_buffers = None
+    ctx.set_option("pack16", 1)
+    r1 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
+    ctx._nw_buffers = None
+    if not same(r0, r1):
+        bad = np.nonzero(r0[4] != r1[4])[0]
+        print("MISMATCH pack16 0 vs 1:", la, lb, n, spec, "score diffs at", bad[:8], flush=True)
+        for p in range(n):
+            o, l0, l1 = int(r0[0][p]), int(r0[3][p]), int(r1[3][p])
+            if l0 != l1 or not np.array_equal(r0[1][o:o + l0], r1[1][o:o + l1]) or not np.array_equal(r0[2][o:o + l0], r1[2][o:o + l1]):
+                print(" pair", p, "score", r0[4][p], r1[4][p], "\n ", r0[1][o:o + l0].tobytes(), "\n ", r0[2][o:o + l0].tobytes(),
+                      "\n ", r1[1][o:o + l1].tobytes(), "\n ", r1[2][o:o + l1].tobytes())
+                break
+        sys.exit(1)
+    if trials % 4 == 0:      # the oracle on a few pairs of the batch
+        osc = O.Scoring.from_buffer_copy(bytes(sc))
+        for p in range(0, n, max(1, n // 6)):
+            _, score, sa, sb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            o, ln = int(r1[0][p]), int(r1[3][p])
+            if score != int(r1[4][p]) or sa != r1[1][o:o + ln].tobytes() or sb != r1[2][o:o + ln].tobytes():
+                print("MISMATCH vs oracle:", la, lb, n, spec, "pair", p, score, int(r1[4][p]), flush=True)
+                sys.exit(1)
+            oracle_pairs += 1
+    trials += 1
+    pairs += n
+print(f"x2_check: {trials} uniform batches, {pairs} pairs: pack16 = 1 identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
+
+from bench import WORKLOADS  # noqa: E402
+for name, n in (("C2", 10000), ("C5share", 125000)):
+    gen, kwargs, _, is_sw, spec, _ = WORKLOADS["C2"]
+    batch = getattr(W, gen)(n, **kwargs)
+    sc = S.make_scoring(spec)
+    for pk in (0, 1, 0, 1):
+        ctx.set_option("pack16", pk)
+        ts = []
+        for it in range(7):
+            t0 = time.perf_counter()
+            ctx.nw_batch(batch, sc, raw=True)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print(f"{name} pack16={pk}: " + " ".join("%.3f" % t for t in ts[2:]) + " ms", flush=True)

@@ -446,6 +446,38 @@ def test_direction_byte_paths_every_width(ctx, max_len):
                 assert rc == 0 and got[p] == want, (max_len, spec, "sw", max_hits, p)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (9, 1), (5, 3), (63, 64), (64, 33), (127, 70), (128, 128), (150, 150), (191, 40),
+                                   (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45)])
+def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
+    """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
+    int16 halves; option pack16): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
+    kernel's (pack16 = 0) for every columns-per-lane instantiation, odd and even pair counts (the last wave of an odd
+    launch holds one pair), unrelated and related sequences, gap_open = 0, sub-batches cut at odd pairs -- and a scoring
+    whose scores could leave int16 is NOT packed (same results through the 32-bit kernel)."""
+    la, lb = shape
+    rng = W.Rng(9100 + 7 * la + lb)
+    dna = np.frombuffer(b"ACGT", np.uint8)
+    for n, spec, n_sub in ((1, {"preset": "default"}, 0), (2, {"init": [2, -3, 0, -2, 0, 0, 0, 0, 0, 1], "wildcards": []}, 0),
+                           (37, {"preset": "default"}, 3), (64, {"init": [3, -1, -7, -1, 0, 0, 0, 0, 0, 0], "wildcards": []}, 0),
+                           (21, {"init": [40, -60, -90, -30, 0, 0, 0, 0, 0, 0], "wildcards": []}, 2)):
+        a = dna[rng.below(4, n * la).astype(np.int64)].reshape(n, la)
+        b = dna[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+        k = min(la, lb)
+        keep = rng.unit(n * k).reshape(n, k) < 0.8          # half of the pairs related: b = a with substitutions
+        b[: n // 2, :k] = np.where(keep[: n // 2], a[: n // 2, :k], b[: n // 2, :k])
+        batch = W._fixed_batch(a, b)
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        opts(pack16=1, subbatches=n_sub)
+        packed = ctx.nw_batch(batch, sc)
+        opts(pack16=0, subbatches=n_sub)
+        plain = ctx.nw_batch(batch, sc)
+        assert packed == plain, (shape, n, spec)
+        for p in range(n):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
+
+
 @pytest.mark.parametrize("dirs", [1, 0], ids=["directions", "three-matrices"])
 def test_nw_batch_in_several_chunks(ctx, dirs):
     """seqalign_nw_batch on a batch that does not fit one chunk (tiny chunk budget): per-chunk scratch (descriptor block,
