@@ -345,6 +345,7 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
  *   pack16          1 | 0                   direction-byte fills take two pairs per wave in packed int16 where every pair of a
  *                                           chunk has the same shape, the scoring is match / mismatch and scores fit int16
+ *   walk_overlap    1 | 0                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
  *   cpl, wpb, lds_pad, sweep_trace, timing  tuning experiments / development aids
  * Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */

@@ -370,11 +370,12 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   } else if ((rc = reserve_arenas(ctx, c.cells * 4))) {
     return rc;
   }
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
     if (!ctx->copy_streams[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[k], hipStreamNonBlocking));
+  // The walks: with direction bytes the fill is bound by VALU issue and a walk by the latency of its dependent byte loads,
+  // so a group's walk runs on its own stream beside the next group's fills; the three-matrix fill saturates HBM and a walk
+  // beside it only slows both down (profiles/r03/r03_nw_pipeline.md), so there the walk stays in the fills' stream.
   hipStream_t sf = ctx->stream, su = ctx->copy_streams[0], sd = ctx->copy_streams[1];
-  // pinned / device buffers are reused by the next call: never leave work in flight
-  StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd);
 
   // sub-batch s = pairs [cut[s], cut[s + 1]) of the chunk, cut at equal cells; group g = sub-batches [gcut[g], gcut[g + 1])
   std::vector<uint64_t> cut(n_sub + 1, n);
@@ -391,9 +392,13 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     if (cut[s] - cut[gcut.back()] >= kGroupPairs && n - cut[s] >= kGroupPairs / 2) gcut.push_back(s);
   gcut.push_back(n_sub);
   const uint32_t n_grp = (uint32_t)gcut.size() - 1;
+  const bool walk_beside = use_dirs && ctx->opt.walk_overlap && n_grp > 1;   // (one group: nothing to run beside)
+  hipStream_t sw = walk_beside ? ctx->copy_streams[2] : sf;
+  // pinned / device buffers are reused by the next call: never leave work in flight
+  StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd), sync_w(sw);
 
-  EventList ev;   // [0, n_sub): upload of s done; [n_sub, n_sub + n_grp): walk of g done; then: download of g done
-  for (uint32_t k = 0; k < n_sub + 2 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
+  EventList ev;   // [0, n_sub): upload of s done; [n_sub, n_sub + n_grp): walk of g done; then: download of g done; then: fills of g done
+  for (uint32_t k = 0; k < n_sub + 3 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, su));
 
   uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
@@ -458,9 +463,13 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel;
-        hipError_t e = sa_launch_nw_traceback(t, sf);
+        if (sw != sf) {
+          HIP_TRY(hipEventRecord(ev.ev[n_sub + 2 * n_grp + g], sf));
+          HIP_TRY(hipStreamWaitEvent(sw, ev.ev[n_sub + 2 * n_grp + g], 0));
+        }
+        hipError_t e = sa_launch_nw_traceback(t, sw);
         if (e != hipSuccess) return fail_hip(e, "traceback launch");
-        HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sf));
+        HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sw));
         HIP_TRY(hipStreamWaitEvent(sd, ev.ev[n_sub + g], 0));
         if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_chars + 2 * c0, d_chars + 2 * c0, 2 * (c1 - c0), hipMemcpyDeviceToHost, sd));
         HIP_TRY(hipMemcpyAsync(h_meta + 4 * g0, d_meta + 4 * g0, (g1 - g0) * 16, hipMemcpyDeviceToHost, sd));

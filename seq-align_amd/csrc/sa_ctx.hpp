@@ -206,6 +206,8 @@ struct SaOptions {
                                   //                   where it applies, instead of the three matrices
   bool pack16 = true;             // pack16            0|1: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)
                                   //                   where they apply (every pair of the chunk the same shape, match / mismatch scoring)
+  bool walk_overlap = true;       // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
+                                  //                   while the next group fills (a VALU-bound fill next to a latency-bound walk)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)
@@ -225,7 +227,7 @@ struct seqalign_ctx {
   SaOptions opt;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream (created on first use): work that overlaps the main stream's kernels
-  hipStream_t copy_streams[2] = {nullptr, nullptr};   // seqalign_nw_batch's pipeline (sa_batch.hip): upload, download; created on first use
+  hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr};   // seqalign_nw_batch's pipeline (sa_batch.hip): upload, download, walks; created on first use
   size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
   size_t chunk_budget_default = 0;
   // device scratch for the host-level entry points

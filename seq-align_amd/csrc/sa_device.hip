@@ -5,6 +5,13 @@
 // the runtime or a device is missing every entry point reports it.
 #include "sa_ctx.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
+#include <sched.h>
+#include <time.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -139,6 +146,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
   if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
   if (is("pack16")) { o.pack16 = num != 0; return true; }
+  if (is("walk_overlap")) { o.walk_overlap = num != 0; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {
     if (num != 0 && num < (1 << 20)) return false;
@@ -156,7 +164,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -576,6 +584,128 @@ int sa_host::cached_scoring(seqalign_ctx *ctx, const scoring_t *sc, int is_sw, s
   return SEQALIGN_OK;
 }
 
+// ---- the legacy single-pair call's pinned block and the combiner of concurrent callers
+namespace {
+// OneBlock: [0, 4 KiB) the leader's descriptor arrays for up to kOneCombine requests | sequences | M | A | B
+constexpr size_t kOneCombine = 64;
+constexpr size_t kOneSeqAt = 4096, kOneSeqBytes = 60 * 1024;
+constexpr size_t kOneMatAt = 64 * 1024, kOneMatrixBytes = 704 * 1024;   // 180 224 cells per matrix (150 x 150: 22 801)
+constexpr size_t kOneBlockBytes = kOneMatAt + 3 * kOneMatrixBytes;
+
+struct OneRequest {
+  seqalign_ctx *ctx = nullptr;
+  seqalign_dev_scoring *dsc = nullptr;
+  uint64_t fp = 0;
+  int is_sw = 0;
+  uint32_t len_a = 0, len_b = 0;
+  uint64_t block_dev = 0;   // device address of the caller's OneBlock
+  uint64_t status = 0;
+  int rc = SEQALIGN_OK;
+  bool taken = false;                 // (under the combiner's mutex) part of a launch that is in flight
+  std::atomic<bool> done{false};      // set by that launch's leader after its wait; the owner spins on it
+};
+// At most kOneRounds launches in flight: a caller that finds fewer leads one (with everything waiting for its scoring,
+// after giving the callers of the last launches up to 20 us to join), the others wait to be taken by the next leader --
+// alone, a thread's every call is its own launch as before; with more, the launches carry several pairs each and overlap
+// three deep.  A launch takes ~50 us whatever it carries (one wave per pair, 120 rows one after the other).  Measured
+// with examples/legacy_threads.c (pairs per second against one thread): 2 threads 1.9x, 4: 2.9x, 8: 4.8x, 16: 7.0x
+// (one launch per call, rounds 3: 8 threads 3.3-4.0x; kOneRounds 1 / 2 / 3 / 4 / 8 without the gathering: 3.6 / 4.0 /
+// 4.3 / 4.2 / 3.8x).
+constexpr int kOneRounds = 3;
+struct OneCombiner {
+  std::mutex m;
+  std::vector<OneRequest *> waiting;
+  std::atomic<int> in_flight{0};
+  std::atomic<int> n_waiting{0};
+  std::atomic<int> recent_group{1};   // size of the last launches' groups (decaying maximum): how many callers to expect
+};
+OneCombiner g_one;
+
+// One launch + one wait for a group of requests that share the device and the scoring (the leader's upload is used: same
+// fingerprint = same tables).  Descriptors go into the LEADER's block; every address in them is absolute (arena base 0),
+// and the three matrices of every request sit kOneMatrixBytes apart, so gap_a / gap_b are "match_scores + a constant".
+int run_one_group(OneRequest *lead, const std::vector<OneRequest *> &grp) {
+  seqalign_ctx *ctx = lead->ctx;
+  char *h = ctx->h_one.as<char>(), *d = static_cast<char *>(ctx->one_dev);
+  uint64_t *off_a = reinterpret_cast<uint64_t *>(h), *off_b = off_a + kOneCombine, *mat = off_b + kOneCombine;
+  uint32_t *la = reinterpret_cast<uint32_t *>(mat + kOneCombine), *lb = la + kOneCombine;
+  uint64_t *st = reinterpret_cast<uint64_t *>(lb + kOneCombine);
+  seqalign_dev_batch_t db;
+  db.n_pairs = grp.size(); db.max_len_a = 0; db.max_len_b = 0;
+  for (size_t k = 0; k < grp.size(); ++k) {
+    const OneRequest *q = grp[k];
+    off_a[k] = q->block_dev + kOneSeqAt; off_b[k] = off_a[k] + q->len_a;
+    mat[k] = (q->block_dev + kOneMatAt) / 4;
+    la[k] = q->len_a; lb[k] = q->len_b; st[k] = 0;
+    db.max_len_a = std::max(db.max_len_a, q->len_a); db.max_len_b = std::max(db.max_len_b, q->len_b);
+  }
+  db.arena = nullptr;
+  db.off_a = reinterpret_cast<const uint64_t *>(d); db.off_b = db.off_a + kOneCombine; db.mat_off = db.off_b + kOneCombine;
+  db.len_a = reinterpret_cast<const uint32_t *>(db.mat_off + kOneCombine); db.len_b = db.len_a + kOneCombine;
+  db.status = reinterpret_cast<uint64_t *>(d + (reinterpret_cast<char *>(st) - h));
+  db.match_scores = nullptr;
+  db.gap_a_scores = reinterpret_cast<int32_t *>(kOneMatrixBytes);
+  db.gap_b_scores = reinterpret_cast<int32_t *>(2 * kOneMatrixBytes);
+  hipStream_t stream = ctx->stream;
+  int rc = sa_host::fill_device(ctx, lead->dsc, &db, SEQALIGN_KERNEL_AUTO, stream, nullptr, nullptr, nullptr);
+  // kernel end + wait: the GPU's writes to the (coherent) pinned blocks are visible
+  // (polled: a blocking wait adds the wake-up of a sleeping thread to every pair; a launch of this size takes ~50 us)
+  hipError_t e = hipErrorNotReady;
+  for (unsigned spins = 0; rc == SEQALIGN_OK && spins < 20000 && (e = hipStreamQuery(stream)) == hipErrorNotReady; ++spins) __builtin_ia32_pause();
+  if (e == hipErrorNotReady || rc != SEQALIGN_OK) e = hipStreamSynchronize(stream);
+  if (rc == SEQALIGN_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+  for (size_t k = 0; k < grp.size(); ++k) { grp[k]->status = st[k]; grp[k]->rc = rc; }
+  return rc;
+}
+
+int combine_and_run(OneRequest *req) {
+  OneCombiner &g = g_one;
+  { std::lock_guard<std::mutex> lk(g.m); g.waiting.push_back(req); g.n_waiting.fetch_add(1, std::memory_order_relaxed); }
+  constexpr long long gather_ns = 20000;   // measured (examples/legacy_threads.c, 8 threads): 0 -> 4.3x, 10-40 us -> 4.6-4.8x one thread
+  for (unsigned spins = 0; !req->done.load(std::memory_order_acquire); ++spins) {
+    if (g.in_flight.load(std::memory_order_relaxed) < kOneRounds) {
+      if (spins == 0) {
+        // callers that were in the last launches are probably on their way: give them a moment to join this one
+        const int expect = g.recent_group.load(std::memory_order_relaxed);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (g.n_waiting.load(std::memory_order_relaxed) < expect && !req->done.load(std::memory_order_acquire)) {
+          clock_gettime(CLOCK_MONOTONIC, &t1);
+          if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > gather_ns) break;
+          __builtin_ia32_pause();
+        }
+        if (req->done.load(std::memory_order_acquire)) break;
+      }
+      std::unique_lock<std::mutex> lk(g.m);
+      if (!req->taken && g.in_flight.load(std::memory_order_relaxed) < kOneRounds) {
+        // lead: take every waiting request of my device and scoring, mine first
+        g.in_flight.fetch_add(1, std::memory_order_relaxed);
+        std::vector<OneRequest *> grp{req}, rest;
+        for (OneRequest *q : g.waiting) {
+          if (q == req) continue;
+          const bool mine = q->ctx->device == req->ctx->device && q->fp == req->fp && q->is_sw == req->is_sw;
+          (mine && grp.size() < kOneCombine ? grp : rest).push_back(q);
+        }
+        for (OneRequest *q : grp) q->taken = true;
+        g.waiting.swap(rest);
+        g.n_waiting.fetch_sub((int)grp.size(), std::memory_order_relaxed);
+        { const int prev = g.recent_group.load(std::memory_order_relaxed);
+          g.recent_group.store(std::max<int>((int)grp.size(), prev - (prev > 1 ? 1 : 0)), std::memory_order_relaxed); }
+        lk.unlock();
+        run_one_group(req, grp);
+        g.in_flight.fetch_sub(1, std::memory_order_release);
+        for (OneRequest *q : grp)
+          if (q != req) q->done.store(true, std::memory_order_release);   // (q may be gone the moment this is visible)
+        return req->rc;
+      }
+    }
+    // a launch that carries (or will carry) my request is on its way: ~50 us.  Spin, politely after a while.
+    if (spins < 4000) __builtin_ia32_pause(); else sched_yield();
+  }
+  return req->rc;
+}
+}  // namespace
+
 extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is_sw, const char *a, size_t len_a,
                                 const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
   if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
@@ -584,47 +714,34 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
   { int rc = cached_scoring(ctx, sc, is_sw, &dsc); if (rc) return rc; }
   const uint64_t cells = ((uint64_t)len_a + 1) * ((uint64_t)len_b + 1);
   if (cells >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
-  if (cells * 12 + len_a + len_b <= ((uint64_t)2 << 20)) {
-    // A small pair -- what this entry point is for -- in TWO runtime calls: a launch and a wait.  Everything the pair
-    // needs lives in ONE block of pinned host memory that the GPU reads and writes in place over PCIe,
-    //     [off_a off_b mat_off | len_a len_b | seq_a seq_b ... | M | A | B | status]      (M, A, B 4 KiB aligned)
-    // -- a few hundred bytes of sequence read, the matrices written as the fill's usual aligned 1 KiB blocks (a
-    // 150 x 150 pair's 270 KB take ~7 us of a ~50 us kernel).  No staging copies, so no copy engine latency either.
-    // The batch machinery costs eight runtime calls per pair, an upload / download pair through device memory four;
-    // with several threads in here at once (one context each) it is the runtime's own serialisation of those calls
-    // that bounds the pairs per second (8 threads: 3.4x one thread with four calls).
-    const size_t S = (size_t)((cells * 4 + 4095) & ~4095ull), seq_at = 64, m_at = (seq_at + len_a + len_b + 4095) & ~(size_t)4095;
-    const size_t total = m_at + 3 * S + 64;
+  if (cells * 4 <= kOneMatrixBytes && len_a + len_b <= kOneSeqBytes) {
+    // A small pair -- what this entry point is for.  Everything the pair needs lives in ONE block of pinned host memory
+    // per calling thread that the GPU reads and writes in place over PCIe (fixed geometry, OneBlock below): a few hundred
+    // bytes of sequence read, the matrices written as the fill's usual aligned 1 KiB blocks (a 150 x 150 pair's 270 KB
+    // take ~7 us of a ~50 us kernel); no staging copies, so no copy engine latency either.  One pair then costs TWO
+    // runtime calls, a launch and a wait -- and with several threads in here at once it is the runtime's own
+    // serialisation of those calls that bounds the pairs per second (8 threads, one launch each: 3.3-4.0x one thread).
+    // So concurrent callers COMBINE (combine_and_run): whoever finds no launch in flight becomes the leader, takes every
+    // waiting request with its scoring, fills them all with one launch + one wait into their own blocks, and wakes them.
     int rc;
-    if (total > ctx->h_one.cap) {
-      if ((rc = ctx->h_one.reserve(total))) return rc;
+    if (ctx->h_one.cap < kOneBlockBytes) {
+      if ((rc = ctx->h_one.reserve(kOneBlockBytes))) return rc;
       ctx->one_dev = nullptr;
       HIP_TRY(hipHostGetDevicePointer(&ctx->one_dev, ctx->h_one.p, 0));
     }
-    char *h = ctx->h_one.as<char>(), *d = static_cast<char *>(ctx->one_dev);
-    uint64_t *hq = reinterpret_cast<uint64_t *>(h);
-    hq[0] = 0; hq[1] = len_a; hq[2] = 0;                       // off_a, off_b, mat_off
-    uint32_t *hl = reinterpret_cast<uint32_t *>(h + 24);
-    hl[0] = (uint32_t)len_a; hl[1] = (uint32_t)len_b;
-    if (len_a) memcpy(h + seq_at, a, len_a);
-    if (len_b) memcpy(h + seq_at + len_a, b, len_b);
-    hipStream_t st = ctx->stream;
-    StreamSyncOnExit sync(st);
-    seqalign_dev_batch_t db;
-    db.n_pairs = 1; db.arena = reinterpret_cast<const uint8_t *>(d + seq_at);
-    db.off_a = reinterpret_cast<const uint64_t *>(d); db.off_b = db.off_a + 1; db.mat_off = db.off_a + 2;
-    db.len_a = reinterpret_cast<const uint32_t *>(d + 24); db.len_b = db.len_a + 1;
-    db.match_scores = reinterpret_cast<int32_t *>(d + m_at); db.gap_a_scores = reinterpret_cast<int32_t *>(d + m_at + S);
-    db.gap_b_scores = reinterpret_cast<int32_t *>(d + m_at + 2 * S); db.status = reinterpret_cast<uint64_t *>(d + m_at + 3 * S);
-    db.max_len_a = (uint32_t)len_a; db.max_len_b = (uint32_t)len_b;
-    if ((rc = fill_device(ctx, dsc, &db, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr))) return rc;
-    HIP_TRY(hipStreamSynchronize(st));   // kernel end + wait: the GPU's writes to the (coherent) pinned block are visible
-    memcpy(M, h + m_at, cells * 4);
-    memcpy(A, h + m_at + S, cells * 4);
-    memcpy(B, h + m_at + 2 * S, cells * 4);
-    const uint64_t stw = *reinterpret_cast<const uint64_t *>(h + m_at + 3 * S);
-    if (status) *status = stw;
-    return stw == ~0ull ? SEQALIGN_OK : SEQALIGN_E_UNKNOWN_PAIR;
+    char *h = ctx->h_one.as<char>();
+    if (len_a) memcpy(h + kOneSeqAt, a, len_a);
+    if (len_b) memcpy(h + kOneSeqAt + len_a, b, len_b);
+    OneRequest req;
+    req.ctx = ctx; req.dsc = dsc; req.fp = ctx->cached_fp[is_sw ? 1 : 0]; req.is_sw = is_sw ? 1 : 0;
+    req.len_a = (uint32_t)len_a; req.len_b = (uint32_t)len_b;
+    req.block_dev = reinterpret_cast<uint64_t>(ctx->one_dev);
+    if ((rc = combine_and_run(&req))) return rc;
+    memcpy(M, h + kOneMatAt, cells * 4);
+    memcpy(A, h + kOneMatAt + kOneMatrixBytes, cells * 4);
+    memcpy(B, h + kOneMatAt + 2 * kOneMatrixBytes, cells * 4);
+    if (status) *status = req.status;
+    return req.status == ~0ull ? SEQALIGN_OK : SEQALIGN_E_UNKNOWN_PAIR;
   }
   // one arena: a then b
   std::vector<char> arena(len_a + len_b + 1);

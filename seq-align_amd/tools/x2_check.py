@@ -92,11 +92,12 @@ for name, n in (("C2", 10000), ("C5share", 125000)):
     gen, kwargs, _, is_sw, spec, _ = WORKLOADS["C2"]
     batch = getattr(W, gen)(n, **kwargs)
     sc = S.make_scoring(spec)
-    for pk in (0, 1, 0, 1):
+    for pk, wo in ((0, 0), (0, 1), (1, 0), (1, 1), (1, 0), (1, 1)):
         ctx.set_option("pack16", pk)
+        ctx.set_option("walk_overlap", wo)
         ts = []
         for it in range(7):
             t0 = time.perf_counter()
             ctx.nw_batch(batch, sc, raw=True)
             ts.append((time.perf_counter() - t0) * 1e3)
-        print(f"{name} pack16={pk}: " + " ".join("%.3f" % t for t in ts[2:]) + " ms", flush=True)
+        print(f"{name} pack16={pk} walk_overlap={wo}: " + " ".join("%.3f" % t for t in ts[2:]) + " ms", flush=True)

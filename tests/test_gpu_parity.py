@@ -1067,14 +1067,13 @@ def test_legacy_sw_fetch_matches_oracle_hit_lists(ctx):
 
 def test_legacy_api_one_aligner_per_thread_runs_in_parallel(ctx):
     """The reference's aligner_align mutates only its own aligner_t (src/alignment.c:170-202), so one aligner per thread
-    runs in parallel (SURVEY 8b "Threading").  Here every calling thread gets its own device context.  A plain-C
-    program written the way a seq-align user would write it (examples/legacy_threads.c: pthreads, one nw_aligner_t per
-    thread, needleman_wunsch_align) must get the single-thread answers in every thread and well over twice the
-    single-thread pairs per second with 8 threads (rounds 1-2: one context behind one mutex, 1x; measured here: 3.3-3.6x
-    at 8 threads, 4.0x at 16 -- 43-51 k pairs/s against 13 k -- what bounds it is the HIP runtime's own serialisation of
-    launch + wait across threads, ~20 us per pair and process, not anything in this library: the call is down to ONE
-    launch and ONE wait per pair, the GPU reading and writing a pinned block in place).  (Python threads cannot show
-    it: the interpreter's own per-call work is serial.)"""
+    runs in parallel (SURVEY 8b "Threading").  Here every calling thread gets its own device context, and callers that
+    are in the library at the same time share launches (sa_device.hip: combine_and_run -- a launch takes ~50 us whatever
+    it carries).  A plain-C program written the way a seq-align user would write it (examples/legacy_threads.c: pthreads,
+    one nw_aligner_t per thread, needleman_wunsch_align) must get the single-thread answers in every thread and well
+    over three times the single-thread pairs per second with 8 threads (rounds 1-2: one context behind one mutex, 1x;
+    one launch per call and thread: 3.3-4.0x; measured with shared launches: 4.8x at 8 threads, 7.1x at 16 -- 73 k and
+    105 k pairs/s against 15 k).  (Python threads cannot show it: the interpreter's own per-call work is serial.)"""
     import subprocess
     exe = Path(S.__file__).resolve().parents[2] / "bin" / "legacy_threads"
     assert exe.exists(), "seq-align_amd/bin/legacy_threads is built by `make` (__graft_entry__.build)"
@@ -1085,9 +1084,9 @@ def test_legacy_api_one_aligner_per_thread_runs_in_parallel(ctx):
         res = json.loads(out.stdout.strip().splitlines()[-1])
         assert res["identical"] is True
         best = res if best is None or res["speedup"] > best["speedup"] else best
-        if best["speedup"] > 2.5:
+        if best["speedup"] > 3.5:
             break
-    assert best["speedup"] > 2.5, best
+    assert best["speedup"] > 3.5, best
 
 
 def test_legacy_api_sees_scoring_edits_between_calls(ctx):
