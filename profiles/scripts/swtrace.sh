@@ -15,10 +15,9 @@ for f in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r["Direction"] + " " + r.get("Bytes", r.get("Size", "?"))))
 ev.sort()
-# the last call = everything after the last fill launch
-last_fill = max(i for i, e in enumerate(ev) if "fill" in e[2])
-i0 = last_fill
-while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 300000 and "probe" not in ev[i0 - 1][2]: i0 -= 1
+# calls are separated by > 1 ms of nothing
+i0 = len(ev) - 1
+while i0 > 0 and ev[i0][0] - max(e[1] for e in ev[:i0]) < 1000000: i0 -= 1
 t0 = ev[i0][0]
 for s, e, n in ev[i0:]:
     print("%9.3f %9.3f  %8.1f us  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e3, n))

@@ -164,13 +164,25 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   // plain scorings, rows up to 512 columns: the fill writes match_scores + one byte of directions per cell instead of the
   // three matrices (sa_fill_dirs.hip); the directions go where gap_a_scores would have gone
   bool dirs_used = false;
-  if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
+  // every pair of the chunk the same shape (reads against windows of one length), match / mismatch scoring: the packed
+  // two-pairs-per-wave fill (sa_fill_dirs_x2.hip); every pair's cells then start on a multiple of 256
+  uint64_t stride = 0;
+  {
+    bool same_shape = true;
+    for (uint64_t k = 1; k < n && same_shape; ++k)
+      same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
+    if (same_shape && sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
+      stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+  }
+  if ((rc = reserve_arenas(ctx, (stride ? n * stride : c.cells) * 4))) return rc;
   // (only when the sweep will run in its rows-in-registers form: not with the strip / LDS forms forced by an option)
   const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0;
   cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
+  if (!allow_dirs) stride = 0;
+  cand.uniform_stride = stride;
   seqalign_dev_batch_t d;
   bool reported = false;
-  if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported))) return rc;
+  if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported, stride))) return rc;
   hipError_t e;
   if (!reported) {   // a fill kernel that cannot report them itself: one pass over match_scores
     SaReduceParams r;

@@ -280,7 +280,7 @@ struct Chunk {
 std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell = 12, const uint64_t *extra_bytes = nullptr);
 int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, const seqalign_dev_scoring *sc,
               seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
-              bool *cand_done = nullptr);
+              bool *cand_done = nullptr, uint64_t uniform_stride = 0);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                  int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0);
@@ -288,6 +288,7 @@ bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t 
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
 // cells start on a multiple of 256)
 bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
+bool sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)
 int fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const seqalign_dev_scoring *sc,

@@ -352,7 +352,10 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     p.cand_min = cand->cand_min; p.cand_count = cand->cand_count; p.cand_box = cand->cand_box; p.cand_rows = cand->cand_rows;
     p.cand_rows_off = cand->hit_off;
     if (sa_dirs_fill_applicable(p, batch->max_len_a, cand->dirs)) {
-      e = sa_launch_fill_dirs(p, batch->max_len_a, cand->dirs, st);
+      p.uniform_stride = ctx->opt.pack16 ? cand->uniform_stride : 0;
+      e = sa_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs)
+              ? sa_launch_fill_dirs_x2(p, batch->max_len_a, cand->dirs, st)
+              : sa_launch_fill_dirs(p, batch->max_len_a, cand->dirs, st);
       if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
       *cand->dirs_used = true;
       if (cand_done) *cand_done = true;
@@ -416,6 +419,18 @@ bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_s
   int32_t s = 0; uint64_t t = 0;
   p.best_score = &s; p.best_index = &t;
   return sa_nw_dirs_fill_applicable(p, max_len_a, reinterpret_cast<const uint8_t *>((uintptr_t)256));
+}
+
+// the same question for the SW multi-hit path's fill (match_scores + directions)
+bool sa_host::sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
+  if (!ctx->opt.pack16 || !ctx->opt.sweep_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO) return false;
+  seqalign_dev_batch_t b;
+  memset(&b, 0, sizeof(b));
+  SaFillParams p = make_params(ctx, scoring, &b);
+  uint32_t u = 0; int32_t mn = 0; uint64_t o = 0;
+  p.cand_min = &mn; p.cand_count = &u; p.cand_box = &u; p.cand_rows = &u; p.cand_rows_off = &o;
+  p.uniform_stride = 256;
+  return sa_dirs_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)1024));
 }
 
 bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {

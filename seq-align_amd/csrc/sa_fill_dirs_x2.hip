@@ -40,6 +40,9 @@ __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elemen
 __device__ __forceinline__ uint32_t pk_lt(pk16 x, pk16 y) { return pk_bits(pk_subs(x, y) >> 15); }
 // mask ? a : b, bit by bit (v_bfi_b32)
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// 0xFFFF in every half where x > 0, for x >= 0
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b);
+__device__ __forceinline__ uint32_t pos_mask(pk16 x) { return pk_bits(pk_splat(0) - __builtin_bit_cast(pk16, pk_min_u16(pk_bits(x), 0x00010001u))); }
 __device__ __forceinline__ pk16 pk_shr1(pk16 src, pk16 lane0) {
   return pk_from((uint32_t)wave_shr1((int)pk_bits(src), (int)pk_bits(lane0)));
 }
@@ -252,6 +255,221 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   }
 }
 
+// ---- Smith-Waterman, match_scores + directions (the packed form of fill_dirs_kernel)
+// Same outputs as fill_dirs_kernel for both pairs of the wave: match_scores (int32 in HBM; the rings hold them as the
+// int16 they are computed in, the flush widens them), the direction byte, the candidates' count / box / columns per row.
+// Floor 0: max(x, 0) is a real instruction here, and a state whose score is 0 gets the code 3 ("the walk ends").
+template <int CPL, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint32_t pair0 = 2 * unit;
+  if (pair0 >= p.n_pairs) return;
+  const bool two = pair0 + 1 < p.n_pairs;
+  const uint32_t pair1 = two ? pair0 + 1 : pair0;
+
+  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
+  const uint64_t mo0 = p.mat_off[pair0], mo1 = p.mat_off[pair1];   // multiples of 256 cells
+  int32_t *const gm0 = p.M + mo0, *const gm1 = p.M + mo1;
+  uint8_t *const gd0 = dirs_arena + mo0, *const gd1 = dirs_arena + mo1;
+  const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
+  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  const uint32_t ones = kBoth;
+
+  // LDS per wave: two rings of R int16 scores, two rings of R direction bytes
+  uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (6 * R);
+  uint16_t *rm0 = reinterpret_cast<uint16_t *>(ring), *rm1 = rm0 + R;
+  uint8_t *rd0 = ring + 4 * R, *rd1 = rd0 + R;
+  uint32_t wv = 0, rv = 0;
+  auto flush_block = [&]() __attribute__((always_inline)) {
+    typedef int v4i_a __attribute__((ext_vector_type(4)));
+    const uint32_t o = (rv & (R - 1)) + 4 * lane;
+    const uint2 q0 = *reinterpret_cast<const uint2 *>(rm0 + o), q1 = *reinterpret_cast<const uint2 *>(rm1 + o);
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(rd0 + o), d1 = *reinterpret_cast<const uint32_t *>(rd1 + o);
+    const v4i_a m0 = {(int)(q0.x & 0xffffu), (int)(q0.x >> 16), (int)(q0.y & 0xffffu), (int)(q0.y >> 16)};   // scores are >= 0
+    __builtin_nontemporal_store(m0, reinterpret_cast<v4i_a *>(gm0 + rv + 4 * lane));
+    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
+    if (two) {
+      const v4i_a m1 = {(int)(q1.x & 0xffffu), (int)(q1.x >> 16), (int)(q1.y & 0xffffu), (int)(q1.y >> 16)};
+      __builtin_nontemporal_store(m1, reinterpret_cast<v4i_a *>(gm1 + rv + 4 * lane));
+      __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    }
+    rv += 256;
+  };
+  auto append_row = [&](const pk16 (&mv)[CPL], const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
+    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      const uint32_t mb = pk_bits(mv[c]);
+      rm0[o] = (uint16_t)mb; rm1[o] = (uint16_t)(mb >> 16);         // ds_write_b16 / ds_write_b16_d16_hi
+      rd0[o] = (uint8_t)dv[c]; rd1[o] = (uint8_t)(dv[c] >> 16);     // ds_write_b8 / ds_write_b8_d16_hi
+    }
+    wv += W;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (wv - rv >= 256u) flush_block();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+
+  uint32_t fa[CPL], valid[CPL];           // my columns' characters of seq_a (one pair per half); all ones where the column exists
+  pk16 X[CPL], Yp[CPL], Ap[CPL];          // previous row: max3(M,A,B), max(M,B), A
+  pk16 c1[CPL], c2[CPL], c3[CPL];         // gap_b scan constants (sa_rowsweep.hpp), floor 0
+  uint32_t T[CPL], TY4[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const uint32_t g = lane * CPL + c;
+    const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
+    const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
+    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    valid[c] = g <= la ? 0xffffffffu : 0u;
+    X[c] = Yp[c] = Ap[c] = zero;                            // row 0: borders are 0 (alignment.c:51-57)
+    T[c] = 1u * kBoth; TY4[c] = 8u * kBoth;                 // (A == max3 and B >= M hold on a row of zeros; never followed)
+    const int g_ext = (int)g * p.ext;
+    c1[c] = pk_splat(p.open1 - g_ext); c2[c] = pk_splat(-g_ext); c3[c] = pk_splat(g_ext);
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+
+  // candidates per pair (as fill_dirs_kernel): any cell >= min_score, the box, the columns per row (lane granularity)
+  uint32_t cand_n[2] = {0, 0}, box_rmin[2] = {0xffffffffu, 0xffffffffu}, box_rmax[2] = {0, 0},
+           box_cmin[2] = {0xffffffffu, 0xffffffffu}, box_cmax[2] = {0, 0};
+  const pk16 thr = pk16{(short)min(max(p.cand_min[pair0], 1), 32767), (short)min(max(p.cand_min[pair1], 1), 32767)};
+  uint32_t *cand_rows0 = p.cand_rows + 2ull * p.cand_rows_off[pair0], *cand_rows1 = p.cand_rows + 2ull * p.cand_rows_off[pair1];
+  if (lane == 0) {
+    *reinterpret_cast<uint2 *>(cand_rows0) = make_uint2(0xffffffffu, 0u);   // row 0: borders only
+    if (two) *reinterpret_cast<uint2 *>(cand_rows1) = make_uint2(0xffffffffu, 0u);
+  }
+  uint32_t rr_lo[2] = {0xffffffffu, 0xffffffffu}, rr_hi[2] = {0, 0};
+
+  {  // row 0: scores 0, every state ends
+    pk16 mv[CPL];
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { mv[c] = zero; dv[c] = 0x3fu * kBoth; }
+    append_row(mv, dv);
+  }
+
+  uint32_t chunk_code = 0;
+  for (uint32_t j = 1; j <= lb; ++j) {
+    const int q = (j - 1) & (kWave - 1);
+    if (q == 0) {
+      const uint32_t r = j + lane;
+      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    }
+    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);
+    // up-left of my first column: the left lane's last column on the previous row; lane 0 (the border column): far
+    // enough below zero that M = max(.., 0) = 0
+    const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
+    const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
+    pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
+      const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
+      const pk16 m = pk_max(pk_adds(xd, s), zero);                                         // alignment.c:101-116
+      const pk16 ae = pk_adds(Ap[c], ext);
+      const pk16 a = pk_max(pk_max(pk_adds(Yp[c], open1), ae), zero);                      // alignment.c:128-135
+      // where a walk goes from here (alignment.c:311-327); a state whose score is 0: 3
+      const uint32_t opened = pk_lt(ae, a);
+      const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);
+      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
+      dv[c] = bfi(pos_mask(m), td, 3u * kBoth) | bfi(pos_mask(a), dA, 12u * kBoth);
+    }
+    pk16 Pm[CPL], e;
+    {
+      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      pk16 P[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 zl = (c == 0) ? zin : z[c - 1];
+        pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
+        if (c == 0) w = (lane == 0) ? c2[0] : w;     // gap_b of (0, j) is the floor (0)
+        P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
+      }
+      e = pk_wave_scan_max_excl(P[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
+    }
+    {
+      const pk16 al = pk_shr1_zero(av[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
+        const pk16 b = bv[c];
+        const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
+        const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
+        const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
+        dv[c] |= bfi(pos_mask(b), dB, 48u * kBoth);
+        const pk16 yn = pk_max(mv[c], b);
+        const uint32_t m_wins = pk_lt(b, mv[c]);
+        const uint32_t a_loses = pk_lt(av[c], yn);
+        const uint32_t ty4 = bfi(m_wins, 0u, 8u * kBoth);
+        X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
+        T[c] = bfi(a_loses, ty4 >> 2, kBoth);
+        TY4[c] = ty4;
+      }
+    }
+    append_row(mv, dv);
+
+    // candidates of this row, per pair (lane granularity is enough: the sweep needs bounds)
+    pk16 best = pk_from(pk_bits(mv[0]) & valid[0]);
+#pragma unroll
+    for (int c = 1; c < CPL; ++c) best = pk_max(best, pk_from(pk_bits(mv[c]) & valid[c]));
+    const uint32_t below = pk_lt(best, thr);                      // 0xFFFF in the halves without a candidate in my columns
+    const unsigned long long any0 = __ballot((below & 0xffffu) == 0), any1 = __ballot((below >> 16) == 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned long long any = h ? any1 : any0;
+      uint32_t row_lo = 0xffffffffu, row_hi = 0;
+      if (any) {
+        row_lo = (uint32_t)__builtin_ctzll(any) * CPL;
+        row_hi = (uint32_t)(63 - __builtin_clzll(any)) * CPL + (CPL - 1);
+        cand_n[h] = 1;
+        box_cmin[h] = min(box_cmin[h], row_lo);
+        box_cmax[h] = max(box_cmax[h], row_hi);
+        box_rmin[h] = min(box_rmin[h], j);
+        box_rmax[h] = j;
+      }
+      if (lane == q) { rr_lo[h] = row_lo; rr_hi[h] = row_hi; }
+    }
+    if (q == kWave - 1 || j == lb) {
+      if (lane <= q) {
+        *reinterpret_cast<uint2 *>(cand_rows0 + 2ull * (j - q + lane)) = make_uint2(rr_lo[0], min(rr_hi[0], W - 1));
+        if (two) *reinterpret_cast<uint2 *>(cand_rows1 + 2ull * (j - q + lane)) = make_uint2(rr_lo[1], min(rr_hi[1], W - 1));
+      }
+    }
+  }
+  while (rv < wv) flush_block();
+
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !two) break;
+      const uint32_t pr = h ? pair1 : pair0;
+      p.cand_count[pr] = cand_n[h];
+      uint32_t *box = p.cand_box + 4ull * pr;
+      box[0] = box_rmin[h]; box[1] = box_rmax[h]; box[2] = box_cmin[h]; box[3] = min(box_cmax[h], W - 1);
+      p.status[pr] = ~0ull;   // plain scorings have a score for every pair of characters
+    }
+  }
+}
+
+template <int CPL, int R>
+static hipError_t launch_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  const int wpb = 4;
+  const uint32_t units = (p.n_pairs + 1) / 2;
+  const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
+  hipLaunchKernelGGL((fill_dirs_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 6 * R, stream, p, dirs);
+  return hipGetLastError();
+}
+
 template <int CPL, int R>
 static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
   const int wpb = 4;
@@ -288,4 +506,23 @@ hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, 
   if (need <= 5) return sa::launch_nw_dirs_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_nw_dirs_x2_cpl<6, 1024>(p, dirs, stream);
   return sa::launch_nw_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+}
+
+// ---- Smith-Waterman multi-hit: match_scores + directions, two pairs per wave
+bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
+  if (!sa_dirs_fill_applicable(p, max_len_a, dirs)) return false;
+  if (p.K > 1 || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
+  return sa_x2_scores_fit(p, max_len_a, max_len_b);
+}
+
+hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
+  if (p.n_pairs == 0) return hipSuccess;
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  if (need <= 1) return sa::launch_dirs_x2_cpl<1, 512>(p, dirs, stream);
+  if (need <= 2) return sa::launch_dirs_x2_cpl<2, 512>(p, dirs, stream);
+  if (need <= 3) return sa::launch_dirs_x2_cpl<3, 512>(p, dirs, stream);
+  if (need <= 4) return sa::launch_dirs_x2_cpl<4, 512>(p, dirs, stream);
+  if (need <= 5) return sa::launch_dirs_x2_cpl<5, 1024>(p, dirs, stream);
+  if (need <= 6) return sa::launch_dirs_x2_cpl<6, 1024>(p, dirs, stream);
+  return sa::launch_dirs_x2_cpl<8, 1024>(p, dirs, stream);
 }

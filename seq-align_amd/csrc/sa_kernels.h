@@ -79,6 +79,8 @@ struct SaCandBox {
                                  sa_fill_dirs.hip's domain the fill writes match_scores + directions there INSTEAD of the three
                                  matrices and sets *dirs_used (gap_a / gap_b are then not written at all)                     */
   bool *dirs_used;
+  uint64_t uniform_stride;    /* != 0: the chunk's layout is SaFillParams::uniform_stride's (every pair the same shape, cells
+                                 k * uniform_stride apart): the packed two-pairs-per-wave fill may take it (sa_fill_dirs_x2.hip) */
 };
 
 /* SW multi-hit enumeration: the reverse sweep (sa_sw_sweep.hip) */
@@ -211,6 +213,8 @@ hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uin
 bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
+bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
+hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);
 /* candidates' count and box from match_scores already in HBM (fills that cannot report them themselves): one
  * pass over M */

@@ -87,6 +87,41 @@ while time.time() < t_end:
     pairs += n
 print(f"x2_check: {trials} uniform batches, {pairs} pairs: pack16 = 1 identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
 
+# ---- Smith-Waterman multi-hit: the packed fill of match_scores + directions (fill_dirs_x2_kernel)
+t_end = time.time() + seconds
+sw_trials = sw_pairs = sw_oracle = 0
+while time.time() < t_end:
+    v = rng.below(1 << 20, 12).astype(int)
+    la, lb = shapes[sw_trials % len(shapes)] if sw_trials < 2 * len(shapes) else (int(1 + v[0] % 511), int(1 + v[1] % 300))
+    n = int(1 + v[2] % 300)
+    match, mismatch = int(1 + v[3] % 5), -int(v[4] % 6)
+    go, ge = -int(v[5] % 12), -int(v[6] % 4)
+    spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+    sc = S.make_scoring(spec)
+    batch = uniform_batch(n, la, lb, bool(v[8] & 1))
+    thr = int(1 + v[9] % max(2, match * min(la, lb) // 2))
+    max_hits = int(1 + v[10] % 8)
+    ctx.set_option("pack16", 0)
+    r0 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
+    ctx.set_option("pack16", 1)
+    r1 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
+    if r0 != r1:
+        bad = [p for p in range(n) if r0[p] != r1[p]]
+        print("SW MISMATCH pack16 0 vs 1:", la, lb, n, spec, "thr", thr, "max_hits", max_hits, "pairs", bad[:6], flush=True)
+        print(r0[bad[0]][:3], "\n", r1[bad[0]][:3])
+        sys.exit(1)
+    if sw_trials % 4 == 0:
+        osc = O.Scoring.from_buffer_copy(bytes(sc))
+        for p in range(0, n, max(1, n // 5)):
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
+            if rc != 0 or r1[p] != want:
+                print("SW MISMATCH vs oracle:", la, lb, n, spec, "thr", thr, "max_hits", max_hits, "pair", p, flush=True)
+                sys.exit(1)
+            sw_oracle += 1
+    sw_trials += 1
+    sw_pairs += n
+print(f"x2_check: SW multi-hit: {sw_trials} uniform batches, {sw_pairs} pairs: pack16 = 1 hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
+
 from bench import WORKLOADS  # noqa: E402
 for name, n in (("C2", 10000), ("C5share", 125000)):
     gen, kwargs, _, is_sw, spec, _ = WORKLOADS["C2"]
@@ -101,3 +136,17 @@ for name, n in (("C2", 10000), ("C5share", 125000)):
             ctx.nw_batch(batch, sc, raw=True)
             ts.append((time.perf_counter() - t0) * 1e3)
         print(f"{name} pack16={pk} walk_overlap={wo}: " + " ".join("%.3f" % t for t in ts[2:]) + " ms", flush=True)
+
+for name in ("C3",):
+    gen, kwargs, n, is_sw, spec, _ = WORKLOADS[name]
+    batch = getattr(W, gen)(n, **kwargs)
+    sc = S.make_scoring(spec)
+    thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
+    for pk in (0, 1, 0, 1):
+        ctx.set_option("pack16", pk)
+        ts = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            nh = ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * n + 8, raw=True)[0]
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print(f"{name} sw_batch(max_hits=4) pack16={pk}: {nh} hits " + " ".join("%.3f" % t for t in ts[2:]) + " ms", flush=True)

@@ -478,6 +478,42 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
             assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (9, 2), (5, 40), (63, 64), (64, 33), (127, 70), (150, 200), (191, 40), (192, 25),
+                                   (255, 90), (300, 60), (383, 20), (450, 30), (511, 45)])
+def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
+    """The SW multi-hit path on batches whose pairs all have one shape: the packed fill of match_scores + directions
+    (sa_fill_dirs_x2.hip: fill_dirs_x2_kernel, two pairs per wave in int16 halves; the sweep and the hit walks read what
+    it wrote).  Hit lists (score, positions, strings, order: smith_waterman.c:71-86, 137-277) equal the oracle's and the
+    one-pair kernel's (pack16 = 0) for every columns-per-lane instantiation, odd and even pair counts, planted repeats
+    (several hits per pair, ties), low thresholds, max_hits 1 / 3 / unlimited."""
+    la, lb = shape
+    rng = W.Rng(9500 + 7 * la + lb)
+    dna = np.frombuffer(b"ACGT", np.uint8)
+    for n, spec, thr, max_hits in ((1, {"preset": "default"}, 3, 1 << 20), (2, {"init": [2, -3, 0, -2, 0, 0, 0, 0, 0, 1], "wildcards": []}, 4, 3),
+                                   (37, {"preset": "default"}, 5, 1 << 20), (64, {"init": [3, -1, -7, -1, 0, 0, 0, 0, 0, 0], "wildcards": []}, 9, 1),
+                                   (21, {"init": [1, -1, -2, 0, 0, 0, 0, 0, 0, 0], "wildcards": []}, 2, 6)):
+        a = dna[rng.below(4, n * la).astype(np.int64)].reshape(n, la)
+        b = dna[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+        k = min(la, lb)
+        if k >= 8:          # half of the pairs: a piece of a planted in b, twice where it fits (repeats -> several hits, ties)
+            piece = max(4, k // 3)
+            for r in range(n // 2):
+                src = int(rng.below(la - piece + 1, 1)[0])
+                for dst in {int(rng.below(lb - piece + 1, 1)[0]), int(rng.below(lb - piece + 1, 1)[0])}:
+                    b[r, dst:dst + piece] = a[r, src:src + piece]
+        batch = W._fixed_batch(a, b)
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        opts(pack16=1)
+        packed = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
+        opts(pack16=0)
+        plain = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
+        assert packed == plain, (shape, n, spec)
+        for p in range(n):
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
+            assert rc == 0 and packed[p] == want, (shape, n, spec, p)
+
+
 @pytest.mark.parametrize("dirs", [1, 0], ids=["directions", "three-matrices"])
 def test_nw_batch_in_several_chunks(ctx, dirs):
     """seqalign_nw_batch on a batch that does not fit one chunk (tiny chunk budget): per-chunk scratch (descriptor block,
