@@ -32,7 +32,9 @@ std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget
 // *best_done tells whether the fill kernel delivered it.
 int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c,
                        const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done,
-                       const SaCandBox *cand, bool *cand_done) {
+                       const SaCandBox *cand, bool *cand_done, uint64_t uniform_stride) {
+  // uniform_stride != 0 (the caller checked that every pair of the chunk has the same shape): pair k's cells start at
+  // k * uniform_stride instead of back to back (the packed fills' layout, sa_fill_dirs_x2.hip)
   const uint64_t n = c.count;
   int rc;
   StageTimer tm(ctx->opt.timing);
@@ -49,12 +51,13 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     h_off_a[k] = pos; pos += b->len_a[p];
     h_off_b[k] = pos; pos += b->len_b[p];
     h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
-    h_mat[k] = cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    h_mat[k] = uniform_stride ? k * uniform_stride : cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
   }
+  const uint64_t mat_total = uniform_stride ? n * uniform_stride : c.cells;
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
-  if ((rc = reserve_arenas(ctx, c.cells * 4))) return rc;
+  if ((rc = reserve_arenas(ctx, mat_total * 4))) return rc;
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
   uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
@@ -77,6 +80,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
       return fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>() + k0, ctx->best_index.as<uint64_t>() + k0, bd);
     if (cand) {
       SaCandBox sub = *cand;   // per-pair arrays move with the range; hit_off holds absolute offsets into the scratch arena
+      sub.uniform_stride = uniform_stride;
       sub.cand_count += k0; sub.cand_box += 4 * k0; sub.cand_min += k0; sub.hit_off += k0;
       bool used = false;
       sub.dirs_used = cand->dirs_used ? &used : nullptr;
@@ -356,7 +360,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
   // (sa_fill_dirs_x2.hip); each pair's bytes then start on a 256-byte boundary
   uint64_t stride = 0, mat_total = c.cells;
-  if (use_dirs && same_shape && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
+  if (use_dirs && same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
     for (uint64_t k = 0; k < n; ++k) h_mat[k] = k * stride;
     mat_total = n * stride;

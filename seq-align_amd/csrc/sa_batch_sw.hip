@@ -171,7 +171,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     bool same_shape = true;
     for (uint64_t k = 1; k < n && same_shape; ++k)
       same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
-    if (same_shape && sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
+    if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
   }
   if ((rc = reserve_arenas(ctx, (stride ? n * stride : c.cells) * 4))) return rc;

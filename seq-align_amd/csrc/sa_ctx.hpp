@@ -204,8 +204,9 @@ struct SaOptions {
                                   //                   it applies (plain scorings, rows <= 512 columns), instead of the three matrices
   bool sweep_dirs = true;         // sweep_dirs        0|1: the multi-hit path fills match_scores + direction bytes (sa_fill_dirs.hip)
                                   //                   where it applies, instead of the three matrices
-  bool pack16 = true;             // pack16            0|1: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)
-                                  //                   where they apply (every pair of the chunk the same shape, match / mismatch scoring)
+  int pack16 = 1;                 // pack16            0|1|2: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)
+                                  //                   where they apply (every pair of the chunk the same shape, match / mismatch scoring):
+                                  //                   never | chunks of >= 2 048 pairs | whatever the chunk's size (tests)
   bool walk_overlap = true;       // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
                                   //                   while the next group fills (a VALU-bound fill next to a latency-bound walk)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
@@ -288,6 +289,9 @@ bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t 
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
 // cells start on a multiple of 256)
 bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
+// Two pairs per wave halve the waves of a launch: below ~2 000 pairs of a chunk (a quarter of the chip's wave slots) the
+// one-pair kernels are as fast or faster (tools/x2_crossover.py, C2 / C3 shapes: 1 024 pairs +3 %, 2 048: -3 %, 8 192: -10 %)
+constexpr uint64_t kPackedFillMinPairs = 2048;
 bool sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)

@@ -145,7 +145,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
   if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
   if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
-  if (is("pack16")) { o.pack16 = num != 0; return true; }
+  if (is("pack16")) { if (num < 0 || num > 2) return false; o.pack16 = (int)num; return true; }
   if (is("walk_overlap")) { o.walk_overlap = num != 0; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {

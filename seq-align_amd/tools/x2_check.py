@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The packed two-pairs-per-wave direction fills (sa_fill_dirs_x2.hip, option pack16) against the one-pair kernels
-(pack16 = 0) and the oracle on uniform batches, then their timing on C2 and C5's share.
+(pack16 = 0) and the oracle on uniform batches (pack16 = 2: the packed kernels whatever the batch's size), then their timing on C2 and C5's share.
 
     python seq-align_amd/tools/x2_check.py [seconds]
 """
@@ -61,7 +61,7 @@ while time.time() < t_end:
     ctx.set_option("pack16", 0)
     r0 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
     ctx._nw_buffers = None
-    ctx.set_option("pack16", 1)
+    ctx.set_option("pack16", 2)
     r1 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
     ctx._nw_buffers = None
     if not same(r0, r1):
@@ -85,7 +85,7 @@ while time.time() < t_end:
             oracle_pairs += 1
     trials += 1
     pairs += n
-print(f"x2_check: {trials} uniform batches, {pairs} pairs: pack16 = 1 identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
+print(f"x2_check: {trials} uniform batches, {pairs} pairs: packed (pack16 = 2) identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
 
 # ---- Smith-Waterman multi-hit: the packed fill of match_scores + directions (fill_dirs_x2_kernel)
 t_end = time.time() + seconds
@@ -103,7 +103,7 @@ while time.time() < t_end:
     max_hits = int(1 + v[10] % 8)
     ctx.set_option("pack16", 0)
     r0 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
-    ctx.set_option("pack16", 1)
+    ctx.set_option("pack16", 2)
     r1 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
     if r0 != r1:
         bad = [p for p in range(n) if r0[p] != r1[p]]
@@ -120,7 +120,7 @@ while time.time() < t_end:
             sw_oracle += 1
     sw_trials += 1
     sw_pairs += n
-print(f"x2_check: SW multi-hit: {sw_trials} uniform batches, {sw_pairs} pairs: pack16 = 1 hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
+print(f"x2_check: SW multi-hit: {sw_trials} uniform batches, {sw_pairs} pairs: packed (pack16 = 2) hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
 
 from bench import WORKLOADS  # noqa: E402
 for name, n in (("C2", 10000), ("C5share", 125000)):

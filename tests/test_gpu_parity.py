@@ -450,7 +450,7 @@ def test_direction_byte_paths_every_width(ctx, max_len):
                                    (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45)])
 def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
     """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
-    int16 halves; option pack16): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
+    int16 halves; option pack16 -- 2: also for chunks below the 2 048 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
     kernel's (pack16 = 0) for every columns-per-lane instantiation, odd and even pair counts (the last wave of an odd
     launch holds one pair), unrelated and related sequences, gap_open = 0, sub-batches cut at odd pairs -- and a scoring
     whose scores could leave int16 is NOT packed (same results through the 32-bit kernel)."""
@@ -468,7 +468,7 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
         batch = W._fixed_batch(a, b)
         sc = S.make_scoring(spec)
         osc = oracle_scoring_of(sc)
-        opts(pack16=1, subbatches=n_sub)
+        opts(pack16=2, subbatches=n_sub)
         packed = ctx.nw_batch(batch, sc)
         opts(pack16=0, subbatches=n_sub)
         plain = ctx.nw_batch(batch, sc)
@@ -504,7 +504,7 @@ def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
         batch = W._fixed_batch(a, b)
         sc = S.make_scoring(spec)
         osc = oracle_scoring_of(sc)
-        opts(pack16=1)
+        opts(pack16=2)
         packed = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
         opts(pack16=0)
         plain = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
