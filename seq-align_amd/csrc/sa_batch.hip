@@ -108,7 +108,14 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   uint64_t filled_to = 0;
   for (uint64_t k0 = 0; k0 < n;) {
     uint64_t k1 = k0;
-    while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < slice_bytes)) k1 = std::min(n, k1 + kPack);
+    if (uniform_stride && n_sub > 1) {
+      // the packed fills run two pairs per wave: slices of a quarter of C3's 10 000 pairs are 1 000-2 000 waves on a chip
+      // with 8 192 wave slots, and the slices run one after the other (C3: 1.06 + 1.44 ms where one launch takes 2.15).
+      // One small slice to start on while the rest is packed and shipped, then everything else in one launch.
+      k1 = k0 == 0 ? std::min(n, kPack) : n;
+    } else {
+      while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < slice_bytes)) k1 = std::min(n, k1 + kPack);
+    }
     if (n - k1 < kPack) k1 = n;   // no crumb at the end
     parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
       for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
