@@ -474,13 +474,17 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel;
-        if (sw != sf) {
+        // the last group's walk has no fill to run beside: it stays in the fills' stream, right behind the last fill (on
+        // its own stream it waited for the previous group's download -- streams share hardware queues; rocprofv3
+        // timeline of C5's share: 0.6 ms)
+        hipStream_t sg = g + 1 < n_grp ? sw : sf;
+        if (sg != sf) {
           HIP_TRY(hipEventRecord(ev.ev[n_sub + 2 * n_grp + g], sf));
-          HIP_TRY(hipStreamWaitEvent(sw, ev.ev[n_sub + 2 * n_grp + g], 0));
+          HIP_TRY(hipStreamWaitEvent(sg, ev.ev[n_sub + 2 * n_grp + g], 0));
         }
-        hipError_t e = sa_launch_nw_traceback(t, sw);
+        hipError_t e = sa_launch_nw_traceback(t, sg);
         if (e != hipSuccess) return fail_hip(e, "traceback launch");
-        HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sw));
+        HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sg));
         HIP_TRY(hipStreamWaitEvent(sd, ev.ev[n_sub + g], 0));
         if (c1 > c0) HIP_TRY(hipMemcpyAsync(h_chars + 2 * c0, d_chars + 2 * c0, 2 * (c1 - c0), hipMemcpyDeviceToHost, sd));
         HIP_TRY(hipMemcpyAsync(h_meta + 4 * g0, d_meta + 4 * g0, (g1 - g0) * 16, hipMemcpyDeviceToHost, sd));
