@@ -25,6 +25,24 @@ std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget
   return out;
 }
 
+// The context's auxiliary streams: [0] uploads, [1] downloads, [2] walks beside fills.  What they are for is running
+// BESIDE the kernels of ctx->stream, and that takes separate hardware queues: the runtime multiplexes all streams of one
+// priority over four of them, assigned as streams are first used -- a process that has used another stream or two of its
+// own before the first host-level call (bench.py: a torch stream for the fills) gets the walk stream on the fills' queue,
+// and the pipeline runs fill, walk and download one after the other (rocprofv3 timeline, C5's share: 7.2 instead of 5.8
+// ms).  Streams of another PRIORITY come from another pool of queues, so uploads are a low-priority stream and downloads
+// and walks high-priority ones, whatever the application has created at the default priority.
+static int ensure_copy_streams(seqalign_ctx *ctx, int count) {
+  int least = 0, greatest = 0;
+  bool have_range = false;
+  for (int k = 0; k < count; ++k) {
+    if (ctx->copy_streams[k]) continue;
+    if (!have_range) { HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest)); have_range = true; }
+    HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_streams[k], hipStreamNonBlocking, k == 0 ? least : greatest));
+  }
+  return SEQALIGN_OK;
+}
+
 // Upload one chunk (sequences packed back to back, matrices packed in pair
 // order) and run the fill.  On return the device buffers of ctx hold the
 // results; the stream is NOT synchronised.
@@ -97,7 +115,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   constexpr uint64_t kPack = 2048;
   const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20)) ? 4 : 1;
   const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)8 << 20);
-  if (!ctx->copy_streams[0]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[0], hipStreamNonBlocking));
+  { int rc_s = ensure_copy_streams(ctx, 1); if (rc_s) return rc_s; }
   hipStream_t su = ctx->copy_streams[0];
   StreamSyncOnExit sync_u(su);
   EventList ev;
@@ -381,8 +399,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   } else if ((rc = reserve_arenas(ctx, c.cells * 4))) {
     return rc;
   }
-  for (int k = 0; k < 3; ++k)
-    if (!ctx->copy_streams[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_streams[k], hipStreamNonBlocking));
+  if ((rc = ensure_copy_streams(ctx, 3))) return rc;
   // The walks: with direction bytes the fill is bound by VALU issue and a walk by the latency of its dependent byte loads,
   // so a group's walk runs on its own stream beside the next group's fills; the three-matrix fill saturates HBM and a walk
   // beside it only slows both down (profiles/r03/r03_nw_pipeline.md), so there the walk stays in the fills' stream.
@@ -496,8 +513,13 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   tm.lap("nw pipelined: all sub-batches packed + enqueued");
 
   std::atomic<int> first_error{SEQALIGN_OK};
+  double wait_ms = 0, copy_ms = 0;   // (option timing: the lap below split into waiting for the GPU / copying out)
+  auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
   for (g = 0; g < n_grp; ++g) {   // strings of group g from the pinned block into the caller's buffers
+    const double t_w = now_ms();
     HIP_TRY(hipEventSynchronize(ev.ev[n_sub + n_grp + g]));
+    const double t_c = now_ms();
+    wait_ms += t_c - t_w;
     const uint64_t k0 = cut[gcut[g]], k1 = cut[gcut[g + 1]];
     if (k1 == k0) continue;
     const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
@@ -514,8 +536,10 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         out_score[p] = (int32_t)h_meta[4 * k + 2];
       }
     });
+    copy_ms += now_ms() - t_c;
     if ((rc = first_error.load())) return rc;
   }
+  if (ctx->opt.timing) fprintf(stderr, "[seqalign timing] nw pipelined: waiting for the groups %.3f ms, copying their strings out %.3f ms\n", wait_ms, copy_ms);
   tm.lap("nw pipelined: all groups unpacked");
   return SEQALIGN_OK;
 }

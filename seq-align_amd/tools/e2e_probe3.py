@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""bench.py's steps before its `e2e` measurement, one variant per run: which of them costs seqalign_nw_batch its speed.
+    python e2e_probe3.py <variant>     full | no_choice | no_arenas | packed | only_wavefront | only_rowscan | only_strips | only_wgstream | only_stream"""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "seq-align_amd" / "python")); sys.path.insert(0, str(ROOT))
+import numpy as np, torch
+import seqalign_amd as S
+from seqalign_amd import workloads as W
+variant = sys.argv[1]
+torch.cuda.set_device(0)
+batch = W.dna_nw_indexed(0, 125000, seed=5, length=150)
+ctx = S.Context(0)
+sc = S.make_scoring({"preset": "default"})
+h = ctx.upload_scoring(sc, 0)
+db = None
+if variant != "no_arenas":
+    db = S.DeviceBatch(batch, 0, placement="packed" if variant == "packed" else "spread", ctx=ctx)
+    names = {"only_wavefront": [S.KERNEL_WAVEFRONT], "only_rowscan": [S.KERNEL_ROWSCAN], "only_stream": [S.KERNEL_STREAM],
+             "only_strips": [S.KERNEL_STRIPS], "only_wgstream": [S.KERNEL_WGSTREAM], "no_choice": [], "packed": []}
+    for k in names.get(variant, [S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM, S.KERNEL_STRIPS, S.KERNEL_WGSTREAM]):
+        db.time_fill_ms(ctx, h, k, 6)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 7:
+    ctx.nw_batch(batch, sc, raw=True)
+ts = []
+for it in range(8):
+    t1 = time.perf_counter(); ctx.nw_batch(batch, sc, raw=True); ts.append((time.perf_counter() - t1) * 1e3)
+print(variant, " ".join("%.2f" % t for t in ts), flush=True)
