@@ -75,7 +75,8 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
-  if ((rc = reserve_arenas(ctx, mat_total * 4))) return rc;
+  const bool no_matrices = cand && cand->best_only;   // direction bytes + the best cell only (the caller's cand->dirs)
+  if (!no_matrices && (rc = reserve_arenas(ctx, mat_total * 4))) return rc;
   hipStream_t st = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
   uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
@@ -89,11 +90,21 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
     d.mat_off = dv_mat + k0;
     d.match_scores = ctx->M.as<int32_t>(); d.gap_a_scores = ctx->A.as<int32_t>(); d.gap_b_scores = ctx->B.as<int32_t>();
+    if (no_matrices) d.match_scores = d.gap_a_scores = d.gap_b_scores = nullptr;
     d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
     return d;
   };
   auto fill_range = [&](uint64_t k0, uint64_t k1, bool *bd, bool *cd, bool *du) -> int {
     const seqalign_dev_batch_t d = range_desc(k0, k1);
+    if (best_done && no_matrices) {
+      SaCandBox sub = *cand;
+      bool used = false;
+      sub.dirs_used = &used; sub.uniform_stride = uniform_stride;
+      const int r = fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>() + k0,
+                                ctx->best_index.as<uint64_t>() + k0, bd, &sub, nullptr);
+      if (du) *du = used;
+      return r;
+    }
     if (best_done)
       return fill_device(ctx, sc, &d, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>() + k0, ctx->best_index.as<uint64_t>() + k0, bd);
     if (cand) {

@@ -158,7 +158,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     return rc;
   HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_hitoff.p, hit_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-  SaCandBox cand;
+  SaCandBox cand{};
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
   cand.cand_rows = d_keys.as<uint32_t>(); cand.hit_off = d_hitoff.as<uint64_t>();
   // plain scorings, rows up to 512 columns: the fill writes match_scores + one byte of directions per cell instead of the
@@ -400,8 +400,29 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   int rc;
   seqalign_dev_batch_t d;
   bool have_best = false;   // the stream kernel reports the best cell itself
-  if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) return rc;
   const uint64_t n = c.count;
+  // Every pair of the chunk the same shape, match / mismatch scoring, scores inside int16: the fill writes only a byte of
+  // directions per cell and finds the best cell itself, two pairs per wave (sa_fill_dirs_x2.hip: fill_sw_best_x2_kernel);
+  // the walk follows the bytes.  No match_scores, no gap matrices: they are not even allocated.
+  bool dirs_used = false;
+  uint64_t stride = 0;
+  {
+    bool same_shape = true;
+    for (uint64_t k = 1; k < n && same_shape; ++k)
+      same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
+    if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
+      stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+  }
+  if (stride) {
+    if ((rc = ctx->dirs.reserve(n * stride + 4096))) return rc;
+    SaCandBox bc;
+    memset(&bc, 0, sizeof(bc));
+    bc.dirs = ctx->dirs.as<uint8_t>(); bc.dirs_used = &dirs_used; bc.best_only = true; bc.uniform_stride = stride;
+    if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best, &bc, nullptr, stride))) return rc;
+    if (!dirs_used || !have_best) { set_last_error("seqalign_sw_batch: internal error: the best-hit direction fill did not run"); return SEQALIGN_E_HIP; }
+  } else if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) {
+    return rc;
+  }
   if (!have_best) {
     if ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8))) return rc;
     SaReduceParams r;
@@ -434,7 +455,9 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
   t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
   t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
-  if ((rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st))) return rc;
+  if (dirs_used) rc = sw_traceback_dirs(ctx, sc, &d, &t, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), st);
+  else rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st);
+  if (rc) return rc;
   uint32_t *h_meta = reinterpret_cast<uint32_t *>(h_off + n);
   HIP_TRY(hipMemcpyAsync(h_meta, d_meta, n * 32, hipMemcpyDeviceToHost, st));
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs

@@ -292,6 +292,9 @@ bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring
 // Two pairs per wave halve the waves of a launch: below ~2 000 pairs of a chunk (a quarter of the chip's wave slots) the
 // one-pair kernels are as fast or faster (tools/x2_crossover.py, C2 / C3 shapes: 1 024 pairs +3 %, 2 048: -3 %, 8 192: -10 %)
 constexpr uint64_t kPackedFillMinPairs = 2048;
+bool sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
+int sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b, const seqalign_trace_t *t,
+                      const uint8_t *dirs, const int32_t *start_score, void *stream);
 bool sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int check_batch(const seqalign_batch_t *b);
 // chunked fill of a host batch with an uploaded scoring, matrices copied back (also the legacy single-pair path)

@@ -346,6 +346,21 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     else p.best_score = nullptr, p.best_index = nullptr;
   }
   if (cand && cand->dirs_used) *cand->dirs_used = false;
+  if (cand && cand->best_only) {
+    // the SW best-hit path's own fill: direction bytes + the best cell, nothing else (fill_sw_best_x2_kernel); the caller
+    // asked sw_best_x2_applicable first and has no matrices to fall back to
+    p.best_score = best_score; p.best_index = best_index;
+    p.uniform_stride = cand->uniform_stride;
+    if (!cand->dirs || !cand->dirs_used || !sa_sw_best_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs)) {
+      set_last_error("internal error: the best-hit direction fill was asked for a batch outside its domain");
+      return SEQALIGN_E_ARG;
+    }
+    e = sa_launch_fill_sw_best_x2(p, batch->max_len_a, cand->dirs, st);
+    if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
+    *cand->dirs_used = true;
+    if (best_done) *best_done = true;
+    return SEQALIGN_OK;
+  }
   if (cand && cand->dirs && cand->dirs_used && ctx->opt.sweep_dirs && kernel == SEQALIGN_KERNEL_AUTO &&
       ctx->opt.kernel == SEQALIGN_KERNEL_AUTO) {
     // the SW multi-hit path's own fill: match_scores + a byte of directions per cell (sa_fill_dirs.hip)
@@ -419,6 +434,40 @@ bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_s
   int32_t s = 0; uint64_t t = 0;
   p.best_score = &s; p.best_index = &t;
   return sa_nw_dirs_fill_applicable(p, max_len_a, reinterpret_cast<const uint8_t *>((uintptr_t)256));
+}
+
+// ... and for the SW best-hit path's fill (directions + the best cell)
+bool sa_host::sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
+  if (!ctx->opt.pack16 || !ctx->opt.sweep_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || ctx->opt.traceback_host) return false;
+  seqalign_dev_batch_t b;
+  memset(&b, 0, sizeof(b));
+  SaFillParams p = make_params(ctx, scoring, &b);
+  int32_t s = 0; uint64_t t = 0;
+  p.best_score = &s; p.best_index = &t;
+  p.uniform_stride = 256;
+  return sa_sw_best_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)1024));
+}
+
+// SW walks from start_index on direction bytes (the best-hit path): seqalign_sw_traceback_device's launch with the bytes
+// and the start scores in place of the matrices
+int sa_host::sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b,
+                               const seqalign_trace_t *t, const uint8_t *dirs, const int32_t *start_score, void *stream) {
+  if (!ctx || !sc || !b || !t || !dirs || !start_score || !t->start_index || !t->out_pos) return SEQALIGN_E_ARG;
+  if (b->n_pairs == 0) return SEQALIGN_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SaTraceParams p;
+  memset(&p, 0, sizeof(p));
+  p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
+  p.mat_off = b->mat_off; p.dirs = dirs; p.start_score = start_score; p.fill_status = nullptr;
+  p.code = sc->d_code; p.table = sc->d_table; p.str_off = t->str_off; p.out_a = t->out_a; p.out_b = t->out_b;
+  p.out_head = t->out_head; p.out_len = t->out_len; p.out_score = t->out_score; p.trace_status = t->status;
+  p.start_index = t->start_index; p.out_pos = t->out_pos;
+  p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
+  p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
+  p.tune_walker = ctx->opt.trace_kernel;
+  hipError_t e = sa_launch_nw_traceback(p, st);
+  if (e != hipSuccess) return fail_hip(e, "traceback launch");
+  return SEQALIGN_OK;
 }
 
 // the same question for the SW multi-hit path's fill (match_scores + directions)

@@ -461,6 +461,190 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   }
 }
 
+// ---- Smith-Waterman, best hit only (seqalign_sw_batch with max_hits = 1): directions + the best cell, no match_scores
+// The best-hit path needs from the matrices what seqalign_nw_batch needs -- where a walk goes -- plus where it starts:
+// the best match_scores cell in the reference's hit order (score descending, then column, then row ascending:
+// smith_waterman.c:71-86).  So this fill writes the direction byte only (1 B per cell, as fill_nw_dirs_x2_kernel) and
+// tracks, per column, the highest score and the first row that reached it; the pair's best cell and score go to
+// best_index / best_score (index 0, score 0: no cell above 0).
+template <int CPL, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint32_t pair0 = 2 * unit;
+  if (pair0 >= p.n_pairs) return;
+  const bool two = pair0 + 1 < p.n_pairs;
+  const uint32_t pair1 = two ? pair0 + 1 : pair0;
+
+  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
+  uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
+  const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
+  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  const uint32_t ones = kBoth;
+
+  uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
+  uint32_t wv = 0, rv = 0;
+  auto flush_block = [&]() __attribute__((always_inline)) {
+    const uint32_t o = (rv & (R - 1)) + 4 * lane;
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
+    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
+    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
+    if (two) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    rv += 256;
+  };
+  auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
+    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      ring0[o] = (uint8_t)dv[c];
+      ring1[o] = (uint8_t)(dv[c] >> 16);
+    }
+    wv += W;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (wv - rv >= 256u) flush_block();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+
+  uint32_t fa[CPL], valid[CPL];
+  pk16 X[CPL], Yp[CPL], Ap[CPL], c1[CPL], c2[CPL], c3[CPL];
+  uint32_t T[CPL], TY4[CPL];
+  pk16 best_s[CPL];                       // per column: the highest score so far ...
+  uint32_t best_r[CPL];                   // ... and the first row that reached it (one pair per half)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const uint32_t g = lane * CPL + c;
+    const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
+    const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
+    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    valid[c] = g <= la ? 0xffffffffu : 0u;
+    X[c] = Yp[c] = Ap[c] = zero;
+    T[c] = 1u * kBoth; TY4[c] = 8u * kBoth;
+    best_s[c] = zero; best_r[c] = 0;
+    const int g_ext = (int)g * p.ext;
+    c1[c] = pk_splat(p.open1 - g_ext); c2[c] = pk_splat(-g_ext); c3[c] = pk_splat(g_ext);
+  }
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  {
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dv[c] = 0x3fu * kBoth;   // row 0: scores 0, every state ends
+    append_row(dv);
+  }
+
+  uint32_t chunk_code = 0;
+  for (uint32_t j = 1; j <= lb; ++j) {
+    const int q = (j - 1) & (kWave - 1);
+    if (q == 0) {
+      const uint32_t r = j + lane;
+      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    }
+    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);
+    const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
+    const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
+    const uint32_t row_pk = j * kBoth;    // (rows < 32 768: the launcher's score bound implies it)
+    pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
+    uint32_t dv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
+      const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
+      const pk16 m = pk_max(pk_adds(xd, s), zero);
+      const pk16 ae = pk_adds(Ap[c], ext);
+      const pk16 a = pk_max(pk_max(pk_adds(Yp[c], open1), ae), zero);
+      const uint32_t opened = pk_lt(ae, a);
+      const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);
+      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
+      dv[c] = bfi(pos_mask(m), td, 3u * kBoth) | bfi(pos_mask(a), dA, 12u * kBoth);
+      // the best cell of my column: a strictly higher score moves it (the first row keeps a tie)
+      const pk16 mine = pk_from(pk_bits(m) & valid[c]);
+      const uint32_t up = pk_lt(best_s[c], mine);
+      best_s[c] = pk_max(best_s[c], mine);
+      best_r[c] = bfi(up, row_pk, best_r[c]);
+    }
+    pk16 Pm[CPL], e;
+    {
+      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      pk16 P[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 zl = (c == 0) ? zin : z[c - 1];
+        pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
+        if (c == 0) w = (lane == 0) ? c2[0] : w;
+        P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
+      }
+      e = pk_wave_scan_max_excl(P[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
+    }
+    {
+      const pk16 al = pk_shr1_zero(av[CPL - 1]);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
+        const pk16 b = bv[c];
+        const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
+        const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
+        const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
+        dv[c] |= bfi(pos_mask(b), dB, 48u * kBoth);
+        const pk16 yn = pk_max(mv[c], b);
+        const uint32_t m_wins = pk_lt(b, mv[c]);
+        const uint32_t a_loses = pk_lt(av[c], yn);
+        const uint32_t ty4 = bfi(m_wins, 0u, 8u * kBoth);
+        X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
+        T[c] = bfi(a_loses, ty4 >> 2, kBoth);
+        TY4[c] = ty4;
+      }
+    }
+    append_row(dv);
+  }
+  while (rv < wv) flush_block();
+
+  // the pair's best cell: highest score, then lowest column, then lowest row (per column: the first row above)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && !two) break;
+    int b = 0;
+    uint32_t tie = 0;   // (column << 16) | row
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int sc_ = h ? (int)best_s[c].y : (int)best_s[c].x;
+      const uint32_t row = h ? best_r[c] >> 16 : best_r[c] & 0xffffu;
+      if (sc_ > b) { b = sc_; tie = ((uint32_t)(lane * CPL + c) << 16) | row; }
+    }
+    unsigned long long key = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)~tie;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o);
+      key = other > key ? other : key;
+    }
+    if (lane == 0) {
+      const uint32_t t = ~(uint32_t)key, col = t >> 16, row = t & 0xffffu;
+      const int score = (int)(key >> 32);
+      const uint32_t pr = h ? pair1 : pair0;
+      p.best_score[pr] = score;
+      p.best_index[pr] = score > 0 ? (uint64_t)row * W + col : 0;
+      p.status[pr] = ~0ull;
+    }
+  }
+}
+
+template <int CPL, int R>
+static hipError_t launch_sw_best_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  const int wpb = 4;
+  const uint32_t units = (p.n_pairs + 1) / 2;
+  const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
+  hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  return hipGetLastError();
+}
+
 template <int CPL, int R>
 static hipError_t launch_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
   const int wpb = 4;
@@ -525,4 +709,26 @@ hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uin
   if (need <= 5) return sa::launch_dirs_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_dirs_x2_cpl<6, 1024>(p, dirs, stream);
   return sa::launch_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+}
+
+// ---- Smith-Waterman best hit: directions + the best cell, two pairs per wave
+bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
+  // the domain of the direction fills (sa_dirs_fill_applicable) without the candidates' outputs
+  if (!(p.flags & SA_F_IS_SW) || sa::needs_general(p) || (p.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH))) return false;
+  if (p.K > 1 || p.ext > 0 || max_len_a + 1 > 8 * sa::kWave || max_len_b >= 32768) return false;
+  if (!dirs || ((uintptr_t)dirs & 255) || !p.best_score || !p.best_index) return false;
+  if (p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
+  return sa_x2_scores_fit(p, max_len_a, max_len_b);
+}
+
+hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
+  if (p.n_pairs == 0) return hipSuccess;
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  if (need <= 1) return sa::launch_sw_best_x2_cpl<1, 512>(p, dirs, stream);
+  if (need <= 2) return sa::launch_sw_best_x2_cpl<2, 512>(p, dirs, stream);
+  if (need <= 3) return sa::launch_sw_best_x2_cpl<3, 512>(p, dirs, stream);
+  if (need <= 4) return sa::launch_sw_best_x2_cpl<4, 512>(p, dirs, stream);
+  if (need <= 5) return sa::launch_sw_best_x2_cpl<5, 1024>(p, dirs, stream);
+  if (need <= 6) return sa::launch_sw_best_x2_cpl<6, 1024>(p, dirs, stream);
+  return sa::launch_sw_best_x2_cpl<8, 1024>(p, dirs, stream);
 }

@@ -79,6 +79,10 @@ struct SaCandBox {
                                  sa_fill_dirs.hip's domain the fill writes match_scores + directions there INSTEAD of the three
                                  matrices and sets *dirs_used (gap_a / gap_b are then not written at all)                     */
   bool *dirs_used;
+  bool best_only;             /* dirs + dirs_used as above, but for the best-hit path: no candidate outputs (the cand_* members
+                                 are NULL), the fill writes ONLY the direction bytes and reports the best cell through the
+                                 best_score / best_index arguments (sa_fill_dirs_x2.hip: fill_sw_best_x2_kernel); the chunk's
+                                 three matrices are not even allocated */
   uint64_t uniform_stride;    /* != 0: the chunk's layout is SaFillParams::uniform_stride's (every pair the same shape, cells
                                  k * uniform_stride apart): the packed two-pairs-per-wave fill may take it (sa_fill_dirs_x2.hip) */
 };
@@ -171,6 +175,8 @@ struct SaTraceParams {
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
   const int32_t *nw_score;     /* NW behind the directions-only fill (dirs != NULL): per pair the end cell's score ...            */
   const uint64_t *nw_state;    /* ... and the matrix the walk starts in (0 MATCH, 1 GAP_A, 2 GAP_B)                                */
+  const int32_t *start_score;  /* SW walks on direction bytes from start_index (the best-hit path behind fill_sw_best_x2_kernel, which
+                                  writes no match_scores): the start cell's score                                                  */
 };
 
 /* substitution lookup flavour */
@@ -213,6 +219,8 @@ hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uin
 bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
+bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
+hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
 hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream);

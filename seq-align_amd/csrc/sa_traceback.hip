@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) traceback_dirs_kernel(const SaTraceParams 
   char *ob = p.out_b + p.str_off[w];
   uint32_t x, y, head = la + lb;
   sw_walk_start(p, w, pair, W, x, y);
-  const int score = p.M[mo + (uint64_t)y * W + x];
+  const int score = p.start_score ? p.start_score[w] : p.M[mo + (uint64_t)y * W + x];
   const uint32_t end_x = x, end_y = y;
   uint32_t st = MAT_MATCH;
   for (;;) {
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(64) traceback_dirs_tile_kernel(const SaTracePa
     x = la; y = lb; st = (uint32_t)p.nw_state[w]; score = p.nw_score[w];
   } else {
     sw_walk_start(p, w, pair, W, x, y);
-    st = MAT_MATCH; score = p.M[mo + (uint64_t)y * W + x];
+    st = MAT_MATCH; score = p.start_score ? p.start_score[w] : p.M[mo + (uint64_t)y * W + x];
   }
   const uint32_t end_x = x, end_y = y;
   uint32_t ox = 0, oy = 0;
@@ -412,7 +412,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip
-      if (!p.hit_keys || !p.out_pos) return hipErrorInvalidValue;
+      if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<false>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     }
