@@ -221,6 +221,7 @@ struct seqalign_dev_scoring {
   sa_flat_scoring_t flat;   // host copy (table pointer owned)
   uint16_t *d_code = nullptr;
   int32_t *d_table = nullptr;
+  int32_t table_abs_max = 0;   // largest |entry| of the table (sentinels excluded): the packed fills' int16 bound
 };
 
 struct seqalign_ctx {

@@ -262,6 +262,11 @@ extern "C" int seqalign_scoring_upload(seqalign_ctx_t *ctx, const scoring_t *sco
     seqalign_scoring_release(ctx, h);
     return fail_hip(e, "scoring upload");
   }
+  for (size_t k = 0; k < (size_t)h->flat.n_classes * h->flat.n_classes; ++k) {
+    const int32_t v = h->flat.table[k];
+    if (v == SA_S_BLOCKED || v == SA_S_UNKNOWN) continue;   // (such scorings never reach the packed fills)
+    h->table_abs_max = std::max(h->table_abs_max, v < 0 ? (v == INT32_MIN ? INT32_MAX : -v) : v);
+  }
   *out = h;
   return SEQALIGN_OK;
 }
@@ -290,6 +295,7 @@ static SaFillParams make_params(const seqalign_ctx *ctx, const seqalign_dev_scor
   p.best_score = nullptr; p.best_index = nullptr;
   p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr; p.cand_rows_off = nullptr;
   p.uniform_stride = 0;
+  p.table_abs_max = s->table_abs_max;
   return p;
 }
 

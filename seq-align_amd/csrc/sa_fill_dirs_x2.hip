@@ -85,11 +85,71 @@ __device__ __forceinline__ pk16 pk_wave_scan_max_excl(pk16 v) {
 
 constexpr uint32_t kBoth = 0x00010001u;   // a 1 in each half
 
+// The substitution score of my columns against this row's character, both pairs at once.
+//   SA_SUBST_SIMPLE (K <= 1): equal characters -> gen_eq, else gen_ne = gen_eq + min(fa ^ fb, 1) * (gen_ne - gen_eq).
+//   SA_SUBST_LDS: the K x K table (int16 in LDS, behind the rings), row = class of the seq_a character; the two pairs'
+//   scores are two 16-bit LDS reads into the two halves of one register.  Class 0 x class 0 holds the "equal" score of
+//   characters outside the table: different characters get gen_ne (subst_score in sa_fill_common.hpp).
+template <int SUBST, int CPL>
+struct SubstX2 {
+  uint32_t fa[CPL];                                   // folded characters of seq_a, one pair per half
+  uint32_t ar0[SUBST == SA_SUBST_LDS ? CPL : 1];      // LDS byte address of the table row of pair 0's / pair 1's character
+  uint32_t ar1[SUBST == SA_SUBST_LDS ? CPL : 1];
+  uint32_t a0[SUBST == SA_SUBST_LDS ? CPL : 1];       // 0xFFFF per half where the seq_a character is of class 0
+  pk16 s_eq, s_delta, s_ne;
+  uint32_t fb = 0, kb0 = 0, kb1 = 0, b0 = 0;          // this row (wave-uniform): characters, table columns * 2, class-0 mask
+  __device__ __forceinline__ void init(const SaFillParams &p) {
+    s_eq = pk_splat(p.gen_eq); s_ne = pk_splat(p.gen_ne); s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  }
+  __device__ __forceinline__ void set_column(int c, uint32_t code0, uint32_t code1, uint32_t K, uint32_t tbl_lds) {
+    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    if constexpr (SUBST == SA_SUBST_LDS) {
+      ar0[c] = tbl_lds + (code0 >> 8) * K * 2u; ar1[c] = tbl_lds + (code1 >> 8) * K * 2u;
+      a0[c] = ((code0 >> 8) ? 0u : 0xffffu) | ((code1 >> 8) ? 0u : 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void set_row(uint32_t codes) {   // codes = pair 0's code | pair 1's code << 16 (uniform)
+    fb = codes & 0x00ff00ffu;
+    if constexpr (SUBST == SA_SUBST_LDS) {
+      kb0 = ((codes >> 8) & 0xffu) * 2u; kb1 = (codes >> 24) * 2u;
+      b0 = (kb0 ? 0u : 0xffffu) | (kb1 ? 0u : 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ pk16 score(int c) const {
+    const uint32_t ne01 = pk_min_u16(fa[c] ^ fb, 0x00010001u);
+    if constexpr (SUBST == SA_SUBST_SIMPLE) {
+      return pk_mad(ne01, s_delta, s_eq);
+    } else {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      const char *l = reinterpret_cast<const char *>(lds_base);
+      const short v0 = *reinterpret_cast<const short *>(l + ar0[c] + kb0);
+      const short v1 = *reinterpret_cast<const short *>(l + ar1[c] + kb1);
+      const uint32_t differ = pk_bits(pk_splat(0) - pk_from(ne01));            // 0xFFFF where the characters differ
+      return pk_from(bfi(a0[c] & b0 & differ, pk_bits(s_ne), pk_bits(pk16{v0, v1})));
+    }
+  }
+};
+
+static inline size_t table_lds_bytes(const SaFillParams &p) { return (((size_t)p.K * p.K * 2u) + 15u) & ~(size_t)15u; }
+
+// the table into LDS as int16 (every thread of the workgroup, before anyone leaves)
+template <int SUBST>
+__device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tbl_lds) {
+  if constexpr (SUBST == SA_SUBST_LDS) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+    short *t = reinterpret_cast<short *>(reinterpret_cast<char *>(lds_base) + tbl_lds);
+    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) t[k] = (short)p.table[k];
+    __syncthreads();
+  }
+}
+
 // ---- Needleman-Wunsch, directions only (the packed form of fill_nw_dirs_kernel)
-template <int CPL, int R>
+template <int CPL, int SUBST, int R>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -103,9 +163,9 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
   uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
-  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  SubstX2<SUBST, CPL> sub;
+  sub.init(p);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
-  const uint32_t ones = kBoth;
 
   uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;   // stream positions = cell indices: written up to wv, flushed up to rv
@@ -131,7 +191,6 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
-  uint32_t fa[CPL];                       // my columns' folded characters of seq_a, one pair per half
   pk16 X[CPL], Yp[CPL], Ap[CPL];          // previous row: max3(M,A,B), max(M,B), A
   pk16 c1[CPL], c3[CPL];                  // gap_b scan constants (sa_rowsweep.hpp): open1 - g*ext, g*ext
   uint32_t T[CPL], TY4[CPL];              // previous row: which of M/A/B is the max3 (bits 0-1), B >= M ? 2 : 0 (at bits 2-3)
@@ -141,7 +200,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const uint32_t g = lane * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
-    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    sub.set_column(c, code0, code1, p.K, tbl_lds);
     // row 0 (alignment.c:46-69): the same in both halves
     const int m0 = g ? -32768 : 0, a0 = m0, b0 = g ? bd.edge_gap(g) : 0;
     const int x0 = max3i(m0, a0, b0);
@@ -165,10 +224,10 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const int q = (j - 1) & (kWave - 1);
     if (q == 0) {
       const uint32_t r = j + lane;
-      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);   // this row's folded characters of seq_b (uniform)
+    sub.set_row((uint32_t)read_lane((int)chunk_code, q));   // this row's characters of seq_b (uniform)
     const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (lane 0: the border column, overridden below)
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     const pk16 edge_a = pk_splat(bd.edge_gap(j));   // gap_a of the border cell (0, j) (alignment.c:72-80)
@@ -177,7 +236,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       // substitution: equal characters -> gen_eq, else gen_ne = gen_eq + min(fa ^ fb, 1) * (gen_ne - gen_eq)
-      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 s = sub.score(c);
       const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
       const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
       pk16 m = pk_adds(xd, s);                                                             // alignment.c:101-116
@@ -259,10 +318,12 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 // Same outputs as fill_dirs_kernel for both pairs of the wave: match_scores (int32 in HBM; the rings hold them as the
 // int16 they are computed in, the flush widens them), the direction byte, the candidates' count / box / columns per row.
 // Floor 0: max(x, 0) is a real instruction here, and a state whose score is 0 gets the code 3 ("the walk ends").
-template <int CPL, int R>
+template <int CPL, int SUBST, int R>
 __global__ void __launch_bounds__(kWave * 4)
 fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (6 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -278,8 +339,8 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   int32_t *const gm0 = p.M + mo0, *const gm1 = p.M + mo1;
   uint8_t *const gd0 = dirs_arena + mo0, *const gd1 = dirs_arena + mo1;
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
-  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
-  const uint32_t ones = kBoth;
+  SubstX2<SUBST, CPL> sub;
+  sub.init(p);
 
   // LDS per wave: two rings of R int16 scores, two rings of R direction bytes
   uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (6 * R);
@@ -316,7 +377,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
-  uint32_t fa[CPL], valid[CPL];           // my columns' characters of seq_a (one pair per half); all ones where the column exists
+  uint32_t valid[CPL];                    // all ones where my column exists
   pk16 X[CPL], Yp[CPL], Ap[CPL];          // previous row: max3(M,A,B), max(M,B), A
   pk16 c1[CPL], c2[CPL], c3[CPL];         // gap_b scan constants (sa_rowsweep.hpp), floor 0
   uint32_t T[CPL], TY4[CPL];
@@ -325,7 +386,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const uint32_t g = lane * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
-    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    sub.set_column(c, code0, code1, p.K, tbl_lds);
     valid[c] = g <= la ? 0xffffffffu : 0u;
     X[c] = Yp[c] = Ap[c] = zero;                            // row 0: borders are 0 (alignment.c:51-57)
     T[c] = 1u * kBoth; TY4[c] = 8u * kBoth;                 // (A == max3 and B >= M hold on a row of zeros; never followed)
@@ -358,10 +419,10 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const int q = (j - 1) & (kWave - 1);
     if (q == 0) {
       const uint32_t r = j + lane;
-      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);
+    sub.set_row((uint32_t)read_lane((int)chunk_code, q));
     // up-left of my first column: the left lane's last column on the previous row; lane 0 (the border column): far
     // enough below zero that M = max(.., 0) = 0
     const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
@@ -370,7 +431,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     uint32_t dv[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 s = sub.score(c);
       const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
       const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
       const pk16 m = pk_max(pk_adds(xd, s), zero);                                         // alignment.c:101-116
@@ -467,10 +528,12 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 // smith_waterman.c:71-86).  So this fill writes the direction byte only (1 B per cell, as fill_nw_dirs_x2_kernel) and
 // tracks, per column, the highest score and the first row that reached it; the pair's best cell and score go to
 // best_index / best_score (index 0, score 0: no cell above 0).
-template <int CPL, int R>
+template <int CPL, int SUBST, int R>
 __global__ void __launch_bounds__(kWave * 4)
 fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -484,8 +547,8 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
   uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
-  const pk16 s_eq = pk_splat(p.gen_eq), s_delta = pk_splat(p.gen_ne - p.gen_eq);
-  const uint32_t ones = kBoth;
+  SubstX2<SUBST, CPL> sub;
+  sub.init(p);
 
   uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;
@@ -511,7 +574,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
-  uint32_t fa[CPL], valid[CPL];
+  uint32_t valid[CPL];
   pk16 X[CPL], Yp[CPL], Ap[CPL], c1[CPL], c2[CPL], c3[CPL];
   uint32_t T[CPL], TY4[CPL];
   pk16 best_s[CPL];                       // per column: the highest score so far ...
@@ -521,7 +584,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const uint32_t g = lane * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
-    fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
+    sub.set_column(c, code0, code1, p.K, tbl_lds);
     valid[c] = g <= la ? 0xffffffffu : 0u;
     X[c] = Yp[c] = Ap[c] = zero;
     T[c] = 1u * kBoth; TY4[c] = 8u * kBoth;
@@ -542,10 +605,10 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const int q = (j - 1) & (kWave - 1);
     if (q == 0) {
       const uint32_t r = j + lane;
-      if (r <= lb) chunk_code = (p.code[sb0[r - 1]] & 0xffu) | (uint32_t)(p.code[sb1[r - 1]] & 0xffu) << 16;
+      if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    const uint32_t fb = (uint32_t)read_lane((int)chunk_code, q);
+    sub.set_row((uint32_t)read_lane((int)chunk_code, q));
     const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     const uint32_t row_pk = j * kBoth;    // (rows < 32 768: the launcher's score bound implies it)
@@ -553,7 +616,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     uint32_t dv[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const pk16 s = pk_mad(pk_min_u16(fa[c] ^ fb, ones), s_delta, s_eq);
+      const pk16 s = sub.score(c);
       const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
       const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
       const pk16 m = pk_max(pk_adds(xd, s), zero);
@@ -641,7 +704,8 @@ static hipError_t launch_sw_best_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -650,7 +714,8 @@ static hipError_t launch_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipSt
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  hipLaunchKernelGGL((fill_dirs_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 6 * R, stream, p, dirs);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_dirs_x2_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 6 * R, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_dirs_x2_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 6 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -659,7 +724,8 @@ static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -671,12 +737,13 @@ bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_le
   int64_t pen = std::max(mag(p.gen_eq), mag(p.gen_ne));
   pen = std::max(pen, std::max(mag(p.open1), mag(p.ext)));
   pen = std::max(pen, mag(p.gap_open) + mag(p.ext));
+  if (p.K > 1) pen = std::max(pen, (int64_t)p.table_abs_max);
   return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(p.ext) <= 30000;
 }
 
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
   if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs)) return false;
-  if (p.K > 1 || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
+  if (p.K > SA_LDS_TABLE_MAX_K || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
   return sa_x2_scores_fit(p, max_len_a, max_len_b);
 }
 
@@ -695,7 +762,7 @@ hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, 
 // ---- Smith-Waterman multi-hit: match_scores + directions, two pairs per wave
 bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
   if (!sa_dirs_fill_applicable(p, max_len_a, dirs)) return false;
-  if (p.K > 1 || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
+  if (p.K > SA_LDS_TABLE_MAX_K || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
   return sa_x2_scores_fit(p, max_len_a, max_len_b);
 }
 
@@ -715,7 +782,7 @@ hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uin
 bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
   // the domain of the direction fills (sa_dirs_fill_applicable) without the candidates' outputs
   if (!(p.flags & SA_F_IS_SW) || sa::needs_general(p) || (p.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH))) return false;
-  if (p.K > 1 || p.ext > 0 || max_len_a + 1 > 8 * sa::kWave || max_len_b >= 32768) return false;
+  if (p.K > SA_LDS_TABLE_MAX_K || p.ext > 0 || max_len_a + 1 > 8 * sa::kWave || max_len_b >= 32768) return false;
   if (!dirs || ((uintptr_t)dirs & 255) || !p.best_score || !p.best_index) return false;
   if (p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
   return sa_x2_scores_fit(p, max_len_a, max_len_b);

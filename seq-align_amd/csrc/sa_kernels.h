@@ -41,6 +41,7 @@ struct SaFillParams {
   /* != 0: every pair of the launch has the same len_a and len_b and pair k's cells start at mat_off[0] + k * uniform_stride
    * (>= its cell count); the packed two-pairs-per-wave fills (sa_fill_dirs_x2.hip) need a multiple of 256 */
   uint64_t uniform_stride;
+  int32_t table_abs_max;        /* host side only: the largest |entry| of the K x K table (0 for K <= 1): the packed fills' int16 bound */
 };
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit

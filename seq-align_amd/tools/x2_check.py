@@ -24,20 +24,23 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = W.Rng(77)
 ctx = S.Context(0)
 DNA = np.frombuffer(b"ACGT", np.uint8)
+DNAN = np.frombuffer(b"ACGTN", np.uint8)
+PROT = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVBZX", np.uint8)
 
 
-def uniform_batch(n, la, lb, related):
-    a = DNA[rng.below(4, n * la).astype(np.int64)].reshape(n, la)
+def uniform_batch(n, la, lb, related, DNA=DNA):
+    K = len(DNA)
+    a = DNA[rng.below(K, n * la).astype(np.int64)].reshape(n, la)
     if related and la == lb:
         b = W._mutate(a, lb, DNA, rng, 0.08, 0.03)
     elif related:
-        b = DNA[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+        b = DNA[rng.below(K, n * lb).astype(np.int64)].reshape(n, lb)
         k = min(la, lb)
         b[:, :k] = a[:, :k]
         flip = rng.unit(n * k).reshape(n, k) < 0.1
-        b[:, :k] = np.where(flip, DNA[rng.below(4, n * k).astype(np.int64)].reshape(n, k), b[:, :k])
+        b[:, :k] = np.where(flip, DNA[rng.below(K, n * k).astype(np.int64)].reshape(n, k), b[:, :k])
     else:
-        b = DNA[rng.below(4, n * lb).astype(np.int64)].reshape(n, lb)
+        b = DNA[rng.below(K, n * lb).astype(np.int64)].reshape(n, lb)
     return W._fixed_batch(a, b)
 
 
@@ -56,8 +59,11 @@ while time.time() < t_end:
     match, mismatch = int(1 + v[3] % 5), -int(v[4] % 6)
     go, ge = -int(v[5] % 12), -int(v[6] % 4)
     spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+    alpha = DNA
+    if v[11] % 5 == 0:      # a substitution table: BLOSUM62 on protein, or a wildcard
+        spec, alpha = ({"preset": "BLOSUM62"}, PROT) if v[11] % 2 else ({**spec, "wildcards": [["N", int(v[10] % 3) - 1]]}, DNAN)
     sc = S.make_scoring(spec)
-    batch = uniform_batch(n, la, lb, bool(v[8] & 1))
+    batch = uniform_batch(n, la, lb, bool(v[8] & 1), alpha)
     ctx.set_option("pack16", 0)
     r0 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
     ctx._nw_buffers = None
@@ -97,8 +103,12 @@ while time.time() < t_end:
     match, mismatch = int(1 + v[3] % 5), -int(v[4] % 6)
     go, ge = -int(v[5] % 12), -int(v[6] % 4)
     spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+    alpha = DNA
+    if v[11] % 5 == 0:
+        spec, alpha = ({"preset": "BLOSUM62"}, PROT) if v[11] % 2 else ({**spec, "wildcards": [["N", int(v[10] % 3) - 1]]}, DNAN)
+        if "preset" in spec: match = 5
     sc = S.make_scoring(spec)
-    batch = uniform_batch(n, la, lb, bool(v[8] & 1))
+    batch = uniform_batch(n, la, lb, bool(v[8] & 1), alpha)
     thr = int(1 + v[9] % max(2, match * min(la, lb) // 2))
     max_hits = int(1 + v[10] % 8)
     ctx.set_option("pack16", 0)

@@ -452,8 +452,8 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
     """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
     int16 halves; option pack16 -- 2: also for chunks below the 2 048 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
     kernel's (pack16 = 0) for every columns-per-lane instantiation, odd and even pair counts (the last wave of an odd
-    launch holds one pair), unrelated and related sequences, gap_open = 0, sub-batches cut at odd pairs -- and a scoring
-    whose scores could leave int16 is NOT packed (same results through the 32-bit kernel)."""
+    launch holds one pair), unrelated and related sequences, gap_open = 0, sub-batches cut at odd pairs, substitution
+    tables -- and a scoring whose scores could leave int16 is NOT packed (same results through the 32-bit kernel)."""
     la, lb = shape
     rng = W.Rng(9100 + 7 * la + lb)
     dna = np.frombuffer(b"ACGT", np.uint8)
@@ -473,6 +473,26 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
         opts(pack16=0, subbatches=n_sub)
         plain = ctx.nw_batch(batch, sc)
         assert packed == plain, (shape, n, spec)
+        for p in range(n):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
+    # scorings with a substitution table (the K x K table as int16 in LDS, two 16-bit reads per packed cell): BLOSUM62 on
+    # protein, and a wildcard (class 0 x class 0 with different characters takes the mismatch score)
+    for n, spec, alpha in ((33, {"preset": "BLOSUM62"}, b"ARNDCQEGHILKMFPSTWYVBZX"), (18, {"preset": "PAM70"}, b"ARNDCQEGHILKMFPSTWYV"),
+                           (25, {"init": [2, -3, -5, -2, 0, 0, 0, 0, 0, 0], "wildcards": [["N", 0]]}, b"ACGTN")):
+        al = np.frombuffer(alpha, np.uint8)
+        a = al[rng.below(len(al), n * la).astype(np.int64)].reshape(n, la)
+        b = al[rng.below(len(al), n * lb).astype(np.int64)].reshape(n, lb)
+        k = min(la, lb)
+        keep = rng.unit(n * k).reshape(n, k) < 0.7
+        b[: n // 2, :k] = np.where(keep[: n // 2], a[: n // 2, :k], b[: n // 2, :k])
+        batch = W._fixed_batch(a, b)
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        opts(pack16=2, subbatches=0)
+        packed = ctx.nw_batch(batch, sc)
+        opts(pack16=0, subbatches=0)
+        assert packed == ctx.nw_batch(batch, sc), (shape, n, spec)
         for p in range(n):
             rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
             assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
@@ -512,6 +532,29 @@ def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
         for p in range(n):
             rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
             assert rc == 0 and packed[p] == want, (shape, n, spec, p)
+    # substitution tables (BLOSUM62 on protein, a wildcard): best hit (fill_sw_best_x2_kernel) and several hits
+    for n, spec, alpha, thr in ((29, {"preset": "BLOSUM62"}, b"ARNDCQEGHILKMFPSTWYVBZX", 14),
+                                (20, {"init": [2, -3, -5, -2, 0, 0, 0, 0, 0, 0], "wildcards": [["N", 0]]}, b"ACGTN", 6)):
+        al = np.frombuffer(alpha, np.uint8)
+        a = al[rng.below(len(al), n * la).astype(np.int64)].reshape(n, la)
+        b = al[rng.below(len(al), n * lb).astype(np.int64)].reshape(n, lb)
+        k = min(la, lb)
+        if k >= 8:
+            piece = max(4, k // 2)
+            for r in range(n // 2):
+                src, dst = int(rng.below(la - piece + 1, 1)[0]), int(rng.below(lb - piece + 1, 1)[0])
+                b[r, dst:dst + piece] = a[r, src:src + piece]
+        batch = W._fixed_batch(a, b)
+        sc = S.make_scoring(spec)
+        osc = oracle_scoring_of(sc)
+        for max_hits in (1, 5):
+            opts(pack16=2)
+            packed = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
+            opts(pack16=0)
+            assert packed == ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16), (shape, n, spec, max_hits)
+            for p in range(n):
+                rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), thr, max_hits)
+                assert rc == 0 and packed[p] == want, (shape, n, spec, max_hits, p)
 
 
 @pytest.mark.parametrize("dirs", [1, 0], ids=["directions", "three-matrices"])
