@@ -1168,6 +1168,70 @@ def test_legacy_api_one_aligner_per_thread_runs_in_parallel(ctx):
     assert best["speedup"] > 3.2, best
 
 
+def test_legacy_api_concurrent_callers_with_different_scorings(ctx):
+    """Concurrent callers of the reference-shaped API share launches (sa_device.hip: combine_and_run), but only callers
+    with the SAME scoring and algorithm: six threads -- three scorings, NW and SW mixed, pairs of different sizes, each
+    thread its own aligner -- must all get what the oracle gets, call after call (ctypes releases the GIL during a call,
+    so the threads really are in the library together)."""
+    import threading
+    lib = S.lib()
+    specs = [{"preset": "default"}, {"init": [2, -3, -5, -2, 0, 0, 0, 0, 0, 0]}, {"init": [3, -1, 0, -1, 0, 0, 0, 0, 0, 1]}]
+    rng = W.Rng(7717)
+
+    def rand(n):
+        return bytes(b"ACGT"[i] for i in rng.below(4, n))
+
+    jobs = []
+    for t in range(6):
+        spec, is_sw = specs[t % 3], t >= 3
+        osc = oracle_scoring_of(S.make_scoring(spec))
+        pairs = []
+        for k in range(40):
+            a = rand(int(8 + rng.below(120, 1)[0]))
+            b = a[3:] if k % 3 == 0 else rand(int(8 + rng.below(120, 1)[0]))
+            if is_sw:
+                rc, hits = O.oracle_sw(osc, a, b, 0, 1)
+                want = (hits[0]["score"], hits[0]["a"], hits[0]["b"]) if hits else None
+            else:
+                rc, s_, ra, rb = O.oracle_nw(osc, a, b)
+                want = (s_, ra.decode(), rb.decode())
+            pairs.append((a, b, want))
+        jobs.append((spec, is_sw, pairs))
+    errors = []
+
+    def work(spec, is_sw, pairs):
+        try:
+            sc = S.make_scoring(spec)
+            res = C.c_void_p(lib.alignment_create(C.c_size_t(512)))
+            al = C.c_void_p(lib.smith_waterman_new() if is_sw else lib.needleman_wunsch_new())
+            for rep in range(5):
+                for a, b, want in pairs:
+                    if is_sw:
+                        lib.smith_waterman_align2(a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), al)
+                        got = None
+                        if lib.smith_waterman_fetch(al, res) == 1:
+                            r = O.Alignment.from_address(res.value)
+                            got = (r.score, C.string_at(r.result_a).decode(), C.string_at(r.result_b).decode())
+                    else:
+                        lib.needleman_wunsch_align2(a, b, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), al, res)
+                        r = O.Alignment.from_address(res.value)
+                        got = (r.score, C.string_at(r.result_a).decode(), C.string_at(r.result_b).decode())
+                    if got != want:
+                        errors.append((spec, is_sw, a, b, got, want))
+                        return
+            (lib.smith_waterman_free if is_sw else lib.needleman_wunsch_free)(al)
+            lib.alignment_free(res)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[:2]
+
+
 def test_legacy_api_sees_scoring_edits_between_calls(ctx):
     """The per-pair API keeps the flattened scoring on the device while the caller's
     scoring_t is unchanged; an edit through the same pointer must be picked up."""
