@@ -135,7 +135,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   int rc;
   DevBuf &d_min = ctx->e[0], &d_keys = ctx->e[1], &d_box = ctx->e[3], &d_rows = ctx->e[4],
          &d_rowoff = ctx->e[5], &d_walk = ctx->e[6], &d_hits = ctx->e[7], &d_meta = ctx->e[8],
-         &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10], &d_dst = ctx->e[11];
+         &d_gath_a = ctx->e[9], &d_dst = ctx->e[11];
   // sources of asynchronous H2D copies: declared BEFORE the guard below, so that they are destroyed after its
   // hipStreamSynchronize on every exit path
   std::vector<uint64_t> hit_off(n + 1, 0), row_off, walk_str, dst_off;
@@ -321,9 +321,12 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   uint32_t *dv_meta = d_hits.as<uint32_t>();
   const uint32_t *h_meta = ctx->h_misc.as<uint32_t>();
   if (nw) {
-    HIP_TRY(hipMemcpyAsync(dv_walk_str, walk_str.data(), nw * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dv_walk_pair, walk_pair.data(), nw * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dv_walk_rank, walk_rank.data(), nw * 4, hipMemcpyHostToDevice, st));
+    // the three lists as the one block they are on the device, from pinned memory: one copy instead of three staged ones
+    if ((rc = ctx->h_desc.reserve(nw * 16 + 16))) return rc;
+    { uint64_t *hw_str = ctx->h_desc.as<uint64_t>();
+      uint32_t *hw_pair = reinterpret_cast<uint32_t *>(hw_str + nw), *hw_rank = hw_pair + nw;
+      memcpy(hw_str, walk_str.data(), nw * 8); memcpy(hw_pair, walk_pair.data(), nw * 4); memcpy(hw_rank, walk_rank.data(), nw * 4);
+      HIP_TRY(hipMemcpyAsync(dv_walk_str, hw_str, nw * 16, hipMemcpyHostToDevice, st)); }
     SaTraceParams t;
     memset(&t, 0, sizeof(t));
     t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b;
@@ -348,20 +351,21 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     dst_off[w] = gathered;
     gathered += h_meta[nw + w];
   }
+  const uint64_t gath_b_at = (gathered + 15) & ~(uint64_t)15;   // a-strings, then b-strings: one buffer, one copy home
   if (nw) {
-    if ((rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
-        (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+    if ((rc = d_gath_a.reserve(gath_b_at + gathered + 16)) || (rc = ctx->h_ta.reserve(gath_b_at + gathered + 16)) ||
+        (rc = ctx->h_desc.reserve(nw * 16 + 16)))
       return rc;
-    HIP_TRY(hipMemcpyAsync(d_dst.p, dst_off.data(), nw * 8, hipMemcpyHostToDevice, st));
+    memcpy(ctx->h_desc.p, dst_off.data(), nw * 8);   // (pinned; the walker lists it held are on the device by now: the stream was waited for)
+    HIP_TRY(hipMemcpyAsync(d_dst.p, ctx->h_desc.p, nw * 8, hipMemcpyHostToDevice, st));
     if ((e = sa_launch_gather_hits(ctx->t_out_a.as<char>(), ctx->t_out_b.as<char>(), dv_walk_str, dv_meta, dv_meta + nw,
-                                   d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_b.as<char>(), (uint32_t)nw, st)) != hipSuccess)
+                                   d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_a.as<char>() + gath_b_at, (uint32_t)nw, st)) != hipSuccess)
       return fail_hip(e, "gather hits");
-    HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gath_b_at + gathered, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
   tm.lap("sw: gather + strings D2H");
-  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  const char *ha = ctx->h_ta.as<char>(), *hb = ha + gath_b_at;
   // where every hit goes in the caller's buffers (a prefix over the lengths), then the copies on the thread pool
   uint64_t n_out = 0;
   bool no_room = false;
@@ -463,24 +467,25 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
   // a hit is much shorter than its slot of len_a + len_b characters: pack the strings on the device, bring back
   // what was written (C3: 2 x 1.7 MB instead of 2 x 11.5 MB over PCIe)
-  DevBuf &d_dst = ctx->e[11], &d_gath_a = ctx->e[9], &d_gath_b = ctx->e[10];
+  DevBuf &d_dst = ctx->e[11], &d_gath_a = ctx->e[9];
   uint64_t gathered = 0;
   for (uint64_t k = 0; k < n; ++k) {
     if (h_meta[3 * n + k]) return (int)h_meta[3 * n + k];
     dst_off[k] = gathered;
     gathered += h_meta[n + k];
   }
-  if ((rc = d_dst.reserve(n * 8 + 16)) || (rc = d_gath_a.reserve(gathered + 16)) || (rc = d_gath_b.reserve(gathered + 16)) ||
-      (rc = ctx->h_ta.reserve(gathered + 16)) || (rc = ctx->h_tb.reserve(gathered + 16)))
+  const uint64_t gath_b_at = (gathered + 15) & ~(uint64_t)15;   // a-strings, then b-strings: one buffer, one copy home
+  if ((rc = d_dst.reserve(n * 8 + 16)) || (rc = d_gath_a.reserve(gath_b_at + gathered + 16)) ||
+      (rc = ctx->h_ta.reserve(gath_b_at + gathered + 16)) || (rc = ctx->h_desc.reserve(n * 8 + 16)))
     return rc;
-  HIP_TRY(hipMemcpyAsync(d_dst.p, dst_off.data(), n * 8, hipMemcpyHostToDevice, st));
+  memcpy(ctx->h_desc.p, dst_off.data(), n * 8);   // (pinned; run_chunk's descriptors left it with the stream's last wait)
+  HIP_TRY(hipMemcpyAsync(d_dst.p, ctx->h_desc.p, n * 8, hipMemcpyHostToDevice, st));
   hipError_t e = sa_launch_gather_hits(ctx->t_out_a.as<char>(), ctx->t_out_b.as<char>(), ctx->t_str_off.as<uint64_t>(), d_meta,
-                                       d_meta + n, d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_b.as<char>(), (uint32_t)n, st);
+                                       d_meta + n, d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_a.as<char>() + gath_b_at, (uint32_t)n, st);
   if (e != hipSuccess) return fail_hip(e, "gather hits");
-  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gathered, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(ctx->h_tb.p, d_gath_b.p, gathered, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gath_b_at + gathered, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  const char *ha = ctx->h_ta.as<char>(), *hb = ctx->h_tb.as<char>();
+  const char *ha = ctx->h_ta.as<char>(), *hb = ha + gath_b_at;
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k;
     const uint32_t len = h_meta[n + k];
