@@ -156,8 +156,13 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if ((rc = d_min.reserve(n * 4)) || (rc = ctx->cand_count.reserve(n * 4)) || (rc = d_box.reserve(n * 16)) ||
       (rc = d_keys.reserve(hit_off[n] * 8 + 16)) || (rc = d_meta.reserve(n * 16 + 16)) || (rc = d_hitoff.reserve((n + 1) * 8)))
     return rc;
-  HIP_TRY(hipMemcpyAsync(d_min.p, min_score + c.first, n * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_hitoff.p, hit_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+  // (from pinned staging: a copy from the caller's pageable array is staged by the runtime and waited for)
+  if ((rc = ctx->h_tb.reserve((n + 1) * 8 + n * 4 + 16))) return rc;
+  { uint64_t *hs_off = ctx->h_tb.as<uint64_t>();
+    int32_t *hs_min = reinterpret_cast<int32_t *>(hs_off + n + 1);
+    memcpy(hs_off, hit_off.data(), (n + 1) * 8); memcpy(hs_min, min_score + c.first, n * 4);
+    HIP_TRY(hipMemcpyAsync(d_hitoff.p, hs_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_min.p, hs_min, n * 4, hipMemcpyHostToDevice, st)); }
   SaCandBox cand{};
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
   cand.cand_rows = d_keys.as<uint32_t>(); cand.hit_off = d_hitoff.as<uint64_t>();
