@@ -363,6 +363,12 @@ size_t seqalign_cigar(const char *result_a, const char *result_b, size_t length,
                       int case_insensitive, char *out, size_t cap);
 
 /* ---- misc ---------------------------------------------------------------------- */
+/* The context's own stream (a hipStream_t as void*): what NULL means wherever a `stream` is passed.  For callers that
+ * keep data in HBM and order their own work (events, copies) with the library's launches -- and a reason not to create
+ * another stream for that: the runtime multiplexes the streams of one priority over four hardware queues, and every
+ * further queue in use makes the host-level calls' own pipelines slower. */
+void *seqalign_ctx_stream(seqalign_ctx_t *ctx);
+
 /* Event pair on a stream for kernel timing (HIP events; bench.py). */
 int seqalign_time_fill_ms(seqalign_ctx_t *ctx,
                           const seqalign_dev_scoring_t *scoring,

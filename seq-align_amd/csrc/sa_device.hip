@@ -504,6 +504,8 @@ extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_de
   return fill_device(ctx, scoring, batch, kernel, stream, nullptr, nullptr, nullptr);
 }
 
+extern "C" void *seqalign_ctx_stream(seqalign_ctx_t *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
                                      const seqalign_dev_batch_t *batch, int kernel, void *stream,
                                      int repeats, float *ms_each) {

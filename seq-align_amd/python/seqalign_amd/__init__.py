@@ -400,7 +400,13 @@ class DeviceBatch:
         self.status = torch.zeros(batch.n_pairs, dtype=torch.int64, device=dev)
         # launches go to a real (non-null) torch stream: a NULL stream handle means
         # "the context's own stream" in the C ABI, and torch events only see torch streams
-        self.stream = torch.cuda.Stream(dev)
+        # (the context's own stream when there is one: a stream of our own would take one more of the runtime's hardware
+        # queues, and the host-level calls measured beside it get slower -- DESIGN.md 3.5c)
+        if ctx is not None and hasattr(lib(), "seqalign_ctx_stream"):
+            lib().seqalign_ctx_stream.restype = C.c_void_p
+            self.stream = torch.cuda.ExternalStream(int(lib().seqalign_ctx_stream(ctx._h)), device=dev)
+        else:
+            self.stream = torch.cuda.Stream(dev)
         self.desc = DevBatchDesc(batch.n_pairs, self.arena.data_ptr(), self.off_a.data_ptr(),
                                  self.len_a.data_ptr(), self.off_b.data_ptr(), self.len_b.data_ptr(),
                                  self.mat_off.data_ptr(), self.M.data_ptr(), self.A.data_ptr(),
@@ -500,7 +506,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
-    "seqalign_arenas_info", "seqalign_ctx_set_option",
+    "seqalign_arenas_info", "seqalign_ctx_set_option", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",

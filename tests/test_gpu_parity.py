@@ -7,6 +7,7 @@ import ctypes as C
 import itertools
 import json
 import os
+import time
 from pathlib import Path
 
 import numpy as np
@@ -875,6 +876,7 @@ def test_arena_allocator(ctx):
     and readable (chunks mapped back to back), and the memory comes back on free."""
     import torch
     lib = S.lib()
+    torch.cuda.empty_cache()      # (torch's cached blocks are not the library's: the checks below make it cache gigabytes)
     free0 = torch.cuda.mem_get_info(0)[0]
     for nbytes, placed in ((1 << 20, False), (300 << 20, True), ((1 << 30) + 12345 * 4096, True)):
         ptrs = (C.c_void_p * 3)()
@@ -901,6 +903,7 @@ def test_arena_allocator(ctx):
         assert lib.seqalign_arenas_free(ctx._h, ptrs) == 0
         assert not any(ptrs)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)      # spacer chunks and arenas all returned
     with S.Context(0) as plain:
         plain.set_option("arena_scan_gib", 0)
