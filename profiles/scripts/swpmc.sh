@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX from the repo root: bash profiles/scripts/swpmc.sh  -> gpurun_out/swpmc_<cfg>.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for w in C3 C4; do
+for w in ${SW_CFGS:-C3 C4}; do
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
              "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
@@ -18,7 +18,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
     con = sqlite3.connect(f)
     for name, cname, val in con.execute("select kernel_name, counter_name, value from counters_collection"):
-        for k in ("sw_sweep_kernel", "sw_sweep_dirs_kernel", "fill_dirs_kernel", "traceback_dirs_kernel", "fill_stream_kernel"):
+        for k in ("sw_sweep_kernel", "sw_sweep_dirs_kernel", "fill_dirs_kernel", "fill_dirs_x2_kernel", "fill_sw_best_x2_kernel", "traceback_dirs_kernel", "traceback_dirs_tile_kernel", "fill_stream_kernel"):
             if k in name:
                 acc[name.split("(")[0][-70:]][cname].append(float(val))
 out = {"workload": sys.argv[2], "command": "seq-align_amd/tools/sw_enum_profile.py %s 4 (3 calls)" % sys.argv[2], "per_launch": {}}
