@@ -447,8 +447,8 @@ def test_direction_byte_paths_every_width(ctx, max_len):
                 assert rc == 0 and got[p] == want, (max_len, spec, "sw", max_hits, p)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (9, 1), (5, 3), (63, 64), (64, 33), (127, 70), (128, 128), (150, 150), (191, 40),
-                                   (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45)])
+@pytest.mark.parametrize("shape", [(0, 0), (0, 7), (7, 0), (1, 1), (1, 9), (9, 1), (5, 3), (63, 64), (64, 33), (127, 70), (128, 128), (150, 150),
+                                   (191, 40), (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45)])
 def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
     """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
     int16 halves; option pack16 -- 2: also for chunks below the 2 048 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
@@ -499,8 +499,8 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
             assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (9, 2), (5, 40), (63, 64), (64, 33), (127, 70), (150, 200), (191, 40), (192, 25),
-                                   (255, 90), (300, 60), (383, 20), (450, 30), (511, 45)])
+@pytest.mark.parametrize("shape", [(0, 0), (0, 6), (6, 0), (1, 1), (9, 2), (5, 40), (63, 64), (64, 33), (127, 70), (150, 200), (191, 40),
+                                   (192, 25), (255, 90), (300, 60), (383, 20), (450, 30), (511, 45)])
 def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
     """The SW multi-hit path on batches whose pairs all have one shape: the packed fill of match_scores + directions
     (sa_fill_dirs_x2.hip: fill_dirs_x2_kernel, two pairs per wave in int16 halves; the sweep and the hit walks read what
