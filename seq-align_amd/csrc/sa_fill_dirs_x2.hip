@@ -211,6 +211,11 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const int g_ext = (int)g * p.ext;
     c1[c] = pk_splat(p.open1 - g_ext); c3[c] = pk_splat(g_ext);
   }
+  // The border column (lane 0, my column 0; alignment.c:72-80) comes out of the recurrence by itself, no selects in the loop:
+  //   gap_a(0, j) = gap_open + j * ext = gap_a(0, j - 1) + ext if the chain starts at "gap_a(0, 0) = gap_open" (max(M, B) of the
+  //   cell above is the floor from row 1 on, and 0 + open1 = the same value on row 1);
+  //   gap_b(0, j) = the floor: the cell "to the left" is the 0 the lane shift gives lane 0, plus a constant that is the floor.
+  if (lane == 0) { Ap[0] = pk_splat(p.gap_open); c1[0] = floor_; }
   __builtin_amdgcn_s_waitcnt(kWaitVm0);
   {
     uint32_t dv[CPL];
@@ -230,7 +235,6 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     sub.set_row((uint32_t)read_lane((int)chunk_code, q));   // this row's characters of seq_b (uniform)
     const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (lane 0: the border column, overridden below)
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
-    const pk16 edge_a = pk_splat(bd.edge_gap(j));   // gap_a of the border cell (0, j) (alignment.c:72-80)
     pk16 z[CPL];
     uint32_t dv[CPL];
 #pragma unroll
@@ -242,7 +246,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       pk16 m = pk_adds(xd, s);                                                             // alignment.c:101-116
       const pk16 ae = pk_adds(Ap[c], ext);
       pk16 a = pk_max(pk_adds(Yp[c], open1), ae);                                          // alignment.c:128-135
-      if (c == 0) { m = lane == 0 ? floor_ : m; a = lane == 0 ? edge_a : a; }              // the border column
+      if (c == 0) m = lane == 0 ? floor_ : m;                                              // the border column's match score
       const uint32_t opened = pk_lt(ae, a);                                                // gap_a + ext is NOT the max
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);                                 // GAP_A (1) first, else B >= M ? 2 : 0
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
@@ -257,7 +261,6 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       for (int c = 0; c < CPL; ++c) {
         const pk16 zl = (c == 0) ? zin : z[c - 1];
         pk16 w = pk_adds(zl, c1[c]);
-        if (c == 0) w = (lane == 0) ? floor_ : w;     // gap_b of (0, j) is the floor
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
       e = pk_wave_scan_max_excl(P[CPL - 1]);
@@ -451,7 +454,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       for (int c = 0; c < CPL; ++c) {
         const pk16 zl = (c == 0) ? zin : z[c - 1];
         pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
-        if (c == 0) w = (lane == 0) ? c2[0] : w;     // gap_b of (0, j) is the floor (0)
+        // (lane 0, column 0: the lane shift gives 0 for the cell to the left, and max(0 + open1, 0) = 0 = gap_b of the border)
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
       e = pk_wave_scan_max_excl(P[CPL - 1]);
@@ -640,7 +643,6 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       for (int c = 0; c < CPL; ++c) {
         const pk16 zl = (c == 0) ? zin : z[c - 1];
         pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
-        if (c == 0) w = (lane == 0) ? c2[0] : w;
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
       e = pk_wave_scan_max_excl(P[CPL - 1]);
