@@ -38,8 +38,10 @@ __device__ __forceinline__ pk16 pk_subs(pk16 a, pk16 b) { return __builtin_eleme
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }        // v_pk_max_i16
 // 0xFFFF in every half where x < y
 __device__ __forceinline__ uint32_t pk_lt(pk16 x, pk16 y) { return pk_bits(pk_subs(x, y) >> 15); }
-// mask ? a : b, bit by bit (v_bfi_b32)
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// mask ? a : b, bit by bit, and a three-way OR: gfx950's v_bitop3_b32 issues in 2 cycles where v_bfi_b32 / v_or3_b32 /
+// v_and_or_b32 take 4 (tools/probes/valu_rate_probe.hip), and the compiler picks the latter when left to itself
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
 // 0xFFFF in every half where x > 0, for x >= 0
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b);
 __device__ __forceinline__ uint32_t pos_mask(pk16 x) { return pk_bits(pk_splat(0) - __builtin_bit_cast(pk16, pk_min_u16(pk_bits(x), 0x00010001u))); }
@@ -236,7 +238,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (lane 0: the border column, overridden below)
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     pk16 z[CPL];
-    uint32_t dv[CPL];
+    uint32_t dv[CPL], dvA[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       // substitution: equal characters -> gen_eq, else gen_ne = gen_eq + min(fa ^ fb, 1) * (gen_ne - gen_eq)
@@ -250,7 +252,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       const uint32_t opened = pk_lt(ae, a);                                                // gap_a + ext is NOT the max
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);                                 // GAP_A (1) first, else B >= M ? 2 : 0
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
-      dv[c] = td | dA;
+      dv[c] = td; dvA[c] = dA;
     }
     pk16 Pm[CPL];                         // de-trended gap_b: prefix max up to and including my column
     pk16 e;                               //                   prefix max of the lanes to my left
@@ -278,7 +280,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
         const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
         const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
         const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
-        dv[c] |= dB;
+        dv[c] = or3(dv[c], dvA[c], dB);
         const pk16 yn = pk_max(mv[c], b);
         const uint32_t m_wins = pk_lt(b, mv[c]);      // B < M
         const uint32_t a_loses = pk_lt(av[c], yn);    // A < max(M, B)
@@ -431,7 +433,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
-    uint32_t dv[CPL];
+    uint32_t dv[CPL], dvA[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const pk16 s = sub.score(c);
@@ -444,7 +446,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       const uint32_t opened = pk_lt(ae, a);
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
-      dv[c] = bfi(pos_mask(m), td, 3u * kBoth) | bfi(pos_mask(a), dA, 12u * kBoth);
+      dv[c] = bfi(pos_mask(m), td, 3u * kBoth); dvA[c] = bfi(pos_mask(a), dA, 12u * kBoth);
     }
     pk16 Pm[CPL], e;
     {
@@ -470,7 +472,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
         const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
         const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
         const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
-        dv[c] |= bfi(pos_mask(b), dB, 48u * kBoth);
+        dv[c] = or3(dv[c], dvA[c], bfi(pos_mask(b), dB, 48u * kBoth));
         const pk16 yn = pk_max(mv[c], b);
         const uint32_t m_wins = pk_lt(b, mv[c]);
         const uint32_t a_loses = pk_lt(av[c], yn);
@@ -616,7 +618,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     const uint32_t row_pk = j * kBoth;    // (rows < 32 768: the launcher's score bound implies it)
     pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
-    uint32_t dv[CPL];
+    uint32_t dv[CPL], dvA[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const pk16 s = sub.score(c);
@@ -628,7 +630,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       const uint32_t opened = pk_lt(ae, a);
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
-      dv[c] = bfi(pos_mask(m), td, 3u * kBoth) | bfi(pos_mask(a), dA, 12u * kBoth);
+      dv[c] = bfi(pos_mask(m), td, 3u * kBoth); dvA[c] = bfi(pos_mask(a), dA, 12u * kBoth);
       // the best cell of my column: a strictly higher score moves it (the first row keeps a tie)
       const pk16 mine = pk_from(pk_bits(m) & valid[c]);
       const uint32_t up = pk_lt(best_s[c], mine);
@@ -658,7 +660,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
         const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
         const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
         const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
-        dv[c] |= bfi(pos_mask(b), dB, 48u * kBoth);
+        dv[c] = or3(dv[c], dvA[c], bfi(pos_mask(b), dB, 48u * kBoth));
         const pk16 yn = pk_max(mv[c], b);
         const uint32_t m_wins = pk_lt(b, mv[c]);
         const uint32_t a_loses = pk_lt(av[c], yn);
