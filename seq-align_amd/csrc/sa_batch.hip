@@ -396,10 +396,35 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
   // (sa_fill_dirs_x2.hip); each pair's bytes then start on a 256-byte boundary
   uint64_t stride = 0, mat_total = c.cells;
+  // ... and a chunk whose pairs are MOSTLY of one shape (reads of one length, some trimmed): the pairs of that shape through
+  // the packed kernel, the others through the one-pair kernel, each launch with the list of its pairs (SaFillParams::
+  // pair_list); every pair's bytes start on a 256-byte boundary then
+  uint32_t modal_a = 0, modal_b = 0;
+  bool mixed = false;
   if (use_dirs && same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
     for (uint64_t k = 0; k < n; ++k) h_mat[k] = k * stride;
     mat_total = n * stride;
+  } else if (use_dirs && !same_shape && ctx->opt.pack16 && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2)) {
+    // the majority shape, if there is one (Boyer-Moore vote, then an exact count: two passes of compares, no hashing --
+    // a hash map over 125 000 pairs cost more host time than the packed kernel saves)
+    uint64_t best_key = 0, votes = 0, best_count = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint64_t key = (uint64_t)h_len_a[k] << 32 | h_len_b[k];
+      if (votes == 0) { best_key = key; votes = 1; } else if (key == best_key) ++votes; else --votes;
+    }
+    for (uint64_t k = 0; k < n; ++k) best_count += ((uint64_t)h_len_a[k] << 32 | h_len_b[k]) == best_key;
+    modal_a = (uint32_t)(best_key >> 32); modal_b = (uint32_t)best_key;
+    if ((best_count >= kPackedFillMinPairs || (ctx->opt.pack16 == 2 && best_count >= 2)) && best_count * 2 >= n &&
+        nw_dirs_x2_applicable(ctx, sc, modal_a, modal_b)) {
+      mixed = true;
+      uint64_t at = 0;
+      for (uint64_t k = 0; k < n; ++k) {
+        h_mat[k] = at;
+        at += (((uint64_t)(h_len_a[k] + 1ull) * (h_len_b[k] + 1ull)) + 255u) & ~(uint64_t)255u;
+      }
+      mat_total = at;
+    }
   }
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16)) || (rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8)) ||
       (rc = ctx->t_out_a.reserve(2 * total + 16)) || (rc = ctx->t_meta.reserve(n * 16)) ||
@@ -435,6 +460,25 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   hipStream_t sw = walk_beside ? ctx->copy_streams[2] : sf;
   // pinned / device buffers are reused by the next call: never leave work in flight
   StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd), sync_w(sw);
+
+  // mixed chunk: per sub-batch, the pairs of the modal shape and the others (indices into the chunk's arrays)
+  std::vector<uint32_t> list_at;   // [2 s] / [2 s + 1]: where sub-batch s's modal / other pairs start in the list; [2 n_sub]: its end
+  uint32_t *dv_list = nullptr;
+  if (mixed) {
+    if ((rc = ctx->h_misc.reserve(n * 4 + 16)) || (rc = ctx->pair_list.reserve(n * 4 + 16))) return rc;
+    uint32_t *h_list = ctx->h_misc.as<uint32_t>();
+    list_at.assign(2 * n_sub + 1, 0);
+    uint32_t at = 0;
+    for (uint32_t s2 = 0; s2 < n_sub; ++s2) {
+      list_at[2 * s2] = at;
+      for (uint64_t k = cut[s2]; k < cut[s2 + 1]; ++k) if (h_len_a[k] == modal_a && h_len_b[k] == modal_b) h_list[at++] = (uint32_t)k;
+      list_at[2 * s2 + 1] = at;
+      for (uint64_t k = cut[s2]; k < cut[s2 + 1]; ++k) if (!(h_len_a[k] == modal_a && h_len_b[k] == modal_b)) h_list[at++] = (uint32_t)k;
+    }
+    list_at[2 * n_sub] = at;
+    dv_list = ctx->pair_list.as<uint32_t>();
+    HIP_TRY(hipMemcpyAsync(dv_list, h_list, n * 4, hipMemcpyHostToDevice, su));
+  }
 
   EventList ev;   // [0, n_sub): upload of s done; [n_sub, n_sub + n_grp): walk of g done; then: download of g done; then: fills of g done
   for (uint32_t k = 0; k < n_sub + 3 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
@@ -475,7 +519,15 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     HIP_TRY(hipStreamWaitEvent(sf, ev.ev[s], 0));
     if (k1 > k0) {
       const seqalign_dev_batch_t d = dev_range(k0, k1);
-      if (use_dirs) {
+      if (use_dirs && mixed) {
+        // one launch over the whole chunk's arrays with this sub-batch's list: the modal shape's pairs two per wave, the others
+        // one per wave, side by side in one grid
+        const seqalign_dev_batch_t dm = dev_range(0, n);
+        const uint32_t m0 = list_at[2 * s], m1 = list_at[2 * s + 1], r1 = list_at[2 * s + 2];
+        if ((rc = nw_dirs_fill_mixed(ctx, sc, &dm, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), ctx->best_index.as<uint64_t>(),
+                                     sf, dv_list + m0, m1 - m0, r1 - m1, modal_a, modal_b)))
+          return rc;
+      } else if (use_dirs) {
         bool used = false;
         if ((rc = nw_dirs_fill(ctx, sc, &d, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>() + k0,
                                ctx->best_index.as<uint64_t>() + k0, sf, &used, stride)))

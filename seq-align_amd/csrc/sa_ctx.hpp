@@ -233,7 +233,7 @@ struct seqalign_ctx {
   size_t chunk_budget = 0;   // bytes of device memory one host-level chunk may use
   size_t chunk_budget_default = 0;
   // device scratch for the host-level entry points
-  sa_host::DevBuf arena, off_a, len_a, off_b, len_b, mat_off, status;
+  sa_host::DevBuf arena, off_a, pair_list, status;   // (off_a holds all five descriptor arrays; pair_list: nw_chunk_pipelined's mixed chunks)
   sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
   SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
   sa_host::HostBuf h_one;            // the legacy single-pair call: descriptor + sequences + three matrices + status of ONE pair,
@@ -285,7 +285,11 @@ int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, cons
               bool *cand_done = nullptr, uint64_t uniform_stride = 0);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
-                 int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0);
+                 int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0,
+                 const uint32_t *pair_list = nullptr, uint32_t list_count = 0);
+int nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
+                       int32_t *end_score, uint64_t *end_state, void *stream, const uint32_t *list, uint32_t n_modal, uint32_t n_rest,
+                       uint32_t modal_a, uint32_t modal_b);
 bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a);
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
 // cells start on a multiple of 256)

@@ -225,7 +225,7 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; ++k) if (ctx->cached[k]) seqalign_scoring_release(ctx, ctx->cached[k]);
   if (ctx->arena_set) sa_arenas_destroy(sa_arenas_take(ctx->M.p));
-  for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->len_a, &ctx->off_b, &ctx->len_b, &ctx->mat_off,
+  for (DevBuf *b : {&ctx->arena, &ctx->off_a, &ctx->pair_list,
                     &ctx->status, &ctx->best_score, &ctx->best_index, &ctx->dirs,
                     &ctx->cand_count, &ctx->cand_off, &ctx->cand_cap, &ctx->cand_index, &ctx->cand_score,
                     &ctx->t_str_off, &ctx->t_out_a, &ctx->t_out_b, &ctx->t_meta})
@@ -295,6 +295,7 @@ static SaFillParams make_params(const seqalign_ctx *ctx, const seqalign_dev_scor
   p.best_score = nullptr; p.best_index = nullptr;
   p.cand_min = nullptr; p.cand_count = nullptr; p.cand_box = nullptr; p.cand_rows = nullptr; p.cand_rows_off = nullptr;
   p.uniform_stride = 0;
+  p.pair_list = nullptr;
   p.table_abs_max = s->table_abs_max;
   return p;
 }
@@ -416,19 +417,42 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
 // (and nothing launched) when the scoring or the batch is outside that kernel's domain, or the option nw_dirs is off.
 int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                           uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, bool *used,
-                          uint64_t uniform_stride) {
+                          uint64_t uniform_stride, const uint32_t *pair_list, uint32_t list_count) {
   *used = false;
   if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || batch->n_pairs == 0 || batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_OK;
   SaFillParams p = make_params(ctx, scoring, batch);
   p.best_score = end_score; p.best_index = end_state;
   if (!sa_nw_dirs_fill_applicable(p, batch->max_len_a, dirs)) return SEQALIGN_OK;
   (void)hipGetLastError();
+  if (pair_list) {   // pairs pair_list[0 .. list_count) of the batch's arrays (batch->max_len_a / _b: of THOSE pairs)
+    if (list_count == 0) { *used = true; return SEQALIGN_OK; }
+    p.pair_list = pair_list; p.n_pairs = list_count;
+  }
   p.uniform_stride = ctx->opt.pack16 ? uniform_stride : 0;
   hipError_t e = sa_nw_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, dirs)
                      ? sa_launch_fill_nw_dirs_x2(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream)
                      : sa_launch_fill_nw_dirs(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream);
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   *used = true;
+  return SEQALIGN_OK;
+}
+// the same for a chunk whose pairs are mostly of one shape (modal_a x modal_b): pairs list[0 .. n_modal) two per wave, pairs
+// list[n_modal .. n_modal + n_rest) one per wave, in one grid (sa_fill_dirs_x2.hip: fill_nw_dirs_mixed_kernel).  `batch`: the whole
+// chunk's arrays (the list holds indices into them); every pair's bytes start on a multiple of 256.
+int sa_host::nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
+                                uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, const uint32_t *list,
+                                uint32_t n_modal, uint32_t n_rest, uint32_t modal_a, uint32_t modal_b) {
+  if (n_modal + n_rest == 0) return SEQALIGN_OK;
+  SaFillParams p = make_params(ctx, scoring, batch);
+  p.best_score = end_score; p.best_index = end_state;
+  p.pair_list = list; p.uniform_stride = 256;
+  if (!list || !sa_nw_dirs_fill_applicable(p, batch->max_len_a, dirs) || !sa_nw_dirs_x2_applicable(p, modal_a, modal_b, dirs)) {
+    set_last_error("seqalign_nw_batch: internal error: the mixed directions-only fill was asked for a chunk outside its domain");
+    return SEQALIGN_E_ARG;
+  }
+  (void)hipGetLastError();
+  hipError_t e = sa_launch_fill_nw_dirs_mixed(p, batch->max_len_a, dirs, n_modal, n_rest, stream ? (hipStream_t)stream : ctx->stream);
+  if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   return SEQALIGN_OK;
 }
 // whether nw_dirs_fill would take this batch (decided before any buffer is reserved)

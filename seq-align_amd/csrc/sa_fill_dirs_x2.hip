@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "sa_rowsweep.hpp"
+#include "sa_fill_nw_dirs_x1.hpp"
 
 namespace sa {
 
@@ -146,20 +147,11 @@ __device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tb
 }
 
 // ---- Needleman-Wunsch, directions only (the packed form of fill_nw_dirs_kernel)
+// one wave's work: the directions-only NW fill of pairs pair0 (low halves) and pair1 (high halves; `two` = there is one)
 template <int CPL, int SUBST, int R>
-__global__ void __launch_bounds__(kWave * 4)
-fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
-  load_table_x2<SUBST>(p, tbl_lds);
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint32_t pair0 = 2 * unit;
-  if (pair0 >= p.n_pairs) return;
-  const bool two = pair0 + 1 < p.n_pairs;          // an odd launch: the last wave's high halves shadow its low ones
-  const uint32_t pair1 = two ? pair0 + 1 : pair0;
-
+__device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair0,
+                                                const uint32_t pair1, const bool two, const int lane, uint8_t *ring0,
+                                                const uint32_t tbl_lds) {
   const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;   // (the same for every pair: the launcher checked)
   const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
@@ -169,7 +161,7 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   sub.init(p);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
-  uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
+  uint8_t *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;   // stream positions = cell indices: written up to wv, flushed up to rv
   auto flush_block = [&]() __attribute__((always_inline)) {
     const uint32_t o = (rv & (R - 1)) + 4 * lane;
@@ -316,6 +308,57 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
       p.best_index[pr] = st;
       p.status[pr] = ~0ull;
     }
+  }
+}
+
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (2 * unit >= p.n_pairs) return;
+  const bool two = 2 * unit + 1 < p.n_pairs;       // an odd launch: the last wave's high halves shadow its low ones
+  const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
+  const uint32_t pair1 = two ? (p.pair_list ? p.pair_list[2 * unit + 1] : 2 * unit + 1) : pair0;
+
+  nw_dirs_x2_wave<CPL, SUBST, R>(p, dirs_arena, pair0, pair1, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+}
+
+// The same for a chunk whose pairs are MOSTLY of one shape, in ONE grid: the first x2_blocks workgroups take the n_modal
+// pairs of the modal shape two per wave (p.pair_list[0 .. n_modal)), the others the n_rest remaining pairs one per wave
+// (p.pair_list[n_modal ..), fill_nw_dirs_kernel's body).  Two launches would run one after the other, and a launch of a
+// few hundred one-pair waves takes as long as its longest pair's rows however few they are (tools/mixed_check.py).
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t x2_blocks, const uint32_t n_modal,
+                          const uint32_t n_rest) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t waves = blockDim.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (blockIdx.x < x2_blocks) {   // (uniform per workgroup)
+    const uint32_t tbl_lds = waves * (2 * R);
+    load_table_x2<SUBST>(p, tbl_lds);
+    const uint32_t unit = blockIdx.x * waves + wave;
+    if (2 * unit >= n_modal) return;
+    const bool two = 2 * unit + 1 < n_modal;
+    const uint32_t pair0 = p.pair_list[2 * unit], pair1 = two ? p.pair_list[2 * unit + 1] : pair0;
+    nw_dirs_x2_wave<CPL, SUBST, R>(p, dirs_arena, pair0, pair1, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+  } else {
+    const int32_t *table = p.table;
+    if constexpr (SUBST == SA_SUBST_LDS) {
+      int32_t *tbl = lds + (waves * R) / 4;
+      for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) tbl[k] = p.table[k];
+      __syncthreads();
+      table = tbl;
+    }
+    const uint32_t slot = (blockIdx.x - x2_blocks) * waves + wave;
+    if (slot >= n_rest) return;
+    nw_dirs_x1_wave<CPL, SUBST, R>(p, dirs_arena, p.pair_list[n_modal + slot], lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
   }
 }
 
@@ -733,6 +776,20 @@ static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   return hipGetLastError();
 }
 
+template <int CPL, int R>
+static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest, hipStream_t stream) {
+  const int wpb = 4;
+  const uint32_t x2_blocks = ((n_modal + 1) / 2 + wpb - 1) / wpb, x1_blocks = (n_rest + wpb - 1) / wpb;
+  const dim3 grid(x2_blocks + x1_blocks), block(kWave * wpb);
+  if (p.K <= 1) {
+    hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs, x2_blocks, n_modal, n_rest);
+  } else {
+    const size_t lds = std::max((size_t)wpb * 2 * R + table_lds_bytes(p), (size_t)wpb * R + (((size_t)p.K * p.K + 3u) & ~(size_t)3u) * sizeof(int32_t));
+    hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_LDS, R>), grid, block, lds, stream, p, dirs, x2_blocks, n_modal, n_rest);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace sa
 
 // every score the recurrence can produce for pairs up to max_len_a x max_len_b, de-trended or not, stays inside int16
@@ -802,4 +859,19 @@ hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, 
   if (need <= 5) return sa::launch_sw_best_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_sw_best_x2_cpl<6, 1024>(p, dirs, stream);
   return sa::launch_sw_best_x2_cpl<8, 1024>(p, dirs, stream);
+}
+
+// ---- NW, a chunk whose pairs are mostly of one shape: both kinds of waves in one grid (p.pair_list: modal pairs, then the rest)
+hipError_t sa_launch_fill_nw_dirs_mixed(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest,
+                                        hipStream_t stream) {
+  if (n_modal + n_rest == 0) return hipSuccess;
+  if (!p.pair_list) return hipErrorInvalidValue;
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);   // (of the widest pair: the packed waves take it too)
+  if (need <= 1) return sa::launch_nw_dirs_mixed_cpl<1, 512>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 2) return sa::launch_nw_dirs_mixed_cpl<2, 512>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 3) return sa::launch_nw_dirs_mixed_cpl<3, 512>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 4) return sa::launch_nw_dirs_mixed_cpl<4, 512>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 5) return sa::launch_nw_dirs_mixed_cpl<5, 1024>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 6) return sa::launch_nw_dirs_mixed_cpl<6, 1024>(p, dirs, n_modal, n_rest, stream);
+  return sa::launch_nw_dirs_mixed_cpl<8, 1024>(p, dirs, n_modal, n_rest, stream);
 }

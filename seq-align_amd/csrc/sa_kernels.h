@@ -41,6 +41,10 @@ struct SaFillParams {
   /* != 0: every pair of the launch has the same len_a and len_b and pair k's cells start at mat_off[0] + k * uniform_stride
    * (>= its cell count); the packed two-pairs-per-wave fills (sa_fill_dirs_x2.hip) need a multiple of 256 */
   uint64_t uniform_stride;
+  const uint32_t *pair_list;    /* optional (the direction fills of seqalign_nw_batch): the launch takes pairs pair_list[0 .. n_pairs)
+                                   of the descriptor arrays instead of pairs 0 .. n_pairs -- a chunk whose pairs are MOSTLY of one
+                                   shape goes through the packed kernel with the list of those, the others through the one-pair
+                                   kernel with the list of the rest */
   int32_t table_abs_max;        /* host side only: the largest |entry| of the K x K table (0 for K <= 1): the packed fills' int16 bound */
 };
 
@@ -220,6 +224,8 @@ hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uin
 bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
+hipError_t sa_launch_fill_nw_dirs_mixed(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest,
+                                        hipStream_t stream);
 bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs);

@@ -499,6 +499,40 @@ def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
             assert rc == 0 and packed[p] == (s_, ra, rb), (shape, n, spec, p)
 
 
+@pytest.mark.parametrize("n_sub", [0, 3])
+def test_nw_batch_mostly_one_shape(ctx, opts, n_sub):
+    """A chunk whose pairs are MOSTLY of one shape (reads of one length, some trimmed): the pairs of that shape go through the
+    packed kernel and the others through the one-pair kernel, each launch with the list of its pairs (sa_batch.hip:
+    nw_chunk_pipelined, SaFillParams::pair_list).  Strings and scores equal the oracle's and the one-pair path's, with the
+    odd ones (other lengths, empty sequences) scattered through the batch, for one and for several sub-batches, at a
+    size where the packed kernel is chosen by itself (2 600 pairs) and forced on a small batch."""
+    rng = W.Rng(4242 + n_sub)
+    sc = S.make_scoring({"preset": "default"})
+    osc = oracle_scoring_of(sc)
+
+    def rand(n):
+        return bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+
+    for n, pk in ((2600, 1), (90, 2)):
+        pairs = []
+        for k in range(n):
+            if k % 7 == 3:      # the odd ones
+                la, lb = int(rng.below(160, 1)[0]), int(rng.below(160, 1)[0])
+            else:
+                la, lb = 100, 100
+            a = rand(la)
+            b = (a[: lb] + rand(max(0, lb - la))) if k % 2 else rand(lb)
+            pairs.append((a, b))
+        batch = W.from_pairs(pairs)
+        opts(pack16=pk, subbatches=n_sub)
+        got = ctx.nw_batch(batch, sc)
+        opts(pack16=0, subbatches=n_sub)
+        assert got == ctx.nw_batch(batch, sc), (n, pk)
+        for p in range(0, n, 1 if n < 200 else 23):
+            rc, s_, ra, rb = O.oracle_nw(osc, pairs[p][0], pairs[p][1])
+            assert rc == 0 and got[p] == (s_, ra, rb), (n, pk, p)
+
+
 @pytest.mark.parametrize("shape", [(0, 0), (0, 6), (6, 0), (1, 1), (9, 2), (5, 40), (63, 64), (64, 33), (127, 70), (150, 200), (191, 40),
                                    (192, 25), (255, 90), (300, 60), (383, 20), (450, 30), (511, 45)])
 def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
