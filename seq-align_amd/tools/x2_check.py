@@ -93,6 +93,51 @@ while time.time() < t_end:
     pairs += n
 print(f"x2_check: {trials} uniform batches, {pairs} pairs: packed (pack16 = 2) identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
 
+# ---- NW, chunks that are MOSTLY of one shape: the modal shape's pairs two per wave, the others one per wave, in one grid
+t_end = time.time() + seconds / 2
+mx_trials = mx_pairs = mx_oracle = 0
+while time.time() < t_end:
+    v = rng.below(1 << 20, 12).astype(int)
+    la, lb = int(1 + v[0] % 400), int(1 + v[1] % 300)
+    n = int(4 + v[2] % 400)
+    match, mismatch = int(1 + v[3] % 5), -int(v[4] % 6)
+    go, ge = -int(v[5] % 12), -int(v[6] % 4)
+    spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+    sc = S.make_scoring(spec)
+    odd_every = int(3 + v[8] % 6)
+    lens = rng.below(511, 2 * n).astype(int)
+    pairs = []
+    for k in range(n):
+        if k % odd_every == 1:
+            xa, xb = int(lens[2 * k]), int(lens[2 * k + 1] % 300)
+        else:
+            xa, xb = la, lb
+        a = bytes(b"ACGT"[i] for i in rng.below(4, xa)) if xa else b""
+        b = (a[: xb] + (bytes(b"ACGT"[i] for i in rng.below(4, xb - xa)) if xb > xa else b"")) if k % 2 else (bytes(b"ACGT"[i] for i in rng.below(4, xb)) if xb else b"")
+        pairs.append((a, b))
+    batch = W.from_pairs(pairs)
+    ctx.set_option("subbatches", int(v[9] % 4))
+    ctx.set_option("pack16", 0)
+    r0 = ctx.nw_batch(batch, sc)
+    ctx.set_option("pack16", 2)
+    r1 = ctx.nw_batch(batch, sc)
+    ctx.set_option("subbatches", 0)
+    if r0 != r1:
+        bad = [p for p in range(n) if r0[p] != r1[p]]
+        print("MIXED MISMATCH pack16 0 vs 2:", la, lb, n, spec, "pairs", bad[:6], flush=True)
+        sys.exit(1)
+    if mx_trials % 4 == 0:
+        osc = O.Scoring.from_buffer_copy(bytes(sc))
+        for p in range(0, n, max(1, n // 6)):
+            _, score, sa, sb = O.oracle_nw(osc, pairs[p][0], pairs[p][1])
+            if r1[p] != (score, sa, sb):
+                print("MIXED MISMATCH vs oracle:", la, lb, n, spec, "pair", p, flush=True)
+                sys.exit(1)
+            mx_oracle += 1
+    mx_trials += 1
+    mx_pairs += n
+print(f"x2_check: NW mostly-one-shape: {mx_trials} batches, {mx_pairs} pairs: mixed grid (pack16 = 2) identical to pack16 = 0; {mx_oracle} pairs against the oracle", flush=True)
+
 # ---- Smith-Waterman multi-hit: the packed fill of match_scores + directions (fill_dirs_x2_kernel)
 t_end = time.time() + seconds
 sw_trials = sw_pairs = sw_oracle = 0
