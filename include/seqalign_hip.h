@@ -344,8 +344,9 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
  *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where every pair of a
- *                                           chunk has the same shape, the scoring is match / mismatch and scores fit int16:
- *                                           for chunks of >= 2 048 pairs | never | whatever the chunk's size
+ *                                           chunk has the same shape (seqalign_nw_batch: more than half of them; the others go one
+ *                                           per wave in the same launch) and scores fit int16: for chunks of >= 2 048 pairs |
+ *                                           never | whatever the chunk's size
  *   walk_overlap    1 | 0                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
  *   cpl, wpb, lds_pad, sweep_trace, timing  tuning experiments / development aids
