@@ -11,7 +11,7 @@ using namespace sa_host;
 std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget, size_t bytes_per_cell, const uint64_t *extra_bytes) {
   std::vector<Chunk> out;
   Chunk c;
-  const uint64_t per_cell = std::max<size_t>(bytes_per_cell, 12);
+  const uint64_t per_cell = std::max<size_t>(bytes_per_cell, 1);
   uint64_t used = 0;   // device bytes of the chunk being built: its cells + what each of its pairs needs besides (extra_bytes[p])
   for (uint64_t p = 0; p < b->n_pairs; ++p) {
     const uint64_t cells = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
@@ -607,17 +607,351 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   return SEQALIGN_OK;
 }
 
+// ---- seqalign_nw_batch on direction bytes: MOVES home, nothing staged --------------------------------------------------
+// What the round-3 pipeline above spent outside its kernels on C2 (10 k pairs, 0.89 ms per call, of which fill 0.20 + walk
+// 0.12): a serial pass over the pairs for the offsets, packing on 10 of 32 threads, a descriptor copy and a sequence copy
+// (two copy-engine latencies + 3 MB at 40 GB/s before the fill could start), 6 MB of gapped strings home through the
+// runtime's blit kernel, unpacking on 10 threads again -- and each of the pool's dispatches paid for waking 31 sleeping
+// threads.  Here, for chunks the direction-byte fill takes (plain scorings, rows <= 512 columns):
+//   * the fill reads the packed sequences and the descriptor arrays IN PLACE from pinned host memory (300 B per pair over
+//     PCIe, hidden behind 0.2 ms of arithmetic), so the kernel is launched the moment the host has packed -- no copy, no
+//     event, no second stream on the way in (option zero_copy & 1);
+//   * the walk sends home two bits per alignment column instead of two characters (sa_traceback.hip: which of the two
+//     strings has a gap there), written in place into pinned host memory (zero_copy & 2): C2 0.83 MB instead of 6.1 MB, no
+//     blit kernel beside the next fill; the host threads expand them against the caller's sequences straight into the
+//     caller's buffers (host/sa_moves.c: vpexpandb, 64 columns per instruction);
+//   * every pass over the pairs is parallel, in blocks of kHostBlk pairs: sizes per block, a serial prefix over the
+//     BLOCKS, then offsets + packing per block; the pool's workers stay awake between the dispatches of a call.
+// Same kernels for the fill, same sub-batch / group structure as above for chunks large enough to pipeline.
+namespace {
+constexpr uint64_t kHostBlk = 512;
+struct BlkSum {
+  uint64_t chars = 0, cells = 0, cells256 = 0;
+  uint32_t max_a = 0, max_b = 0;
+  bool same = true, too_large = false;
+};
+// sizes of pairs [first, first + n) per block of kHostBlk; `same`: every pair of the block has the shape of pair `first`
+void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, std::vector<BlkSum> &blk) {
+  const uint64_t nb = (n + kHostBlk - 1) / kHostBlk;
+  blk.assign(nb, BlkSum());
+  if (!n) return;
+  const uint32_t la0 = b->len_a[first], lb0 = b->len_b[first];
+  parallel_for(nb, [&](uint64_t bi) {
+    BlkSum s;
+    for (uint64_t k = bi * kHostBlk, e = std::min(n, (bi + 1) * kHostBlk); k < e; ++k) {
+      const uint32_t la = b->len_a[first + k], lb = b->len_b[first + k];
+      const uint64_t cells = (uint64_t)(la + 1ull) * (lb + 1ull);
+      s.chars += (uint64_t)la + lb; s.cells += cells; s.cells256 += (cells + 255u) & ~(uint64_t)255u;
+      s.max_a = std::max(s.max_a, la); s.max_b = std::max(s.max_b, lb);
+      s.same = s.same && la == la0 && lb == lb0;
+      s.too_large = s.too_large || cells >= (1ull << 31);
+    }
+    blk[bi] = s;
+  });
+}
+hipError_t wait_event_spinning(hipEvent_t e) {
+  // a group is a fraction of a millisecond away: poll first (a blocking wait adds the wake-up of a sleeping thread)
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 1;; ++spins) {
+    const hipError_t q = hipEventQuery(e);
+    if (q != hipErrorNotReady) return q;
+    __builtin_ia32_pause();
+    if ((spins & 63u) == 0) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipEventSynchronize(e);
+    }
+  }
+}
+}  // namespace
+
+static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c, const seqalign_dev_scoring *sc,
+                          const std::vector<BlkSum> &blk, const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                          int32_t *out_score) {
+  const uint64_t n = c.count, nb = blk.size();
+  int rc;
+  StageTimer tm(ctx->opt.timing);
+  // in place over PCIe, measured (tools/nw_moves_bench.py, profiles/r04/r04_nw_moves_bench.txt): READING the sequences in
+  // place costs more than it saves (C2 0.58 -> 0.65 ms, C5's share 3.8 -> 4.6: the fills' 64-byte reads are bound by the
+  // read requests the GPU keeps in flight on the link, ~11 GB/s, where the copy engine moves 40-50); WRITING the moves in
+  // place pays when the walker stores them coalesced (one wave per walk, whole words of 64 lanes: C2 0.58 -> 0.51 ms) and
+  // loses when every lane stores its own 4 bytes (one lane per walk, the large groups: C5's share 3.6 -> 4.4).  So auto =
+  // sequences through the copy engine, moves in place exactly when the walks run one wave each.
+  const bool auto_zc = ctx->opt.zero_copy == 4u;
+  const bool tile_walks = ctx->opt.trace_kernel ? ctx->opt.trace_kernel == 2 : n < 32768;
+  const bool zc_in = !auto_zc && (ctx->opt.zero_copy & 1u) != 0, zc_out = auto_zc ? tile_walks : (ctx->opt.zero_copy & 2u) != 0;
+  bool same_shape = true;
+  for (const BlkSum &s : blk) same_shape = same_shape && s.same;
+
+  // ---- layout of the direction bytes: pairs back to back / every pair of ONE shape on a multiple of 256 cells (the packed
+  // two-pairs-per-wave fill) / mostly one shape: every pair on a multiple of 256, the modal shape's pairs packed
+  enum { kBackToBack, kUniform, kMixed } layout = kBackToBack;
+  uint64_t stride = 0;
+  uint32_t modal_a = 0, modal_b = 0;
+  const bool may_pack = ctx->opt.pack16 && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2);
+  if (same_shape && may_pack && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
+    layout = kUniform;
+    stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+  } else if (!same_shape && may_pack) {
+    // the majority shape, if there is one (Boyer-Moore vote, then an exact count: two passes of compares, no hashing)
+    uint64_t best_key = 0, votes = 0, best_count = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint64_t key = (uint64_t)batch->len_a[c.first + k] << 32 | batch->len_b[c.first + k];
+      if (votes == 0) { best_key = key; votes = 1; } else if (key == best_key) ++votes; else --votes;
+    }
+    for (uint64_t k = 0; k < n; ++k) best_count += ((uint64_t)batch->len_a[c.first + k] << 32 | batch->len_b[c.first + k]) == best_key;
+    modal_a = (uint32_t)(best_key >> 32); modal_b = (uint32_t)best_key;
+    if ((best_count >= kPackedFillMinPairs || (ctx->opt.pack16 == 2 && best_count >= 2)) && best_count * 2 >= n &&
+        nw_dirs_x2_applicable(ctx, sc, modal_a, modal_b))
+      layout = kMixed;
+  }
+  // where each block's pairs start: characters (sequences, string slots) and cells
+  std::vector<uint64_t> chars_at(nb + 1, 0), cells_at(nb + 1, 0);
+  for (uint64_t bi = 0; bi < nb; ++bi) {
+    chars_at[bi + 1] = chars_at[bi] + blk[bi].chars;
+    const uint64_t in_blk = std::min(n, (bi + 1) * kHostBlk) - bi * kHostBlk;
+    cells_at[bi + 1] = cells_at[bi] + (layout == kUniform ? in_blk * stride : layout == kMixed ? blk[bi].cells256 : blk[bi].cells);
+  }
+  const uint64_t total = chars_at[nb], mat_total = cells_at[nb];
+
+  // ---- buffers.  Pinned: descriptors, sequences, moves, per-pair words; device: the direction bytes and what the fill
+  // tells the walk (end score / state, status) -- plus staging twins of the pinned blocks when zero_copy is off
+  const size_t desc_bytes = (4 * n + 1) * sizeof(uint64_t) + 2 * n * sizeof(uint32_t);
+  const uint64_t move_words = 2 * ((total >> 5) + n) + 2;
+  if ((rc = ctx->h_desc.reserve(desc_bytes)) || (rc = ctx->h_arena.reserve(total + 64)) ||
+      (rc = ctx->h_ta.reserve(move_words * 4)) || (rc = ctx->h_tmeta.reserve(n * 8)) ||
+      (rc = ctx->dirs.reserve(mat_total + 4096)) || (rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)) ||
+      (rc = ctx->status.reserve(n * 8)))
+    return rc;
+  if (!zc_in && ((rc = ctx->arena.reserve(total + 64)) || (rc = ctx->off_a.reserve(desc_bytes)))) return rc;
+  if (!zc_out && ((rc = ctx->t_out_a.reserve(move_words * 4)) || (rc = ctx->t_meta.reserve(n * 8)))) return rc;
+  if ((rc = ensure_copy_streams(ctx, 3))) return rc;
+  hipStream_t sf = ctx->stream, su = ctx->copy_streams[0], sd = ctx->copy_streams[1];
+
+  uint64_t *h_off_a = ctx->h_desc.as<uint64_t>(), *h_off_b = h_off_a + n, *h_mat = h_off_b + n, *h_slot = h_mat + n;
+  uint32_t *h_len_a = reinterpret_cast<uint32_t *>(h_slot + n + 1), *h_len_b = h_len_a + n;
+  uint8_t *h_seq = ctx->h_arena.as<uint8_t>();
+  uint32_t *h_moves = ctx->h_ta.as<uint32_t>(), *h_meta = ctx->h_tmeta.as<uint32_t>();
+  // offsets: per block from its base (parallel)
+  parallel_for(nb, [&](uint64_t bi) {
+    uint64_t pos = chars_at[bi], cell = cells_at[bi];
+    for (uint64_t k = bi * kHostBlk, e = std::min(n, (bi + 1) * kHostBlk); k < e; ++k) {
+      const uint32_t la = batch->len_a[c.first + k], lb = batch->len_b[c.first + k];
+      h_slot[k] = pos; h_off_a[k] = pos; pos += la; h_off_b[k] = pos; pos += lb;
+      h_len_a[k] = la; h_len_b[k] = lb;
+      h_mat[k] = cell;
+      const uint64_t cells = (uint64_t)(la + 1ull) * (lb + 1ull);
+      cell += layout == kUniform ? stride : layout == kMixed ? ((cells + 255u) & ~(uint64_t)255u) : cells;
+    }
+  });
+  h_slot[n] = total;
+
+  // sub-batch s = blocks [bcut[s], bcut[s + 1]), cut at equal cells; group g = sub-batches [gcut[g], gcut[g + 1])
+  const uint32_t n_sub = (uint32_t)std::min<uint64_t>(pick_subbatches(ctx, c), nb);
+  std::vector<uint64_t> bcut(n_sub + 1, nb);
+  bcut[0] = 0;
+  { uint64_t bi = 0;
+    for (uint32_t s = 1; s < n_sub; ++s) {
+      const uint64_t want = mat_total / n_sub * s;
+      while (bi < nb && cells_at[bi] < want) ++bi;
+      bcut[s] = std::max(bi, bcut[s - 1]);
+    } }
+  auto pair_at = [&](uint64_t bi) { return std::min(n, bi * kHostBlk); };
+  constexpr uint64_t kGroupPairs = 32768;
+  std::vector<uint32_t> gcut{0};
+  for (uint32_t s = 1; s < n_sub; ++s)
+    if (pair_at(bcut[s]) - pair_at(bcut[gcut.back()]) >= kGroupPairs && n - pair_at(bcut[s]) >= kGroupPairs / 2) gcut.push_back(s);
+  gcut.push_back(n_sub);
+  const uint32_t n_grp = (uint32_t)gcut.size() - 1;
+  const bool walk_beside = ctx->opt.walk_overlap && n_grp > 1;
+  hipStream_t sw = walk_beside ? ctx->copy_streams[2] : sf;
+  StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd), sync_w(sw);   // pinned / device buffers are reused by the next call
+
+  // mixed chunk: per sub-batch, the pairs of the modal shape and then the others (indices into the chunk's arrays)
+  std::vector<uint32_t> list_at;
+  const uint32_t *dv_list = nullptr;
+  if (layout == kMixed) {
+    if ((rc = ctx->h_misc.reserve(n * 4 + 16)) || (!zc_in && (rc = ctx->pair_list.reserve(n * 4 + 16)))) return rc;
+    uint32_t *h_list = ctx->h_misc.as<uint32_t>();
+    list_at.assign(2 * n_sub + 1, 0);
+    uint32_t at = 0;
+    for (uint32_t s2 = 0; s2 < n_sub; ++s2) {
+      const uint64_t k0 = pair_at(bcut[s2]), k1 = pair_at(bcut[s2 + 1]);
+      list_at[2 * s2] = at;
+      for (uint64_t k = k0; k < k1; ++k) if (h_len_a[k] == modal_a && h_len_b[k] == modal_b) h_list[at++] = (uint32_t)k;
+      list_at[2 * s2 + 1] = at;
+      for (uint64_t k = k0; k < k1; ++k) if (!(h_len_a[k] == modal_a && h_len_b[k] == modal_b)) h_list[at++] = (uint32_t)k;
+    }
+    list_at[2 * n_sub] = at;
+    if (zc_in) dv_list = ctx->h_misc.dev_as<uint32_t>();
+    else { dv_list = ctx->pair_list.as<uint32_t>(); HIP_TRY(hipMemcpyAsync(ctx->pair_list.p, h_list, n * 4, hipMemcpyHostToDevice, su)); }
+  }
+
+  EventList ev;   // [0, n_sub): upload of s done; then per group: walk done / results home / fills done
+  for (uint32_t k = 0; k < n_sub + 3 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
+  if (!zc_in) HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, su));
+
+  const uint64_t *dv_off_a = zc_in ? ctx->h_desc.dev_as<uint64_t>() : ctx->off_a.as<uint64_t>();
+  const uint64_t *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
+  const uint32_t *dv_len_a = reinterpret_cast<const uint32_t *>(dv_slot + n + 1), *dv_len_b = dv_len_a + n;
+  const uint8_t *dv_seq = zc_in ? ctx->h_arena.dev_as<uint8_t>() : ctx->arena.as<uint8_t>();
+  uint32_t *dv_moves = zc_out ? ctx->h_ta.dev_as<uint32_t>() : ctx->t_out_a.as<uint32_t>();
+  uint32_t *dv_meta = zc_out ? ctx->h_tmeta.dev_as<uint32_t>() : ctx->t_meta.as<uint32_t>();
+  auto dev_range = [&](uint64_t k0, uint64_t k1) {
+    seqalign_dev_batch_t d;
+    d.n_pairs = k1 - k0; d.arena = dv_seq;
+    d.off_a = dv_off_a + k0; d.len_a = dv_len_a + k0; d.off_b = dv_off_b + k0; d.len_b = dv_len_b + k0;
+    d.mat_off = dv_mat + k0;
+    d.match_scores = d.gap_a_scores = d.gap_b_scores = nullptr;
+    d.status = ctx->status.as<uint64_t>() + k0; d.max_len_a = c.max_a; d.max_len_b = c.max_b;
+    return d;
+  };
+  auto move_word = [&](uint64_t k) { return 2 * ((h_slot[k] >> 5) + k); };   // (sa_traceback.hip: move_slot)
+  tm.lap("nw moves: sizes, offsets, buffers");
+
+  uint32_t g = 0;
+  for (uint32_t s = 0; s < n_sub; ++s) {
+    const uint64_t b0 = bcut[s], b1 = bcut[s + 1], k0 = pair_at(b0), k1 = pair_at(b1);
+    if (k1 > k0) {
+      parallel_for(b1 - b0, [&](uint64_t bi) {   // host: this sub-batch's sequences into the pinned arena
+        for (uint64_t k = (b0 + bi) * kHostBlk, e = std::min(n, (b0 + bi + 1) * kHostBlk); k < e; ++k) {
+          const uint64_t p = c.first + k;
+          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], h_len_a[k]);
+          memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], h_len_b[k]);
+        }
+      });
+      if (!zc_in) {
+        const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
+        if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, su));
+        HIP_TRY(hipEventRecord(ev.ev[s], su));
+        HIP_TRY(hipStreamWaitEvent(sf, ev.ev[s], 0));
+      }
+      const seqalign_dev_batch_t d = dev_range(k0, k1);
+      if (layout == kMixed) {
+        const seqalign_dev_batch_t dm = dev_range(0, n);
+        const uint32_t m0 = list_at[2 * s], m1 = list_at[2 * s + 1], r1 = list_at[2 * s + 2];
+        if ((rc = nw_dirs_fill_mixed(ctx, sc, &dm, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), ctx->best_index.as<uint64_t>(),
+                                     sf, dv_list + m0, m1 - m0, r1 - m1, modal_a, modal_b)))
+          return rc;
+      } else {
+        bool used = false;
+        if ((rc = nw_dirs_fill(ctx, sc, &d, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>() + k0,
+                               ctx->best_index.as<uint64_t>() + k0, sf, &used, layout == kUniform ? stride : 0)))
+          return rc;
+        if (!used) { set_last_error("seqalign_nw_batch: internal error: directions-only fill refused a batch it had accepted"); return SEQALIGN_E_HIP; }
+      }
+    }
+    if (s + 1 == gcut[g + 1]) {   // the group is filled: walk it
+      const uint64_t g0 = pair_at(bcut[gcut[g]]), g1 = k1;
+      if (g1 > g0) {
+        const seqalign_dev_batch_t d = dev_range(g0, g1);
+        SaTraceParams t;
+        memset(&t, 0, sizeof(t));
+        t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b; t.mat_off = d.mat_off;
+        t.code = sc->d_code; t.table = sc->d_table;
+        t.str_off = dv_slot + g0;
+        t.moves = dv_moves + 2 * g0;        // walk w of the launch is pair g0 + w: words 2 ((slot >> 5) + g0 + w)
+        t.out_meta2 = dv_meta + 2 * g0;
+        t.fill_status = d.status;
+        t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
+        t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
+        t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
+        t.tune_walker = ctx->opt.trace_kernel;
+        // the last group's walk has no fill to run beside: it stays in the fills' stream, right behind the last fill
+        hipStream_t sg = g + 1 < n_grp ? sw : sf;
+        if (sg != sf) {
+          HIP_TRY(hipEventRecord(ev.ev[n_sub + 2 * n_grp + g], sf));
+          HIP_TRY(hipStreamWaitEvent(sg, ev.ev[n_sub + 2 * n_grp + g], 0));
+        }
+        hipError_t e = sa_launch_nw_traceback(t, sg);
+        if (e != hipSuccess) return fail_hip(e, "traceback launch");
+        if (zc_out) {
+          HIP_TRY(hipEventRecord(ev.ev[n_sub + n_grp + g], sg));
+        } else {
+          HIP_TRY(hipEventRecord(ev.ev[n_sub + g], sg));
+          HIP_TRY(hipStreamWaitEvent(sd, ev.ev[n_sub + g], 0));
+          const uint64_t w0 = move_word(g0), w1 = g1 < n ? move_word(g1) : move_words - 2;
+          HIP_TRY(hipMemcpyAsync(h_moves + w0, ctx->t_out_a.as<uint32_t>() + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost, sd));
+          HIP_TRY(hipMemcpyAsync(h_meta + 2 * g0, ctx->t_meta.as<uint32_t>() + 2 * g0, (g1 - g0) * 8, hipMemcpyDeviceToHost, sd));
+          HIP_TRY(hipEventRecord(ev.ev[n_sub + n_grp + g], sd));
+        }
+      } else {
+        HIP_TRY(hipEventRecord(ev.ev[n_sub + n_grp + g], sf));
+      }
+      ++g;
+    }
+  }
+  tm.lap("nw moves: packed + enqueued");
+
+  // the groups' moves, as they land, expanded into the caller's strings
+  std::atomic<uint64_t> first_bad{~0ull};
+  for (g = 0; g < n_grp; ++g) {
+    { const hipError_t e = wait_event_spinning(ev.ev[n_sub + n_grp + g]); if (e != hipSuccess) return fail_hip(e, "waiting for a group's walk"); }
+    const uint64_t b0 = bcut[gcut[g]], b1 = bcut[gcut[g + 1]];
+    constexpr uint64_t kOut = 128;   // pairs per task: C2's 10 000 pairs over all 32 threads
+    const uint64_t k_lo = pair_at(b0), k_hi = pair_at(b1);
+    parallel_for((k_hi - k_lo + kOut - 1) / kOut, [&](uint64_t blk_i) {
+      for (uint64_t k = k_lo + blk_i * kOut, e = std::min(k_hi, k_lo + (blk_i + 1) * kOut); k < e; ++k) {
+        const uint64_t p = c.first + k;
+        const uint32_t n_moves = h_meta[2 * k + 1];
+        int prc = SEQALIGN_OK;
+        if (n_moves >= SA_MOVES_ERR) {
+          prc = (int)(n_moves & 15u);
+        } else {
+          const uint32_t nw = (h_len_a[k] + h_len_b[k] + 31u) >> 5;
+          const uint32_t *pa = h_moves + move_word(k);
+          prc = sa_expand_nw_moves(batch->arena + batch->off_a[p], h_len_a[k], batch->arena + batch->off_b[p], h_len_b[k], pa, pa + nw,
+                                   nw, n_moves, out_a + str_off[p], out_b + str_off[p], &out_len[p]);
+          out_score[p] = (int32_t)h_meta[2 * k];
+        }
+        if (prc != SEQALIGN_OK) {   // the LOWEST failing pair's code is the call's (whatever thread meets it first)
+          uint64_t seen = first_bad.load(std::memory_order_relaxed);
+          const uint64_t mine = k << 8 | (uint64_t)prc;
+          while (mine < seen && !first_bad.compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {}
+        }
+      }
+    });
+  }
+  tm.lap("nw moves: groups expanded");
+  if (first_bad.load() != ~0ull) return (int)(first_bad.load() & 255u);
+  return SEQALIGN_OK;
+}
+
 extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                  const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
                                  int32_t *out_score) {
   if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
-  int rc = check_batch(batch);
-  if (rc) return rc;
+  const seqalign_batch_t *b = batch;
+  if (!b || (b->n_pairs && (!b->arena || !b->off_a || !b->off_b || !b->len_a || !b->len_b))) return SEQALIGN_E_ARG;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
+  int rc;
+  // one parallel pass over the lengths: validity (check_batch) and the sizes chunk planning needs
+  std::vector<BlkSum> blk;
+  scan_blocks(batch, 0, batch->n_pairs, blk);
+  Chunk whole;
+  whole.count = batch->n_pairs;
+  uint64_t cells256 = 0;
+  for (const BlkSum &s : blk) {
+    if (s.too_large) return SEQALIGN_E_TOO_LARGE;
+    whole.cells += s.cells; whole.seq_bytes += s.chars; cells256 += s.cells256;
+    whole.max_a = std::max(whole.max_a, s.max_a); whole.max_b = std::max(whole.max_b, s.max_b);
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   seqalign_dev_scoring *sc = nullptr;
   if ((rc = cached_scoring(ctx, scoring, 0, &sc))) return rc;
   const bool on_host = traceback_on_host(ctx);
+  if (!on_host && ctx->opt.nw_moves && nw_dirs_applicable(ctx, sc, whole.max_a)) {
+    // direction bytes (1 B per cell, every pair rounded up to 256 at most) + ~64 B per pair of descriptors and results:
+    // C5's 1 M pairs are 23 GB -- one chunk, where 12 B per cell cut them into six
+    if (cells256 + 64 * batch->n_pairs + whole.seq_bytes <= ctx->chunk_budget)
+      return nw_chunk_moves(ctx, batch, whole, sc, blk, str_off, out_a, out_b, out_len, out_score);
+    std::vector<uint64_t> extra(batch->n_pairs, 256 + 64);
+    for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 1, extra.data())) {
+      scan_blocks(batch, c.first, c.count, blk);
+      if ((rc = nw_chunk_moves(ctx, batch, c, sc, blk, str_off, out_a, out_b, out_len, out_score))) return rc;
+    }
+    return SEQALIGN_OK;
+  }
   // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
   const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;
   for (const Chunk &c : plan_chunks(batch, budget)) {

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -40,22 +41,29 @@ namespace sa_host {
 class HostPool {
  public:
   static HostPool &get() { static HostPool pool; return pool; }
+  unsigned threads() const { return (unsigned)workers_.size() + 1; }
   void run(uint64_t n, const std::function<void(uint64_t)> &fn) {
     if (n == 0) return;
     if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
     std::lock_guard<std::mutex> one_job(job_mu_);
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; next_.store(0); pending_ = (unsigned)workers_.size(); ++generation_;
+    fn_ = &fn; n_ = n; next_.store(0, std::memory_order_relaxed);
+    pending_.store((unsigned)workers_.size(), std::memory_order_relaxed);
+    generation_.fetch_add(1);                       // (seq_cst: ordered against the sleepers' count below)
+    if (sleepers_.load() > 0) { { std::lock_guard<std::mutex> lk(mu_); } cv_.notify_all(); }
+    for (uint64_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k);
+    // the workers are at most one task behind: spin, politely after a while
+    for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
+      if (spins < 20000) __builtin_ia32_pause(); else sched_yield();
     }
-    cv_.notify_all();
-    for (uint64_t k; (k = next_.fetch_add(1)) < n;) fn(k);
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
     fn_ = nullptr;
   }
 
  private:
+  // A host-level call dispatches several short jobs a few tens of microseconds apart (descriptors, packing per sub-batch,
+  // unpacking per group), and a caller that aligns batch after batch comes back within a millisecond: waking 31 sleeping
+  // threads through a condition variable costs 30-60 us per dispatch, several times what a job of C2's size takes.  So a
+  // worker that runs out of work keeps looking for the next job for kSpinNs before it goes to sleep.
+  static constexpr long long kSpinNs = 400000;
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
     cpu_set_t mask;
@@ -65,33 +73,43 @@ class HostPool {
     for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
   }
   ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    stop_.store(true);
+    generation_.fetch_add(1);
+    { std::lock_guard<std::mutex> lk(mu_); }
     cv_.notify_all();
     for (auto &th : workers_) th.join();
   }
+  static long long now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1000000000ll + t.tv_nsec; }
   void loop() {
     uint64_t seen = 0;
     for (;;) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return generation_ != seen; });
-      seen = generation_;
-      if (stop_) return;
+      const long long t0 = now_ns();
+      for (unsigned spins = 1; generation_.load(std::memory_order_acquire) == seen; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 255u) == 0 && now_ns() - t0 > kSpinNs) {
+          std::unique_lock<std::mutex> lk(mu_);
+          sleepers_.fetch_add(1);
+          cv_.wait(lk, [&] { return generation_.load() != seen; });
+          sleepers_.fetch_sub(1);
+          break;
+        }
+      }
+      seen = generation_.load(std::memory_order_acquire);
+      if (stop_.load()) return;
       const std::function<void(uint64_t)> *fn = fn_;
       const uint64_t n = n_;
-      lk.unlock();
-      for (uint64_t k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
-      lk.lock();
-      if (--pending_ == 0) done_cv_.notify_one();
+      for (uint64_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*fn)(k);
+      pending_.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> workers_;
   std::mutex mu_, job_mu_;
-  std::condition_variable cv_, done_cv_;
+  std::condition_variable cv_;
   const std::function<void(uint64_t)> *fn_ = nullptr;
-  uint64_t n_ = 0, generation_ = 0;
-  std::atomic<uint64_t> next_{0};
-  unsigned pending_ = 0;
-  bool stop_ = false;
+  uint64_t n_ = 0;
+  std::atomic<uint64_t> generation_{0}, next_{0};
+  std::atomic<unsigned> pending_{0}, sleepers_{0};
+  std::atomic<bool> stop_{false};
 };
 
 template <class F>
@@ -165,19 +183,23 @@ struct DevBuf {   // grow-only device scratch
 
 struct HostBuf {  // grow-only pinned staging
   void *p = nullptr;
+  void *dev = nullptr;   // the same memory as the GPU addresses it: kernels read / write it in place over PCIe
   size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return SEQALIGN_OK;
     if (p) (void)hipHostFree(p);
-    p = nullptr; cap = 0;
+    p = nullptr; dev = nullptr; cap = 0;
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipHostMalloc"); }
+    e = hipHostGetDevicePointer(&dev, p, 0);
+    if (e != hipSuccess) { (void)hipHostFree(p); p = nullptr; dev = nullptr; return fail_hip(e, "hipHostGetDevicePointer"); }
     cap = want;
     return SEQALIGN_OK;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
   template <class T> T *as() const { return static_cast<T *>(p); }
+  template <class T> T *dev_as() const { return static_cast<T *>(dev); }
 };
 
 
@@ -209,6 +231,12 @@ struct SaOptions {
                                   //                   never | chunks of >= 2 048 pairs | whatever the chunk's size (tests)
   bool walk_overlap = true;       // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
                                   //                   while the next group fills (a VALU-bound fill next to a latency-bound walk)
+  bool nw_moves = true;           // nw_moves          0|1: seqalign_nw_batch's direction-byte path sends home two bits per alignment column (which of
+                                  //                   the two strings has a gap there) and the host expands them against the sequences it still
+                                  //                   holds (host/sa_moves.c), instead of the two gapped strings
+  uint32_t zero_copy = 4;         // zero_copy         0..3 | auto: that path's kernels read the packed sequences + descriptors from (1) and write
+                                  //                   the moves to (2) pinned host memory in place, instead of staging copies either way;
+                                  //                   auto (4): moves in place when the walks run one wave each (coalesced words)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)

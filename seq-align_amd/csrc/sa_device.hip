@@ -147,6 +147,8 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
   if (is("pack16")) { if (num < 0 || num > 2) return false; o.pack16 = (int)num; return true; }
   if (is("walk_overlap")) { o.walk_overlap = num != 0; return true; }
+  if (is("nw_moves")) { o.nw_moves = num != 0; return true; }
+  if (is("zero_copy")) { if (eq("auto")) { o.zero_copy = 4; return true; } if (num < 0 || num > 3) return false; o.zero_copy = (uint32_t)num; return true; }
   if (is("timing")) { o.timing = num != 0; return true; }
   if (is("chunk_bytes")) {
     if (num != 0 && num < (1 << 20)) return false;
@@ -164,7 +166,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);

@@ -182,7 +182,16 @@ struct SaTraceParams {
   const uint64_t *nw_state;    /* ... and the matrix the walk starts in (0 MATCH, 1 GAP_A, 2 GAP_B)                                */
   const int32_t *start_score;  /* SW walks on direction bytes from start_index (the best-hit path behind fill_sw_best_x2_kernel, which
                                   writes no match_scores): the start cell's score                                                  */
+  /* walks on direction bytes that send home MOVES instead of strings (host/sa_moves.c): per walked column one bit "gap in
+   * seq_a" (the walk stood in GAP_A) and one bit "gap in seq_b", forward column order, right-aligned in the walk's slot --
+   * walk w owns words [2 ((str_off[w] >> 5) + w), + 2 nw) of `moves`, nw = (len_a + len_b + 31) >> 5: plane A, then plane B
+   * (str_off is the prefix of len_a + len_b, so the slots do not overlap); out_a / out_b / out_meta4 are not used, the two
+   * words of walk w go to out_meta2[2w..]: score, then the number of walked columns -- or 0xFFFFFFF0 | SEQALIGN_E_* .
+   * SW walks also need out_pos for nothing: the host derives the hit's position from the planes (sa_expand_sw_moves). */
+  uint32_t *moves;
+  uint32_t *out_meta2;
 };
+#define SA_MOVES_ERR 0xFFFFFFF0u
 
 /* substitution lookup flavour */
 enum { SA_SUBST_SIMPLE = 0, SA_SUBST_LDS = 1, SA_SUBST_GLOBAL = 2 };

@@ -253,6 +253,115 @@ __global__ void __launch_bounds__(64) traceback_dirs_tile_kernel(const SaTracePa
 }
 
 // ---------------------------------------------------------------------------
+// The NW walks on direction bytes, sending home MOVES instead of strings (SaTraceParams::moves, host/sa_moves.c): what a
+// walk knows is one of three states per column; the two gapped strings of needleman_wunsch.c:82-145 are that plus the
+// sequences the host still holds.  So the walk emits one bit per column and plane -- "gap in a" (it stood in GAP_A), "gap
+// in b" (GAP_B) -- 32 columns per word, a word's bits set from the top down because the walk runs backwards; the host expands them
+// (vpexpandb: 64 columns per instruction).  2 bits per column cross PCIe instead of 16, the walk reads no characters and
+// stores two words per 32 steps instead of two bytes per step, and the columns the walk does not visit (the padding of
+// needleman_wunsch.c:117-132) are not sent at all: they follow from the lengths.
+struct MoveSlot {
+  uint32_t *plane_a, *plane_b;   // nw words each
+  int nw;
+};
+__device__ __forceinline__ MoveSlot move_slot(const SaTraceParams &p, uint32_t w, uint32_t la, uint32_t lb) {
+  const int nw = (int)((la + lb + 31u) >> 5);
+  uint32_t *base = p.moves + 2ull * ((p.str_off[w] >> 5) + w);
+  return MoveSlot{base, base + nw, nw};
+}
+__device__ __forceinline__ void write_moves_meta(const SaTraceParams &p, uint32_t w, uint32_t pair, int score, uint32_t n_moves) {
+  if (p.fill_status && p.fill_status[pair] != ~0ull) n_moves = SA_MOVES_ERR | 5u;   // SEQALIGN_E_UNKNOWN_PAIR
+  *reinterpret_cast<uint2 *>(p.out_meta2 + 2ull * w) = make_uint2((uint32_t)score, n_moves);
+}
+
+// one lane per walk: a word of each plane leaves as soon as its 32 columns are known
+__global__ void __launch_bounds__(64) traceback_nw_moves_lane_kernel(const SaTraceParams p) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= p.n_pairs) return;
+  const uint32_t la = p.len_a[w], lb = p.len_b[w], W = la + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[w];
+  const MoveSlot s = move_slot(p, w, la, lb);
+  uint32_t x = la, y = lb, st = (uint32_t)p.nw_state[w], k = 0, acc_a = 0, acc_b = 0;
+  while (x > 0 && y > 0) {
+    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    const uint32_t bit = 0x80000000u >> (k & 31u);   // the walk runs backwards: a word's columns arrive last first
+    acc_a |= st == MAT_GAP_A ? bit : 0u;
+    acc_b |= st == MAT_GAP_B ? bit : 0u;
+    if ((++k & 31u) == 0) {
+      const int j = s.nw - (int)(k >> 5);   // the walk's word number k/32 - 1 from the end
+      s.plane_a[j] = acc_a; s.plane_b[j] = acc_b;
+      acc_a = acc_b = 0;
+    }
+    x -= (st != MAT_GAP_A);
+    y -= (st != MAT_GAP_B);
+    st = f;
+  }
+  if (k & 31u) {   // (the unfinished word: its columns sit at the top, where they belong)
+    const int j = s.nw - 1 - (int)(k >> 5);
+    s.plane_a[j] = acc_a; s.plane_b[j] = acc_b;
+  }
+  write_moves_meta(p, w, w, p.nw_score[w], k);
+}
+
+// one wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk); lane l keeps word l of the current block
+// of 64 words per plane in a register, a block leaves as one coalesced store per plane
+__global__ void __launch_bounds__(64) traceback_nw_moves_tile_kernel(const SaTraceParams p) {
+  constexpr int kT = 64;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
+  const int lane = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  const uint32_t la = p.len_a[w], lb = p.len_b[w], W = la + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[w];
+  const MoveSlot s = move_slot(p, w, la, lb);
+  uint32_t x = la, y = lb, st = (uint32_t)p.nw_state[w], k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
+  uint32_t ox = 0, oy = 0;
+  bool loaded = false;
+  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  // block q = the walk's words 64 q .. 64 q + 63 counted from the end; slot 63 - (j & 63) of the block holds word j, and slot t
+  // of block q is plane word nw - 64 (q + 1) + t
+  auto flush = [&](int q, int first_slot) {
+    const int at = s.nw - 64 * (q + 1) + lane;
+    if (lane >= first_slot) { s.plane_a[at] = reg_a; s.plane_b[at] = reg_b; }
+  };
+  while (x > 0 && y > 0) {
+    if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
+      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
+      oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const uint32_t r = oy + lane;
+      if (r <= lb) {
+        const uint8_t *src = Dg + (uint64_t)r * W + ox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);
+      loaded = true;
+    }
+    const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
+    const uint32_t bit = 0x80000000u >> (k & 31u);   // the walk runs backwards: a word's columns arrive last first
+    acc_a |= st == MAT_GAP_A ? bit : 0u;
+    acc_b |= st == MAT_GAP_B ? bit : 0u;
+    if ((++k & 31u) == 0) {
+      const int j = (int)(k >> 5) - 1;
+      if (lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
+      acc_a = acc_b = 0;
+      if ((j & 63) == 63) flush(j >> 6, 0);
+    }
+    x -= (st != MAT_GAP_A);
+    y -= (st != MAT_GAP_B);
+    st = f;
+  }
+  if (k) {
+    const int j = (int)((k - 1) >> 5);   // the last word the walk touched
+    if ((k & 31u) && lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
+    flush(j >> 6, 63 - (j & 63));
+  }
+  if (lane == 0) write_moves_meta(p, w, w, p.nw_score[w], k);
+}
+
+// ---------------------------------------------------------------------------
 // One WAVE per pair, the walk's neighbourhood staged in LDS.
 //
 // A step needs the three matrices at ONE predecessor cell and the two sequence
@@ -409,6 +518,11 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
     const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < 32768;
     if (p.nw_state) {   // NW behind the directions-only fill
       if (!p.nw_score) return hipErrorInvalidValue;
+      if (p.moves) {    // ... sending home moves instead of strings
+        if (!p.out_meta2) return hipErrorInvalidValue;
+        if (tiles) hipLaunchKernelGGL(sa::traceback_nw_moves_tile_kernel, dim3(p.n_pairs), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL(sa::traceback_nw_moves_lane_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+      } else
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip

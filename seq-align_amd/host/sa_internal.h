@@ -74,6 +74,18 @@ int sa_reverse_move_rc(const sa_view_t *v, int *matrix, int32_t *score,
 int sa_nw_traceback(const sa_view_t *v, char *out_a, char *out_b,
                     size_t *out_len, int32_t *out_score);
 
+/* ---- alignments as bit planes (sa_moves.c) ---------------------------------- */
+/* What the device walkers on direction bytes send home instead of the two gapped strings: per walked column one bit
+ * "gap in seq_a" and one bit "gap in seq_b", forward column order, right-aligned in n_words uint32 per plane. */
+int sa_expand_nw_moves(const char *a, uint32_t len_a, const char *b, uint32_t len_b, const uint32_t *plane_a,
+                       const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, char *out_a, char *out_b,
+                       uint32_t *out_len);
+int sa_expand_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t end_y, const uint32_t *plane_a,
+                       const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, char *out_a, char *out_b,
+                       uint32_t pos[4]);
+int sa_moves_uses_simd(void);
+void sa_moves_force_scalar(int on);
+
 /* SW hit enumeration over candidate cells (index list, any order; sorted here).
  * `seen` is a caller-provided zeroed bitmap of W*H bits. */
 typedef int (*sa_hit_sink_t)(void *user, int32_t score, size_t end_x, size_t end_y,

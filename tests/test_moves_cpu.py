@@ -1,0 +1,135 @@
+"""CPU tier: the host half of the "moves instead of strings" path (seq-align_amd/host/sa_moves.c).
+
+The device walkers on direction bytes send home two bit planes per alignment ("gap in a", "gap in b" per walked
+column); the host expands them against the sequences into the reference's pair of gapped strings
+(reference src/needleman_wunsch.c:82-145, src/smith_waterman.c:187-255).  Here the planes are derived from the ORACLE's
+alignments exactly as a walk would emit them, expanded by the product's host code (SIMD and scalar loops), and compared
+with the oracle's strings.  No device involved.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import orclib as O
+import seqalign_amd as S
+
+
+def planes_from_alignment(ra: bytes, rb: bytes, la: int, lb: int, stop_at_border: bool):
+    """What a backwards walk over the alignment (ra, rb) emits: per walked column one bit per plane, right-aligned in
+    n_words words; a global walk stops when x == 0 or y == 0 (the reference pads the rest, needleman_wunsch.c:117-132)."""
+    n_words = (la + lb + 31) >> 5
+    bits_a = np.zeros(32 * n_words, np.uint8)
+    bits_b = np.zeros(32 * n_words, np.uint8)
+    x, y, k = la, lb, 0
+    for col in range(len(ra) - 1, -1, -1):
+        if stop_at_border and (x == 0 or y == 0):
+            break
+        ga, gb = ra[col:col + 1] == b"-", rb[col:col + 1] == b"-"
+        bits_a[32 * n_words - 1 - k] = ga
+        bits_b[32 * n_words - 1 - k] = gb
+        x -= not ga
+        y -= not gb
+        k += 1
+    pack = lambda bits: np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+    return pack(bits_a), pack(bits_b), n_words, k
+
+
+def expand_nw(lib, a, b, pa, pb, n_words, n_moves):
+    oa = C.create_string_buffer(len(a) + len(b) + 1)
+    ob = C.create_string_buffer(len(a) + len(b) + 1)
+    n = C.c_uint32(0)
+    # garbage in the words the walk did not reach must not matter
+    rc = lib.sa_expand_nw_moves(a, C.c_uint32(len(a)), b, C.c_uint32(len(b)), pa.ctypes.data_as(C.c_void_p),
+                                pb.ctypes.data_as(C.c_void_p), C.c_uint32(n_words), C.c_uint32(n_moves), oa, ob, C.byref(n))
+    return rc, oa.value, ob.value, n.value
+
+
+@pytest.mark.parametrize("scalar", [0, 1])
+def test_nw_moves_expand_to_the_oracle_strings(scalar):
+    lib = S.lib()
+    lib.sa_moves_force_scalar(C.c_int(scalar))
+    rng = random.Random(11 + scalar)
+    specs = [{"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, {"init": [2, -3, -1, -1, 0, 0, 0, 0, 0, 0]},
+             {"init": [1, -1, 0, -2, 0, 0, 0, 0, 0, 0]}]
+    try:
+        for trial in range(400):
+            osc = O.build_scoring(specs[trial % 3], "oracle")
+            la = rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 150, 151, 300, rng.randrange(0, 520)])
+            lb = rng.choice([0, 1, 5, 64, 127, 128, 150, 400, rng.randrange(0, 700)])
+            a = bytes(rng.choice(b"ACGT") for _ in range(la))
+            if trial % 2:   # related pair: long runs of matches, a few gaps
+                b = bytearray(a)
+                for _ in range(rng.randrange(0, 6)):
+                    if b and rng.random() < 0.5:
+                        at = rng.randrange(len(b)); del b[at:at + rng.randrange(1, 9)]
+                    else:
+                        at = rng.randrange(len(b) + 1); b[at:at] = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(1, 9)))
+                b = bytes(b)
+                lb = len(b)
+            else:
+                b = bytes(rng.choice(b"ACGT") for _ in range(lb))
+            rc, score, ra, rb = O.oracle_nw(osc, a, b)
+            assert rc == 0
+            pa, pb, n_words, n_moves = planes_from_alignment(ra, rb, la, lb, True)
+            if n_words:   # poison what the walk did not write
+                first = 32 * n_words - n_moves
+                for plane in (pa, pb):
+                    for w in range(first // 32):
+                        plane[w] = 0xDEADBEEF
+                    if first % 32:
+                        plane[first // 32] |= np.uint32((1 << (first % 32)) - 1)
+            rc, ga, gb, n = expand_nw(lib, a, b, pa, pb, n_words, n_moves)
+            assert rc == 0 and (ga, gb, n) == (ra, rb, len(ra)), (trial, la, lb)
+    finally:
+        lib.sa_moves_force_scalar(C.c_int(0))
+
+
+def test_nw_moves_reject_planes_that_are_no_walk():
+    lib = S.lib()
+    a, b = b"ACGT", b"AC"
+    n_words = 1
+    pa = np.zeros(n_words, np.uint32)
+    pb = np.zeros(n_words, np.uint32)
+    rc, *_ = expand_nw(lib, a, b, pa, pb, n_words, 3)      # three MATCH moves over a 2-character seq_b
+    assert rc == S.E_TRACEBACK
+    rc, *_ = expand_nw(lib, a, b, pa, pb, n_words, 40)     # more moves than the slot holds
+    assert rc == S.E_TRACEBACK
+
+
+@pytest.mark.parametrize("scalar", [0, 1])
+def test_sw_moves_expand_to_the_oracle_hits(scalar):
+    lib = S.lib()
+    lib.sa_moves_force_scalar(C.c_int(scalar))
+    rng = random.Random(5 + scalar)
+    osc = O.build_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    try:
+        done = 0
+        for trial in range(200):
+            lb = rng.randrange(40, 400)
+            b = bytes(rng.choice(b"ACGT") for _ in range(lb))
+            o = rng.randrange(0, lb - 30)
+            a = bytearray(b[o:o + rng.randrange(30, 160)])
+            for _ in range(rng.randrange(0, 5)):
+                at = rng.randrange(len(a))
+                if rng.random() < 0.5: del a[at:at + rng.randrange(1, 4)]
+                else: a[at:at] = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(1, 4)))
+            a = bytes(a)
+            rc, hits = O.oracle_sw(osc, a, b, 10, 3)
+            assert rc == 0
+            for h in hits:
+                pos_a, pos_b, len_a, len_b = h["pos_a"], h["pos_b"], h["len_a"], h["len_b"]
+                ra, rb = h["a"].encode(), h["b"].encode()
+                pa, pb, n_words, n_moves = planes_from_alignment(ra, rb, len(a), len(b), False)
+                oa = C.create_string_buffer(len(a) + len(b) + 1)
+                ob = C.create_string_buffer(len(a) + len(b) + 1)
+                pos = (C.c_uint32 * 4)()
+                rc = lib.sa_expand_sw_moves(a, b, C.c_uint32(pos_a + len_a), C.c_uint32(pos_b + len_b),
+                                            pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p), C.c_uint32(n_words),
+                                            C.c_uint32(n_moves), oa, ob, pos)
+                assert rc == 0 and (oa.value, ob.value, list(pos)) == (ra, rb, [pos_a, pos_b, len_a, len_b])
+                done += 1
+        assert done > 100
+    finally:
+        lib.sa_moves_force_scalar(C.c_int(0))
