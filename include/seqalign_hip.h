@@ -353,6 +353,51 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  * Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */
 int seqalign_ctx_set_option(seqalign_ctx_t *ctx, const char *key, const char *value);
 
+/* The value in force (as text: what seqalign_ctx_set_option would take) -- for callers that change an option for a
+ * while and put it back.  Returns SEQALIGN_E_ARG for an unknown key or when cap is too small. */
+int seqalign_ctx_get_option(const seqalign_ctx_t *ctx, const char *key, char *value, size_t cap);
+
+/* ---- what the last call launched ------------------------------------------------ */
+/* Which kernels the context's last call (any entry point above that launches) put on the device, and for how many
+ * pairs / walks each: the fills of src/alignment.c:28-168 come in several forms (three matrices, direction bytes, two
+ * pairs per wave in packed int16 ...) chosen per chunk from the scoring and the shapes, and results are identical
+ * whichever runs -- so a test (or a user wondering where the time goes) asks HERE which one did.  launches[k] /
+ * items[k] are indexed by SEQALIGN_K_*; a call that chunks or pipelines its batch adds up all its launches. */
+enum {
+  SEQALIGN_K_FILL_WAVEFRONT = 0,   /* three matrices, sa_fill_wavefront.hip                                        */
+  SEQALIGN_K_FILL_ROWSCAN,         /* ... sa_fill_rowscan.hip                                                      */
+  SEQALIGN_K_FILL_STREAM,          /* ... sa_fill_stream.hip (the headline kernel)                                 */
+  SEQALIGN_K_FILL_STRIPS,          /* ... sa_fill_strips.hip                                                       */
+  SEQALIGN_K_FILL_WGSTREAM,        /* ... sa_fill_wgstream.hip                                                     */
+  SEQALIGN_K_FILL_NW_DIRS,         /* NW, direction bytes only, one pair per wave (items: pairs)                   */
+  SEQALIGN_K_FILL_NW_DIRS_X2,      /* NW, direction bytes only, two pairs per wave in packed int16                 */
+  SEQALIGN_K_FILL_SW_DIRS,         /* SW, match_scores + direction bytes, one pair per wave                        */
+  SEQALIGN_K_FILL_SW_DIRS_X2,      /* SW, match_scores + direction bytes, two pairs per wave                       */
+  SEQALIGN_K_FILL_SW_BEST_X2,      /* SW best hit: direction bytes + the best cell, two pairs per wave             */
+  SEQALIGN_K_SW_REDUCE,            /* sa_reduce.hip: the separate max-reduction over match_scores                  */
+  SEQALIGN_K_SW_BOX,               /* sa_reduce.hip: candidates' box / rows from match_scores in HBM               */
+  SEQALIGN_K_SWEEP_REGS,           /* multi-hit sweep on three matrices, rows in registers                         */
+  SEQALIGN_K_SWEEP_LDS,            /* ... winners of two rows in LDS (wide pairs)                                  */
+  SEQALIGN_K_SWEEP_STRIPS,         /* ... one wave per strip (few wide pairs)                                      */
+  SEQALIGN_K_SWEEP_DIRS,           /* multi-hit sweep on match_scores + direction bytes, one pair per wave         */
+  SEQALIGN_K_SWEEP_DIRS_X2,        /* ... two pairs per wave                                                       */
+  SEQALIGN_K_WALK_LANE,            /* traceback on three matrices, one lane per walk (items: walks)                */
+  SEQALIGN_K_WALK_WAVE,            /* ... one wave per walk, LDS tiles                                             */
+  SEQALIGN_K_WALK_DIRS_LANE,       /* traceback on direction bytes, strings out, one lane per walk                 */
+  SEQALIGN_K_WALK_DIRS_TILE,       /* ... one wave per walk, LDS tiles                                             */
+  SEQALIGN_K_WALK_MOVES_LANE,      /* traceback on direction bytes, two bits per column out (host/sa_moves.c)      */
+  SEQALIGN_K_WALK_MOVES_TILE,      /* ... one wave per walk                                                        */
+  SEQALIGN_K_COUNT
+};
+#define SEQALIGN_K_MAX 32
+typedef struct {
+  uint32_t launches[SEQALIGN_K_MAX];
+  uint64_t items[SEQALIGN_K_MAX];
+} seqalign_call_info_t;
+int seqalign_ctx_last_call_info(const seqalign_ctx_t *ctx, seqalign_call_info_t *out);
+/* "fill_stream", "fill_nw_dirs_x2", ... ; NULL for a kind that does not exist */
+const char *seqalign_kernel_kind_name(int kind);
+
 /* ---- CIGAR -------------------------------------------------------------------- */
 /* The reference has no CIGAR output (its result is the pair of gapped strings, src/alignment.h:33-40); this
  * is the derived format: run-length encoding of the alignment's columns with seq_a as the query and seq_b as

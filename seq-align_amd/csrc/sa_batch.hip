@@ -254,6 +254,7 @@ extern "C" int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *
                                    int is_sw, const uint64_t *mat_off, int32_t *M, int32_t *A, int32_t *B,
                                    uint64_t *status) {
   if (!ctx || !scoring || !mat_off || !M || !A || !B) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   int rc = check_batch(batch);
   if (rc) return rc;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
@@ -624,14 +625,20 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
 //     BLOCKS, then offsets + packing per block; the pool's workers stay awake between the dispatches of a call.
 // Same kernels for the fill, same sub-batch / group structure as above for chunks large enough to pipeline.
 namespace {
-constexpr uint64_t kHostBlk = 512;
+// pairs per host task: 512 (C2: 20 tasks for 32 threads would leave a third of them idle -- but a task below ~10 us is
+// all dispatch); fewer when the caller forces more sub-batches than such blocks (sub-batches are cut at block boundaries)
+uint64_t host_block_pairs(const seqalign_ctx *ctx, uint64_t n) {
+  uint64_t blk = 512;
+  if (ctx->opt.subbatches > 1) while (blk > 1 && n / blk < 2ull * ctx->opt.subbatches) blk /= 2;
+  return blk;
+}
 struct BlkSum {
   uint64_t chars = 0, cells = 0, cells256 = 0;
   uint32_t max_a = 0, max_b = 0;
   bool same = true, too_large = false;
 };
-// sizes of pairs [first, first + n) per block of kHostBlk; `same`: every pair of the block has the shape of pair `first`
-void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, std::vector<BlkSum> &blk) {
+// sizes of pairs [first, first + n) per block of kHostBlk pairs; `same`: every pair of the block has the shape of pair `first`
+void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, uint64_t kHostBlk, std::vector<BlkSum> &blk) {
   const uint64_t nb = (n + kHostBlk - 1) / kHostBlk;
   blk.assign(nb, BlkSum());
   if (!n) return;
@@ -666,8 +673,8 @@ hipError_t wait_event_spinning(hipEvent_t e) {
 }  // namespace
 
 static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, const Chunk &c, const seqalign_dev_scoring *sc,
-                          const std::vector<BlkSum> &blk, const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
-                          int32_t *out_score) {
+                          const std::vector<BlkSum> &blk, uint64_t kHostBlk, const uint64_t *str_off, char *out_a, char *out_b,
+                          uint32_t *out_len, int32_t *out_score) {
   const uint64_t n = c.count, nb = blk.size();
   int rc;
   StageTimer tm(ctx->opt.timing);
@@ -747,6 +754,8 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   h_slot[n] = total;
 
   // sub-batch s = blocks [bcut[s], bcut[s + 1]), cut at equal cells; group g = sub-batches [gcut[g], gcut[g + 1])
+  // (tried: a short last sub-batch as a group of its own, so that the walk + results + expansion nothing runs beside are
+  // short -- C5's share 3.95 -> 4.05 ms, the extra launch and the quarter-size fill cost what the shorter tail saves)
   const uint32_t n_sub = (uint32_t)std::min<uint64_t>(pick_subbatches(ctx, c), nb);
   std::vector<uint64_t> bcut(n_sub + 1, nb);
   bcut[0] = 0;
@@ -787,9 +796,17 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
     else { dv_list = ctx->pair_list.as<uint32_t>(); HIP_TRY(hipMemcpyAsync(ctx->pair_list.p, h_list, n * 4, hipMemcpyHostToDevice, su)); }
   }
 
-  EventList ev;   // [0, n_sub): upload of s done; then per group: walk done / results home / fills done
-  for (uint32_t k = 0; k < n_sub + 3 * n_grp; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
-  if (!zc_in) HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, su));
+  EventList ev;   // [0, n_sub): upload of s done; then per group: walk done / results home / fills done; last: descriptors up
+  for (uint32_t k = 0; k < n_sub + 3 * n_grp + 1; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
+  if (!zc_in) {
+    // the descriptor arrays (44 B per pair: C5's share 5.5 MB, more than a sub-batch's sequences) go up on the download
+    // stream, which has nothing to do yet, beside the first sub-batch's sequences on the upload stream: two copy engines
+    // (C5's share 4.2 -> 4.05 ms against the same copy ahead of the sequences on the upload stream)
+    HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, sd));
+    HIP_TRY(hipEventRecord(ev.ev[n_sub + 3 * n_grp], sd));
+    HIP_TRY(hipStreamWaitEvent(sf, ev.ev[n_sub + 3 * n_grp], 0));
+    if (sw != sf) HIP_TRY(hipStreamWaitEvent(sw, ev.ev[n_sub + 3 * n_grp], 0));
+  }
 
   const uint64_t *dv_off_a = zc_in ? ctx->h_desc.dev_as<uint64_t>() : ctx->off_a.as<uint64_t>();
   const uint64_t *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n, *dv_slot = dv_mat + n;
@@ -921,13 +938,15 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
                                  const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
                                  int32_t *out_score) {
   if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   const seqalign_batch_t *b = batch;
   if (!b || (b->n_pairs && (!b->arena || !b->off_a || !b->off_b || !b->len_a || !b->len_b))) return SEQALIGN_E_ARG;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
   int rc;
   // one parallel pass over the lengths: validity (check_batch) and the sizes chunk planning needs
   std::vector<BlkSum> blk;
-  scan_blocks(batch, 0, batch->n_pairs, blk);
+  const uint64_t blk_pairs = host_block_pairs(ctx, batch->n_pairs);
+  scan_blocks(batch, 0, batch->n_pairs, blk_pairs, blk);
   Chunk whole;
   whole.count = batch->n_pairs;
   uint64_t cells256 = 0;
@@ -944,11 +963,12 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     // direction bytes (1 B per cell, every pair rounded up to 256 at most) + ~64 B per pair of descriptors and results:
     // C5's 1 M pairs are 23 GB -- one chunk, where 12 B per cell cut them into six
     if (cells256 + 64 * batch->n_pairs + whole.seq_bytes <= ctx->chunk_budget)
-      return nw_chunk_moves(ctx, batch, whole, sc, blk, str_off, out_a, out_b, out_len, out_score);
+      return nw_chunk_moves(ctx, batch, whole, sc, blk, blk_pairs, str_off, out_a, out_b, out_len, out_score);
     std::vector<uint64_t> extra(batch->n_pairs, 256 + 64);
     for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 1, extra.data())) {
-      scan_blocks(batch, c.first, c.count, blk);
-      if ((rc = nw_chunk_moves(ctx, batch, c, sc, blk, str_off, out_a, out_b, out_len, out_score))) return rc;
+      const uint64_t bp = host_block_pairs(ctx, c.count);
+      scan_blocks(batch, c.first, c.count, bp, blk);
+      if ((rc = nw_chunk_moves(ctx, batch, c, sc, blk, bp, str_off, out_a, out_b, out_len, out_score))) return rc;
     }
     return SEQALIGN_OK;
   }

@@ -623,6 +623,7 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
                                  const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
                                  uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
   if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   *n_hits = 0;
   int rc = check_batch(batch);
   if (rc) return rc;

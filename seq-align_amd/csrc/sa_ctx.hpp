@@ -273,12 +273,25 @@ struct seqalign_ctx {
   sa_host::DevBuf strip_progress;                        // sa_fill_strips.hip: rows done per (pair, strip)
   sa_host::HostBuf h_desc, h_arena, h_M, h_A, h_B, h_misc, h_ta, h_tb, h_tmeta;
   // the last scorings uploaded through cached_scoring (host-level entry points, legacy single-pair path): [is_sw]
+  seqalign_call_info_t call_info = {};   // what the last call launched (seqalign_ctx_last_call_info)
+  int call_depth = 0;                    // entry points nest (seqalign_nw_batch -> seqalign_fill_batch_device): the outermost resets
   seqalign_dev_scoring *cached[2] = {nullptr, nullptr};
   uint64_t cached_fp[2] = {0, 0};
 };
 
 
 namespace sa_host {
+
+// Every C-ABI entry point that launches opens one: the outermost scope of a call clears the context's record and points
+// the calling thread's recorder (sa_record_launch, sa_kernels.h) at it.
+struct CallScope {
+  seqalign_ctx *ctx;
+  seqalign_call_info_t *prev;
+  explicit CallScope(seqalign_ctx *c);
+  ~CallScope();
+  CallScope(const CallScope &) = delete;
+  CallScope &operator=(const CallScope &) = delete;
+};
 
 // grow the context's three matrix arenas together (spread placement, sa_placement.hip)
 int reserve_arenas(seqalign_ctx *ctx, size_t bytes);

@@ -10,7 +10,9 @@
 #include <condition_variable>
 #include <mutex>
 
+#include <errno.h>
 #include <sched.h>
+#include <strings.h>
 #include <time.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -42,6 +44,41 @@ extern "C" const char *seqalign_strerror(int code) {
     case SEQALIGN_E_TOO_LARGE: return "pair too large (>= 2^31 cells)";
   }
   return "unknown error";
+}
+
+// ------------------------------------------------ what a call launched ---
+static thread_local seqalign_call_info_t *tl_recorder = nullptr;
+
+void sa_record_launch(int kind, uint64_t items) {
+  if (!tl_recorder || kind < 0 || kind >= SEQALIGN_K_COUNT) return;
+  tl_recorder->launches[kind] += 1;
+  tl_recorder->items[kind] += items;
+}
+
+sa_host::CallScope::CallScope(seqalign_ctx *c) : ctx(c), prev(tl_recorder) {
+  if (!ctx) return;
+  if (ctx->call_depth++ == 0) memset(&ctx->call_info, 0, sizeof(ctx->call_info));
+  tl_recorder = &ctx->call_info;
+}
+sa_host::CallScope::~CallScope() {
+  if (!ctx) return;
+  --ctx->call_depth;
+  tl_recorder = prev;
+}
+
+extern "C" int seqalign_ctx_last_call_info(const seqalign_ctx_t *ctx, seqalign_call_info_t *out) {
+  if (!ctx || !out) return SEQALIGN_E_ARG;
+  *out = ctx->call_info;
+  return SEQALIGN_OK;
+}
+
+extern "C" const char *seqalign_kernel_kind_name(int kind) {
+  static const char *names[SEQALIGN_K_COUNT] = {
+      "fill_wavefront", "fill_rowscan", "fill_stream", "fill_strips", "fill_wgstream", "fill_nw_dirs", "fill_nw_dirs_x2",
+      "fill_sw_dirs", "fill_sw_dirs_x2", "fill_sw_best_x2", "sw_reduce", "sw_box", "sweep_regs", "sweep_lds", "sweep_strips",
+      "sweep_dirs", "sweep_dirs_x2", "walk_lane", "walk_wave", "walk_dirs_lane", "walk_dirs_tile", "walk_moves_lane",
+      "walk_moves_tile"};
+  return kind >= 0 && kind < SEQALIGN_K_COUNT ? names[kind] : nullptr;
 }
 
 // ----------------------------------------------------------------- context ---
@@ -118,47 +155,97 @@ extern "C" int seqalign_device_count(void) {
 // ----------------------------------------------------------------- options ---
 // key = the environment variable's name without SEQALIGN_, lower case.  Returns false for an unknown key or a
 // value outside the key's range (nothing is changed then).
+static bool parse_int(const char *val, long long *out) {   // the whole string is one integer, nothing else
+  if (!val || !*val) return false;
+  char *end = nullptr;
+  errno = 0;
+  const long long v = strtoll(val, &end, 10);
+  if (errno || end == val || *end) return false;
+  *out = v;
+  return true;
+}
+static bool parse_bool(const char *val, bool *out) {       // 1 / 0, true / false, on / off, yes / no (any case)
+  static const char *yes[] = {"1", "true", "on", "yes"}, *no[] = {"0", "false", "off", "no"};
+  for (const char *y : yes) if (!strcasecmp(val, y)) { *out = true; return true; }
+  for (const char *n : no) if (!strcasecmp(val, n)) { *out = false; return true; }
+  return false;
+}
+
+static const char *const kKernelNames[] = {"auto", "wavefront", "rowscan", "stream", "strips", "wgstream"};
+static const char *const kWalkerNames[] = {"auto", "lane", "wave"};
+static const char *const kSweepModes[] = {"auto", "pair", "strips"};
+
 static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   SaOptions &o = ctx->opt;
   auto is = [&](const char *k) { return !strcmp(key, k); };
   auto eq = [&](const char *v) { return !strcmp(val, v); };
-  const long long num = atoll(val);
-  if (is("kernel")) {
-    static const char *names[] = {"auto", "wavefront", "rowscan", "stream", "strips", "wgstream"};
-    for (int k = 0; k < 6; ++k) if (eq(names[k])) { o.kernel = k; return true; }
-    return false;
-  }
-  if (is("cpl")) { if (num < 0 || num > 16) return false; o.cpl = (uint32_t)num; return true; }
-  if (is("wpb")) { if (num != 0 && num != 1 && num != 2 && num != 4 && num != 8) return false; o.wpb = (uint32_t)num; return true; }
-  if (is("lds_pad")) { if (num < 0 || num > 160 * 1024) return false; o.lds_pad = (uint32_t)num; return true; }
+  auto name_of = [&](const char *const *names, int n, int *out) { for (int k = 0; k < n; ++k) if (eq(names[k])) { *out = k; return true; } return false; };
+  // a numeric key takes an integer and nothing else ("abc", "1x", "" are refused, not read as 0), inside its range
+  auto number = [&](long long lo, long long hi, long long *out) { long long v; if (!parse_int(val, &v) || v < lo || v > hi) return false; *out = v; return true; };
+  auto flag = [&](bool *out) { return parse_bool(val, out); };
+  long long num = 0;
+  int idx = 0;
+  if (is("kernel")) { if (!name_of(kKernelNames, 6, &idx)) return false; o.kernel = idx; return true; }
+  if (is("cpl")) { if (!number(0, 16, &num)) return false; o.cpl = (uint32_t)num; return true; }
+  if (is("wpb")) { if (!number(0, 8, &num) || (num != 0 && num != 1 && num != 2 && num != 4 && num != 8)) return false; o.wpb = (uint32_t)num; return true; }
+  if (is("lds_pad")) { if (!number(0, 160 * 1024, &num)) return false; o.lds_pad = (uint32_t)num; return true; }
   if (is("traceback")) { if (!eq("host") && !eq("device")) return false; o.traceback_host = eq("host"); return true; }
-  if (is("trace_kernel")) {
-    if (eq("auto")) o.trace_kernel = 0; else if (eq("lane")) o.trace_kernel = 1; else if (eq("wave")) o.trace_kernel = 2; else return false;
-    return true;
-  }
-  if (is("sweep_mode")) {
-    if (eq("auto")) o.sweep_mode = 0; else if (eq("pair")) o.sweep_mode = 1; else if (eq("strips")) o.sweep_mode = 2; else return false;
-    return true;
-  }
-  if (is("sweep_strip")) { if (num != 0 && num != 64 && num != 128 && num != 256) return false; o.sweep_strip = (uint32_t)num; return true; }
-  if (is("sweep_cpl")) { if (num != 0 && num != 1 && num != 2 && num != 4) return false; o.sweep_cpl = (uint32_t)num; return true; }
-  if (is("sweep_trace")) { o.sweep_trace = num != 0; return true; }
-  if (is("sweep_dirs")) { o.sweep_dirs = num != 0; return true; }
-  if (is("nw_dirs")) { o.nw_dirs = num != 0; return true; }
-  if (is("pack16")) { if (num < 0 || num > 2) return false; o.pack16 = (int)num; return true; }
-  if (is("walk_overlap")) { o.walk_overlap = num != 0; return true; }
-  if (is("nw_moves")) { o.nw_moves = num != 0; return true; }
-  if (is("zero_copy")) { if (eq("auto")) { o.zero_copy = 4; return true; } if (num < 0 || num > 3) return false; o.zero_copy = (uint32_t)num; return true; }
-  if (is("timing")) { o.timing = num != 0; return true; }
+  if (is("trace_kernel")) { if (!name_of(kWalkerNames, 3, &idx)) return false; o.trace_kernel = (uint32_t)idx; return true; }
+  if (is("sweep_mode")) { if (!name_of(kSweepModes, 3, &idx)) return false; o.sweep_mode = idx; return true; }
+  if (is("sweep_strip")) { if (!number(0, 256, &num) || (num != 0 && num != 64 && num != 128 && num != 256)) return false; o.sweep_strip = (uint32_t)num; return true; }
+  if (is("sweep_cpl")) { if (!number(0, 4, &num) || num == 3) return false; o.sweep_cpl = (uint32_t)num; return true; }
+  if (is("sweep_trace")) return flag(&o.sweep_trace);
+  if (is("sweep_dirs")) return flag(&o.sweep_dirs);
+  if (is("nw_dirs")) return flag(&o.nw_dirs);
+  if (is("pack16")) { if (!number(0, 2, &num)) return false; o.pack16 = (int)num; return true; }
+  if (is("walk_overlap")) return flag(&o.walk_overlap);
+  if (is("nw_moves")) return flag(&o.nw_moves);
+  if (is("zero_copy")) { if (eq("auto")) { o.zero_copy = 4; return true; } if (!number(0, 3, &num)) return false; o.zero_copy = (uint32_t)num; return true; }
+  if (is("timing")) return flag(&o.timing);
   if (is("chunk_bytes")) {
-    if (num != 0 && num < (1 << 20)) return false;
+    if (!number(0, (long long)1 << 60, &num) || (num != 0 && num < (1 << 20))) return false;
     o.chunk_bytes = (size_t)num;
     if (num) ctx->chunk_budget = (size_t)num; else ctx->chunk_budget = ctx->chunk_budget_default;
     return true;
   }
-  if (is("subbatches")) { if (num < 0 || num > 256) return false; o.subbatches = (uint32_t)num; return true; }
-  if (is("arena_scan_gib")) { if (num < 0 || num > 1024) return false; o.arena_scan_gib = (uint32_t)num; return true; }
-  if (is("arena_quality")) { const double q = atof(val); if (!(q > 0.5 && q < 1.5)) return false; o.arena_quality = (float)q; return true; }
+  if (is("subbatches")) { if (!number(0, 256, &num)) return false; o.subbatches = (uint32_t)num; return true; }
+  if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
+  if (is("arena_quality")) {
+    char *end = nullptr;
+    const double q = strtod(val, &end);
+    if (end == val || *end || !(q > 0.5 && q < 1.5)) return false;
+    o.arena_quality = (float)q;
+    return true;
+  }
+  return false;
+}
+
+// the value in force, as set_option would take it
+static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *out) {
+  const SaOptions &o = ctx->opt;
+  auto is = [&](const char *k) { return !strcmp(key, k); };
+  auto n = [&](long long v) { *out = std::to_string(v); return true; };
+  if (is("kernel")) { *out = kKernelNames[o.kernel]; return true; }
+  if (is("cpl")) return n(o.cpl);
+  if (is("wpb")) return n(o.wpb);
+  if (is("lds_pad")) return n(o.lds_pad);
+  if (is("traceback")) { *out = o.traceback_host ? "host" : "device"; return true; }
+  if (is("trace_kernel")) { *out = kWalkerNames[o.trace_kernel]; return true; }
+  if (is("sweep_mode")) { *out = kSweepModes[o.sweep_mode]; return true; }
+  if (is("sweep_strip")) return n(o.sweep_strip);
+  if (is("sweep_cpl")) return n(o.sweep_cpl);
+  if (is("sweep_trace")) return n(o.sweep_trace);
+  if (is("sweep_dirs")) return n(o.sweep_dirs);
+  if (is("nw_dirs")) return n(o.nw_dirs);
+  if (is("pack16")) return n(o.pack16);
+  if (is("walk_overlap")) return n(o.walk_overlap);
+  if (is("nw_moves")) return n(o.nw_moves);
+  if (is("zero_copy")) { if (o.zero_copy == 4) { *out = "auto"; return true; } return n(o.zero_copy); }
+  if (is("timing")) return n(o.timing);
+  if (is("chunk_bytes")) return n((long long)o.chunk_bytes);
+  if (is("subbatches")) return n(o.subbatches);
+  if (is("arena_scan_gib")) return n(o.arena_scan_gib);
+  if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
   return false;
 }
 
@@ -182,6 +269,14 @@ extern "C" int seqalign_ctx_set_option(seqalign_ctx_t *ctx, const char *key, con
     set_last_error(std::string("seqalign_ctx_set_option: no option \"") + key + "\" with value \"" + value + "\"");
     return SEQALIGN_E_ARG;
   }
+  return SEQALIGN_OK;
+}
+
+extern "C" int seqalign_ctx_get_option(const seqalign_ctx_t *ctx, const char *key, char *value, size_t cap) {
+  if (!ctx || !key || !value) return SEQALIGN_E_ARG;
+  std::string v;
+  if (!get_option(ctx, key, &v) || v.size() + 1 > cap) return SEQALIGN_E_ARG;
+  memcpy(value, v.c_str(), v.size() + 1);
   return SEQALIGN_OK;
 }
 
@@ -395,6 +490,8 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     if (reports) { if (cand_done) *cand_done = true; }
     else p.cand_count = nullptr;
   }
+  if (which >= SEQALIGN_KERNEL_WAVEFRONT && which <= SEQALIGN_KERNEL_WGSTREAM)
+    sa_record_launch(SEQALIGN_K_FILL_WAVEFRONT + (which - SEQALIGN_KERNEL_WAVEFRONT), batch->n_pairs);
   switch (which) {
     case SEQALIGN_KERNEL_WAVEFRONT: e = sa_launch_fill_wavefront(p, batch->max_len_a, st); break;
     case SEQALIGN_KERNEL_STREAM: e = sa_launch_fill_stream(p, batch->max_len_a, st); break;
@@ -527,6 +624,7 @@ bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_de
 
 extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
                                           const seqalign_dev_batch_t *batch, int kernel, void *stream) {
+  CallScope scope(ctx);
   return fill_device(ctx, scoring, batch, kernel, stream, nullptr, nullptr, nullptr);
 }
 
@@ -536,6 +634,7 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
                                      const seqalign_dev_batch_t *batch, int kernel, void *stream,
                                      int repeats, float *ms_each) {
   if (!ctx || repeats <= 0 || !ms_each) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   EventList events;   // destroyed on every exit path
   for (int r = 0; r < 2 * repeats; ++r) HIP_TRY(events.add());
@@ -555,6 +654,7 @@ extern "C" int seqalign_time_fill_ms(seqalign_ctx_t *ctx, const seqalign_dev_sco
 static int launch_traceback(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b,
                             const seqalign_trace_t *t, void *stream, bool sw) {
   if (!ctx || !sc || !b || !t) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   if (sw && (!t->start_index || !t->out_pos)) return SEQALIGN_E_ARG;
   if (b->n_pairs == 0) return SEQALIGN_OK;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -587,6 +687,7 @@ extern "C" int seqalign_sw_traceback_device(seqalign_ctx_t *ctx, const seqalign_
 
 extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_reduce_t *r, void *stream) {
   if (!ctx || !r) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
   if (r->n_pairs == 0) return SEQALIGN_OK;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   SaReduceParams p;
@@ -807,6 +908,7 @@ int combine_and_run(OneRequest *req) {
 extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is_sw, const char *a, size_t len_a,
                                 const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
   if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
+  CallScope scope(ctx);
   HIP_TRY(hipSetDevice(ctx->device));
   seqalign_dev_scoring *dsc = nullptr;
   { int rc = cached_scoring(ctx, sc, is_sw, &dsc); if (rc) return rc; }

@@ -298,6 +298,7 @@ bool sa_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const ui
 
 hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_FILL_SW_DIRS, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_dirs_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_dirs_cpl<2, 512>(p, dirs, stream);
@@ -319,6 +320,7 @@ bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const
 
 hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_FILL_NW_DIRS, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_nw_dirs_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_nw_dirs_cpl<2, 512>(p, dirs, stream);

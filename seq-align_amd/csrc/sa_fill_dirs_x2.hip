@@ -810,6 +810,7 @@ bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_nw_dirs_x2_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_nw_dirs_x2_cpl<2, 512>(p, dirs, stream);
@@ -829,6 +830,7 @@ bool sa_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t m
 
 hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_FILL_SW_DIRS_X2, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_dirs_x2_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_dirs_x2_cpl<2, 512>(p, dirs, stream);
@@ -851,6 +853,7 @@ bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X2, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_sw_best_x2_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_sw_best_x2_cpl<2, 512>(p, dirs, stream);
@@ -866,6 +869,9 @@ hipError_t sa_launch_fill_nw_dirs_mixed(const SaFillParams &p, uint32_t max_len_
                                         hipStream_t stream) {
   if (n_modal + n_rest == 0) return hipSuccess;
   if (!p.pair_list) return hipErrorInvalidValue;
+  // one grid, two kinds of waves: the modal shape's pairs two per wave, the rest one per wave
+  if (n_modal) sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, n_modal);
+  if (n_rest) sa_record_launch(SEQALIGN_K_FILL_NW_DIRS, n_rest);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);   // (of the widest pair: the packed waves take it too)
   if (need <= 1) return sa::launch_nw_dirs_mixed_cpl<1, 512>(p, dirs, n_modal, n_rest, stream);
   if (need <= 2) return sa::launch_nw_dirs_mixed_cpl<2, 512>(p, dirs, n_modal, n_rest, stream);

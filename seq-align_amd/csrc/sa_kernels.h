@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "seqalign_hip.h"
+
 /* Everything one fill launch needs; passed by value as the kernarg. */
 struct SaFillParams {
   const uint8_t *arena;
@@ -192,6 +194,11 @@ struct SaTraceParams {
   uint32_t *out_meta2;
 };
 #define SA_MOVES_ERR 0xFFFFFFF0u
+
+/* ---- which kernels a call launched (seqalign_ctx_last_call_info, include/seqalign_hip.h: SEQALIGN_K_*) ------------------
+ * Every launcher below reports what it launches and for how many pairs / walks to the calling thread's recorder
+ * (sa_device.hip), which the C-ABI entry points point at their context for the duration of the call. */
+void sa_record_launch(int kind, uint64_t items);
 
 /* substitution lookup flavour */
 enum { SA_SUBST_SIMPLE = 0, SA_SUBST_LDS = 1, SA_SUBST_GLOBAL = 2 };

@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(kWave) sw_box_kernel(const SaReduceParams p, c
 
 hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, uint32_t max_len_b, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_SW_BOX, p.n_pairs);
   hipLaunchKernelGGL(sa::sw_box_init_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, stream, c, p.n_pairs);
   const uint32_t rows_per_block = std::max<uint32_t>(sa::kBoxRows, (max_len_b + 65535u) / 65535u);   // (grid.y limit)
   const uint32_t row_blocks = (max_len_b + rows_per_block) / rows_per_block;
@@ -270,6 +271,7 @@ hipError_t sa_launch_sw_box(const SaReduceParams &p, const SaCandBox &c, uint32_
 
 hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  sa_record_launch(SEQALIGN_K_SW_REDUCE, p.n_pairs);
   if (p.slices > 1 && !p.cand_count && !p.cand_cap && p.n_pairs <= 32768u) {   // few long pairs, best cell only
     hipLaunchKernelGGL(sa::sw_best_init_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, stream, p.best_index, p.n_pairs);
     hipLaunchKernelGGL(sa::sw_best_slices_kernel, dim3(p.n_pairs, p.slices), dim3(sa::kWave), 0, stream, p, p.slices);

@@ -877,6 +877,7 @@ hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.dirs) {   // behind sa_fill_dirs.hip: match_scores + a byte of directions per cell (rows up to 512 columns)
     const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;
     if (need > 8 || p.strip_progress) return hipErrorInvalidValue;
+    sa_record_launch(SEQALIGN_K_SWEEP_DIRS, p.n_pairs);
     if (need <= 2) sa::launch_sweep_dirs<2>(p, stream);
     else if (need <= 3) sa::launch_sweep_dirs<3>(p, stream);
     else if (need <= 4) sa::launch_sweep_dirs<4>(p, stream);
@@ -893,6 +894,7 @@ hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;   // columns per lane for the widest row
   int forced = (int)p.tune_cpl;
   if (forced != 1 && forced != 2 && forced != 4) forced = 0;
+  sa_record_launch(p.strip_progress ? SEQALIGN_K_SWEEP_STRIPS : (!forced && need <= 8) ? SEQALIGN_K_SWEEP_REGS : SEQALIGN_K_SWEEP_LDS, p.n_pairs);
   if (p.strip_progress) {
     if (p.strip_columns == 64) sa::launch_sweep<1, sa::SA_ROWS_STRIP>(p, stream);
     else if (p.strip_columns == 128) sa::launch_sweep<2, sa::SA_ROWS_STRIP>(p, stream);

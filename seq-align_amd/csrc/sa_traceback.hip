@@ -520,13 +520,17 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (!p.nw_score) return hipErrorInvalidValue;
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
+        sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
         if (tiles) hipLaunchKernelGGL(sa::traceback_nw_moves_tile_kernel, dim3(p.n_pairs), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL(sa::traceback_nw_moves_lane_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
-      } else
+      } else {
+      sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+      }
     } else {            // SW hits behind sa_fill_dirs.hip
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
+      sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<false>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     }
@@ -539,6 +543,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   // SW walks (a hit is ~the shorter sequence long): the tiled walker also wins with 10 000 walks (C3: 0.58 -> 0.47 ms,
   // C4: 0.88 -> 0.45 ms)
   const bool lane_kernel = p.tune_walker ? p.tune_walker == 1 : (!sw && p.n_pairs >= 2048);
+  sa_record_launch(lane_kernel ? SEQALIGN_K_WALK_LANE : SEQALIGN_K_WALK_WAVE, p.n_pairs);
   if (lane_kernel) {
     const dim3 grid((p.n_pairs + 63) / 64), block(64);   // one wave per workgroup: spread over all CUs
     if (sw) hipLaunchKernelGGL(sa::traceback_kernel<true>, grid, block, 0, stream, p);

@@ -104,6 +104,7 @@ def lib():
         l = C.CDLL(str(LIB_PATH))
         l.seqalign_strerror.restype = C.c_char_p
         l.seqalign_last_error.restype = C.c_char_p
+        l.seqalign_kernel_kind_name.restype = C.c_char_p
         l.needleman_wunsch_new.restype = C.c_void_p
         l.smith_waterman_new.restype = C.c_void_p
         l.alignment_create.restype = C.c_void_p
@@ -151,7 +152,15 @@ def batch_desc(batch: "workloads.Batch") -> BatchDesc:
 
 OPTION_DEFAULTS = {"kernel": "auto", "cpl": 0, "wpb": 0, "lds_pad": 0, "traceback": "device", "trace_kernel": "auto",
                    "sweep_mode": "auto", "sweep_strip": 0, "sweep_cpl": 0, "sweep_trace": 0, "sweep_dirs": 1, "nw_dirs": 1, "pack16": 1, "walk_overlap": 1, "timing": 0, "chunk_bytes": 0,
-                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045}
+                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "nw_moves": 1, "zero_copy": "auto"}
+
+
+K_MAX = 32
+
+
+class CallInfo(C.Structure):
+    """seqalign_call_info_t (include/seqalign_hip.h)."""
+    _fields_ = [("launches", C.c_uint32 * K_MAX), ("items", C.c_uint64 * K_MAX)]
 
 
 class ArenaInfo(C.Structure):
@@ -190,23 +199,43 @@ class Context:
 
     # ---- options (seqalign_ctx_set_option: key = SEQALIGN_<KEY> in lower case) -----------------
     def set_option(self, key: str, value) -> None:
+        if isinstance(value, (bool, np.bool_)):
+            value = int(value)          # str(True) is "True": the library takes 1 / 0 (and true / false, on / off, yes / no)
         _check(lib().seqalign_ctx_set_option(self._h, key.encode(), str(value).encode()), f"seqalign_ctx_set_option({key}={value})")
 
+    def get_option(self, key: str) -> str:
+        """The value in force, as text (what set_option would take)."""
+        buf = C.create_string_buffer(64)
+        _check(lib().seqalign_ctx_get_option(self._h, key.encode(), buf, C.c_size_t(64)), f"seqalign_ctx_get_option({key})")
+        return buf.value.decode()
+
     def options(self, **kv):
-        """Context manager: set options on THIS context, put the given defaults back on exit.
-        `with ctx.options(traceback="host"): ...`; the values restored are OPTION_DEFAULTS'."""
+        """Context manager: set options on THIS context, put back on exit what was in force before -- whatever set it
+        (SEQALIGN_* at context creation, an earlier set_option): `with ctx.options(traceback="host"): ...`."""
         ctx = self
 
         class _Scope:
             def __enter__(self_inner):
+                self_inner.before = {k: ctx.get_option(k) for k in kv}
                 for k, v in kv.items():
                     ctx.set_option(k, v)
                 return ctx
 
             def __exit__(self_inner, *exc):
-                for k in kv:
-                    ctx.set_option(k, OPTION_DEFAULTS[k])
+                for k, v in self_inner.before.items():
+                    ctx.set_option(k, v)
         return _Scope()
+
+    def last_call(self) -> dict:
+        """seqalign_ctx_last_call_info as {kind name: (launches, items)} for the kinds the last call launched."""
+        info = CallInfo()
+        _check(lib().seqalign_ctx_last_call_info(self._h, C.byref(info)), "seqalign_ctx_last_call_info")
+        out = {}
+        for k in range(K_MAX):
+            if info.launches[k]:
+                name = lib().seqalign_kernel_kind_name(C.c_int(k))
+                out[name.decode() if name else f"kind{k}"] = (int(info.launches[k]), int(info.items[k]))
+        return out
 
     # ---- scoring -----------------------------------------------------------
     def upload_scoring(self, scoring: Scoring, is_sw: int) -> C.c_void_p:
@@ -506,7 +535,8 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
-    "seqalign_arenas_info", "seqalign_ctx_set_option", "seqalign_ctx_stream",
+    "seqalign_arenas_info", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
+    "seqalign_kernel_kind_name", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",

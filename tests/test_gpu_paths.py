@@ -1,0 +1,212 @@
+"""GPU tier: WHICH kernels a call launched (seqalign_ctx_last_call_info), and the packed int16 fills at the edge of
+their admission bound.
+
+Every form of the fill / sweep / walk gives the same results (that is what test_gpu_parity.py checks), so equal results
+cannot tell whether the packed two-pairs-per-wave kernels (sa_fill_dirs_x2.hip) ran or silently declined.  These tests
+ask the library what it launched -- and run the packed kernels where their scores come closest to leaving int16:
+the arithmetic the halves must reproduce is the reference's plain-int recurrence, src/alignment.c:101-155.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import orclib as O
+import seqalign_amd as S
+from seqalign_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with S.Context(0) as c:
+        yield c
+
+
+@pytest.fixture
+def opts(ctx):
+    changed = {}
+
+    def set_(**kv):
+        for k, v in kv.items():
+            changed.setdefault(k, ctx.get_option(k))
+            ctx.set_option(k, v)
+    yield set_
+    for k, v in changed.items():
+        ctx.set_option(k, v)
+
+
+def osc_of(sc):
+    return O.Scoring.from_buffer_copy(bytes(sc))
+
+
+def uniform(n, la, lb, seed, alpha=b"ACGT", related=0.5):
+    rng = W.Rng(seed)
+    al = np.frombuffer(alpha, np.uint8)
+    a = al[rng.below(len(al), n * la).astype(np.int64)].reshape(n, la)
+    b = al[rng.below(len(al), n * lb).astype(np.int64)].reshape(n, lb)
+    k = min(la, lb)
+    if k:
+        keep = rng.unit(n * k).reshape(n, k) < 0.8
+        m = int(n * related)
+        b[:m, :k] = np.where(keep[:m], a[:m, :k], b[:m, :k])
+    return W._fixed_batch(a, b)
+
+
+# ------------------------------------------------------------------ which kernels ran ---
+
+def test_nw_batch_reports_its_kernels(ctx, opts):
+    sc = S.make_scoring({"preset": "default"})
+    batch = uniform(64, 150, 150, 1)
+    opts(pack16=2)
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call() == {"fill_nw_dirs_x2": (1, 64), "walk_moves_tile": (1, 64)}
+    opts(pack16=1)          # 64 pairs: below the size from which packing pays
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call() == {"fill_nw_dirs": (1, 64), "walk_moves_tile": (1, 64)}
+    opts(pack16=2, trace_kernel="lane")
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call() == {"fill_nw_dirs_x2": (1, 64), "walk_moves_lane": (1, 64)}
+    opts(trace_kernel="auto", nw_moves=0)     # strings home instead of moves
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call() == {"fill_nw_dirs_x2": (1, 64), "walk_dirs_tile": (1, 64)}
+    opts(nw_moves=1, nw_dirs=0)               # three matrices
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call() == {"fill_stream": (1, 64), "walk_wave": (1, 64)}
+    opts(nw_dirs=1, subbatches=3)
+    ctx.nw_batch(batch, sc)
+    got = ctx.last_call()
+    assert got["fill_nw_dirs_x2"][1] == 64 and got["fill_nw_dirs_x2"][0] in (2, 3) and got["walk_moves_tile"][1] == 64
+    # a scoring with flags is outside the direction fills' domain
+    opts(subbatches=0)
+    ctx.nw_batch(batch, S.make_scoring({"init": [1, -2, -4, -1, 1, 1, 0, 0, 0, 0]}))
+    assert set(ctx.last_call()) == {"fill_stream", "walk_wave"}
+    # at a size where the packed kernel is the library's own choice
+    big = uniform(2304, 100, 120, 2)
+    opts(pack16=1)
+    ctx.nw_batch(big, sc)
+    assert ctx.last_call() == {"fill_nw_dirs_x2": (1, 2304), "walk_moves_tile": (1, 2304)}
+
+
+def test_mostly_one_shape_reports_both_kinds_of_waves(ctx, opts):
+    sc = S.make_scoring({"preset": "default"})
+    rng = W.Rng(77)
+    pairs = []
+    for k in range(300):
+        la, lb = (100, 100) if k % 5 else (int(rng.below(150, 1)[0]), int(rng.below(150, 1)[0]))
+        pairs.append((bytes(b"ACGT"[i] for i in rng.below(4, la)), bytes(b"ACGT"[i] for i in rng.below(4, lb))))
+    batch = W.from_pairs(pairs)
+    n_modal = sum(1 for a, b in pairs if (len(a), len(b)) == (100, 100))
+    opts(pack16=2)
+    ctx.nw_batch(batch, sc)
+    got = ctx.last_call()
+    assert got["fill_nw_dirs_x2"][1] == n_modal and got["fill_nw_dirs"][1] == 300 - n_modal
+    opts(pack16=0)
+    ctx.nw_batch(batch, sc)
+    assert ctx.last_call()["fill_nw_dirs"] == (1, 300) and "fill_nw_dirs_x2" not in ctx.last_call()
+
+
+def test_sw_batch_reports_its_kernels(ctx, opts):
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    batch = uniform(48, 120, 200, 3)
+    opts(pack16=2)
+    ctx.sw_batch(batch, sc, 20, max_hits=4)
+    got = ctx.last_call()
+    assert got["fill_sw_dirs_x2"] == (1, 48) and "fill_sw_dirs" not in got and "fill_stream" not in got
+    assert any(k.startswith("sweep_dirs") for k in got) and any(k.startswith("walk_dirs") for k in got)
+    ctx.sw_batch(batch, sc, 20, max_hits=1)
+    got = ctx.last_call()
+    assert got["fill_sw_best_x2"] == (1, 48) and "sw_reduce" not in got
+    opts(pack16=0)
+    ctx.sw_batch(batch, sc, 20, max_hits=4)
+    got = ctx.last_call()
+    assert got["fill_sw_dirs"] == (1, 48) and "fill_sw_dirs_x2" not in got
+    opts(sweep_dirs=0)
+    ctx.sw_batch(batch, sc, 20, max_hits=4)
+    got = ctx.last_call()
+    assert "fill_stream" in got and "sweep_regs" in got and not any("dirs" in k for k in got)
+
+
+def test_device_level_calls_report_too(ctx):
+    sc = S.make_scoring({"preset": "default"})
+    batch = uniform(32, 90, 90, 4)
+    h = ctx.upload_scoring(sc, 0)
+    db = S.DeviceBatch(batch, 0)
+    for kernel, name in ((S.KERNEL_STREAM, "fill_stream"), (S.KERNEL_ROWSCAN, "fill_rowscan"), (S.KERNEL_WAVEFRONT, "fill_wavefront")):
+        db.fill(ctx, h, kernel)
+        assert ctx.last_call() == {name: (1, 32)}
+    ctx.release_scoring(h)
+
+
+# --------------------------------------------------------- the int16 bound at its edge ---
+
+def x2_bound(la, lb, match, mismatch, gap_open, gap_extend):
+    """sa_x2_scores_fit (csrc/sa_fill_dirs_x2.hip): every score of a la x lb pair stays inside int16 when this is <= 30 000."""
+    pen = max(abs(match), abs(mismatch), abs(gap_open + gap_extend), abs(gap_extend), abs(gap_open) + abs(gap_extend))
+    return (la + lb + 2) * pen + (la + 1) * abs(gap_extend)
+
+
+def edge_cases():
+    """(la, lb, scoring numbers, bound) just inside and just outside the bound, at the widest admitted row and at read size."""
+    out = []
+    for la, lb in ((511, 300), (150, 150), (300, 300), (64, 511)):
+        for ext in (-1, -7):
+            inside = outside = None
+            for pen in range(8, 200):
+                b = x2_bound(la, lb, pen, -pen, -(pen + ext) if pen + ext > 0 else 0, ext)
+                if b <= 30000 and b >= 29400:
+                    inside = (pen, b)
+                if b > 30000 and outside is None:
+                    outside = (pen, b)
+            if inside:
+                out.append((la, lb, inside[0], ext, inside[1], True))
+            if outside:
+                out.append((la, lb, outside[0], ext, outside[1], False))
+    return out
+
+
+def worst_case_pairs(la, lb, seed):
+    """Identical sequences (the highest scores), nothing in common (the lowest: all mismatches or all gaps), one long gap,
+    and random ones -- all of ONE shape."""
+    rng = W.Rng(seed)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+    base = rnd(max(la, lb))
+    pairs = [(base[:la], base[:lb]), (b"A" * la, b"C" * lb), (b"A" * la, b"A" * lb), (base[:la], base[::-1][:lb]),
+             (rnd(la), rnd(lb)), (b"AC" * (la // 2) + b"A" * (la % 2), b"CA" * (lb // 2) + b"C" * (lb % 2)),
+             ((b"A" * (la // 2) + base)[:la], (base + b"A" * lb)[:lb])]
+    return pairs
+
+
+@pytest.mark.parametrize("la,lb,pen,ext,bound,packs", edge_cases(), ids=lambda v: str(v))
+def test_packed_fills_at_the_edge_of_int16(ctx, opts, la, lb, pen, ext, bound, packs):
+    """Scorings whose admission bound evaluates to just under / just over 30 000 on worst-case inputs at that shape: packed
+    (and equal to the oracle) / NOT packed (the 32-bit kernels take the chunk, same results).  Three score profiles per
+    bound: match-heavy, mismatch-heavy, gap-heavy."""
+    assert (bound <= 30000) == packs
+    go = -(pen + ext) if pen + ext > 0 else 0            # gap_open + gap_extend = -pen: the first gap character costs `pen`
+    profiles = [(pen, -pen, go, ext), (max(1, pen // 3), -pen, go, ext), (pen, -max(1, pen // 2), min(0, go // 4), ext)]
+    opts(pack16=2)
+    for match, mismatch, gap_open, gap_extend in profiles:
+        spec = {"init": [match, mismatch, gap_open, gap_extend, 0, 0, 0, 0, 0, 0], "wildcards": []}
+        fits = x2_bound(la, lb, match, mismatch, gap_open, gap_extend) <= 30000
+        sc = S.make_scoring(spec)
+        osc = osc_of(sc)
+        pairs = worst_case_pairs(la, lb, 31 * la + lb + pen)
+        batch = W.from_pairs(pairs)
+        got = ctx.nw_batch(batch, sc)
+        info = ctx.last_call()
+        assert ("fill_nw_dirs_x2" in info) == fits, (spec, info)
+        if not fits:
+            assert info.get("fill_nw_dirs", (0, 0))[1] == len(pairs), (spec, info)
+        for p, (a, b) in enumerate(pairs):
+            rc, s_, ra, rb = O.oracle_nw(osc, a, b)
+            assert rc == 0 and got[p] == (s_, ra, rb), (spec, "nw", p)
+        for max_hits in (1, 3):
+            thr = max(1, match * 2)
+            got_sw = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
+            info = ctx.last_call()
+            assert (("fill_sw_best_x2" if max_hits == 1 else "fill_sw_dirs_x2") in info) == fits, (spec, max_hits, info)
+            for p, (a, b) in enumerate(pairs):
+                rc, want = O.oracle_sw(osc, a, b, thr, max_hits)
+                assert rc == 0 and got_sw[p] == want, (spec, "sw", max_hits, p)
