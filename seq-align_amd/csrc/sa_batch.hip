@@ -275,17 +275,18 @@ int sa_host::fill_batch_uploaded(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     // four: three pageable copies, each waited for, and the status.)
     const size_t small = c.cells * 4;
     if (3 * small <= ((size_t)4 << 20)) {
-      if ((rc = ctx->h_M.reserve(3 * small + c.count * 8 + 64))) break;
+      const size_t status_at = (3 * small + 7) & ~(size_t)7;   // (uint64 words: 8-byte aligned whatever the cell count)
+      if ((rc = ctx->h_M.reserve(status_at + c.count * 8 + 64))) break;
       char *pin = ctx->h_M.as<char>();
       hipStream_t st = ctx->stream;
       StreamSyncOnExit sync(st);
       HIP_TRY(hipMemcpyAsync(pin, ctx->M.p, small, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(pin + small, ctx->A.p, small, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(pin + 2 * small, ctx->B.p, small, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(pin + 3 * small, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(pin + status_at, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       uint64_t dev_cell = 0;
-      const uint64_t *h_status = reinterpret_cast<const uint64_t *>(pin + 3 * small);
+      const uint64_t *h_status = reinterpret_cast<const uint64_t *>(pin + status_at);
       for (uint64_t k = 0; k < c.count; ++k) {
         const uint64_t p = c.first + k, cells = (uint64_t)(batch->len_a[p] + 1ull) * (batch->len_b[p] + 1ull);
         memcpy(M + mat_off[p], pin + dev_cell * 4, cells * 4);
@@ -576,7 +577,9 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   }
   tm.lap("nw pipelined: all sub-batches packed + enqueued");
 
-  std::atomic<int> first_error{SEQALIGN_OK};
+  // an error is the LOWEST failing pair's, whichever worker meets one first; pairs without an error have been written by
+  // then (outputs are unspecified after a failed call)
+  std::atomic<uint64_t> first_bad{~0ull};
   double wait_ms = 0, copy_ms = 0;   // (option timing: the lap below split into waiting for the GPU / copying out)
   auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
   for (g = 0; g < n_grp; ++g) {   // strings of group g from the pinned block into the caller's buffers
@@ -592,7 +595,12 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
         const uint64_t p = c.first + k;
         const uint32_t head = h_meta[4 * k], len = h_meta[4 * k + 1], status = h_meta[4 * k + 3];
-        if (status) { int expected = SEQALIGN_OK; first_error.compare_exchange_strong(expected, (int)status); continue; }
+        if (status) {
+          uint64_t seen = first_bad.load(std::memory_order_relaxed);
+          const uint64_t mine = k << 8 | (uint64_t)(status & 255u);
+          while (mine < seen && !first_bad.compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {}
+          continue;
+        }
         memcpy(out_a + str_off[p], ha + h_slot[k] + head, len);   // left-align (needleman_wunsch.c:135-145)
         memcpy(out_b + str_off[p], hb + h_slot[k] + head, len);
         out_a[str_off[p] + len] = out_b[str_off[p] + len] = '\0';
@@ -601,8 +609,8 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       }
     });
     copy_ms += now_ms() - t_c;
-    if ((rc = first_error.load())) return rc;
   }
+  if (first_bad.load() != ~0ull) return (int)(first_bad.load() & 255u);
   if (ctx->opt.timing) fprintf(stderr, "[seqalign timing] nw pipelined: waiting for the groups %.3f ms, copying their strings out %.3f ms\n", wait_ms, copy_ms);
   tm.lap("nw pipelined: all groups unpacked");
   return SEQALIGN_OK;

@@ -264,6 +264,7 @@ struct seqalign_ctx {
   sa_host::DevBuf arena, off_a, pair_list, status;   // (off_a holds all five descriptor arrays; pair_list: nw_chunk_pipelined's mixed chunks)
   sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
   SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
+  uint32_t arena_walks = 0;          // how often reserve_arenas has placed them (the first walk is the full one)
   sa_host::HostBuf h_one;            // the legacy single-pair call: descriptor + sequences + three matrices + status of ONE pair,
   void *one_dev = nullptr;           // pinned, read and written in place by the GPU (sa_fill_one_pair); its device address
   sa_host::DevBuf dirs;              // seqalign_nw_batch: one byte of directions per cell (sa_fill_dirs.hip)

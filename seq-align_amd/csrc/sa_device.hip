@@ -82,10 +82,19 @@ extern "C" const char *seqalign_kernel_kind_name(int kind) {
 }
 
 // ----------------------------------------------------------------- context ---
-static SaPlacementOpts placement_opts(const seqalign_ctx *ctx) {
+// explicit = seqalign_arenas_alloc (the caller asked for placed arenas and keeps them); otherwise the context's own scratch
+// growing under a host-level call: the first time a context gets the full walk, later growths -- rare: the arenas grow by
+// half each time -- look around in a quarter of the free memory and 16 GiB at most, so that a long-lived process does not
+// repeat a 160 GiB walk whenever a batch is larger than the last
+static SaPlacementOpts placement_opts(const seqalign_ctx *ctx, bool explicit_call) {
   SaPlacementOpts o;
   o.scan_bytes = (size_t)ctx->opt.arena_scan_gib << 30;
   o.quality_stop = ctx->opt.arena_quality;
+  o.free_fraction = 0.6f;
+  if (!explicit_call) {
+    o.free_fraction = 0.25f;
+    if (ctx->arena_walks > 0) o.scan_bytes = std::min<size_t>(o.scan_bytes, (size_t)16 << 30);
+  }
   return o;
 }
 
@@ -99,10 +108,11 @@ int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
     ctx->arena_set = nullptr;
   }
   ctx->M = DevBuf(); ctx->A = DevBuf(); ctx->B = DevBuf();   // views of the set, never freed on their own
-  const size_t want = bytes + bytes / 8 + 4096;
+  const size_t want = bytes + (ctx->arena_walks ? bytes / 2 : bytes / 8) + 4096;
   SaArenaSet *set = nullptr;
-  hipError_t e = sa_arenas_create(ctx->device, want, ctx->stream, placement_opts(ctx), &set);
+  hipError_t e = sa_arenas_create(ctx->device, want, ctx->stream, placement_opts(ctx, false), &set);
   if (e != hipSuccess) return fail_hip(e, "matrix arenas");
+  ctx->arena_walks++;
   ctx->arena_set = set;
   void *const *a = sa_arenas_base(set);
   ctx->M.p = a[0]; ctx->A.p = a[1]; ctx->B.p = a[2];
@@ -114,7 +124,7 @@ extern "C" int seqalign_arenas_alloc(seqalign_ctx_t *ctx, uint64_t bytes_each, v
   if (!ctx || !arenas || !bytes_each) return SEQALIGN_E_ARG;
   HIP_TRY(hipSetDevice(ctx->device));
   SaArenaSet *set = nullptr;
-  hipError_t e = sa_arenas_create(ctx->device, (size_t)bytes_each, ctx->stream, placement_opts(ctx), &set);
+  hipError_t e = sa_arenas_create(ctx->device, (size_t)bytes_each, ctx->stream, placement_opts(ctx, true), &set);
   if (e != hipSuccess) return fail_hip(e, "matrix arenas");
   for (int k = 0; k < 3; ++k) arenas[k] = sa_arenas_base(set)[k];
   if (quality) *quality = sa_arenas_info(set)->quality;

@@ -271,6 +271,7 @@ struct SaArenaInfo {   /* = seqalign_arena_info_t (include/seqalign_hip.h) */
 struct SaPlacementOpts {
   size_t scan_bytes;     /* device memory the walk may hold transiently besides the arenas; 0 = allocate plainly */
   float quality_stop;    /* probe ratio that ends the walk */
+  float free_fraction;   /* ... and never more than this share of the memory free at its start (0: the default, 0.6) */
 };
 struct SaArenaSet;
 hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out);

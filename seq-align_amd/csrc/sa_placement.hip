@@ -202,6 +202,12 @@ namespace {
 std::mutex g_sets_mu;
 std::map<void *, SaArenaSet *> g_sets;   // by base[0]
 
+// One walk per device at a time, process-wide: a walk sizes itself from the memory that is free when it starts and holds
+// tens of GiB of chunks for a moment -- two of them at once (two contexts, two threads of the legacy API) would each claim
+// their share of the SAME free memory and could drive the device out of memory under a third party's hipMalloc.
+constexpr int kMaxDevices = 64;
+std::mutex g_walk_mu[kMaxDevices];
+
 void register_set(SaArenaSet *s) {
   std::lock_guard<std::mutex> lk(g_sets_mu);
   g_sets[s->base[0]] = s;
@@ -249,12 +255,18 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   const size_t chunk = (size_t)512 << 20;
   size_t free_b = 0, total_b = 0;
   const VmmEnv env = vmm_env(device);
+  std::unique_lock<std::mutex> one_walk;
+  if (opt.scan_bytes && device >= 0 && device < kMaxDevices) one_walk = std::unique_lock<std::mutex>(g_walk_mu[device]);
   // small arenas are not bandwidth-bound; without the VMM API, or without room to look around, allocate plainly
   const bool place = opt.scan_bytes && bytes >= ((size_t)256 << 20) && env.ok && g_retired_va.load() < kRetiredVaLimit &&
                      hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   const size_t per = (bytes + chunk - 1) / chunk;                       // chunks per arena
-  const size_t budget = place ? std::min<size_t>(opt.scan_bytes + 3 * per * chunk, free_b / 10 * 6) : 0;
+  // what the walk may hold at its peak: the arenas + scan_bytes, and never more than `free_fraction` of what is free NOW --
+  // re-checked as the pool grows (grow_to), because other tenants of the device keep allocating while we look around
+  const double frac = opt.free_fraction > 0 ? opt.free_fraction : 0.6;
+  const size_t budget = place ? std::min<size_t>(opt.scan_bytes + 3 * per * chunk, (size_t)(free_b * frac)) : 0;
   const size_t pool_max = budget / chunk;
+  const size_t keep_free = place ? (size_t)(free_b * (1.0 - frac)) : 0;   // what must stay free for everybody else
   // the way out whenever placing is not possible (any more): three plain allocations, probed if large enough to matter
   auto plain = [&]() -> hipError_t {
     (void)hipGetLastError();
@@ -271,6 +283,10 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   pool.reserve(pool_max);
   auto grow_to = [&](size_t n) {   // false: the device has no more to give (another tenant): work with what we have
     while (pool.size() < n) {
+      if (pool.size() % 16 == 15) {   // every 8 GiB: is the device still as empty as the budget assumed?
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess && f < keep_free) return false;
+      }
       Handle h;
       if (hipMemCreate(&h, chunk, &env.prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
       pool.push_back(h);

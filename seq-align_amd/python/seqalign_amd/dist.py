@@ -46,6 +46,7 @@ def stdout_to_stderr():
 
 class Group:
     """Thin wrapper so that world_size 1 needs no communication at all."""
+    _made = 0   # store-backed Groups this process has created (part of their key prefix)
 
     def __init__(self, backend: str | None = None, device=None):
         self.rank, self.local_rank, self.world = env_world()
@@ -66,7 +67,13 @@ class Group:
                                is_master=(self.rank == 0 and not agent), timeout=timedelta(seconds=1800),
                                wait_for_workers=False)
             self._tcp = tcp
-            self.store = PrefixStore(f"seqalign/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/", tcp)
+            # The agent's store outlives worker restarts, and a process may make several Groups: every incarnation gets
+            # its own key space -- the restart count torchrun hands the workers, and the number of Groups this process has
+            # made before (every rank makes them in the same order) -- or a barrier would return at once on the keys of
+            # the previous incarnation and max / sum / gather would read its values.
+            incarnation = f"r{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/g{Group._made}"
+            Group._made += 1
+            self.store = PrefixStore(f"seqalign/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{incarnation}/", tcp)
         else:
             import torch.distributed as dist
             kwargs = {}
