@@ -315,10 +315,30 @@ def run(args) -> int:
     db = S.DeviceBatch(batch, local, placement=args.placement, ctx=ctx)   # arenas from seqalign_arenas_alloc
     t_placed = time.perf_counter()
 
-    # kernel choice: measured, not guessed
+    # `e2e` cold: the host-level call right after the placement, before anything else has run -- the first call (it sizes the
+    # context's scratch buffers, uploads the scoring) and the median of the next five, no waiting
+    e2e_cold = None
+    if not args.no_e2e:
+        if is_sw:
+            thr0 = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
+            cold_fn = lambda: ctx.sw_batch(batch, sc, thr0, max_hits=1, hit_cap=batch.n_pairs + 8, raw=True)
+        else:
+            cold_fn = lambda: ctx.nw_batch(batch, sc, raw=True)
+        ts = []
+        for _ in range(6):
+            t1 = time.perf_counter()
+            cold_fn()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        e2e_cold = {"first_call_ms": ts[0], "cold_ms": float(np.median(ts[1:])),
+                    "s_after_placement": time.perf_counter() - t_placed}
+
+    # kernel choice: measured, not guessed -- among the kernels that have ever won a configuration (stream: rows up to 768
+    # columns; wgstream: longer rows); --all-kernels also times the correctness paths (wavefront, rowscan, strips)
     if args.kernel == "auto":
         best = None
-        for k in (S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM, S.KERNEL_STRIPS, S.KERNEL_WGSTREAM):
+        candidates = ((S.KERNEL_WAVEFRONT, S.KERNEL_ROWSCAN, S.KERNEL_STREAM, S.KERNEL_STRIPS, S.KERNEL_WGSTREAM) if args.all_kernels
+                      else (S.KERNEL_STREAM, S.KERNEL_WGSTREAM))
+        for k in candidates:
             ms = db.time_fill_ms(ctx, h, k, 6)[1:]
             m = float(np.median(ms))
             if best is None or m < best[1]:
@@ -365,10 +385,14 @@ def run(args) -> int:
         wall_mine = float(np.median(walls))
         wall = grp.max_float(wall_mine)
         e2e = {"call": call, "ms": wall * 1e3, "value": total_cells / wall / 1e9, "unit": "GCUPS",
-               "includes": "host pack, H2D, fill, device traceback, D2H of the strings, host unpack",
+               "first_call_ms": grp.max_float(e2e_cold["first_call_ms"]), "cold_ms": grp.max_float(e2e_cold["cold_ms"]),
+               "cold_measured_s_after_placement": round(e2e_cold["s_after_placement"], 2),
+               "launched": ctx.last_call(),
+               "includes": "host pack, H2D, fill, device traceback, results home, host expansion into the caller's strings",
                "path": ("plain scoring: the fill writes one byte of directions per cell (NW) / match_scores + that byte (SW, "
-                        "max_hits > 1) instead of the three matrices, the walks follow the bytes (DESIGN.md 3.5b); "
-                        "`value` / `roofline` above are the three-matrix fill, the BASELINE metric"),
+                        "max_hits > 1) instead of the three matrices, the walks follow the bytes (DESIGN.md 3.5b) and send home two "
+                        "bits per alignment column, which the host expands (NW; DESIGN.md 3.5d); `value` / `roofline` above are "
+                        "the three-matrix fill, the BASELINE metric"),
                "ms_this_rank": wall_mine * 1e3}
         if is_sw:   # the multi-hit path: reverse sweep + one traceback per hit
             fn4 = lambda: ctx.sw_batch(batch, sc, thr, max_hits=4, hit_cap=4 * batch.n_pairs + 8, raw=True)
@@ -388,6 +412,22 @@ def run(args) -> int:
         db.fill(ctx, h, kernel, order_after_current=False)
     torch.cuda.synchronize()
     grp.barrier()
+
+    # N > 1: what ONE GPU does on this workload with the others idle (rank 0, a few steps) -- the base the 1 -> N efficiency
+    # should be read against: the N = 1 line of this file is C2 (10 k pairs), the N > 1 lines are C5's 125 k-pair shares
+    scale_base = None
+    if world > 1:
+        if rank == 0:
+            n_alone = max(3, min(20, args.steps))
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            for _ in range(n_alone):
+                db.fill(ctx, h, kernel, order_after_current=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t_a
+            scale_base = {"workload": f"{workload} share of one GPU ({batch.n_pairs} pairs), rank 0 alone, {n_alone} steps",
+                          "per_gpu_alone_gcups": batch.cells() * n_alone / dt / 1e9}
+        grp.barrier()
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -445,7 +485,8 @@ def run(args) -> int:
                        "parallelism": f"pair-sharded x{world}, no data-path collective; control plane: {backend}",
                        "arena_placement": args.placement, "arena_placement_quality": round(db.placement_quality, 3),
                        "arena_placement_search": db.placement_info,
-                       "cells_per_step_per_gpu": batch.cells(), "ranks_share_devices": folded},
+                       "cells_per_step_per_gpu": batch.cells(), "ranks_share_devices": folded,
+                       **({"scale_base": scale_base} if scale_base else {})},
             "bit_exact_vs_oracle": bool(bit_exact),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -454,6 +495,14 @@ def run(args) -> int:
         }
         if e2e:
             e2e.pop("ms_this_rank", None)
+            rec = ROOT / "profiles" / "e2e_roofline.json"
+            if rec.exists():
+                try:
+                    r = json.loads(rec.read_text()).get(f"{workload}:{batch.n_pairs}")
+                    if r:
+                        e2e["roofline"] = r     # bound, kernel, kernel_ms, instructions, frac + where they come from
+                except Exception:
+                    pass
             out["e2e"] = e2e
         out["per_rank"] = per_rank
         worst_q = min((r["arena_placement_quality"] for r in per_rank if r["arena_placement_quality"] is not None
@@ -499,6 +548,8 @@ def main() -> int:
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="C5 at N > 1: weak = 125k pairs per GPU (default), strong = 1M pairs over the N ranks")
     ap.add_argument("--kernel", default="auto", choices=["auto", "wavefront", "rowscan", "stream", "strips", "wgstream"])
+    ap.add_argument("--all-kernels", action="store_true",
+                    help="--kernel auto also times wavefront / rowscan / strips (correctness paths that have never won a configuration)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")

@@ -408,6 +408,13 @@ const char *seqalign_kernel_kind_name(int kind);
 size_t seqalign_cigar(const char *result_a, const char *result_b, size_t length, int extended,
                       int case_insensitive, char *out, size_t cap);
 
+/* ---- diagnostics ---------------------------------------------------------------- */
+/* The host legs of seqalign_nw_batch's direction-byte path alone, no device involved: sizes, offsets and packing of the
+ * sequences (pack_ms), then the expansion of synthetic all-MATCH moves into the caller's strings (expand_ms); averages
+ * over `iterations`.  What one rank's CPU share sustains when N ranks do this at once (seq-align_amd/tools/host_scale.py). */
+int seqalign_host_legs_nw(const seqalign_batch_t *batch, const uint64_t *str_off, char *out_a, char *out_b,
+                          uint32_t *out_len, int iterations, double *pack_ms, double *expand_ms);
+
 /* ---- misc ---------------------------------------------------------------------- */
 /* The context's own stream (a hipStream_t as void*): what NULL means wherever a `stream` is passed.  For callers that
  * keep data in HBM and order their own work (events, copies) with the library's launches -- and a reason not to create

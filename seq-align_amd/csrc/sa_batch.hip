@@ -644,6 +644,7 @@ struct BlkSum {
   uint64_t chars = 0, cells = 0, cells256 = 0;
   uint32_t max_a = 0, max_b = 0;
   bool same = true, too_large = false;
+  bool packed = true;   // the block's sequences lie in the caller's arena as they will in ours: a, b, a, b, ... back to back
 };
 // sizes of pairs [first, first + n) per block of kHostBlk pairs; `same`: every pair of the block has the shape of pair `first`
 void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, uint64_t kHostBlk, std::vector<BlkSum> &blk) {
@@ -660,6 +661,8 @@ void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, uint64_t
       s.max_a = std::max(s.max_a, la); s.max_b = std::max(s.max_b, lb);
       s.same = s.same && la == la0 && lb == lb0;
       s.too_large = s.too_large || cells >= (1ull << 31);
+      s.packed = s.packed && b->off_b[first + k] == b->off_a[first + k] + la &&
+                 (k + 1 == e || b->off_a[first + k + 1] == b->off_b[first + k] + lb);
     }
     blk[bi] = s;
   });
@@ -839,6 +842,11 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
     const uint64_t b0 = bcut[s], b1 = bcut[s + 1], k0 = pair_at(b0), k1 = pair_at(b1);
     if (k1 > k0) {
       parallel_for(b1 - b0, [&](uint64_t bi) {   // host: this sub-batch's sequences into the pinned arena
+        if (blk[b0 + bi].packed) {   // the caller's arena already has them back to back (any batch built pair by pair): one copy
+          const uint64_t k = (b0 + bi) * kHostBlk;
+          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[c.first + k], blk[b0 + bi].chars);
+          return;
+        }
         for (uint64_t k = (b0 + bi) * kHostBlk, e = std::min(n, (b0 + bi + 1) * kHostBlk); k < e; ++k) {
           const uint64_t p = c.first + k;
           memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], h_len_a[k]);
@@ -939,6 +947,65 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   }
   tm.lap("nw moves: groups expanded");
   if (first_bad.load() != ~0ull) return (int)(first_bad.load() & 255u);
+  return SEQALIGN_OK;
+}
+
+// The HOST legs of nw_chunk_moves alone -- sizes, offsets, packing the sequences; then the expansion of (synthetic: all
+// MATCH) moves into the caller's strings -- with no device involved: what a rank's CPU share must sustain per call when
+// eight ranks do this at once on two sockets (tools/host_scale.py).  Plain memory instead of pinned; same loops, same pool.
+extern "C" int seqalign_host_legs_nw(const seqalign_batch_t *batch, const uint64_t *str_off, char *out_a, char *out_b,
+                                     uint32_t *out_len, int iterations, double *pack_ms, double *expand_ms) {
+  if (!batch || !str_off || !out_a || !out_b || !out_len || iterations <= 0 || !pack_ms || !expand_ms) return SEQALIGN_E_ARG;
+  const uint64_t n = batch->n_pairs, kHostBlk = 512;
+  if (!n) return SEQALIGN_OK;
+  std::vector<BlkSum> blk;
+  std::vector<uint64_t> off_a(n), off_b(n), mat(n), slot(n + 1), chars_at, cells_at;
+  std::vector<uint32_t> la(n), lb(n);
+  std::vector<uint8_t> seq;
+  std::vector<uint32_t> moves;
+  auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+  double t_pack = 0, t_expand = 0;
+  for (int it = 0; it < iterations; ++it) {
+    const double t0 = now_ms();
+    scan_blocks(batch, 0, n, kHostBlk, blk);
+    const uint64_t nb = blk.size();
+    chars_at.assign(nb + 1, 0); cells_at.assign(nb + 1, 0);
+    for (uint64_t bi = 0; bi < nb; ++bi) { chars_at[bi + 1] = chars_at[bi] + blk[bi].chars; cells_at[bi + 1] = cells_at[bi] + blk[bi].cells256; }
+    const uint64_t total = chars_at[nb];
+    if (seq.size() < total + 64) seq.resize(total + 64);
+    if (moves.size() < 2 * ((total >> 5) + n) + 2) moves.assign(2 * ((total >> 5) + n) + 2, 0u);
+    parallel_for(nb, [&](uint64_t bi) {
+      uint64_t pos = chars_at[bi], cell = cells_at[bi];
+      for (uint64_t k = bi * kHostBlk, e = std::min(n, (bi + 1) * kHostBlk); k < e; ++k) {
+        la[k] = batch->len_a[k]; lb[k] = batch->len_b[k];
+        slot[k] = pos; off_a[k] = pos; pos += la[k]; off_b[k] = pos; pos += lb[k];
+        mat[k] = cell; cell += (((uint64_t)(la[k] + 1ull) * (lb[k] + 1ull)) + 255u) & ~(uint64_t)255u;
+      }
+    });
+    parallel_for(nb, [&](uint64_t bi) {
+      if (blk[bi].packed) { memcpy(seq.data() + off_a[bi * kHostBlk], batch->arena + batch->off_a[bi * kHostBlk], blk[bi].chars); return; }
+      for (uint64_t k = bi * kHostBlk, e = std::min(n, (bi + 1) * kHostBlk); k < e; ++k) {
+        memcpy(seq.data() + off_a[k], batch->arena + batch->off_a[k], la[k]);
+        memcpy(seq.data() + off_b[k], batch->arena + batch->off_b[k], lb[k]);
+      }
+    });
+    const double t1 = now_ms();
+    constexpr uint64_t kOut = 128;
+    std::atomic<int> bad{0};
+    parallel_for((n + kOut - 1) / kOut, [&](uint64_t bi) {
+      for (uint64_t k = bi * kOut, e = std::min(n, (bi + 1) * kOut); k < e; ++k) {
+        const uint32_t nw = (la[k] + lb[k] + 31u) >> 5;
+        const uint32_t *pa = moves.data() + 2 * ((slot[k] >> 5) + k);
+        if (sa_expand_nw_moves(batch->arena + batch->off_a[k], la[k], batch->arena + batch->off_b[k], lb[k], pa, pa + nw, nw,
+                               std::min(la[k], lb[k]), out_a + str_off[k], out_b + str_off[k], &out_len[k]))
+          bad.store(1);
+      }
+    });
+    const double t2 = now_ms();
+    if (bad.load()) return SEQALIGN_E_TRACEBACK;
+    t_pack += t1 - t0; t_expand += t2 - t1;
+  }
+  *pack_ms = t_pack / iterations; *expand_ms = t_expand / iterations;
   return SEQALIGN_OK;
 }
 

@@ -69,6 +69,11 @@ static void expand_vbmi2(const char *src, const uint32_t *plane, uint32_t n_word
     const uint64_t m = n_cols - c < 64 ? n_cols - c : 64;
     const uint64_t valid = m == 64 ? ~0ull : ((1ull << m) - 1);
     const uint64_t keep = ~plane_bits64(plane, n_words, first_bit + c) & valid;   /* columns that take a character */
+    if (keep == ~0ull) {   /* 64 columns without a gap: most of a read's alignment */
+      _mm512_storeu_si512((void *)(dst + c), _mm512_loadu_si512((const void *)src));
+      src += 64;
+      continue;
+    }
     const unsigned n_chars = (unsigned)__builtin_popcountll(keep);
     /* masked load: bytes past the sequence's end are never touched */
     const __m512i chars = _mm512_maskz_loadu_epi8(n_chars == 64 ? ~0ull : ((1ull << n_chars) - 1), src);

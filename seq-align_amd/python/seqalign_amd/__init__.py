@@ -536,7 +536,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
     "seqalign_arenas_info", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
-    "seqalign_kernel_kind_name", "seqalign_ctx_stream",
+    "seqalign_kernel_kind_name", "seqalign_host_legs_nw", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
