@@ -133,6 +133,22 @@ def gpu_numa_cpus(device: int, sysfs: Path = Path("/sys")):
         return None, []
 
 
+def cgroup_cpu_quota():
+    """CPUs the container's cgroup grants (cpu.max / cfs_quota_us), or None: what the scheduler enforces whatever the
+    affinity mask shows (the 1-GPU development boxes show 256 CPUs and grant 16)."""
+    try:
+        q, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if q == "max" else max(1, int(q) // int(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        return None if q <= 0 else max(1, q // period)
+    except (OSError, ValueError):
+        return None
+
+
 def pin_rank(node, cpus, local_rank: int, local_world: int, nodes_of_ranks: list) -> dict:
     """Pin this process to its share of its GPU's NUMA node: the node's CPUs are dealt out evenly among the local
     ranks whose GPUs hang off the same node, in rank order (hyper-thread siblings -- cpu c and c + n/2 on this
@@ -304,6 +320,16 @@ def run(args) -> int:
     if world > 1 and not args.no_pin:
         nodes = grp.gather_objects(node)
         pin = pin_rank(node, node_cpus, rank, world, nodes)
+    if world > 1 and "SEQALIGN_HOST_THREADS" not in os.environ:
+        # the library sizes its worker pool to min(CPUs in the mask, the cgroup's CPU quota, 32) -- per PROCESS; N ranks in one
+        # container share the quota, so each gets its share of it (the pool is created at the first host-level call)
+        quota = cgroup_cpu_quota()
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if quota:
+            share = min(share, max(2, quota // world))
+        os.environ["SEQALIGN_HOST_THREADS"] = str(max(1, min(32, share)))
+        pin["host_threads"] = int(os.environ["SEQALIGN_HOST_THREADS"])
+        pin["cgroup_cpu_quota"] = quota
 
     gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
     batch, global_pairs, first_pair = make_shard(workload, rank, world, args.pairs, args.scaling)

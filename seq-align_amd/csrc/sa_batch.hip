@@ -32,7 +32,7 @@ std::vector<Chunk> sa_host::plan_chunks(const seqalign_batch_t *b, size_t budget
 // and the pipeline runs fill, walk and download one after the other (rocprofv3 timeline, C5's share: 7.2 instead of 5.8
 // ms).  Streams of another PRIORITY come from another pool of queues, so uploads are a low-priority stream and downloads
 // and walks high-priority ones, whatever the application has created at the default priority.
-static int ensure_copy_streams(seqalign_ctx *ctx, int count) {
+int sa_host::ensure_copy_streams(seqalign_ctx *ctx, int count) {
   int least = 0, greatest = 0;
   bool have_range = false;
   for (int k = 0; k < count; ++k) {

@@ -185,10 +185,81 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
   if (!allow_dirs) stride = 0;
   cand.uniform_stride = stride;
+  // ---- ONE trip for everything, when the call is the common kind: direction bytes, one wave per pair in the sweep, a few
+  // hits per pair wanted.  The hit walks are launched BEFORE anybody has seen the sweep's counts -- max_hits walks per pair,
+  // walk w = hit w % max_hits of pair w / max_hits, those beyond a pair's hits return at once (sa_traceback.hip) -- and send
+  // home two bits per column into fixed slots of pinned memory (host/sa_moves.c), so nothing has to be sized, gathered or
+  // copied by a second and third launch + wait: counts, per-walk words and moves are all there after one synchronisation,
+  // and the host threads expand the hits straight into the caller's buffers.  (Round 3: counts -> walker lists -> walks ->
+  // lengths -> gather -> strings, three waits.)  Sweep and walks follow the chunk's last fill, in the fills' stream.
+  // (Measured, profiles/r04/r04_sw_pipeline.txt: on a second stream, with equal slices so that a slice's sweep runs beside
+  // the next slice's fill -- both issue vector instructions 50-70 % of the time, neither is bound by memory -- the two
+  // kernels simply share the SIMDs: C3's sweep of 4 096 pairs 0.62 -> 1.97 ms beside a fill, the call 4.6 -> 5.4 ms; and a
+  // sweep on the second, high-priority stream alone behind an event starts 80 us late and runs 0.93 instead of 0.80 ms on C4.)
+  // A pair that needs the host between sweep and walks -- more than 64 hits (keys unsorted), an error to weigh against
+  // max_hits -- sends the whole chunk down the three-trip path below, which starts from the same counts.
+  const bool trace = ctx->opt.sweep_trace;   // development aid: per-pair counters on stderr
+  DevBuf &d_trace = ctx->e[12];
+  const bool may_one_trip = allow_dirs && ctx->opt.sweep_mode == 0 && !trace && ctx->opt.nw_moves && max_hits <= 8 &&
+                            n * max_hits <= ((uint64_t)4 << 20) && c.max_a + 1 <= 512;
+  SaSweepParams q;
+  memset(&q, 0, sizeof(q));
+  auto sweep_params = [&](const seqalign_dev_batch_t &dd, uint64_t k0, uint64_t k1, bool dirs) {
+    SaSweepParams r;
+    memset(&r, 0, sizeof(r));
+    r.arena = dd.arena; r.off_a = dd.off_a; r.len_a = dd.len_a; r.off_b = dd.off_b; r.len_b = dd.len_b;
+    r.mat_off = dd.mat_off; r.M = dd.match_scores; r.A = dd.gap_a_scores; r.B = dd.gap_b_scores;
+    r.code = sc->d_code; r.table = sc->d_table; r.cand_count = cand.cand_count + k0; r.cand_box = cand.cand_box + 4 * k0;
+    r.min_score = d_min.as<int32_t>() + k0; r.hit_keys = d_keys.as<unsigned long long>(); r.hit_off = d_hitoff.as<uint64_t>() + k0;
+    r.err_key = d_meta.as<unsigned long long>() + k0;
+    r.hit_count = reinterpret_cast<uint32_t *>(d_meta.as<unsigned long long>() + n) + k0; r.status = r.hit_count + n;
+    r.n_pairs = (uint32_t)(k1 - k0); r.K = sc->flat.n_classes; r.open1 = sc->flat.open1; r.ext = sc->flat.ext;
+    r.gen_eq = sc->flat.gen_eq; r.gen_ne = sc->flat.gen_ne; r.flags = sc->flat.flags;
+    r.max_len_a = c.max_a; r.layout = layout; r.tune_cpl = ctx->opt.sweep_cpl;
+    r.dirs = dirs ? cand.dirs : nullptr;
+    return r;
+  };
+  hipError_t e;
+  bool piped = may_one_trip, piped_any = false;
+  const uint64_t nwalk = n * max_hits;
+  if (may_one_trip) {
+    const uint64_t move_words = 2ull * max_hits * ((c.seq_bytes >> 5) + n) + 2;
+    if ((rc = ctx->h_ta.reserve(move_words * 4)) || (rc = ctx->h_B.reserve(nwalk * 16 + 16)) || (rc = ctx->h_tmeta.reserve(n * 16 + 64)))   // (h_misc is fetch_status')
+      return rc;
+  }
+  auto after_fill = [&](uint64_t k0, uint64_t k1, const seqalign_dev_batch_t &dd, bool dirs, bool cand_reported) -> int {
+    if (!piped || !dirs || !cand_reported) { piped = false; return SEQALIGN_OK; }   // not the common kind: everything below, for the whole chunk
+    hipError_t he;
+    const SaSweepParams r = sweep_params(dd, k0, k1, true);
+    if ((he = sa_launch_sw_sweep(r, st)) != hipSuccess) return fail_hip(he, "sw sweep");
+    SaTraceParams t;
+    memset(&t, 0, sizeof(t));
+    t.arena = dd.arena; t.off_a = dd.off_a; t.len_a = dd.len_a; t.off_b = dd.off_b; t.len_b = dd.len_b; t.mat_off = dd.mat_off;
+    t.M = dd.match_scores; t.code = sc->d_code; t.table = sc->d_table;
+    t.str_off = dd.off_a;                       // (run_chunk packs a, b, a, b, ...: off_a IS the prefix of len_a + len_b)
+    // walk w of the launch is hit w % max_hits of the slice's pair w / max_hits = the chunk's pair k0 + that: its slot is
+    // 2 max_hits ((off_a >> 5) + chunk pair) + ..., so the bases move by the slice's first pair
+    t.moves = ctx->h_ta.dev_as<uint32_t>() + 2ull * max_hits * k0; t.out_meta4 = ctx->h_B.dev_as<uint32_t>() + 4ull * max_hits * k0;
+    t.walks_per_pair = max_hits; t.hit_count = r.hit_count; t.sweep_status = r.status;
+    t.hit_keys = r.hit_keys; t.hit_off = r.hit_off; t.layout = layout; t.fill_status = dd.status;
+    t.n_pairs = (uint32_t)((k1 - k0) * max_hits); t.K = r.K; t.open1 = r.open1; t.ext = r.ext; t.gen_eq = r.gen_eq; t.gen_ne = r.gen_ne;
+    t.flags = r.flags; t.tune_walker = ctx->opt.trace_kernel; t.dirs = r.dirs;
+    if ((he = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(he, "sw hit traceback");
+    piped_any = true;
+    return SEQALIGN_OK;
+  };
   seqalign_dev_batch_t d;
   bool reported = false;
   if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported, stride))) return rc;
-  hipError_t e;
+  // (behind ALL the fills: per slice -- a small first slice's sweep and walks, then the rest's -- C3 took 5.2 instead of 4.7 ms)
+  if (may_one_trip && (rc = after_fill(0, n, d, dirs_used, reported))) return rc;
+  const bool strips_needed = c.max_a + 1 > 512 && (c.max_a + 1 > SA_SWEEP_LDS_COLUMNS || n < 1024);
+  bool strips = false;
+  if (piped && piped_any) {
+    // everything is enqueued on the one stream: one wait for all of it
+    q = sweep_params(d, 0, n, true);
+    tm.lap("sw: fills, sweeps, walks enqueued");
+  } else {
   if (!reported) {   // a fill kernel that cannot report them itself: one pass over match_scores
     SaReduceParams r;
     memset(&r, 0, sizeof(r));
@@ -197,25 +268,14 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   }
 
   // ---- the sweep: every hit of every pair
-  SaSweepParams q;
-  memset(&q, 0, sizeof(q));
-  q.arena = d.arena; q.off_a = d.off_a; q.len_a = d.len_a; q.off_b = d.off_b; q.len_b = d.len_b;
-  q.mat_off = d.mat_off; q.M = d.match_scores; q.A = d.gap_a_scores; q.B = d.gap_b_scores;
-  q.code = sc->d_code; q.table = sc->d_table; q.cand_count = cand.cand_count; q.cand_box = cand.cand_box;
-  q.min_score = d_min.as<int32_t>(); q.hit_keys = d_keys.as<unsigned long long>(); q.hit_off = d_hitoff.as<uint64_t>();
-  q.err_key = d_meta.as<unsigned long long>();
-  q.hit_count = reinterpret_cast<uint32_t *>(q.err_key + n); q.status = q.hit_count + n;
-  q.n_pairs = (uint32_t)n; q.K = sc->flat.n_classes; q.open1 = sc->flat.open1; q.ext = sc->flat.ext;
-  q.gen_eq = sc->flat.gen_eq; q.gen_ne = sc->flat.gen_ne; q.flags = sc->flat.flags;
-  q.max_len_a = c.max_a; q.layout = layout; q.tune_cpl = ctx->opt.sweep_cpl;
-  q.dirs = dirs_used ? cand.dirs : nullptr;
+  q = sweep_params(d, 0, n, dirs_used);
   // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows up to 512 columns in registers,
   // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
   // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  The option sweep_mode = strips | pair
   // forces one (tests, experiments).
   const int mode_opt = ctx->opt.sweep_mode;   // 0 auto, 1 pair, 2 strips
   const uint32_t w_max = c.max_a + 1;
-  bool strips = w_max > 512 && (w_max > SA_SWEEP_LDS_COLUMNS || n < 1024);
+  strips = strips_needed;
   if (mode_opt == 2) strips = true;
   if (mode_opt == 1 && w_max <= SA_SWEEP_LDS_COLUMNS) strips = false;
   if (w_max <= SA_SWEEP_LDS_COLUMNS) q.lds_columns = (c.max_a + 2u) & ~1u;
@@ -242,8 +302,6 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     q.strip_progress = d_prog.as<uint32_t>(); q.strips_per_pair = spp;
     q.bnd = d_rows.as<unsigned long long>(); q.row_off = d_rowoff.as<uint64_t>();
   }
-  const bool trace = ctx->opt.sweep_trace;   // development aid: per-pair counters on stderr
-  DevBuf &d_trace = ctx->e[12];
   if (trace) {
     if ((rc = d_trace.reserve(n * 64))) return rc;
     HIP_TRY(hipMemsetAsync(d_trace.p, 0, n * 64, st));
@@ -251,6 +309,60 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   }
   if ((e = sa_launch_sw_sweep(q, st)) != hipSuccess) return fail_hip(e, "sw sweep");
   tm.lap("sw: enqueue fill + sweep");
+  }
+
+  const bool one_trip = piped && piped_any;
+  if (one_trip) {
+    unsigned long long *h_err = ctx->h_tmeta.as<unsigned long long>();
+    const uint32_t *h_cnt = reinterpret_cast<const uint32_t *>(h_err + n), *h_st = h_cnt + n;
+    HIP_TRY(hipMemcpyAsync(h_err, d_meta.p, n * 16, hipMemcpyDeviceToHost, st));
+    if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // the fill's status words; synchronises the stream
+    tm.lap("sw one trip: wait (fill, sweep, walks)");
+    bool clean = true;
+    for (uint64_t k = 0; k < n && clean; ++k) clean = h_st[k] == 0;
+    if (clean) {
+      const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
+      // where every hit goes in the caller's buffers (a prefix over the lengths), then the expansion on the thread pool
+      std::vector<uint64_t> hit_walk, hit_out;
+      hit_walk.reserve(n); hit_out.reserve(n);
+      bool no_room = false;
+      for (uint64_t k = 0; k < n && !no_room; ++k) {
+        const uint32_t take = std::min(h_cnt[k], max_hits);
+        for (uint32_t j = 0; j < take; ++j) {
+          const uint64_t w = k * max_hits + j;
+          const uint32_t len = h_w[4 * w + 1];
+          if (len >= SA_MOVES_ERR) return (int)(len & 15u);
+          if (*found + hit_walk.size() >= hit_cap || *used_str + len + 1 > str_cap) { no_room = true; break; }
+          hit_walk.push_back(w); hit_out.push_back(*used_str);
+          *used_str += len + 1;
+        }
+      }
+      const uint64_t first_hit = *found, n_out = hit_walk.size();
+      std::atomic<int> bad{SEQALIGN_OK};
+      constexpr uint64_t kPack = 128;
+      parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
+        for (uint64_t i = blk * kPack, e2 = std::min(n_out, (blk + 1) * kPack); i < e2; ++i) {
+          const uint64_t w = hit_walk[i], k = w / max_hits, pp = c.first + k;
+          const uint32_t j = (uint32_t)(w % max_hits), la = batch->len_a[pp], lb = batch->len_b[pp], nwd = (la + lb + 31u) >> 5;
+          // (run_chunk's packed offsets: the prefix of len_a + len_b over the chunk's pairs -- recomputed per pair from the
+          // pinned descriptor block run_chunk left in h_desc)
+          const uint64_t slot = ctx->h_desc.as<uint64_t>()[k];
+          const uint32_t *pa = h_moves + 2ull * max_hits * ((slot >> 5) + k) + 2ull * j * nwd;
+          seqalign_sw_hit_t &h = hits[first_hit + i];
+          uint32_t pos[4];
+          const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3],
+                                             pa, pa + nwd, nwd, h_w[4 * w + 1], out_a + hit_out[i], out_b + hit_out[i], pos);
+          if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); continue; }
+          h.pair = pp; h.score = (int32_t)h_w[4 * w]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+          h.length = h_w[4 * w + 1]; h.str_off = hit_out[i];
+        }
+      });
+      if (bad.load()) return bad.load();
+      *found += n_out;
+      tm.lap("sw one trip: hits expanded");
+      return no_room ? SEQALIGN_E_NOMEM : SEQALIGN_OK;
+    }
+  }
 
   // ---- round trip 1: hit counts and status
   if ((rc = ctx->h_tmeta.reserve(n * 16 + 64))) return rc;
@@ -464,6 +576,57 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   t.str_off = ctx->t_str_off.as<uint64_t>(); t.out_a = ctx->t_out_a.as<char>(); t.out_b = ctx->t_out_b.as<char>();
   t.out_head = d_meta; t.out_len = d_meta + n; t.out_score = reinterpret_cast<int32_t *>(d_meta + 2 * n);
   t.status = d_meta + 3 * n; t.out_pos = d_meta + 4 * n; t.start_index = ctx->best_index.as<uint64_t>();
+  if (dirs_used && ctx->opt.nw_moves) {
+    // the walk sends home two bits per column into the pair's slot of pinned memory, the host expands (as seqalign_nw_batch):
+    // one launch, one wait -- no lengths to fetch before a gather, no gather, no strings over PCIe
+    const uint64_t move_words = 2ull * ((total >> 5) + n) + 2;
+    if ((rc = ctx->h_ta.reserve(move_words * 4)) || (rc = ctx->h_B.reserve(n * 16 + 16))) return rc;   // (h_misc is fetch_status')
+    SaTraceParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.arena = d.arena; tp.off_a = d.off_a; tp.len_a = d.len_a; tp.off_b = d.off_b; tp.len_b = d.len_b; tp.mat_off = d.mat_off;
+    tp.code = sc->d_code; tp.table = sc->d_table; tp.str_off = d.off_a;
+    tp.moves = ctx->h_ta.dev_as<uint32_t>(); tp.out_meta4 = ctx->h_B.dev_as<uint32_t>();
+    tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
+    tp.dirs = ctx->dirs.as<uint8_t>(); tp.fill_status = d.status;
+    tp.n_pairs = (uint32_t)n; tp.K = sc->flat.n_classes; tp.open1 = sc->flat.open1; tp.ext = sc->flat.ext;
+    tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel;
+    hipError_t e2 = sa_launch_nw_traceback(tp, st);
+    if (e2 != hipSuccess) return fail_hip(e2, "sw best-hit traceback");
+    if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+    const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
+    std::vector<uint64_t> hit_pair, hit_out;
+    hit_pair.reserve(n); hit_out.reserve(n);
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint64_t p = c.first + k;
+      const int32_t score = (int32_t)h_w[4 * k];
+      const uint32_t len = h_w[4 * k + 1];
+      if (len >= SA_MOVES_ERR) return (int)(len & 15u);
+      if (score <= 0 || score < min_score[p]) continue;
+      if (found + hit_pair.size() >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
+      hit_pair.push_back(k); hit_out.push_back(used_str);
+      used_str += len + 1;
+    }
+    const uint64_t first_hit = found, n_out = hit_pair.size();
+    std::atomic<int> bad{SEQALIGN_OK};
+    constexpr uint64_t kPack = 128;
+    parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
+      for (uint64_t i = blk * kPack, e3 = std::min(n_out, (blk + 1) * kPack); i < e3; ++i) {
+        const uint64_t k = hit_pair[i], p = c.first + k;
+        const uint32_t la = batch->len_a[p], lb = batch->len_b[p], nwd = (la + lb + 31u) >> 5;
+        const uint32_t *pa = h_moves + 2ull * ((h_off[k] >> 5) + k);
+        uint32_t pos[4];
+        const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3],
+                                           pa, pa + nwd, nwd, h_w[4 * k + 1], out_a + hit_out[i], out_b + hit_out[i], pos);
+        if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); continue; }
+        seqalign_sw_hit_t &h = hits[first_hit + i];
+        h.pair = p; h.score = (int32_t)h_w[4 * k]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+        h.length = h_w[4 * k + 1]; h.str_off = hit_out[i];
+      }
+    });
+    if (bad.load()) return bad.load();
+    found += n_out;
+    return SEQALIGN_OK;
+  }
   if (dirs_used) rc = sw_traceback_dirs(ctx, sc, &d, &t, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), st);
   else rc = seqalign_sw_traceback_device(ctx, sc, &d, &t, st);
   if (rc) return rc;

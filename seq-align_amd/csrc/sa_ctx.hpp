@@ -63,12 +63,18 @@ class HostPool {
   // unpacking per group), and a caller that aligns batch after batch comes back within a millisecond: waking 31 sleeping
   // threads through a condition variable costs 30-60 us per dispatch, several times what a job of C2's size takes.  So a
   // worker that runs out of work keeps looking for the next job for kSpinNs before it goes to sleep.
-  static constexpr long long kSpinNs = 400000;
+  long long kSpinNs = 400000;   // SEQALIGN_HOST_SPIN_US overrides (0: sleep at once)
   HostPool() {
+    if (const char *env = getenv("SEQALIGN_HOST_SPIN_US")) kSpinNs = 1000ll * std::max(0, atoi(env));
     unsigned hw = std::thread::hardware_concurrency();
     cpu_set_t mask;
     if (sched_getaffinity(0, sizeof(mask), &mask) == 0 && CPU_COUNT(&mask) > 0) hw = (unsigned)CPU_COUNT(&mask);
     unsigned want = hw ? std::min(hw, 32u) : 4u;
+    // A container's CPU quota (cgroup cpu.max) is what the scheduler enforces, whatever the affinity mask shows: on a box
+    // that shows 256 CPUs and grants 16, a pool of 32 threads that keep looking for work between jobs burns the quota twice
+    // over and the whole process is throttled for it (tools/host_scale.py on the 1-GPU boxes: 8 x 32 threads 45 ms per call,
+    // 8 x 8 threads 3.7 ms).  So: no more threads than the quota grants.
+    if (const unsigned q = cgroup_cpu_quota()) want = std::min(want, std::max(1u, q));
     if (const char *env = getenv("SEQALIGN_HOST_THREADS")) want = (unsigned)std::max(1, atoi(env));
     for (unsigned t = 1; t < want; ++t) workers_.emplace_back([this] { loop(); });
   }
@@ -78,6 +84,21 @@ class HostPool {
     { std::lock_guard<std::mutex> lk(mu_); }
     cv_.notify_all();
     for (auto &th : workers_) th.join();
+  }
+  // CPUs the cgroup's quota grants (rounded down, 0 = no quota / unknown): cgroup v2 cpu.max, v1 cpu.cfs_quota_us
+  static unsigned cgroup_cpu_quota() {
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (unsigned)std::max<long long>(1, quota / period);
   }
   static long long now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1000000000ll + t.tv_nsec; }
   void loop() {
@@ -325,6 +346,7 @@ std::vector<Chunk> plan_chunks(const seqalign_batch_t *b, size_t budget, size_t 
 int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, const seqalign_dev_scoring *sc,
               seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
               bool *cand_done = nullptr, uint64_t uniform_stride = 0);
+int ensure_copy_streams(seqalign_ctx *ctx, int count);
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                  int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0,

@@ -192,6 +192,12 @@ struct SaTraceParams {
    * SW walks also need out_pos for nothing: the host derives the hit's position from the planes (sa_expand_sw_moves). */
   uint32_t *moves;
   uint32_t *out_meta2;
+  /* SW walks that send home moves: out_meta4[4w..] = score, walked columns, end cell x, y.  walks_per_pair = k > 0: the launch has
+   * k walks per pair, walk w = hit w % k of pair w / k (its key in hit_keys), in the slot 2 k ((str_off[pair] >> 5) + pair) +
+   * 2 (w % k) nw -- str_off then indexed by PAIR -- and walks beyond hit_count[pair], or of a pair with sweep_status != 0,
+   * return without a trace: the launch can be enqueued before anybody has seen the sweep's counts */
+  uint32_t walks_per_pair;
+  const uint32_t *hit_count, *sweep_status;
 };
 #define SA_MOVES_ERR 0xFFFFFFF0u
 

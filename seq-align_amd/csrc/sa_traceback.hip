@@ -264,26 +264,80 @@ struct MoveSlot {
   uint32_t *plane_a, *plane_b;   // nw words each
   int nw;
 };
-__device__ __forceinline__ MoveSlot move_slot(const SaTraceParams &p, uint32_t w, uint32_t la, uint32_t lb) {
+// which pair, which start cell and which slot walk `w` has.  Three ways of numbering walks:
+//   NW                         : walk w = pair w, from the bottom-right cell (nw_state / nw_score from the fill)
+//   SW, walks_per_pair == 0    : walk w = pair w from start_index[w] (the best-hit path), or hit walker_rank[w] of pair
+//                                walker_pair[w] (lists made by the host after it has seen the hit counts)
+//   SW, walks_per_pair == k    : walk w = hit w % k of pair w / k -- launched BEFORE anybody has seen the hit counts: a walk whose
+//                                rank is beyond its pair's hits (or whose pair needs the host: unsorted keys, an error) returns
+struct MoveWalk {
+  uint32_t pair, x, y, st;
+  int score;
+  MoveSlot slot;
+  bool valid;
+};
+template <bool NW>
+__device__ __forceinline__ MoveWalk move_walk(const SaTraceParams &p, uint32_t w) {
+  MoveWalk m;
+  m.valid = true;
+  uint32_t rank = 0, wpp = 1;
+  if constexpr (NW) {
+    m.pair = w;
+  } else if (p.walks_per_pair) {
+    wpp = p.walks_per_pair;
+    m.pair = w / wpp; rank = w % wpp;
+    if (rank >= p.hit_count[m.pair] || (p.sweep_status[m.pair] != 0)) { m.valid = false; return m; }
+  } else {
+    m.pair = p.walker_pair ? p.walker_pair[w] : w;
+    if (p.walker_rank) rank = p.walker_rank[w];
+  }
+  const uint32_t la = p.len_a[m.pair], lb = p.len_b[m.pair], W = la + 1;
   const int nw = (int)((la + lb + 31u) >> 5);
-  uint32_t *base = p.moves + 2ull * ((p.str_off[w] >> 5) + w);
-  return MoveSlot{base, base + nw, nw};
+  uint32_t *base;
+  if (!NW && p.walks_per_pair) base = p.moves + 2ull * wpp * ((p.str_off[m.pair] >> 5) + m.pair) + 2ull * rank * nw;
+  else base = p.moves + 2ull * ((p.str_off[w] >> 5) + w);
+  m.slot = MoveSlot{base, base + nw, nw};
+  if constexpr (NW) {
+    m.x = la; m.y = lb; m.st = (uint32_t)p.nw_state[w]; m.score = p.nw_score[w];
+  } else {
+    m.st = MAT_MATCH;
+    if (p.hit_keys) {
+      const unsigned long long key = p.hit_keys[p.hit_off[m.pair] + lb + 1 + rank];
+      m.y = (uint32_t)key & ((1u << p.layout.row_bits) - 1u);
+      m.x = (uint32_t)(key >> p.layout.row_bits) & ((1u << p.layout.col_bits) - 1u);
+      m.score = p.layout.cap - (int)(key >> (p.layout.row_bits + p.layout.col_bits));   // (the key's score field: cap - score)
+    } else {
+      const uint32_t end = (uint32_t)p.start_index[w];
+      m.x = end % W; m.y = end / W;
+      m.score = p.start_score[w];
+    }
+  }
+  return m;
 }
-__device__ __forceinline__ void write_moves_meta(const SaTraceParams &p, uint32_t w, uint32_t pair, int score, uint32_t n_moves) {
-  if (p.fill_status && p.fill_status[pair] != ~0ull) n_moves = SA_MOVES_ERR | 5u;   // SEQALIGN_E_UNKNOWN_PAIR
-  *reinterpret_cast<uint2 *>(p.out_meta2 + 2ull * w) = make_uint2((uint32_t)score, n_moves);
+// NW: score, walked columns (or SA_MOVES_ERR | code) at out_meta2[2w..]; SW: score, walked columns, end cell at out_meta4[4w..]
+template <bool NW>
+__device__ __forceinline__ void write_moves_meta(const SaTraceParams &p, uint32_t w, const MoveWalk &m, uint32_t end_x, uint32_t end_y,
+                                                 uint32_t n_moves) {
+  if (p.fill_status && p.fill_status[m.pair] != ~0ull) n_moves = SA_MOVES_ERR | 5u;   // SEQALIGN_E_UNKNOWN_PAIR
+  if constexpr (NW) *reinterpret_cast<uint2 *>(p.out_meta2 + 2ull * w) = make_uint2((uint32_t)m.score, n_moves);
+  else *reinterpret_cast<uint4 *>(p.out_meta4 + 4ull * w) = make_uint4((uint32_t)m.score, n_moves, end_x, end_y);
 }
 
 // one lane per walk: a word of each plane leaves as soon as its 32 columns are known
-__global__ void __launch_bounds__(64) traceback_nw_moves_lane_kernel(const SaTraceParams p) {
+template <bool NW>
+__global__ void __launch_bounds__(64) traceback_moves_lane_kernel(const SaTraceParams p) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= p.n_pairs) return;
-  const uint32_t la = p.len_a[w], lb = p.len_b[w], W = la + 1;
-  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[w];
-  const MoveSlot s = move_slot(p, w, la, lb);
-  uint32_t x = la, y = lb, st = (uint32_t)p.nw_state[w], k = 0, acc_a = 0, acc_b = 0;
-  while (x > 0 && y > 0) {
+  const MoveWalk m = move_walk<NW>(p, w);
+  if (!m.valid) return;
+  const uint32_t W = p.len_a[m.pair] + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+  const MoveSlot s = m.slot;
+  uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0;
+  for (;;) {
+    if constexpr (NW) { if (x == 0 || y == 0) break; }
     const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    if constexpr (!NW) { if (f == 3u) break; }   // this state's score is 0: the hit starts here (smith_waterman.c:192)
     const uint32_t bit = 0x80000000u >> (k & 31u);   // the walk runs backwards: a word's columns arrive last first
     acc_a |= st == MAT_GAP_A ? bit : 0u;
     acc_b |= st == MAT_GAP_B ? bit : 0u;
@@ -300,20 +354,27 @@ __global__ void __launch_bounds__(64) traceback_nw_moves_lane_kernel(const SaTra
     const int j = s.nw - 1 - (int)(k >> 5);
     s.plane_a[j] = acc_a; s.plane_b[j] = acc_b;
   }
-  write_moves_meta(p, w, w, p.nw_score[w], k);
+  write_moves_meta<NW>(p, w, m, m.x, m.y, k);
 }
 
 // one wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk); lane l keeps word l of the current block
 // of 64 words per plane in a register, a block leaves as one coalesced store per plane
-__global__ void __launch_bounds__(64) traceback_nw_moves_tile_kernel(const SaTraceParams p) {
+// (walks_per_pair: one workgroup per PAIR, wave r = the pair's hit r -- launched as one workgroup per walk, the 30 000 of C3's
+// 40 000 slots that return at once cost 0.2 ms of workgroup dispatch)
+template <bool NW>
+__global__ void __launch_bounds__(512) traceback_moves_tile_kernel(const SaTraceParams p) {
   constexpr int kT = 64;
-  __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
-  const int lane = threadIdx.x;
-  const uint32_t w = blockIdx.x;
-  const uint32_t la = p.len_a[w], lb = p.len_b[w], W = la + 1;
-  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[w];
-  const MoveSlot s = move_slot(p, w, la, lb);
-  uint32_t x = la, y = lb, st = (uint32_t)p.nw_state[w], k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
+  extern __shared__ __attribute__((aligned(16))) uint8_t tiles[];   // kT * kT per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t *tile = tiles + wave * (kT * kT);
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (w >= p.n_pairs) return;
+  const MoveWalk m = move_walk<NW>(p, w);
+  if (!m.valid) return;   // (wave-uniform)
+  const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+  const MoveSlot s = m.slot;
+  uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
   uint32_t ox = 0, oy = 0;
   bool loaded = false;
   typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
@@ -323,7 +384,8 @@ __global__ void __launch_bounds__(64) traceback_nw_moves_tile_kernel(const SaTra
     const int at = s.nw - 64 * (q + 1) + lane;
     if (lane >= first_slot) { s.plane_a[at] = reg_a; s.plane_b[at] = reg_b; }
   };
-  while (x > 0 && y > 0) {
+  for (;;) {
+    if constexpr (NW) { if (x == 0 || y == 0) break; }
     if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
       ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
       oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
@@ -340,7 +402,8 @@ __global__ void __launch_bounds__(64) traceback_nw_moves_tile_kernel(const SaTra
       loaded = true;
     }
     const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
-    const uint32_t bit = 0x80000000u >> (k & 31u);   // the walk runs backwards: a word's columns arrive last first
+    if constexpr (!NW) { if (f == 3u) break; }
+    const uint32_t bit = 0x80000000u >> (k & 31u);
     acc_a |= st == MAT_GAP_A ? bit : 0u;
     acc_b |= st == MAT_GAP_B ? bit : 0u;
     if ((++k & 31u) == 0) {
@@ -358,7 +421,7 @@ __global__ void __launch_bounds__(64) traceback_nw_moves_tile_kernel(const SaTra
     if ((k & 31u) && lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
     flush(j >> 6, 63 - (j & 63));
   }
-  if (lane == 0) write_moves_meta(p, w, w, p.nw_score[w], k);
+  if (lane == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, k);
 }
 
 // ---------------------------------------------------------------------------
@@ -521,13 +584,23 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
-        if (tiles) hipLaunchKernelGGL(sa::traceback_nw_moves_tile_kernel, dim3(p.n_pairs), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL(sa::traceback_nw_moves_lane_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
+        if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 4096, stream, p);
+        else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       }
+    } else if (p.moves) {   // SW hits, moves home: score, walked columns and end cell per walk in out_meta4
+      if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_meta4) return hipErrorInvalidValue;
+      if (p.walks_per_pair && !(p.hit_keys && p.hit_count && p.sweep_status)) return hipErrorInvalidValue;
+      // (walks_per_pair: most of the launch's walks return at once -- the choice follows the pairs, not the slots)
+      const bool wtiles = p.tune_walker ? p.tune_walker == 2 : (p.walks_per_pair ? p.n_pairs / p.walks_per_pair < 32768 : p.n_pairs < 32768);
+      sa_record_launch(wtiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
+      const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
+      if (wpb > 8) return hipErrorInvalidValue;
+      if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 4096 * wpb, stream, p);
+      else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);

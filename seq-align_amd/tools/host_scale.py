@@ -19,9 +19,11 @@ sys.path.insert(0, str(ROOT / "seq-align_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 
 
-def worker(rank, n_ranks, pairs, iters, cpus, start, q):
+def worker(rank, n_ranks, pairs, iters, cpus, threads, start, q):
     if cpus:
         os.sched_setaffinity(0, cpus)          # before the library creates its pool: the workers inherit the mask
+    if threads and "SEQALIGN_HOST_THREADS" not in os.environ:
+        os.environ["SEQALIGN_HOST_THREADS"] = str(threads)   # bench.py: a rank's share of the container's CPU quota
     import numpy as np
     import seqalign_amd as S
     from seqalign_amd import workloads as W
@@ -45,10 +47,10 @@ def worker(rank, n_ranks, pairs, iters, cpus, start, q):
            "wall_ms_per_call": (time.perf_counter() - t0) * 1e3 / iters, "simd_expand": bool(lib.sa_moves_uses_simd())})
 
 
-def run(n_ranks, pairs, iters, shares):
+def run(n_ranks, pairs, iters, shares, threads):
     ctx = mp.get_context("spawn")
     start, q = ctx.Event(), ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, n_ranks, pairs, iters, shares[r], start, q)) for r in range(n_ranks)]
+    ps = [ctx.Process(target=worker, args=(r, n_ranks, pairs, iters, shares[r], threads, start, q)) for r in range(n_ranks)]
     for p in ps:
         p.start()
     time.sleep(8 if pairs > 50000 else 3)     # everybody has generated its share and warmed up
@@ -77,11 +79,14 @@ def main():
         else:
             per = max(1, len(allowed) // a.ranks)
             shares.append(allowed[(r * per) % len(allowed):(r * per) % len(allowed) + per] or allowed)
-    alone = run(1, a.pairs, a.iters, [shares[0]])
-    together = run(a.ranks, a.pairs, a.iters, shares)
+    from bench import cgroup_cpu_quota
+    quota = cgroup_cpu_quota()
+    threads = min(32, len(shares[0]), max(2, quota // a.ranks)) if quota else None   # what bench.py gives a rank at N = ranks
+    alone = run(1, a.pairs, a.iters, [shares[0]], threads)
+    together = run(a.ranks, a.pairs, a.iters, shares, threads)
     legs = lambda r: r["pack_ms"] + r["expand_ms"]
     print(json.dumps({"host_cpus": len(allowed), "ranks": a.ranks, "pairs_per_rank": a.pairs, "iterations": a.iters,
-                      "cpus_per_rank": len(shares[0]),
+                      "cpus_per_rank": len(shares[0]), "cgroup_cpu_quota": quota, "host_threads_per_rank": threads,
                       "alone": alone[0], "together": together,
                       "legs_ms_alone": round(legs(alone[0]), 3),
                       "legs_ms_together_worst": round(max(legs(r) for r in together), 3),

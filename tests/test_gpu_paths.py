@@ -114,10 +114,16 @@ def test_sw_batch_reports_its_kernels(ctx, opts):
     ctx.sw_batch(batch, sc, 20, max_hits=4)
     got = ctx.last_call()
     assert got["fill_sw_dirs_x2"] == (1, 48) and "fill_sw_dirs" not in got and "fill_stream" not in got
-    assert any(k.startswith("sweep_dirs") for k in got) and any(k.startswith("walk_dirs") for k in got)
+    # the hit walks are launched before the counts are known: max_hits slots per pair, moves home
+    assert got["sweep_dirs"] == (1, 48) and got["walk_moves_tile"] == (1, 4 * 48)
+    opts(nw_moves=0)          # three trips: counts -> walker lists -> strings
+    ctx.sw_batch(batch, sc, 20, max_hits=4)
+    got = ctx.last_call()
+    assert got["sweep_dirs"] == (1, 48) and got["walk_dirs_tile"][0] == 1 and got["walk_dirs_tile"][1] <= 4 * 48
+    opts(nw_moves=1)
     ctx.sw_batch(batch, sc, 20, max_hits=1)
     got = ctx.last_call()
-    assert got["fill_sw_best_x2"] == (1, 48) and "sw_reduce" not in got
+    assert got["fill_sw_best_x2"] == (1, 48) and "sw_reduce" not in got and got["walk_moves_tile"] == (1, 48)
     opts(pack16=0)
     ctx.sw_batch(batch, sc, 20, max_hits=4)
     got = ctx.last_call()
