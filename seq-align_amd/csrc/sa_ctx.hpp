@@ -258,6 +258,7 @@ struct SaOptions {
   uint32_t zero_copy = 4;         // zero_copy         0..3 | auto: that path's kernels read the packed sequences + descriptors from (1) and write
                                   //                   the moves to (2) pinned host memory in place, instead of staging copies either way;
                                   //                   auto (4): moves in place when the walks run one wave each (coalesced words)
+  uint32_t reduce_depth = 0;      // reduce_depth      0|4|8: KiB per wave and step of sw_reduce_kernel (0 = 4; 8 measured slower)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)

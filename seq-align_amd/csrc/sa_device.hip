@@ -211,6 +211,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("walk_overlap")) return flag(&o.walk_overlap);
   if (is("nw_moves")) return flag(&o.nw_moves);
   if (is("zero_copy")) { if (eq("auto")) { o.zero_copy = 4; return true; } if (!number(0, 3, &num)) return false; o.zero_copy = (uint32_t)num; return true; }
+  if (is("reduce_depth")) { if (!number(0, 8, &num) || (num != 0 && num != 4 && num != 8)) return false; o.reduce_depth = (uint32_t)num; return true; }
   if (is("timing")) return flag(&o.timing);
   if (is("chunk_bytes")) {
     if (!number(0, (long long)1 << 60, &num) || (num != 0 && num < (1 << 20))) return false;
@@ -251,6 +252,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("walk_overlap")) return n(o.walk_overlap);
   if (is("nw_moves")) return n(o.nw_moves);
   if (is("zero_copy")) { if (o.zero_copy == 4) { *out = "auto"; return true; } return n(o.zero_copy); }
+  if (is("reduce_depth")) return n(o.reduce_depth);
   if (is("timing")) return n(o.timing);
   if (is("chunk_bytes")) return n((long long)o.chunk_bytes);
   if (is("subbatches")) return n(o.subbatches);
@@ -263,7 +265,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -707,6 +709,7 @@ extern "C" int seqalign_sw_reduce_device(seqalign_ctx_t *ctx, const seqalign_sw_
   p.cand_index = r->cand_index; p.cand_score = r->cand_score;
   p.n_pairs = (uint32_t)r->n_pairs;
   p.slices = 0;
+  p.tune_depth = ctx->opt.reduce_depth;
   hipError_t e = sa_launch_sw_reduce(p, st);
   if (e != hipSuccess) return fail_hip(e, "sw reduce launch");
   return SEQALIGN_OK;

@@ -73,6 +73,7 @@ struct SaReduceParams {
   int32_t *cand_score;
   uint32_t n_pairs;
   uint32_t slices;   /* > 1 (best cell only, few long pairs): that many waves per pair (sa_reduce.hip) */
+  uint32_t tune_depth; /* host side only: 0 = by the launch's size, 4 / 8 = KiB a wave loads per step (option reduce_depth) */
 };
 
 /* candidate count and bounding box per pair, as the stream fill (SA_STREAM_CAND) or sa_launch_sw_box leaves them */

@@ -23,6 +23,7 @@ struct Best {
   int score;
   unsigned idx;
 };
+typedef int v4i_al __attribute__((ext_vector_type(4)));   // 16-byte aligned: the reduction's block loads
 
 __device__ __forceinline__ bool better(int s, unsigned idx, const Best &b, unsigned W) {
   if (s != b.score) return s > b.score;
@@ -32,7 +33,7 @@ __device__ __forceinline__ bool better(int s, unsigned idx, const Best &b, unsig
 }
 
 // COMPACT = false: best cell + number of cells >= min_score only (no positions: no ballots)
-template <bool COMPACT>
+template <bool COMPACT, int kUnroll>
 __global__ void __launch_bounds__(kWave *kWavesPerBlock)
 sw_reduce_kernel(const SaReduceParams p) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -53,43 +54,91 @@ sw_reduce_kernel(const SaReduceParams p) {
   // kUnroll independent 1 KiB loads per wave per step, and the NEXT step's loads are issued
   // before this step's values are examined (software pipeline): with one wave per pair
   // (4 k - 10 k waves) anything less leaves HBM latency exposed (C4: 3.5 TB/s with a
-  // load-wait-compute loop)
-  constexpr int kUnroll = 4;
+  // load-wait-compute loop).
+  // Every load of the wave is a whole ALIGNED 1 KiB block (64 lanes x 16 B), as the fill's stores are: a pair's matrix starts
+  // wherever the pair before it ended (4-byte granularity), and a 1 KiB load that starts mid-line touches 17 lines of 64 B
+  // instead of 16 -- so the stream starts at the 1 KiB boundary at or below the pair's first cell (`skew` cells earlier) and
+  // the cells before the first / behind the last are masked out of the first and last block.
+  // (kUnroll: 4; 8 is the option reduce_depth's experiment)
   constexpr uint32_t kStep = kWave * 4 * kUnroll;
+  const uint32_t skew = (uint32_t)((reinterpret_cast<uintptr_t>(M) >> 2) & 255u);
+  const int32_t *__restrict__ Mal = M - skew;            // 1 KiB aligned
+  const uint32_t span = cells + skew;                    // block-space index v <-> cell v - skew
   auto load_step = [&](uint32_t base, int (&v)[kUnroll][4]) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
-      if (i0 + 4 <= cells) {
-        const v4i_u q = __builtin_nontemporal_load(reinterpret_cast<const v4i_u *>(M + i0));
+      const uint32_t v0 = base + u * (kWave * 4) + lane * 4;
+      if (v0 >= skew && v0 + 4 <= span) {
+        const v4i_al q = __builtin_nontemporal_load(reinterpret_cast<const v4i_al *>(Mal + v0));
         v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[u][k] = (i0 + k < cells) ? M[i0 + k] : 0;
+        for (int k = 0; k < 4; ++k) v[u][k] = (v0 + k >= skew && v0 + k < span) ? Mal[v0 + k] : 0;
       }
+    }
+  };
+  // The best cell in the reference's hit order -- score descending, then column ascending, then index ascending
+  // (smith_waterman.c:71-86) -- as ONE 32-bit maximum per lane: key = score << col_bits | (2^col_bits - 1 - column), strictly
+  // greater wins (a lane meets its cells in ascending index, so the first of equal keys stays).  The column of a lane's
+  // vector follows from the previous one without a division (the stride between a lane's vectors is fixed: 256 cells, its
+  // residue mod W is computed once per pair), and a vector whose largest score cannot beat the lane's key -- nearly every
+  // vector once the lanes have seen a good cell -- costs its max and one compare.  (Until round 4 a tie on the SCORE went
+  // through a division per cell, and with 64 lanes x 4 cells a tie somewhere in the wave is the rule, not the exception, on
+  // a matrix of small scores: the kernel was bound by that branch, 0.72-0.76 of the HBM peak where the same access pattern
+  // without arithmetic reads 0.85, tools/probes/read_probe.hip.)  Scores too large for the key's score field, or rows of
+  // 2^20 columns and more, take the division (never on sequence data: the field holds scores up to 2^(31 - col_bits)).
+  const uint32_t col_bits = 32u - (uint32_t)__builtin_clz(W | 1u);                 // columns 0 .. W - 1 fit
+  const bool keyed = col_bits <= 20 && W >= 4;                                   // (W < 4: a vector wraps the row more than once)
+  const uint32_t col_mask = (1u << col_bits) - 1u;
+  const int score_lim = keyed ? (int)(0x7fffffffu >> col_bits) : 0;                // scores below this fit the key
+  const uint32_t r256 = 256u % W, r1024 = kStep % W;                               // (wave-uniform: scalar divisions, once per pair)
+  // column of this lane's first vector (block-space index lane * 4, cell lane * 4 - skew): cells before the pair's first are
+  // masked, so any residue will do for them -- start from the cell index taken mod W in the unsigned wrap-free way
+  uint32_t col_step0 = (uint32_t)(((uint64_t)lane * 4 + (uint64_t)W * 256u - skew) % W);   // (lane * 4 - skew) mod W; W * 256 >= skew
+  uint32_t bkey = 0;                                                               // score 0, the highest column: nothing
+  uint32_t bidx = 0;
+  bool slow_seen = false;
+  auto update_vector = [&](const int (&q)[4], uint32_t i0, uint32_t c0) __attribute__((always_inline)) {
+    const int m4 = max(max(q[0], q[1]), max(q[2], q[3]));
+    if (__builtin_expect(!keyed || __any(m4 >= score_lim), 0)) {   // a score the key cannot hold (or rows too wide for it): the division
+      slow_seen = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (q[k] > best.score) best = Best{q[k], i0 + k};
+        else if (q[k] == best.score && q[k] > 0 && better(q[k], i0 + k, best, W)) best = Best{q[k], i0 + k};
+      }
+      return;
+    }
+    // can any of the four beat the lane's key?  (its best possible key: the largest score in column 0)
+    if (!__any((((uint32_t)m4 << col_bits) | col_mask) > bkey)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t c = c0 + k;
+      c = c >= W ? c - W : c;
+      const uint32_t key = ((uint32_t)q[k] << col_bits) | (col_mask - c);
+      const bool wins = key > bkey && q[k] > 0;
+      bkey = wins ? key : bkey;
+      bidx = wins ? i0 + k : bidx;
     }
   };
   int nxt[kUnroll][4];
   load_step(0, nxt);
-  for (uint32_t base = 0; base < cells; base += kStep) {
+  for (uint32_t base = 0; base < span; base += kStep) {
     int v[kUnroll][4];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[u][k] = nxt[u][k];
-    if (base + kStep < cells) load_step(base + kStep, nxt);
+    if (base + kStep < span) load_step(base + kStep, nxt);
+    uint32_t cu = col_step0;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t i0 = base + u * (kWave * 4) + lane * 4;
+      const uint32_t i0 = base + u * (kWave * 4) + lane * 4 - skew;   // the cell (wraps below 0 for masked cells: their value is 0)
       uint32_t mine = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // within a lane indices ascend, so a strictly higher score always wins; only a tie
-        // (rare) needs the columns
-        if (v[u][k] > best.score) best = Best{v[u][k], i0 + k};
-        else if (v[u][k] == best.score && v[u][k] > 0 && better(v[u][k], i0 + k, best, W)) best = Best{v[u][k], i0 + k};
-        mine += (v[u][k] >= min_score);
-      }
+      for (int k = 0; k < 4; ++k) mine += (v[u][k] >= min_score);
+      update_vector(v[u], i0, cu);
+      cu += r256; cu = cu >= W ? cu - W : cu;
       if constexpr (!COMPACT) { count += mine; continue; }
       // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
       const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
@@ -110,6 +159,12 @@ sw_reduce_kernel(const SaReduceParams p) {
         }
       }
     }
+    col_step0 += r1024; col_step0 = col_step0 >= W ? col_step0 - W : col_step0;
+  }
+  // the lane's keyed best against what the division path may have found (both in hit order)
+  if (bkey != 0) {
+    const Best kb{(int)(bkey >> col_bits), bidx};
+    if (!slow_seen || better(kb.score, kb.idx, best, W)) best = kb;
   }
 
   // wave reduction of the best cell
@@ -280,7 +335,11 @@ hipError_t sa_launch_sw_reduce(const SaReduceParams &p, hipStream_t stream) {
   }
   const dim3 grid((p.n_pairs + sa::kWavesPerBlock - 1) / sa::kWavesPerBlock),
       block(sa::kWave * sa::kWavesPerBlock);
-  if (p.cand_cap) hipLaunchKernelGGL(sa::sw_reduce_kernel<true>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(sa::sw_reduce_kernel<false>, grid, block, 0, stream, p);
+  // (8 KiB per wave and step only on request: it loses on both configurations -- C3 0.807 against 0.814, C4's 4 000 waves 0.726
+  // against 0.771, tools/reduce_bench.py)
+  const bool deep = p.tune_depth == 8;
+  if (p.cand_cap) hipLaunchKernelGGL((sa::sw_reduce_kernel<true, 4>), grid, block, 0, stream, p);
+  else if (deep) hipLaunchKernelGGL((sa::sw_reduce_kernel<false, 8>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((sa::sw_reduce_kernel<false, 4>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
