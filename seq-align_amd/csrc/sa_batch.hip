@@ -52,12 +52,17 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
                        const seqalign_dev_scoring *sc, seqalign_dev_batch_t *dev_out, bool *best_done,
                        const SaCandBox *cand, bool *cand_done, uint64_t uniform_stride) {
   // uniform_stride != 0 (the caller checked that every pair of the chunk has the same shape): pair k's cells start at
-  // k * uniform_stride instead of back to back (the packed fills' layout, sa_fill_dirs_x2.hip)
+  // k * uniform_stride instead of back to back (the packed fills' layout, sa_fill_dirs_x2.hip).
+  // uniform_stride == kBucketShapes (the caller checked that the packed fill takes the chunk's largest shape): a RAGGED chunk
+  // for the packed fills -- every pair's cells start on a multiple of 256, and each slice of the chunk comes with a list that
+  // pairs up its pairs of equal shape ("bucket by shape"; a pair without a partner has a wave to itself)
+  const bool bucket = uniform_stride == kBucketShapes;
+  if (bucket) uniform_stride = 0;
   const uint64_t n = c.count;
   int rc;
   StageTimer tm(ctx->opt.timing);
   // pinned descriptor block: off_a, off_b, mat_off (u64) then len_a, len_b (u32)
-  const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t));
+  const size_t desc_bytes = n * (3 * sizeof(uint64_t) + 2 * sizeof(uint32_t)) + (bucket ? 2 * n * sizeof(uint32_t) : 0);
   if ((rc = ctx->h_desc.reserve(desc_bytes))) return rc;
   if ((rc = ctx->h_arena.reserve(c.seq_bytes + 16))) return rc;
   uint64_t *h_off_a = ctx->h_desc.as<uint64_t>(), *h_off_b = h_off_a + n, *h_mat = h_off_b + n;
@@ -69,18 +74,48 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     h_off_a[k] = pos; pos += b->len_a[p];
     h_off_b[k] = pos; pos += b->len_b[p];
     h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
-    h_mat[k] = uniform_stride ? k * uniform_stride : cell; cell += (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    h_mat[k] = uniform_stride ? k * uniform_stride : cell;
+    const uint64_t cells_k = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    cell += bucket ? ((cells_k + 255u) & ~(uint64_t)255u) : cells_k;
   }
-  const uint64_t mat_total = uniform_stride ? n * uniform_stride : c.cells;
+  const uint64_t mat_total = uniform_stride ? n * uniform_stride : cell;
+  uint32_t *h_list = reinterpret_cast<uint32_t *>(h_len_b + n);   // (bucket) 2 n entries: the slices' pair lists
   if ((rc = ctx->arena.reserve(c.seq_bytes + 16))) return rc;
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
   const bool no_matrices = cand && cand->best_only;   // direction bytes + the best cell only (the caller's cand->dirs)
   if (!no_matrices && (rc = reserve_arenas(ctx, mat_total * 4))) return rc;
   hipStream_t st = ctx->stream;
+  uint32_t list_len[2] = {0, 0};   // (bucket) entries of the first slice's list and of the second's
+  if (bucket) {
+    // the slices the loop below will make: [0, first) and [first, n)
+    const bool split = n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20) && n >= 2 * (uint64_t)2048;
+    const uint64_t first = split ? 2048 : n;
+    static thread_local std::vector<uint32_t> tl_table;   // the one pair of each shape still waiting for a partner
+    const uint64_t Wb = (uint64_t)c.max_b + 1, entries = ((uint64_t)c.max_a + 1) * Wb;
+    if (tl_table.size() < entries) tl_table.resize(entries);
+    for (int sl = 0; sl < 2; ++sl) {
+      const uint64_t k0 = sl ? first : 0, k1 = sl ? n : first;
+      uint32_t *out = h_list + 2 * k0;
+      uint32_t at = 0;
+      for (uint64_t k = k0; k < k1; ++k) tl_table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]] = ~0u;
+      for (uint64_t k = k0; k < k1; ++k) {
+        uint32_t &slot = tl_table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]];
+        if (slot == ~0u) { slot = (uint32_t)k; continue; }
+        out[at++] = slot; out[at++] = (uint32_t)k;
+        slot = ~0u;
+      }
+      for (uint64_t k = k0; k < k1; ++k) {
+        uint32_t &slot = tl_table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]];
+        if (slot == (uint32_t)k) { out[at++] = (uint32_t)k; out[at++] = (uint32_t)k; slot = ~0u; }   // alone in its wave
+      }
+      list_len[sl] = at;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(ctx->off_a.p, h_off_a, desc_bytes, hipMemcpyHostToDevice, st));
   uint64_t *dv_off_a = ctx->off_a.as<uint64_t>(), *dv_off_b = dv_off_a + n, *dv_mat = dv_off_b + n;
   uint32_t *dv_len_a = reinterpret_cast<uint32_t *>(dv_mat + n), *dv_len_b = dv_len_a + n;
+  const uint32_t *dv_list = dv_len_b + n;
   if (best_done && ((rc = ctx->best_score.reserve(n * 4)) || (rc = ctx->best_index.reserve(n * 8)))) return rc;
   // the fill of pairs [k0, k1) of the chunk (the whole chunk: 0, n) with whatever the caller asked the fill to report
   auto range_desc = [&](uint64_t k0, uint64_t k1) {
@@ -95,6 +130,21 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     return d;
   };
   auto fill_range = [&](uint64_t k0, uint64_t k1, bool *bd, bool *cd, bool *du) -> int {
+    if (bucket) {
+      // the slice's pairs through the packed fill by its list (entries index the CHUNK's arrays: nothing moves with the slice)
+      seqalign_dev_batch_t dc = range_desc(0, n);
+      dc.n_pairs = k1 - k0;
+      SaCandBox sub = *cand;
+      bool used = false;
+      sub.dirs_used = &used; sub.uniform_stride = 256;
+      sub.pair_list = dv_list + 2 * k0; sub.list_count = list_len[k0 ? 1 : 0];
+      const int r = no_matrices
+          ? fill_device(ctx, sc, &dc, SEQALIGN_KERNEL_AUTO, st, ctx->best_score.as<int32_t>(), ctx->best_index.as<uint64_t>(), bd, &sub, nullptr)
+          : fill_device(ctx, sc, &dc, SEQALIGN_KERNEL_AUTO, st, nullptr, nullptr, nullptr, &sub, cd);
+      if (du) *du = used;
+      if (!r && !used) { set_last_error("internal error: the packed fill refused a ragged chunk it had accepted"); return SEQALIGN_E_HIP; }
+      return r;
+    }
     const seqalign_dev_batch_t d = range_desc(k0, k1);
     if (best_done && no_matrices) {
       SaCandBox sub = *cand;
@@ -125,6 +175,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   // start), otherwise once, behind the last slice.
   constexpr uint64_t kPack = 2048;
   const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20)) ? 4 : 1;
+  const bool two_slices = (uniform_stride || bucket) && n_sub > 1;   // (see the loop below: one small slice to start on, then the rest)
   const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)8 << 20);
   { int rc_s = ensure_copy_streams(ctx, 1); if (rc_s) return rc_s; }
   hipStream_t su = ctx->copy_streams[0];
@@ -137,7 +188,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   uint64_t filled_to = 0;
   for (uint64_t k0 = 0; k0 < n;) {
     uint64_t k1 = k0;
-    if (uniform_stride && n_sub > 1) {
+    if (two_slices) {
       // the packed fills run two pairs per wave: slices of a quarter of C3's 10 000 pairs are 1 000-2 000 waves on a chip
       // with 8 192 wave slots, and the slices run one after the other (C3: 1.06 + 1.44 ms where one launch takes 2.15).
       // One small slice to start on while the rest is packed and shipped, then everything else in one launch.
@@ -705,23 +756,15 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   // two-pairs-per-wave fill) / mostly one shape: every pair on a multiple of 256, the modal shape's pairs packed
   enum { kBackToBack, kUniform, kMixed } layout = kBackToBack;
   uint64_t stride = 0;
-  uint32_t modal_a = 0, modal_b = 0;
   const bool may_pack = ctx->opt.pack16 && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2);
   if (same_shape && may_pack && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     layout = kUniform;
     stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
-  } else if (!same_shape && may_pack) {
-    // the majority shape, if there is one (Boyer-Moore vote, then an exact count: two passes of compares, no hashing)
-    uint64_t best_key = 0, votes = 0, best_count = 0;
-    for (uint64_t k = 0; k < n; ++k) {
-      const uint64_t key = (uint64_t)batch->len_a[c.first + k] << 32 | batch->len_b[c.first + k];
-      if (votes == 0) { best_key = key; votes = 1; } else if (key == best_key) ++votes; else --votes;
-    }
-    for (uint64_t k = 0; k < n; ++k) best_count += ((uint64_t)batch->len_a[c.first + k] << 32 | batch->len_b[c.first + k]) == best_key;
-    modal_a = (uint32_t)(best_key >> 32); modal_b = (uint32_t)best_key;
-    if ((best_count >= kPackedFillMinPairs || (ctx->opt.pack16 == 2 && best_count >= 2)) && best_count * 2 >= n &&
-        nw_dirs_x2_applicable(ctx, sc, modal_a, modal_b))
-      layout = kMixed;
+  } else if (!same_shape && may_pack && (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull) <= kShapeTableMax &&
+             nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
+    // ragged (reads trimmed to various lengths): pairs of EQUAL shape are found per sub-batch and go two per wave, the ones
+    // left over one per wave, all in one grid per sub-batch (below: pair_up)
+    layout = kMixed;
   }
   // where each block's pairs start: characters (sequences, string slots) and cells
   std::vector<uint64_t> chars_at(nb + 1, 0), cells_at(nb + 1, 0);
@@ -787,22 +830,40 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   hipStream_t sw = walk_beside ? ctx->copy_streams[2] : sf;
   StreamSyncOnExit sync_f(sf), sync_u(su), sync_d(sd), sync_w(sw);   // pinned / device buffers are reused by the next call
 
-  // mixed chunk: per sub-batch, the pairs of the modal shape and then the others (indices into the chunk's arrays)
+  // mixed chunk: per sub-batch, which pairs go two per wave (consecutive list entries 2u, 2u + 1 have the same shape) and which
+  // alone.  SURVEY 8e's "bucket by shape": a direct-mapped table over (len_a, len_b) holds the one pair of each shape that is
+  // still waiting for a partner -- one pass pairs the pairs up, a second collects who is left -- so a chunk of reads of every
+  // length between 100 and 150 (2 601 shapes, ~6 pairs of each per sub-batch) runs ~5/6 of its pairs through the packed kernel
+  // where round 3's majority vote found no majority at all.  The sub-batches are paired up in parallel, one table each.
   std::vector<uint32_t> list_at;
   const uint32_t *dv_list = nullptr;
   if (layout == kMixed) {
+    const uint64_t entries = (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull);
     if ((rc = ctx->h_misc.reserve(n * 4 + 16)) || (!zc_in && (rc = ctx->pair_list.reserve(n * 4 + 16)))) return rc;
     uint32_t *h_list = ctx->h_misc.as<uint32_t>();
     list_at.assign(2 * n_sub + 1, 0);
-    uint32_t at = 0;
-    for (uint32_t s2 = 0; s2 < n_sub; ++s2) {
+    parallel_for(n_sub, [&](uint64_t s2) {
+      static thread_local std::vector<uint32_t> tl_table;   // (one table per worker thread, kept: <= 4 MiB)
+      std::vector<uint32_t> &table = tl_table;
+      if (table.size() < entries) table.resize(entries);
       const uint64_t k0 = pair_at(bcut[s2]), k1 = pair_at(bcut[s2 + 1]);
-      list_at[2 * s2] = at;
-      for (uint64_t k = k0; k < k1; ++k) if (h_len_a[k] == modal_a && h_len_b[k] == modal_b) h_list[at++] = (uint32_t)k;
-      list_at[2 * s2 + 1] = at;
-      for (uint64_t k = k0; k < k1; ++k) if (!(h_len_a[k] == modal_a && h_len_b[k] == modal_b)) h_list[at++] = (uint32_t)k;
-    }
-    list_at[2 * n_sub] = at;
+      const uint32_t Wb = c.max_b + 1;
+      for (uint64_t k = k0; k < k1; ++k) table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]] = ~0u;   // (only the shapes that occur are reset)
+      uint32_t at = (uint32_t)k0;
+      for (uint64_t k = k0; k < k1; ++k) {
+        uint32_t &slot = table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]];
+        if (slot == ~0u) { slot = (uint32_t)k; continue; }
+        h_list[at++] = slot; h_list[at++] = (uint32_t)k;
+        slot = ~0u;
+      }
+      const uint32_t paired_end = at;
+      for (uint64_t k = k0; k < k1; ++k) {
+        uint32_t &slot = table[(uint64_t)h_len_a[k] * Wb + h_len_b[k]];
+        if (slot == (uint32_t)k) { h_list[at++] = (uint32_t)k; slot = ~0u; }
+      }
+      list_at[2 * s2] = (uint32_t)k0; list_at[2 * s2 + 1] = paired_end;
+    });
+    list_at[2 * n_sub] = (uint32_t)n;
     if (zc_in) dv_list = ctx->h_misc.dev_as<uint32_t>();
     else { dv_list = ctx->pair_list.as<uint32_t>(); HIP_TRY(hipMemcpyAsync(ctx->pair_list.p, h_list, n * 4, hipMemcpyHostToDevice, su)); }
   }
@@ -864,7 +925,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         const seqalign_dev_batch_t dm = dev_range(0, n);
         const uint32_t m0 = list_at[2 * s], m1 = list_at[2 * s + 1], r1 = list_at[2 * s + 2];
         if ((rc = nw_dirs_fill_mixed(ctx, sc, &dm, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), ctx->best_index.as<uint64_t>(),
-                                     sf, dv_list + m0, m1 - m0, r1 - m1, modal_a, modal_b)))
+                                     sf, dv_list + m0, m1 - m0, r1 - m1, c.max_a, c.max_b)))
           return rc;
       } else {
         bool used = false;

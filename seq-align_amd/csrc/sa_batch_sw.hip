@@ -178,13 +178,19 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
     if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+    else if (!same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
+             sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
+      stride = kBucketShapes;   // ragged: run_chunk pairs up the pairs of equal shape, every pair on a multiple of 256 cells
   }
-  if ((rc = reserve_arenas(ctx, (stride ? n * stride : c.cells) * 4))) return rc;
+  uint64_t cells256 = 0;
+  if (stride == kBucketShapes)
+    for (uint64_t k = 0; k < n; ++k) cells256 += (((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1) + 255u) & ~(uint64_t)255u;
+  if ((rc = reserve_arenas(ctx, (stride == kBucketShapes ? cells256 : stride ? n * stride : c.cells) * 4))) return rc;
   // (only when the sweep will run in its rows-in-registers form: not with the strip / LDS forms forced by an option)
   const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0;
   cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
   if (!allow_dirs) stride = 0;
-  cand.uniform_stride = stride;
+  cand.uniform_stride = stride == kBucketShapes ? 256 : stride;
   // ---- ONE trip for everything, when the call is the common kind: direction bytes, one wave per pair in the sweep, a few
   // hits per pair wanted.  The hit walks are launched BEFORE anybody has seen the sweep's counts -- max_hits walks per pair,
   // walk w = hit w % max_hits of pair w / max_hits, those beyond a pair's hits return at once (sa_traceback.hip) -- and send
@@ -533,12 +539,20 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
       same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
     if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+    else if (!same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
+             sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
+      stride = kBucketShapes;   // ragged: run_chunk pairs up the pairs of equal shape
   }
   if (stride) {
-    if ((rc = ctx->dirs.reserve(n * stride + 4096))) return rc;
+    uint64_t dir_bytes = n * stride;
+    if (stride == kBucketShapes) {
+      dir_bytes = 0;
+      for (uint64_t k = 0; k < n; ++k) dir_bytes += (((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1) + 255u) & ~(uint64_t)255u;
+    }
+    if ((rc = ctx->dirs.reserve(dir_bytes + 4096))) return rc;
     SaCandBox bc;
     memset(&bc, 0, sizeof(bc));
-    bc.dirs = ctx->dirs.as<uint8_t>(); bc.dirs_used = &dirs_used; bc.best_only = true; bc.uniform_stride = stride;
+    bc.dirs = ctx->dirs.as<uint8_t>(); bc.dirs_used = &dirs_used; bc.best_only = true; bc.uniform_stride = stride == kBucketShapes ? 256 : stride;
     if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best, &bc, nullptr, stride))) return rc;
     if (!dirs_used || !have_best) { set_last_error("seqalign_sw_batch: internal error: the best-hit direction fill did not run"); return SEQALIGN_E_HIP; }
   } else if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) {

@@ -348,6 +348,9 @@ int run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk &c, cons
               seqalign_dev_batch_t *dev_out, bool *best_done = nullptr, const SaCandBox *cand = nullptr,
               bool *cand_done = nullptr, uint64_t uniform_stride = 0);
 int ensure_copy_streams(seqalign_ctx *ctx, int count);
+// run_chunk's uniform_stride: "a ragged chunk for the packed fills -- pair the pairs up by shape" (sa_batch.hip)
+constexpr uint64_t kBucketShapes = ~(uint64_t)0;
+constexpr uint64_t kShapeTableMax = (uint64_t)1 << 20;   // (len_a + 1) x (len_b + 1) entries of the pairing table: 4 MiB per host thread at most
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                  int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0,

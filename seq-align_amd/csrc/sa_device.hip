@@ -467,6 +467,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     // asked sw_best_x2_applicable first and has no matrices to fall back to
     p.best_score = best_score; p.best_index = best_index;
     p.uniform_stride = cand->uniform_stride;
+    if (cand->pair_list) { p.pair_list = cand->pair_list; p.n_pairs = cand->list_count; }
     if (!cand->dirs || !cand->dirs_used || !sa_sw_best_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs)) {
       set_last_error("internal error: the best-hit direction fill was asked for a batch outside its domain");
       return SEQALIGN_E_ARG;
@@ -484,9 +485,10 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     p.cand_rows_off = cand->hit_off;
     if (sa_dirs_fill_applicable(p, batch->max_len_a, cand->dirs)) {
       p.uniform_stride = ctx->opt.pack16 ? cand->uniform_stride : 0;
-      e = sa_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs)
-              ? sa_launch_fill_dirs_x2(p, batch->max_len_a, cand->dirs, st)
-              : sa_launch_fill_dirs(p, batch->max_len_a, cand->dirs, st);
+      const bool packed = sa_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs);
+      if (packed && cand->pair_list) { p.pair_list = cand->pair_list; p.n_pairs = cand->list_count; }
+      e = packed ? sa_launch_fill_dirs_x2(p, batch->max_len_a, cand->dirs, st)
+                 : sa_launch_fill_dirs(p, batch->max_len_a, cand->dirs, st);
       if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
       *cand->dirs_used = true;
       if (cand_done) *cand_done = true;

@@ -375,10 +375,14 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint32_t pair0 = 2 * unit;
-  if (pair0 >= p.n_pairs) return;
-  const bool two = pair0 + 1 < p.n_pairs;
-  const uint32_t pair1 = two ? pair0 + 1 : pair0;
+  // pairs 2 unit, 2 unit + 1 of the launch -- or, with a pair list (ragged chunks: sa_batch.hip pairs up the pairs of equal
+  // shape), the pairs pair_list[2 unit], pair_list[2 unit + 1] of the descriptor arrays; an entry repeated = a pair that
+  // found no partner and has the wave to itself
+  if (2 * unit >= p.n_pairs) return;
+  const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
+  const uint32_t pair1_ = p.pair_list ? p.pair_list[2 * unit + 1] : (2 * unit + 1 < p.n_pairs ? 2 * unit + 1 : pair0);
+  const bool two = pair1_ != pair0;
+  const uint32_t pair1 = pair1_;
 
   const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
   const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
@@ -585,10 +589,14 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint32_t pair0 = 2 * unit;
-  if (pair0 >= p.n_pairs) return;
-  const bool two = pair0 + 1 < p.n_pairs;
-  const uint32_t pair1 = two ? pair0 + 1 : pair0;
+  // pairs 2 unit, 2 unit + 1 of the launch -- or, with a pair list (ragged chunks: sa_batch.hip pairs up the pairs of equal
+  // shape), the pairs pair_list[2 unit], pair_list[2 unit + 1] of the descriptor arrays; an entry repeated = a pair that
+  // found no partner and has the wave to itself
+  if (2 * unit >= p.n_pairs) return;
+  const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
+  const uint32_t pair1_ = p.pair_list ? p.pair_list[2 * unit + 1] : (2 * unit + 1 < p.n_pairs ? 2 * unit + 1 : pair0);
+  const bool two = pair1_ != pair0;
+  const uint32_t pair1 = pair1_;
 
   const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
   const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];

@@ -93,6 +93,10 @@ struct SaCandBox {
                                  three matrices are not even allocated */
   uint64_t uniform_stride;    /* != 0: the chunk's layout is SaFillParams::uniform_stride's (every pair the same shape, cells
                                  k * uniform_stride apart): the packed two-pairs-per-wave fill may take it (sa_fill_dirs_x2.hip) */
+  const uint32_t *pair_list;  /* != NULL (ragged chunk, every pair's cells on a multiple of 256, uniform_stride = 256): the packed fill takes
+                                 list_count / 2 waves, wave u the pairs pair_list[2u], pair_list[2u + 1] of the descriptor arrays -- equal in
+                                 shape, or the same pair twice (it has the wave to itself)                                               */
+  uint32_t list_count;
 };
 
 /* SW multi-hit enumeration: the reverse sweep (sa_sw_sweep.hip) */

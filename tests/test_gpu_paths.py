@@ -134,6 +134,47 @@ def test_sw_batch_reports_its_kernels(ctx, opts):
     assert "fill_stream" in got and "sweep_regs" in got and not any("dirs" in k for k in got)
 
 
+def test_ragged_batches_take_the_packed_fills(ctx, opts):
+    """"for variable-length batches, sort / bucket by W x H first" -- chunks of reads of many lengths: the pairs of
+    equal shape are paired up on the host and go two per wave (NW: the others one per wave in the same grid; SW: a pair without
+    a partner has a wave to itself).  Results equal the one-pair-per-wave path's and the oracle's; the packed kernels ran."""
+    rng = W.Rng(515)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+    pairs = []
+    for k in range(360):
+        la, lb = int(40 + rng.below(12, 1)[0]), int(70 + rng.below(9, 1)[0])       # 12 x 9 shapes, ~3 pairs of each
+        a = rnd(la)
+        b = (rnd(lb // 3) + a[5:la - 5] + rnd(lb))[:lb] if k % 2 else rnd(lb)       # planted / unrelated
+        pairs.append((a, b))
+    pairs += [(b"", b"ACGT"), (rnd(51), b"")]
+    batch = W.from_pairs(pairs)
+    shapes = {}
+    for a, b in pairs:
+        shapes[(len(a), len(b))] = shapes.get((len(a), len(b)), 0) + 1
+    n_single = sum(v % 2 for v in shapes.values())
+    sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    opts(pack16=2)
+    nw = ctx.nw_batch(batch, sc_nw)
+    info = ctx.last_call()
+    assert info["fill_nw_dirs_x2"][1] == len(pairs) - n_single and info["fill_nw_dirs"][1] == n_single, info
+    sw4 = ctx.sw_batch(batch, sc_sw, 12, max_hits=4, hit_cap=1 << 16)
+    info = ctx.last_call()
+    assert info["fill_sw_dirs_x2"] == (1, 2 * ((len(pairs) - n_single) // 2 + n_single)) and "fill_sw_dirs" not in info, info
+    sw1 = ctx.sw_batch(batch, sc_sw, 12, max_hits=1, hit_cap=1 << 16)
+    info = ctx.last_call()
+    assert "fill_sw_best_x2" in info and "fill_stream" not in info, info
+    opts(pack16=0)
+    assert nw == ctx.nw_batch(batch, sc_nw)
+    assert sw4 == ctx.sw_batch(batch, sc_sw, 12, max_hits=4, hit_cap=1 << 16)
+    assert sw1 == ctx.sw_batch(batch, sc_sw, 12, max_hits=1, hit_cap=1 << 16)
+    o_nw, o_sw = osc_of(sc_nw), osc_of(sc_sw)
+    for p, (a, b) in enumerate(pairs):
+        rc, s_, ra, rb = O.oracle_nw(o_nw, a, b)
+        assert rc == 0 and nw[p] == (s_, ra, rb), p
+        rc, want = O.oracle_sw(o_sw, a, b, 12, 4)
+        assert rc == 0 and sw4[p] == want and sw1[p] == want[:1], p
+
+
 def test_device_level_calls_report_too(ctx):
     sc = S.make_scoring({"preset": "default"})
     batch = uniform(32, 90, 90, 4)
