@@ -1,8 +1,8 @@
-# Timeline of the last seqalign_nw_batch call of seq-align_amd/tools/e2e_probe3.py <variant> (kernels and copies in time order)
+# Timeline of the last seqalign_nw_batch call of seq-align_amd/tools/e2e_probe.py steps <variant> (kernels and copies in time order)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 v=${1:-only_stream}
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/probe3_$v -o t -- python $R/seq-align_amd/tools/e2e_probe3.py $v > $R/gpurun_out/probe3_$v.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/probe3_$v -o t -- python $R/seq-align_amd/tools/e2e_probe.py steps $v > $R/gpurun_out/probe3_$v.log 2>&1
 grep -E "^$v" $R/gpurun_out/probe3_$v.log
 python - $R/gpurun_out/probe3_$v <<'PY'
 import csv, glob, sys

@@ -568,27 +568,26 @@ int sa_host::nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_
   if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
   return SEQALIGN_OK;
 }
-// whether nw_dirs_fill would take this batch (decided before any buffer is reserved)
-bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a) {
-  if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO) return false;
-  seqalign_dev_batch_t b;
-  memset(&b, 0, sizeof(b));
-  SaFillParams p = make_params(ctx, scoring, &b);
-  int32_t s = 0; uint64_t t = 0;
-  p.best_score = &s; p.best_index = &t;
-  return sa_nw_dirs_fill_applicable(p, max_len_a, reinterpret_cast<const uint8_t *>((uintptr_t)256));
+// ---- whether a chunk may be laid out for one of the direction-byte fills: decided BEFORE any buffer is reserved, from the
+// flattened scoring and the shape alone (sa_kernels.h: the kernels' domains) and the context's options
+static SaScoringTraits traits_of(const seqalign_dev_scoring_t *s) {
+  return SaScoringTraits{s->flat.flags, s->flat.n_classes, s->flat.gap_open, s->flat.open1, s->flat.ext, s->flat.gen_eq, s->flat.gen_ne,
+                         s->table_abs_max};
 }
-
-// ... and for the SW best-hit path's fill (directions + the best cell)
+bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a) {
+  return ctx->opt.nw_dirs && ctx->opt.kernel == SEQALIGN_KERNEL_AUTO && sa_domain_nw_dirs(traits_of(scoring), max_len_a);
+}
+bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
+  return ctx->opt.pack16 && nw_dirs_applicable(ctx, scoring, len_a) && sa_domain_nw_dirs_x2(traits_of(scoring), len_a, len_b);
+}
+// ... the SW best-hit path's fill (directions + the best cell)
 bool sa_host::sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
-  if (!ctx->opt.pack16 || !ctx->opt.sweep_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || ctx->opt.traceback_host) return false;
-  seqalign_dev_batch_t b;
-  memset(&b, 0, sizeof(b));
-  SaFillParams p = make_params(ctx, scoring, &b);
-  int32_t s = 0; uint64_t t = 0;
-  p.best_score = &s; p.best_index = &t;
-  p.uniform_stride = 256;
-  return sa_sw_best_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)1024));
+  return ctx->opt.pack16 && ctx->opt.sweep_dirs && ctx->opt.kernel == SEQALIGN_KERNEL_AUTO && !ctx->opt.traceback_host &&
+         sa_domain_sw_best_x2(traits_of(scoring), len_a, len_b);
+}
+// ... and the SW multi-hit path's (match_scores + directions)
+bool sa_host::sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
+  return ctx->opt.pack16 && ctx->opt.sweep_dirs && ctx->opt.kernel == SEQALIGN_KERNEL_AUTO && sa_domain_sw_dirs_x2(traits_of(scoring), len_a, len_b);
 }
 
 // SW walks from start_index on direction bytes (the best-hit path): seqalign_sw_traceback_device's launch with the bytes
@@ -613,28 +612,6 @@ int sa_host::sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t
   return SEQALIGN_OK;
 }
 
-// the same question for the SW multi-hit path's fill (match_scores + directions)
-bool sa_host::sw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
-  if (!ctx->opt.pack16 || !ctx->opt.sweep_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO) return false;
-  seqalign_dev_batch_t b;
-  memset(&b, 0, sizeof(b));
-  SaFillParams p = make_params(ctx, scoring, &b);
-  uint32_t u = 0; int32_t mn = 0; uint64_t o = 0;
-  p.cand_min = &mn; p.cand_count = &u; p.cand_box = &u; p.cand_rows = &u; p.cand_rows_off = &o;
-  p.uniform_stride = 256;
-  return sa_dirs_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)1024));
-}
-
-bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {
-  if (!ctx->opt.pack16 || !nw_dirs_applicable(ctx, scoring, len_a)) return false;
-  seqalign_dev_batch_t b;
-  memset(&b, 0, sizeof(b));
-  SaFillParams p = make_params(ctx, scoring, &b);
-  int32_t s = 0; uint64_t t = 0;
-  p.best_score = &s; p.best_index = &t;
-  p.uniform_stride = 256;
-  return sa_nw_dirs_x2_applicable(p, len_a, len_b, reinterpret_cast<const uint8_t *>((uintptr_t)256));
-}
 
 extern "C" int seqalign_fill_batch_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring,
                                           const seqalign_dev_batch_t *batch, int kernel, void *stream) {

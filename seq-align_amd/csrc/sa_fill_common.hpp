@@ -16,18 +16,7 @@
 
 #include "sa_kernels.h"
 
-// must match seq-align_amd/host/sa_internal.h
-#define SA_S_BLOCKED ((int32_t)INT32_MIN)
-#define SA_S_UNKNOWN ((int32_t)(INT32_MIN + 1))
-enum : uint32_t {
-  SA_F_NO_START_GAP = 1u << 0,
-  SA_F_NO_END_GAP = 1u << 1,
-  SA_F_NO_GAPS_A = 1u << 2,
-  SA_F_NO_GAPS_B = 1u << 3,
-  SA_F_NO_MISMATCH = 1u << 4,
-  SA_F_IS_SW = 1u << 5,
-  SA_F_HAS_SENTINEL = 1u << 6
-};
+// (SA_S_* sentinels and SA_F_* flags: host/sa_internal.h, through sa_kernels.h)
 
 namespace sa {
 

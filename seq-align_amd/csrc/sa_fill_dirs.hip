@@ -289,9 +289,7 @@ static hipError_t launch_dirs_cpl(const SaFillParams &p, uint8_t *dirs, hipStrea
 
 bool sa_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs) {
   // plain scorings only: no free / forbidden gaps, no sentinel scores (the sweep's and the walkers' `plain`), gap_open <= 0
-  if (!(p.flags & SA_F_IS_SW) || sa::needs_general(p) || (p.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH))) return false;
-  if (p.K > SA_LDS_TABLE_MAX_K || p.ext > 0) return false;   // (ext <= 0: what makes the border column come out by itself)
-  if (max_len_a + 1 > 8 * sa::kWave) return false;                      // rows the sweep keeps in registers
+  if (!sa_domain_sw_dirs(sa_traits_of(p), max_len_a)) return false;   // (ext <= 0: what makes the border column come out by itself)
   if (!p.cand_count || !p.cand_box || !p.cand_rows || !p.cand_rows_off || !p.cand_min) return false;
   return ((uintptr_t)p.M & 1023) == 0 && ((uintptr_t)dirs & 255) == 0;   // block boundaries of both streams coincide
 }
@@ -312,9 +310,7 @@ hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_
 // ---- Needleman-Wunsch: directions only (seqalign_nw_batch)
 bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs) {
   // plain scorings only: no flag at all, no sentinel scores, gap_open <= 0, gap_extend <= 0
-  if ((p.flags & ~SA_F_HAS_SENTINEL) != 0 || (p.flags & SA_F_HAS_SENTINEL) || sa::needs_general(p)) return false;
-  if (p.K > SA_LDS_TABLE_MAX_K || p.ext > 0) return false;
-  if (max_len_a + 1 > 8 * sa::kWave) return false;
+  if (!sa_domain_nw_dirs(sa_traits_of(p), max_len_a)) return false;
   return dirs && p.best_score && p.best_index && ((uintptr_t)dirs & 255) == 0;
 }
 

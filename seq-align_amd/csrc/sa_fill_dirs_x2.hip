@@ -802,12 +802,7 @@ static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs,
 
 // every score the recurrence can produce for pairs up to max_len_a x max_len_b, de-trended or not, stays inside int16
 bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b) {
-  auto mag = [](int64_t v) { return v < 0 ? -v : v; };
-  int64_t pen = std::max(mag(p.gen_eq), mag(p.gen_ne));
-  pen = std::max(pen, std::max(mag(p.open1), mag(p.ext)));
-  pen = std::max(pen, mag(p.gap_open) + mag(p.ext));
-  if (p.K > 1) pen = std::max(pen, (int64_t)p.table_abs_max);
-  return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(p.ext) <= 30000;
+  return sa_domain_x2_scores_fit(sa_traits_of(p), max_len_a, max_len_b);
 }
 
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
@@ -852,11 +847,9 @@ hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uin
 // ---- Smith-Waterman best hit: directions + the best cell, two pairs per wave
 bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
   // the domain of the direction fills (sa_dirs_fill_applicable) without the candidates' outputs
-  if (!(p.flags & SA_F_IS_SW) || sa::needs_general(p) || (p.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH))) return false;
-  if (p.K > SA_LDS_TABLE_MAX_K || p.ext > 0 || max_len_a + 1 > 8 * sa::kWave || max_len_b >= 32768) return false;
+  if (!sa_domain_sw_best_x2(sa_traits_of(p), max_len_a, max_len_b)) return false;
   if (!dirs || ((uintptr_t)dirs & 255) || !p.best_score || !p.best_index) return false;
-  if (p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
-  return sa_x2_scores_fit(p, max_len_a, max_len_b);
+  return p.uniform_stride != 0 && (p.uniform_stride & 255u) == 0;
 }
 
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {

@@ -6,6 +6,9 @@
 #include <stdint.h>
 
 #include "seqalign_hip.h"
+extern "C" {
+#include "sa_internal.h"   /* SA_F_* */
+}
 
 /* Everything one fill launch needs; passed by value as the kernarg. */
 struct SaFillParams {
@@ -214,6 +217,53 @@ void sa_record_launch(int kind, uint64_t items);
 /* substitution lookup flavour */
 enum { SA_SUBST_SIMPLE = 0, SA_SUBST_LDS = 1, SA_SUBST_GLOBAL = 2 };
 #define SA_LDS_TABLE_MAX_K 64
+
+/* ---- the DOMAINS of the direction-byte fills: pure functions of (flattened scoring, shape) ---------------------------
+ * Which scorings and shapes a kernel family takes is a property of the scoring's numbers and the pairs' lengths alone; the
+ * launchers add what depends on the launch (output pointers present, block-aligned), and the host-level entry points ask the
+ * same functions BEFORE they lay a chunk out (sa_device.hip: *_applicable) -- from the flattened scoring, no launch needed. */
+struct SaScoringTraits {
+  uint32_t flags, K;
+  int32_t gap_open, open1, ext, gen_eq, gen_ne, table_abs_max;
+};
+inline SaScoringTraits sa_traits_of(const SaFillParams &p) {
+  return SaScoringTraits{p.flags, p.K, p.gap_open, p.open1, p.ext, p.gen_eq, p.gen_ne, p.table_abs_max};
+}
+/* the row sweeps' GENERAL path (free / forbidden gaps, sentinel scores, gap_open > 0): none of the direction fills takes it */
+inline bool sa_scoring_needs_general(const SaScoringTraits &t) {
+  return (t.flags & (SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_HAS_SENTINEL)) || t.open1 > t.ext;
+}
+/* rows the direction fills (and the sweep behind them) keep in one wave's registers: 8 columns per lane */
+inline bool sa_domain_dirs_row(uint32_t max_len_a) { return max_len_a + 1 <= 8 * 64; }
+/* NW, directions only: no flag at all, no sentinel, gap_open <= 0, gap_extend <= 0, a table that fits LDS */
+inline bool sa_domain_nw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
+  return t.flags == 0 && !sa_scoring_needs_general(t) && t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_dirs_row(max_len_a);
+}
+/* SW, match_scores + directions / directions + best cell: the same without the start-gap / mismatch flags */
+inline bool sa_domain_sw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
+  return (t.flags & SA_F_IS_SW) && !sa_scoring_needs_general(t) && !(t.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH)) &&
+         t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_dirs_row(max_len_a);
+}
+/* two pairs per wave in packed int16: every score the recurrence can produce on pairs up to max_len_a x max_len_b, de-trended
+ * or not, stays inside int16 */
+inline bool sa_domain_x2_scores_fit(const SaScoringTraits &t, uint32_t max_len_a, uint32_t max_len_b) {
+  auto mag = [](int64_t v) { return v < 0 ? -v : v; };
+  int64_t pen = mag(t.gen_eq) > mag(t.gen_ne) ? mag(t.gen_eq) : mag(t.gen_ne);
+  if (mag(t.open1) > pen) pen = mag(t.open1);
+  if (mag(t.ext) > pen) pen = mag(t.ext);
+  if (mag(t.gap_open) + mag(t.ext) > pen) pen = mag(t.gap_open) + mag(t.ext);
+  if (t.K > 1 && (int64_t)t.table_abs_max > pen) pen = t.table_abs_max;
+  return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(t.ext) <= 30000;
+}
+inline bool sa_domain_nw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
+  return sa_domain_nw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
+}
+inline bool sa_domain_sw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
+  return sa_domain_sw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
+}
+inline bool sa_domain_sw_best_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
+  return sa_domain_sw_dirs(t, la) && lb < 32768 && sa_domain_x2_scores_fit(t, la, lb);
+}
 
 /* returns hipSuccess or the launch error; never synchronises */
 hipError_t sa_launch_fill_wavefront(const SaFillParams &p, uint32_t max_len_a,

@@ -48,6 +48,21 @@ def same(r0, r1):
     return all(np.array_equal(x, y) for x, y in zip(r0, r1))
 
 
+def near_bound_spec(la, lb, v):
+    """A match / mismatch scoring whose int16 admission bound (sa_x2_scores_fit: (la + lb + 2) pen + (la + 1) |ext| <= 30 000)
+    evaluates to within 2 % of 30 000 for this shape -- where the packed halves come closest to leaving int16 -- or None."""
+    ge = -int(v[6] % 4)
+    pen = (30000 - (la + 1) * abs(ge)) // (la + lb + 2)
+    if pen < 2 or (la + lb + 2) * pen + (la + 1) * abs(ge) < 29400:
+        return None
+    kind = int(v[5] % 3)          # which penalty sits at the bound: match, mismatch, or the first gap character
+    match = pen if kind == 0 else max(1, pen // (2 + int(v[3] % 3)))
+    mismatch = -pen if kind == 1 else -max(0, pen // (1 + int(v[4] % 4)))
+    open1 = pen if kind == 2 else max(abs(ge), pen // (1 + int(v[5] % 5)))
+    go = -(open1 - abs(ge))
+    return {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
+
+
 t_end = time.time() + seconds
 trials = pairs = oracle_pairs = 0
 shapes = [(1, 1), (1, 7), (7, 1), (3, 5), (63, 64), (64, 64), (64, 10), (127, 130), (128, 128), (150, 150), (151, 149), (191, 40),
@@ -60,7 +75,10 @@ while time.time() < t_end:
     go, ge = -int(v[5] % 12), -int(v[6] % 4)
     spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
     alpha = DNA
-    if v[11] % 5 == 0:      # a substitution table: BLOSUM62 on protein, or a wildcard
+    if sw_trials % 5 == 4 and near_bound_spec(la, lb, v):      # a fifth of the scorings at the edge of int16
+        spec = near_bound_spec(la, lb, v)
+        match = spec["init"][0]
+    elif v[11] % 5 == 0:      # a substitution table: BLOSUM62 on protein, or a wildcard
         spec, alpha = ({"preset": "BLOSUM62"}, PROT) if v[11] % 2 else ({**spec, "wildcards": [["N", int(v[10] % 3) - 1]]}, DNAN)
     sc = S.make_scoring(spec)
     batch = uniform_batch(n, la, lb, bool(v[8] & 1), alpha)
@@ -149,7 +167,10 @@ while time.time() < t_end:
     go, ge = -int(v[5] % 12), -int(v[6] % 4)
     spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
     alpha = DNA
-    if v[11] % 5 == 0:
+    if sw_trials % 5 == 4 and near_bound_spec(la, lb, v):      # a fifth of the scorings at the edge of int16
+        spec = near_bound_spec(la, lb, v)
+        match = spec["init"][0]
+    elif v[11] % 5 == 0:
         spec, alpha = ({"preset": "BLOSUM62"}, PROT) if v[11] % 2 else ({**spec, "wildcards": [["N", int(v[10] % 3) - 1]]}, DNAN)
         if "preset" in spec: match = 5
     sc = S.make_scoring(spec)
