@@ -394,11 +394,11 @@ def run(args) -> int:
             while n_calls < 3 or time.perf_counter() < t_end:
                 f()
                 n_calls += 1
-        # The arena placement above created and released up to 160 GiB of HBM chunks, and for ~4.5 s after that the
-        # driver is busy with what it released: every host-level call measures ~30 % slower during that time
-        # (tools/e2e_probe2.py, profiles/r03/r03_after_placement_transient.txt: 7.6 ms instead of 5.8 for C5's share,
-        # back to 5.8 after 4.4 s).  A process pays that once, at start-up; `e2e` is the call's steady state, so keep
-        # calling until 6 s after the placement.
+        # The arena placement above created and released up to 160 GiB of HBM chunks.  In round 3 every host-level call measured
+        # ~30 % slower for 1.4-4.4 s after that (profiles/r03/r03_after_placement_transient.txt) and this loop waited 6 s; with
+        # round 4's host path (moves home, no blit kernel, a worker pool sized to the CPU quota) the same experiment shows no
+        # transient at all (tools/placement_pressure.py, profiles/r04/r04_placement_pressure.txt: 0.49 ms from the first 250 ms
+        # after walks of 24, 64 and 160 GiB).  `cold_ms` above is measured without any wait; this keeps calling for a second.
         while time.perf_counter() - t_placed < args.e2e_after:
             fn()
         settle(fn)
@@ -579,7 +579,7 @@ def main() -> int:
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-after", type=float, default=6.0,
+    ap.add_argument("--e2e-after", type=float, default=1.0,
                     help="seconds after the arena placement before `e2e` is measured (the driver's transient after the placement walk)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to its GPU's NUMA node")
     ap.add_argument("--placement", default="spread", choices=["spread", "packed"],

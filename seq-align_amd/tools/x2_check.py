@@ -75,7 +75,7 @@ while time.time() < t_end:
     go, ge = -int(v[5] % 12), -int(v[6] % 4)
     spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
     alpha = DNA
-    if sw_trials % 5 == 4 and near_bound_spec(la, lb, v):      # a fifth of the scorings at the edge of int16
+    if trials % 5 == 4 and near_bound_spec(la, lb, v):      # a fifth of the scorings at the edge of int16
         spec = near_bound_spec(la, lb, v)
         match = spec["init"][0]
     elif v[11] % 5 == 0:      # a substitution table: BLOSUM62 on protein, or a wildcard
@@ -197,6 +197,50 @@ while time.time() < t_end:
     sw_trials += 1
     sw_pairs += n
 print(f"x2_check: SW multi-hit: {sw_trials} uniform batches, {sw_pairs} pairs: packed (pack16 = 2) hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
+
+# ---- ragged batches: pairs of MANY shapes, paired up by shape on the host (NW: mixed grid; SW: pair lists), against pack16 = 0
+t_end = time.time() + seconds / 2
+rg_trials = rg_pairs = rg_oracle = 0
+while time.time() < t_end:
+    v = rng.below(1 << 20, 12).astype(int)
+    la0, lb0 = int(1 + v[0] % 380), int(1 + v[1] % 280)
+    da, db = int(1 + v[2] % 12), int(1 + v[3] % 9)          # shapes la0 .. la0 + da - 1  x  lb0 .. lb0 + db - 1
+    n = int(4 + v[4] % 500)
+    match, mismatch = int(1 + v[5] % 5), -int(v[6] % 6)
+    go, ge = -int(v[7] % 12), -int(v[8] % 4)
+    spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[9] & 1)], "wildcards": []}
+    sc = S.make_scoring(spec)
+    lens = rng.below(1 << 16, 2 * n).astype(int)
+    pairs = []
+    for k in range(n):
+        xa, xb = la0 + int(lens[2 * k] % da), lb0 + int(lens[2 * k + 1] % db)
+        a = bytes(b"ACGT"[i] for i in rng.below(4, xa))
+        b = (a[: xb] + (bytes(b"ACGT"[i] for i in rng.below(4, xb - xa)) if xb > xa else b"")) if k % 2 else bytes(b"ACGT"[i] for i in rng.below(4, xb))
+        pairs.append((a, b))
+    batch = W.from_pairs(pairs)
+    thr = int(1 + v[10] % max(2, match * min(la0, lb0) // 2))
+    max_hits = int(1 + v[11] % 6)
+    ctx.set_option("subbatches", int(v[9] % 4))
+    res = {}
+    for pk in (0, 2):
+        ctx.set_option("pack16", pk)
+        res[pk] = (ctx.nw_batch(batch, sc), ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8))
+    ctx.set_option("subbatches", 0)
+    if res[0] != res[2]:
+        print("RAGGED MISMATCH pack16 0 vs 2:", la0, lb0, da, db, n, spec, "thr", thr, "max_hits", max_hits, flush=True)
+        sys.exit(1)
+    if rg_trials % 4 == 0:
+        osc = O.Scoring.from_buffer_copy(bytes(sc))
+        for p in range(0, n, max(1, n // 6)):
+            _, score, sa, sb = O.oracle_nw(osc, pairs[p][0], pairs[p][1])
+            rc, want = O.oracle_sw(osc, pairs[p][0], pairs[p][1], thr, max_hits)
+            if res[2][0][p] != (score, sa, sb) or rc != 0 or res[2][1][p] != want:
+                print("RAGGED MISMATCH vs oracle:", la0, lb0, da, db, n, spec, "pair", p, flush=True)
+                sys.exit(1)
+            rg_oracle += 1
+    rg_trials += 1
+    rg_pairs += n
+print(f"x2_check: ragged (bucketed by shape): {rg_trials} batches, {rg_pairs} pairs: NW strings and SW hit lists with pack16 = 2 identical to pack16 = 0; {rg_oracle} pairs against the oracle", flush=True)
 
 from bench import WORKLOADS  # noqa: E402
 for name, n in (("C2", 10000), ("C5share", 125000)):
