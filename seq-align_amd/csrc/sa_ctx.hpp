@@ -242,6 +242,7 @@ struct SaOptions {
   int sweep_mode = 0;             // sweep_mode        auto|pair|strips (sa_batch_sw.hip)
   uint32_t sweep_strip = 0;       // sweep_strip       64|128|256 columns per strip
   uint32_t sweep_cpl = 0;         // sweep_cpl         1|2|4: the LDS form of the sweep
+  bool sweep_ev = true;           // sweep_ev          0|1: the direction-byte sweep carries a walk as one word key << 2 | state (one min3 per cell)
   bool sweep_trace = false;       // sweep_trace       per-pair counters of the sweep on stderr
   bool nw_dirs = true;            // nw_dirs           0|1: seqalign_nw_batch fills ONLY a byte of directions per cell (sa_fill_dirs.hip) where
                                   //                   it applies (plain scorings, rows <= 512 columns), instead of the three matrices

@@ -204,6 +204,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_mode")) { if (!name_of(kSweepModes, 3, &idx)) return false; o.sweep_mode = idx; return true; }
   if (is("sweep_strip")) { if (!number(0, 256, &num) || (num != 0 && num != 64 && num != 128 && num != 256)) return false; o.sweep_strip = (uint32_t)num; return true; }
   if (is("sweep_cpl")) { if (!number(0, 4, &num) || num == 3) return false; o.sweep_cpl = (uint32_t)num; return true; }
+  if (is("sweep_ev")) return flag(&o.sweep_ev);
   if (is("sweep_trace")) return flag(&o.sweep_trace);
   if (is("sweep_dirs")) return flag(&o.sweep_dirs);
   if (is("nw_dirs")) return flag(&o.nw_dirs);
@@ -245,6 +246,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("sweep_mode")) { *out = kSweepModes[o.sweep_mode]; return true; }
   if (is("sweep_strip")) return n(o.sweep_strip);
   if (is("sweep_cpl")) return n(o.sweep_cpl);
+  if (is("sweep_ev")) return n(o.sweep_ev);
   if (is("sweep_trace")) return n(o.sweep_trace);
   if (is("sweep_dirs")) return n(o.sweep_dirs);
   if (is("nw_dirs")) return n(o.nw_dirs);
@@ -265,7 +267,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);

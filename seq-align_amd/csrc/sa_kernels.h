@@ -142,6 +142,7 @@ struct SaSweepParams {
   uint32_t max_len_a;            /* of the chunk: picks the kernel                                    */
   SaKeyLayout layout;
   unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (option sweep_trace) */
+  uint32_t tune_ev;              /* host side only: the direction-byte sweep's second form (walks as key << 2 | state words; option sweep_ev) */
   uint32_t tune_cpl;             /* host side only: 1, 2, 4 forces the LDS form with segments of 64 * that many columns (option sweep_cpl) */
   const uint8_t *dirs;           /* != NULL: the matrices were filled by sa_fill_dirs.hip -- M holds match_scores, dirs one byte
                                     of directions per cell (same cell offsets), A / B are not used                           */

@@ -798,6 +798,166 @@ __global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same sweep, second form (round 4): a walk travels as ONE sortable word, ev = key << 2 | the state it arrives in.
+// The reference's rule "the lowest-ranked arrival wins the cell" (a cell is marked by the first walk, in hit
+// order, that reaches it -- smith_waterman.c:165-277 run sequentially) is then a plain minimum: keys are unique, so the two
+// state bits never decide it, and the winner's state comes along in the word instead of through a pair of selects per
+// arrival.  What a cell sends on is routed when it is produced -- up-left (the winner stood in MATCH), up (GAP_A) or left
+// (GAP_B: inside the row) -- so the next row's arrivals are one v_min3_u32 per cell:
+//     arrivals(c, y) = min3(own candidacy, up-left word of (c + 1, y + 1), up word of (c, y + 1))
+// ~34 instead of ~50 vector instructions per cell slot (the first form: compare + and + two selects per arrival and state).
+// Same hits, same order, same keys in the pair's list as sw_sweep_dirs_kernel (every sweep test runs both: option sweep_ev).
+template <int CPL, typename EvT>
+__global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6 ? 5 : 4)) sw_sweep_dirs_ev_kernel(const SaSweepParams p) {
+  constexpr EvT kNone = ~(EvT)0;
+  const int lane = threadIdx.x;
+  const uint32_t pair = blockIdx.x;
+  if (p.cand_count[pair] == 0) {
+    if (lane == 0) { p.hit_count[pair] = 0; p.status[pair] = 0; p.err_key[pair] = ~0ull; }
+    return;
+  }
+  const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
+  const uint64_t mo = p.mat_off[pair];
+  const int32_t *__restrict__ Mg = p.M + mo;
+  const uint8_t *__restrict__ Dg = p.dirs + mo;
+  unsigned long long *hit_keys = p.hit_keys + p.hit_off[pair] + lb + 1;
+  const uint32_t hit_cap = (uint32_t)min(p.hit_off[pair + 1] - p.hit_off[pair] - (lb + 1), (uint64_t)0xffffffffu);
+  const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1];
+  const int thr = max(p.min_score[pair], 1);
+  const uint32_t cshift = p.layout.row_bits + 2u, sshift = p.layout.row_bits + p.layout.col_bits + 2u;   // (of the ev word)
+  const int cap = p.layout.cap;
+
+  int m[CPL], nm[CPL], thr_c[CPL];
+  uint32_t d[CPL], nd[CPL];
+  EvT out_diag[CPL], out_up[CPL];          // what the cells of the row below send up-left / up (kNone: nothing)
+  EvT col_row[CPL];                        // column << cshift | row << 2 of my cells on the current row
+  uint32_t n_hits = 0;
+  bool overflow = false;
+  const int xl = lane * CPL;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    thr_c[c] = (uint32_t)(xl + c) < W ? thr : INT32_MAX;
+    out_diag[c] = kNone; out_up[c] = kNone;
+    col_row[c] = ((EvT)(uint32_t)(xl + c) << cshift) | ((EvT)rmax << 2);
+  }
+  auto load_row = [&](uint32_t y, int (&dm)[CPL], uint32_t (&dd)[CPL]) __attribute__((always_inline)) {
+    const uint32_t at = y * W + (uint32_t)xl;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { dm[c] = 0; dd[c] = 0x3fu; }
+    if (y < lb) {   // a lane's run may reach past the row's end: that is the next row, still inside the pair's matrix
+      if ((uint32_t)xl < W) {
+        load_run<CPL>(Mg + at, dm);
+        if constexpr (CPL <= 4) {   // the run's direction bytes as one (unaligned) word: one load instead of CPL
+          typedef uint32_t u1_u __attribute__((aligned(1)));
+          const uint32_t q = *reinterpret_cast<const u1_u *>(Dg + at);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) dd[c] = (q >> (8 * c)) & 0xffu;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) dd[c] = Dg[at + c];
+        }
+      }
+    } else {        // the last row: cell by cell
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if ((uint32_t)(xl + c) < W) { dm[c] = Mg[at + c]; dd[c] = Dg[at + c]; }
+    }
+  };
+
+  uint32_t y = rmax;
+  load_row(y, m, d);
+  for (;; --y) {
+    if (y >= 1) load_row(y - 1, nm, nd);
+    bool live = false;
+    // ---- arrivals from below and the cell's own candidacy: one minimum
+    EvT arr[CPL];
+    bool any = false;
+    {
+      const EvT diag_edge = wave_shl1(out_diag[0], kNone);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const EvT own = (m[c] >= thr_c[c]) ? (((EvT)(uint32_t)(cap - m[c]) << sshift) | col_row[c]) : kNone;   // (arrives in MATCH: 0)
+        const EvT dg = c + 1 < CPL ? out_diag[c + 1 < CPL ? c + 1 : c] : diag_edge;
+        arr[c] = min(own, min(dg, out_up[c]));
+        any |= arr[c] != kNone;
+      }
+    }
+    if (!__any(any)) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { out_diag[c] = kNone; out_up[c] = kNone; }
+    } else {
+      // ---- arrivals along the row: my columns right to left, then again while some lane's incoming walk changes
+      EvT in_ev = kNone, win[CPL];
+      uint32_t fdir[CPL];
+      for (;;) {
+        EvT h = in_ev;
+#pragma unroll
+        for (int c = CPL - 1; c >= 0; --c) {
+          const EvT w = min(h, arr[c]);
+          const uint32_t st = (uint32_t)w & 3u;
+          const uint32_t f = (d[c] >> (2u * st)) & 3u;
+          win[c] = w; fdir[c] = f;
+          // it goes on to the left iff it stands in GAP_B and its state's score is not 0 (f == 3: the walk ends here)
+          h = (w != kNone && st == MAT_GAP_B && f != 3u) ? ((w & ~(EvT)3) | f) : kNone;
+        }
+        const EvT nxt = wave_shl1(h, kNone);
+        const bool changed = nxt != in_ev;
+        in_ev = nxt;
+        if (!__any(changed)) break;
+      }
+      // ---- what every cell sends up-left / up; hits = winners whose state has score 0 (rare: one test for the whole row)
+      bool any_hit = false;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const EvT w = win[c];
+        const uint32_t st = (uint32_t)w & 3u, f = fdir[c];
+        const bool has = w != kNone, leaves = has && f != 3u;
+        const EvT on = (w & ~(EvT)3) | f;
+        out_diag[c] = (leaves && st == MAT_MATCH) ? on : kNone;
+        out_up[c] = (leaves && st == MAT_GAP_A) ? on : kNone;
+        live |= leaves;
+        any_hit |= has && f == 3u;
+      }
+      if (__any(any_hit)) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const bool hit = win[c] != kNone && fdir[c] == 3u;
+          const unsigned long long bal = __ballot(hit);
+          if (bal) {
+            const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)(win[c] >> 2);
+            n_hits += (uint32_t)__popcll(bal);
+            if (n_hits > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
+          }
+        }
+      }
+    }
+    if (y == 0 || (!__any(live) && y <= rmin)) break;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { m[c] = nm[c]; d[c] = nd[c]; col_row[c] -= 4; }   // (the row field: y - 1)
+  }
+
+  // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
+  uint32_t status = overflow ? SA_SWEEP_OVERFLOW : 0u;
+  if (n_hits > 1 && !overflow) {
+    if (n_hits <= (uint32_t)kWave) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned long long key = lane < (int)n_hits ? __hip_atomic_load(hit_keys + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n_hits; ++j) rank += lane_value(key, (int)j) < key;
+      if (lane < (int)n_hits) hit_keys[rank] = key;
+    } else {
+      status |= SA_SWEEP_UNSORTED;
+    }
+  }
+  if (lane == 0) {
+    p.hit_count[pair] = n_hits;
+    p.status[pair] = status;
+    p.err_key[pair] = ~0ull;
+  }
+}
+
 // The strips of a pair append to its hit list in no particular order: one wave per pair ranks up to 64 hits
 // afterwards (as the one-wave-per-pair forms do themselves); longer lists are flagged for the host.
 __global__ void __launch_bounds__(kWave) sw_order_hits_kernel(const SaSweepParams p) {
@@ -866,7 +1026,12 @@ uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a, uint32_t st
 namespace sa {
 template <int CPL>
 static void launch_sweep_dirs(const SaSweepParams &p, hipStream_t stream) {
-  const bool key32 = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits <= 31;
+  const uint32_t bits = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits;
+  if (p.tune_ev) {   // key << 2 | state in one word (62-bit keys at most: seqalign_sw_batch's layouts are <= 63 bits, the host path takes the rest)
+    if (bits + 2 <= 32) { hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p); return; }
+    if (bits + 2 <= 64) { hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p); return; }
+  }
+  const bool key32 = bits <= 31;
   if (key32) hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
   else hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
 }

@@ -965,6 +965,8 @@ def test_arena_allocator(ctx):
 SWEEP_VARIANTS = {
     "default": {},                                    # plain scorings, rows <= 512 columns: match_scores + direction bytes
                                                       # (sa_fill_dirs.hip); else three matrices, form by sequence length
+    "first-form": {"sweep_ev": 0},                    # the direction-byte sweep with keys and states in separate registers (round 3's;
+                                                      # default since round 4: a walk as one word key << 2 | state, one min3 per cell)
     "three-matrices": {"sweep_dirs": 0},              # the three-matrix path everywhere (round 2's)
     "segments-64": {"sweep_cpl": 1},                  # 64-column segments: several per row where the walks spread out
     "segments-256": {"sweep_cpl": 4},
