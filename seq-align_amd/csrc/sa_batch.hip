@@ -89,7 +89,7 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   uint32_t list_len[2] = {0, 0};   // (bucket) entries of the first slice's list and of the second's
   if (bucket) {
     // the slices the loop below will make: [0, first) and [first, n)
-    const bool split = n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20) && n >= 2 * (uint64_t)2048;
+    const bool split = false;   // (one launch: see n_sub below)
     const uint64_t first = split ? 2048 : n;
     static thread_local std::vector<uint32_t> tl_table;   // the one pair of each shape still waiting for a partner
     const uint64_t Wb = (uint64_t)c.max_b + 1, entries = ((uint64_t)c.max_a + 1) * Wb;
@@ -174,7 +174,10 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   // while the rest is still being packed and shipped: C3's 11.5 MB of sequences cost 0.35 ms before the fill could
   // start), otherwise once, behind the last slice.
   constexpr uint64_t kPack = 2048;
-  const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20)) ? 4 : 1;
+  // (the packed two-pairs-per-wave fills take the chunk in ONE launch behind the whole upload: a first slice of 2 048 pairs to
+  // start on while the rest is shipped made C3 4.31-4.34 ms where one launch makes 4.22-4.28 -- half as many waves per launch
+  // leave the chip half empty for the length of a pair; option subbatches = 1: one launch for the other fills too)
+  const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20) && ctx->opt.subbatches != 1 && !uniform_stride && !bucket) ? 4 : 1;
   const bool two_slices = (uniform_stride || bucket) && n_sub > 1;   // (see the loop below: one small slice to start on, then the rest)
   const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)8 << 20);
   { int rc_s = ensure_copy_streams(ctx, 1); if (rc_s) return rc_s; }
