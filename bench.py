@@ -524,9 +524,13 @@ def run(args) -> int:
             rec = ROOT / "profiles" / "e2e_roofline.json"
             if rec.exists():
                 try:
-                    r = json.loads(rec.read_text()).get(f"{workload}:{batch.n_pairs}")
+                    table = json.loads(rec.read_text())
+                    r = table.get(f"{workload}:{batch.n_pairs}")
                     if r:
                         e2e["roofline"] = r     # bound, kernel, kernel_ms, instructions, frac + where they come from
+                    r4 = table.get(f"{workload}:{batch.n_pairs}:hits4")
+                    if r4 and "up_to_4_hits" in e2e:
+                        e2e["up_to_4_hits"]["roofline"] = r4
                 except Exception:
                     pass
             out["e2e"] = e2e

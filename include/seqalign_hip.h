@@ -306,7 +306,8 @@ int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx,
  * +-2 %).  The first candidate at or above the option arena_quality (default 1.045) ends the walk, otherwise the best one is kept; all other chunks go
  * straight back.  Bounded by the option arena_scan_gib (default 160; 0 = three plain
  * hipMallocs, what the command-line tools use) and by 60 % of the free device
- * memory; typically 10-60 GiB are held for ~0.1 s.  Arenas under 256 MiB are
+ * memory (re-checked while the walk goes on; a context's own scratch: 25 %, and 16 GiB after its first walk; walks are
+ * serialised per device, process-wide); typically 10-60 GiB are held for ~0.1 s.  Arenas under 256 MiB are
  * allocated plainly.  *quality, if not NULL, receives the probe ratio of the result
  * (< 0: not probed); seqalign_arenas_info tells how it was found.  Arenas are meant
  * to be kept and reused.  Free with seqalign_arenas_free (NOT hipFree). */
@@ -343,14 +344,22 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *   chunk_bytes     0 | >= 1 MiB            device memory one host-level chunk may use
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
- *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where every pair of a
- *                                           chunk has the same shape (seqalign_nw_batch: more than half of them; the others go one
- *                                           per wave in the same launch) and scores fit int16: for chunks of >= 2 048 pairs |
- *                                           never | whatever the chunk's size
+ *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where scores fit int16 --
+ *                                           pairs of EQUAL shape share a wave: a chunk of one shape, or a ragged chunk whose pairs
+ *                                           are paired up by shape on the host (the others: one per wave in the same launch, NW;
+ *                                           a wave to themselves, SW): for chunks of >= 2 048 pairs | never | whatever the size
  *   walk_overlap    1 | 0                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills
+ *   nw_moves        1 | 0                   the walks on direction bytes send home two bits per alignment column (which string has
+ *                                           a gap there) and the host expands them against the caller's sequences, instead of the
+ *                                           gapped strings (seqalign_nw_batch; seqalign_sw_batch: also ONE launch + wait for all
+ *                                           hits of a chunk, the walks launched before the counts are seen); DESIGN.md 3.5d, 3.6c
+ *   zero_copy       auto | 0..3             that path's kernels read the packed sequences (1) / write the moves (2) in pinned host
+ *                                           memory in place; auto: moves in place when the walks run one wave each
+ *   sweep_ev        1 | 0                   the direction-byte sweep carries a walk as one word key << 2 | state
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
- *   cpl, wpb, lds_pad, sweep_trace, timing  tuning experiments / development aids
- * Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */
+ *   cpl, wpb, lds_pad, reduce_depth, sweep_trace, timing   tuning experiments / development aids
+ * Numbers are integers and nothing else ("abc", "1x", "" are refused, not read as 0); switches take 1 / 0, true / false, on / off,
+ * yes / no.  Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */
 int seqalign_ctx_set_option(seqalign_ctx_t *ctx, const char *key, const char *value);
 
 /* The value in force (as text: what seqalign_ctx_set_option would take) -- for callers that change an option for a

@@ -22,4 +22,6 @@ emit sa_fill_dirs_x2.hip fill_dirs_x2_kernel ILi5ELi1ELi1024E "fill_dirs_x2_kern
 emit sa_fill_dirs.hip fill_nw_dirs_kernel ILi3ELi0ELi512E "fill_nw_dirs_kernel<3, 0, 512>"
 emit sa_sw_sweep.hip sw_sweep_dirs_kernel ILi3E "sw_sweep_dirs_kernel<3"
 emit sa_sw_sweep.hip sw_sweep_dirs_kernel ILi5E "sw_sweep_dirs_kernel<5"
+emit sa_sw_sweep.hip sw_sweep_dirs_ev_kernel ILi3Ej "sw_sweep_dirs_ev_kernel<3"
+emit sa_sw_sweep.hip sw_sweep_dirs_ev_kernel ILi5Ej "sw_sweep_dirs_ev_kernel<5"
 echo "]"
