@@ -583,7 +583,7 @@ def main() -> int:
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-after", type=float, default=1.0,
+    ap.add_argument("--e2e-after", type=float, default=2.0,
                     help="seconds after the arena placement before `e2e` is measured (the driver's transient after the placement walk)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to its GPU's NUMA node")
     ap.add_argument("--placement", default="spread", choices=["spread", "packed"],
