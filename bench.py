@@ -444,14 +444,15 @@ def run(args) -> int:
     scale_base = None
     if world > 1:
         if rank == 0:
-            n_alone = max(3, min(20, args.steps))
             torch.cuda.synchronize()
-            t_a = time.perf_counter()
-            for _ in range(n_alone):
-                db.fill(ctx, h, kernel, order_after_current=False)
+            n_alone, t_a = 0, time.perf_counter()
+            while n_alone < 3 or (time.perf_counter() - t_a < 0.25 and n_alone < 400):   # a quarter of a second of back-to-back launches
+                for _ in range(5):
+                    db.fill(ctx, h, kernel, order_after_current=False)
+                n_alone += 5
             torch.cuda.synchronize()
             dt = time.perf_counter() - t_a
-            scale_base = {"workload": f"{workload} share of one GPU ({batch.n_pairs} pairs), rank 0 alone, {n_alone} steps",
+            scale_base = {"workload": f"{workload} share of one GPU ({batch.n_pairs} pairs), rank 0 alone, {n_alone} steps in {dt:.2f} s",
                           "per_gpu_alone_gcups": batch.cells() * n_alone / dt / 1e9}
         grp.barrier()
 
