@@ -447,16 +447,12 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   }
   __builtin_amdgcn_s_waitcnt(kWaitVm0);
 
-  // candidates per pair (as fill_dirs_kernel): any cell >= min_score, the box, the columns per row (lane granularity)
-  uint32_t cand_n[2] = {0, 0}, box_rmin[2] = {0xffffffffu, 0xffffffffu}, box_rmax[2] = {0, 0},
-           box_cmin[2] = {0xffffffffu, 0xffffffffu}, box_cmax[2] = {0, 0};
+  // candidates per pair: whether any cell is >= min_score and the first / last ROW with one -- all the sweep behind this fill
+  // (sw_sweep_dirs*_kernel: whole rows in registers) wants to know; the per-row columns and the box's columns that the
+  // three-matrix fills report serve the LDS / strip forms of the sweep, which never run behind a direction fill.  Kept per
+  // lane (no ballots, no scalar code in the row loop: ~12 instead of ~45 instructions per row) and reduced at the end.
   const pk16 thr = pk16{(short)min(max(p.cand_min[pair0], 1), 32767), (short)min(max(p.cand_min[pair1], 1), 32767)};
-  uint32_t *cand_rows0 = p.cand_rows + 2ull * p.cand_rows_off[pair0], *cand_rows1 = p.cand_rows + 2ull * p.cand_rows_off[pair1];
-  if (lane == 0) {
-    *reinterpret_cast<uint2 *>(cand_rows0) = make_uint2(0xffffffffu, 0u);   // row 0: borders only
-    if (two) *reinterpret_cast<uint2 *>(cand_rows1) = make_uint2(0xffffffffu, 0u);
-  }
-  uint32_t rr_lo[2] = {0xffffffffu, 0xffffffffu}, rr_hi[2] = {0, 0};
+  uint32_t first_row[2] = {0xffffffffu, 0xffffffffu}, last_row[2] = {0, 0};
 
   {  // row 0: scores 0, every state ends
     pk16 mv[CPL];
@@ -531,44 +527,36 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     }
     append_row(mv, dv);
 
-    // candidates of this row, per pair (lane granularity is enough: the sweep needs bounds)
+    // candidates of this row in my columns, per pair
     pk16 best = pk_from(pk_bits(mv[0]) & valid[0]);
 #pragma unroll
     for (int c = 1; c < CPL; ++c) best = pk_max(best, pk_from(pk_bits(mv[c]) & valid[c]));
     const uint32_t below = pk_lt(best, thr);                      // 0xFFFF in the halves without a candidate in my columns
-    const unsigned long long any0 = __ballot((below & 0xffffu) == 0), any1 = __ballot((below >> 16) == 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const unsigned long long any = h ? any1 : any0;
-      uint32_t row_lo = 0xffffffffu, row_hi = 0;
-      if (any) {
-        row_lo = (uint32_t)__builtin_ctzll(any) * CPL;
-        row_hi = (uint32_t)(63 - __builtin_clzll(any)) * CPL + (CPL - 1);
-        cand_n[h] = 1;
-        box_cmin[h] = min(box_cmin[h], row_lo);
-        box_cmax[h] = max(box_cmax[h], row_hi);
-        box_rmin[h] = min(box_rmin[h], j);
-        box_rmax[h] = j;
-      }
-      if (lane == q) { rr_lo[h] = row_lo; rr_hi[h] = row_hi; }
-    }
-    if (q == kWave - 1 || j == lb) {
-      if (lane <= q) {
-        *reinterpret_cast<uint2 *>(cand_rows0 + 2ull * (j - q + lane)) = make_uint2(rr_lo[0], min(rr_hi[0], W - 1));
-        if (two) *reinterpret_cast<uint2 *>(cand_rows1 + 2ull * (j - q + lane)) = make_uint2(rr_lo[1], min(rr_hi[1], W - 1));
-      }
+      const bool has = ((h ? below >> 16 : below & 0xffffu)) == 0;
+      first_row[h] = has ? min(first_row[h], j) : first_row[h];
+      last_row[h] = has ? j : last_row[h];
     }
   }
   while (rv < wv) flush_block();
 
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      first_row[h] = min(first_row[h], (uint32_t)__shfl_xor((int)first_row[h], o));
+      last_row[h] = max(last_row[h], (uint32_t)__shfl_xor((int)last_row[h], o));
+    }
+  }
   if (lane == 0) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h == 1 && !two) break;
       const uint32_t pr = h ? pair1 : pair0;
-      p.cand_count[pr] = cand_n[h];
+      p.cand_count[pr] = first_row[h] != 0xffffffffu;
       uint32_t *box = p.cand_box + 4ull * pr;
-      box[0] = box_rmin[h]; box[1] = box_rmax[h]; box[2] = box_cmin[h]; box[3] = min(box_cmax[h], W - 1);
+      box[0] = first_row[h]; box[1] = last_row[h]; box[2] = 0; box[3] = W - 1;   // (columns: the whole row; see above)
       p.status[pr] = ~0ull;   // plain scorings have a score for every pair of characters
     }
   }
