@@ -359,69 +359,73 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_kernel(const SaTraceP
 
 // one wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk); lane l keeps word l of the current block
 // of 64 words per plane in a register, a block leaves as one coalesced store per plane
-// (walks_per_pair: one workgroup per PAIR, wave r = the pair's hit r -- launched as one workgroup per walk, the 30 000 of C3's
-// 40 000 slots that return at once cost 0.2 ms of workgroup dispatch)
+// (walks_per_pair: one WAVE per pair walks the pair's hits one after the other -- nearly every pair has one; launched as one
+// workgroup per walk slot, the 30 000 of C3's 40 000 slots that return at once cost 0.2 ms of workgroup dispatch, and as one
+// workgroup per pair with a wave per slot, four times the LDS per workgroup held for waves that had nothing to do)
 template <bool NW>
-__global__ void __launch_bounds__(512) traceback_moves_tile_kernel(const SaTraceParams p) {
+__global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceParams p) {
   constexpr int kT = 64;
-  extern __shared__ __attribute__((aligned(16))) uint8_t tiles[];   // kT * kT per wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *tile = tiles + wave * (kT * kT);
-  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (w >= p.n_pairs) return;
-  const MoveWalk m = move_walk<NW>(p, w);
-  if (!m.valid) return;   // (wave-uniform)
-  const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
-  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
-  const MoveSlot s = m.slot;
-  uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
-  uint32_t ox = 0, oy = 0;
-  bool loaded = false;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
+  const int lane = threadIdx.x;
+  const uint32_t reps = (!NW && p.walks_per_pair) ? p.walks_per_pair : 1u;
   typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
-  // block q = the walk's words 64 q .. 64 q + 63 counted from the end; slot 63 - (j & 63) of the block holds word j, and slot t
-  // of block q is plane word nw - 64 (q + 1) + t
-  auto flush = [&](int q, int first_slot) {
-    const int at = s.nw - 64 * (q + 1) + lane;
-    if (lane >= first_slot) { s.plane_a[at] = reg_a; s.plane_b[at] = reg_b; }
-  };
-  for (;;) {
-    if constexpr (NW) { if (x == 0 || y == 0) break; }
-    if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
-      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
-      oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      const uint32_t r = oy + lane;
-      if (r <= lb) {
-        const uint8_t *src = Dg + (uint64_t)r * W + ox;
+  for (uint32_t rep = 0; rep < reps; ++rep) {
+    const uint32_t w = blockIdx.x * reps + rep;
+    if (w >= p.n_pairs) return;
+    const MoveWalk m = move_walk<NW>(p, w);
+    if (!m.valid) return;   // (wave-uniform; a pair's hits are its first ranks: nothing behind an invalid one)
+    const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
+    const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+    const MoveSlot s = m.slot;
+    uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
+    uint32_t ox = 0, oy = 0;
+    bool loaded = false;
+    // block q = the walk's words 64 q .. 64 q + 63 counted from the end; slot 63 - (j & 63) of the block holds word j, and slot t
+    // of block q is plane word nw - 64 (q + 1) + t
+    auto flush = [&](int q, int first_slot) {
+      const int at = s.nw - 64 * (q + 1) + lane;
+      if (lane >= first_slot) { s.plane_a[at] = reg_a; s.plane_b[at] = reg_b; }
+    };
+    for (;;) {
+      if constexpr (NW) { if (x == 0 || y == 0) break; }
+      if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
+        ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
+        oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const uint32_t r = oy + lane;
+        if (r <= lb) {
+          const uint8_t *src = Dg + (uint64_t)r * W + ox;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);
+        loaded = true;
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_s_waitcnt(0);
-      loaded = true;
+      const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
+      if constexpr (!NW) { if (f == 3u) break; }
+      const uint32_t bit = 0x80000000u >> (k & 31u);
+      acc_a |= st == MAT_GAP_A ? bit : 0u;
+      acc_b |= st == MAT_GAP_B ? bit : 0u;
+      if ((++k & 31u) == 0) {
+        const int j = (int)(k >> 5) - 1;
+        if (lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
+        acc_a = acc_b = 0;
+        if ((j & 63) == 63) flush(j >> 6, 0);
+      }
+      x -= (st != MAT_GAP_A);
+      y -= (st != MAT_GAP_B);
+      st = f;
     }
-    const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
-    if constexpr (!NW) { if (f == 3u) break; }
-    const uint32_t bit = 0x80000000u >> (k & 31u);
-    acc_a |= st == MAT_GAP_A ? bit : 0u;
-    acc_b |= st == MAT_GAP_B ? bit : 0u;
-    if ((++k & 31u) == 0) {
-      const int j = (int)(k >> 5) - 1;
-      if (lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
-      acc_a = acc_b = 0;
-      if ((j & 63) == 63) flush(j >> 6, 0);
+    if (k) {
+      const int j = (int)((k - 1) >> 5);   // the last word the walk touched
+      if ((k & 31u) && lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
+      flush(j >> 6, 63 - (j & 63));
     }
-    x -= (st != MAT_GAP_A);
-    y -= (st != MAT_GAP_B);
-    st = f;
+    if (lane == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, k);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the next walk's tile loads behind this walk's LDS reads)
   }
-  if (k) {
-    const int j = (int)((k - 1) >> 5);   // the last word the walk touched
-    if ((k & 31u) && lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
-    flush(j >> 6, 63 - (j & 63));
-  }
-  if (lane == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, k);
 }
 
 // ---------------------------------------------------------------------------
@@ -584,7 +588,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
-        if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 4096, stream, p);
+        if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
@@ -599,7 +603,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       sa_record_launch(wtiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;
-      if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64 * wpb), 4096 * wpb, stream, p);
+      if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
