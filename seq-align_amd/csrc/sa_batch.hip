@@ -179,7 +179,9 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   // leave the chip half empty for the length of a pair; option subbatches = 1: one launch for the other fills too)
   const uint64_t n_sub = (n >= 8192 && c.seq_bytes >= ((uint64_t)4 << 20) && ctx->opt.subbatches != 1 && !uniform_stride && !bucket) ? 4 : 1;
   const bool two_slices = (uniform_stride || bucket) && n_sub > 1;   // (see the loop below: one small slice to start on, then the rest)
-  const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)8 << 20);
+  // (one launch: the upload still goes in slices, packing slice i + 1 beside the copy of slice i -- 2 MiB each, so that the copy
+  // engine starts after ~20 us of packing and never waits for the host: C3's 11.5 MB 0.33 -> 0.28 ms)
+  const uint64_t slice_bytes = n_sub > 1 ? (c.seq_bytes + n_sub - 1) / n_sub : ((uint64_t)2 << 20);
   { int rc_s = ensure_copy_streams(ctx, 1); if (rc_s) return rc_s; }
   hipStream_t su = ctx->copy_streams[0];
   StreamSyncOnExit sync_u(su);
@@ -200,8 +202,10 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
       while (k1 < n && (k1 == k0 || h_off_a[k1] - h_off_a[k0] < slice_bytes)) k1 = std::min(n, k1 + kPack);
     }
     if (n - k1 < kPack) k1 = n;   // no crumb at the end
-    parallel_for((k1 - k0 + kPack - 1) / kPack, [&](uint64_t blk) {
-      for (uint64_t k = k0 + blk * kPack, e = std::min(k1, k0 + (blk + 1) * kPack); k < e; ++k) {
+    // (tasks of 256 pairs: C4's 4 000 pairs in tasks of 2 048 kept two threads busy and fourteen idle)
+    constexpr uint64_t kTask = 256;
+    parallel_for((k1 - k0 + kTask - 1) / kTask, [&](uint64_t blk) {
+      for (uint64_t k = k0 + blk * kTask, e = std::min(k1, k0 + (blk + 1) * kTask); k < e; ++k) {
         const uint64_t p = c.first + k;
         memcpy(h_seq + h_off_a[k], b->arena + b->off_a[p], b->len_a[p]);
         memcpy(h_seq + h_off_b[k], b->arena + b->off_b[p], b->len_b[p]);
@@ -992,6 +996,13 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
     parallel_for((k_hi - k_lo + kOut - 1) / kOut, [&](uint64_t blk_i) {
       for (uint64_t k = k_lo + blk_i * kOut, e = std::min(k_hi, k_lo + (blk_i + 1) * kOut); k < e; ++k) {
         const uint64_t p = c.first + k;
+        if (k + 6 < e) {   // the GPU wrote the moves and the words: every first touch is a miss -- have the pair six ahead on its way
+          const uint64_t kn = k + 6;
+          const uint32_t nwn = (h_len_a[kn] + h_len_b[kn] + 31u) >> 5;
+          const uint32_t *pn = h_moves + move_word(kn);
+          __builtin_prefetch(h_meta + 2 * kn); __builtin_prefetch(pn + nwn - 1); __builtin_prefetch(pn + 2 * nwn - 1);
+          __builtin_prefetch(batch->arena + batch->off_a[c.first + kn]);
+        }
         const uint32_t n_moves = h_meta[2 * k + 1];
         int prc = SEQALIGN_OK;
         if (n_moves >= SA_MOVES_ERR) {

@@ -149,8 +149,13 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   // every pair's part of the scratch arena (its rows' candidate columns, then its hits' keys)
   {
     const int64_t best = best_move(sc);
-    for (uint64_t k = 0; k < n; ++k)
-      hit_off[k + 1] = hit_off[k] + hit_arena_elements(batch->len_a[c.first + k], batch->len_b[c.first + k], min_score[c.first + k], best);
+    uint32_t pa = ~0u, pb = ~0u; int32_t pm = 0; uint64_t pe = 0;   // (reads of one length: the division once per run of equal pairs)
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint32_t xa = batch->len_a[c.first + k], xb = batch->len_b[c.first + k];
+      const int32_t xm = min_score[c.first + k];
+      if (xa != pa || xb != pb || xm != pm) { pa = xa; pb = xb; pm = xm; pe = hit_arena_elements(xa, xb, xm, best); }
+      hit_off[k + 1] = hit_off[k] + pe;
+    }
   }
   DevBuf &d_hitoff = ctx->e[13];
   if ((rc = d_min.reserve(n * 4)) || (rc = ctx->cand_count.reserve(n * 4)) || (rc = d_box.reserve(n * 16)) ||
@@ -326,43 +331,70 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     tm.lap("sw one trip: wait (fill, sweep, walks)");
     bool clean = true;
     for (uint64_t k = 0; k < n && clean; ++k) clean = h_st[k] == 0;
+    tm.lap("sw one trip: statuses checked");
     if (clean) {
       const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
-      // where every hit goes in the caller's buffers (a prefix over the lengths), then the expansion on the thread pool
-      std::vector<uint64_t> hit_walk, hit_out;
-      hit_walk.reserve(n); hit_out.reserve(n);
-      bool no_room = false;
-      for (uint64_t k = 0; k < n && !no_room; ++k) {
-        const uint32_t take = std::min(h_cnt[k], max_hits);
-        for (uint32_t j = 0; j < take; ++j) {
-          const uint64_t w = k * max_hits + j;
-          const uint32_t len = h_w[4 * w + 1];
-          if (len >= SA_MOVES_ERR) return (int)(len & 15u);
-          if (*found + hit_walk.size() >= hit_cap || *used_str + len + 1 > str_cap) { no_room = true; break; }
-          hit_walk.push_back(w); hit_out.push_back(*used_str);
-          *used_str += len + 1;
-        }
-      }
-      const uint64_t first_hit = *found, n_out = hit_walk.size();
+      // where every hit goes in the caller's buffers: hits and string bytes per block of pairs (parallel), a prefix over the
+      // blocks, then every block places and expands its own hits
+      constexpr uint64_t kBlk = 256;
+      const uint64_t nblk = (n + kBlk - 1) / kBlk;
+      std::vector<uint64_t> blk_hits(nblk + 1, 0), blk_bytes(nblk + 1, 0);
       std::atomic<int> bad{SEQALIGN_OK};
-      constexpr uint64_t kPack = 128;
-      parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
-        for (uint64_t i = blk * kPack, e2 = std::min(n_out, (blk + 1) * kPack); i < e2; ++i) {
-          const uint64_t w = hit_walk[i], k = w / max_hits, pp = c.first + k;
-          const uint32_t j = (uint32_t)(w % max_hits), la = batch->len_a[pp], lb = batch->len_b[pp], nwd = (la + lb + 31u) >> 5;
-          // (run_chunk's packed offsets: the prefix of len_a + len_b over the chunk's pairs -- recomputed per pair from the
-          // pinned descriptor block run_chunk left in h_desc)
-          const uint64_t slot = ctx->h_desc.as<uint64_t>()[k];
-          const uint32_t *pa = h_moves + 2ull * max_hits * ((slot >> 5) + k) + 2ull * j * nwd;
-          seqalign_sw_hit_t &h = hits[first_hit + i];
-          uint32_t pos[4];
-          const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3],
-                                             pa, pa + nwd, nwd, h_w[4 * w + 1], out_a + hit_out[i], out_b + hit_out[i], pos);
-          if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); continue; }
-          h.pair = pp; h.score = (int32_t)h_w[4 * w]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
-          h.length = h_w[4 * w + 1]; h.str_off = hit_out[i];
+      parallel_for(nblk, [&](uint64_t bi) {
+        uint64_t hs = 0, bytes = 0;
+        for (uint64_t k = bi * kBlk, e2 = std::min(n, (bi + 1) * kBlk); k < e2; ++k) {
+          const uint32_t take = std::min(h_cnt[k], max_hits);
+          for (uint32_t j = 0; j < take; ++j) {
+            const uint32_t len = h_w[4 * (k * max_hits + j) + 1];
+            if (len >= SA_MOVES_ERR) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, (int)(len & 15u)); continue; }
+            ++hs; bytes += (uint64_t)len + 1;
+          }
         }
+        blk_hits[bi + 1] = hs; blk_bytes[bi + 1] = bytes;
       });
+      if (bad.load()) return bad.load();
+      tm.lap("sw one trip: hits counted");
+      for (uint64_t bi = 0; bi < nblk; ++bi) { blk_hits[bi + 1] += blk_hits[bi]; blk_bytes[bi + 1] += blk_bytes[bi]; }
+      // what fits the caller's buffers: whole blocks while they fit, the first one that does not hit by hit (reported after
+      // what fits is delivered, as the three-trip path does)
+      const uint64_t hit_room = hit_cap > *found ? hit_cap - *found : 0, str_room = str_cap > *used_str ? str_cap - *used_str : 0;
+      bool no_room = blk_hits[nblk] > hit_room || blk_bytes[nblk] > str_room;
+      const uint64_t first_hit = *found, first_str = *used_str;
+      std::atomic<uint64_t> delivered_hits{0}, delivered_bytes{0};
+      parallel_for(nblk, [&](uint64_t bi) {
+        uint64_t hi = blk_hits[bi], at = blk_bytes[bi], done_h = 0, done_b = 0;
+        bool stop = false;
+        for (uint64_t k = bi * kBlk, e2 = std::min(n, (bi + 1) * kBlk); k < e2 && !stop; ++k) {
+          const uint64_t pp = c.first + k;
+          const uint32_t take = std::min(h_cnt[k], max_hits), la = batch->len_a[pp], lb = batch->len_b[pp], nwd = (la + lb + 31u) >> 5;
+          // (run_chunk's packed offsets: the prefix of len_a + len_b over the chunk's pairs, in the pinned descriptor block)
+          const uint64_t slot = ctx->h_desc.as<uint64_t>()[k];
+          if (k + 6 < e2) {   // the GPU wrote these lines: every first touch is a miss -- have the pair six ahead on its way
+            const uint64_t kn = k + 6, sn = ctx->h_desc.as<uint64_t>()[kn];
+            const uint32_t nwn = (batch->len_a[c.first + kn] + batch->len_b[c.first + kn] + 31u) >> 5;
+            const uint32_t *pn = h_moves + 2ull * max_hits * ((sn >> 5) + kn);
+            __builtin_prefetch(h_w + 4 * kn * max_hits); __builtin_prefetch(pn + nwn - 1); __builtin_prefetch(pn + 2 * nwn - 1);
+            __builtin_prefetch(batch->arena + batch->off_a[c.first + kn]);
+          }
+          for (uint32_t j = 0; j < take; ++j, ++hi) {
+            const uint64_t w = k * max_hits + j;
+            const uint32_t len = h_w[4 * w + 1];
+            if (hi >= hit_room || at + len + 1 > str_room) { stop = true; break; }   // (no_room is set: the call reports it)
+            const uint32_t *pa = h_moves + 2ull * max_hits * ((slot >> 5) + k) + 2ull * j * nwd;
+            seqalign_sw_hit_t &h = hits[first_hit + hi];
+            uint32_t pos[4];
+            const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3],
+                                               pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
+            if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); stop = true; break; }
+            h.pair = pp; h.score = (int32_t)h_w[4 * w]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
+            h.length = len; h.str_off = first_str + at;
+            at += (uint64_t)len + 1; ++done_h; done_b += (uint64_t)len + 1;
+          }
+        }
+        delivered_hits.fetch_add(done_h); delivered_bytes.fetch_add(done_b);
+      });
+      const uint64_t n_out = no_room ? std::min<uint64_t>(delivered_hits.load(), hit_room) : blk_hits[nblk];
+      *used_str += no_room ? delivered_bytes.load() : blk_bytes[nblk];
       if (bad.load()) return bad.load();
       *found += n_out;
       tm.lap("sw one trip: hits expanded");
