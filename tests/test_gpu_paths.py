@@ -210,6 +210,67 @@ def test_arena_placement_when_the_device_is_half_full(ctx, opts):
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (256 << 20)
 
 
+@pytest.mark.parametrize("walker", ["wave", "lane"])
+def test_long_walks_cross_move_blocks(ctx, opts, walker):
+    """Walks of several thousand columns: the wave-per-walk walker keeps 64 words (2 048 columns) of each plane in its lanes and
+    stores whole blocks; here walks of up to ~5 000 columns cross two and more block boundaries, end exactly on one (2 048 and
+    4 096 walked columns: identical sequences) and one column past it.  needleman_wunsch.c:82-145 via the oracle."""
+    opts(trace_kernel=walker, pack16=0)
+    rng = W.Rng(808)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+    sc = S.make_scoring({"preset": "default"})
+    osc = osc_of(sc)
+    pairs = []
+    for la, lb in ((300, 4700), (511, 2048), (64, 2047), (2, 4100)):
+        a = rnd(la)
+        pairs.append((a, (a * (lb // max(la, 1) + 1))[:lb]))     # b = a repeated: long runs of matches and long gaps
+        pairs.append((a, rnd(lb)))
+    same = rnd(2048)
+    pairs += [(same[:511], same[:511]), (rnd(100), b""), (b"", rnd(3000))]
+    batch = W.from_pairs(pairs)
+    got = ctx.nw_batch(batch, sc)
+    assert "walk_moves_" + ("tile" if walker == "wave" else "lane") in ctx.last_call()
+    for p, (a, b) in enumerate(pairs):
+        rc, s_, ra, rb = O.oracle_nw(osc, a, b)
+        assert rc == 0 and got[p] == (s_, ra, rb), (walker, p, len(a), len(b))
+    # local hits that long: a read against a window that contains it several times over
+    sw = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osw = osc_of(sw)
+    a = rnd(500)
+    long_pairs = [(a, rnd(300) + a + rnd(200) + a[:400] + rnd(100)), (a, a), (a[:70], rnd(2500) + a[:70])]
+    lb = W.from_pairs(long_pairs)
+    for max_hits in (1, 3):
+        hits = ctx.sw_batch(lb, sw, 40, max_hits=max_hits, hit_cap=64)
+        for p, (x, y) in enumerate(long_pairs):
+            rc, want = O.oracle_sw(osw, x, y, 40, max_hits)
+            assert rc == 0 and hits[p] == want, (walker, max_hits, p)
+
+
+def test_options_are_parsed_strictly_and_put_back(ctx):
+    """seqalign_ctx_set_option: a number is an integer and nothing else, a switch takes 1 / 0, true / false, on / off, yes / no --
+    garbage is refused (SEQALIGN_E_ARG, nothing changes), never read as 0; Context.options() puts back what was in force before,
+    whatever set it (seqalign_ctx_get_option), not the library's defaults."""
+    for key, bad in (("cpl", "abc"), ("cpl", "3x"), ("cpl", ""), ("subbatches", "1e3"), ("nw_dirs", "maybe"), ("pack16", "7"),
+                     ("arena_quality", "fast"), ("zero_copy", "5"), ("no_such_option", "1")):
+        before = None if key == "no_such_option" else ctx.get_option(key)
+        with pytest.raises(S.SeqAlignError) as err:
+            ctx.set_option(key, bad)
+        assert err.value.code == S.E_ARG
+        if before is not None:
+            assert ctx.get_option(key) == before
+    for text, want in (("yes", "1"), ("off", "0"), ("TRUE", "1"), ("no", "0"), (True, "1"), (False, "0"), (1, "1")):
+        ctx.set_option("walk_overlap", text)
+        assert ctx.get_option("walk_overlap") == want
+    ctx.set_option("walk_overlap", 1)
+    ctx.set_option("subbatches", 5)                 # "configured earlier" (as SEQALIGN_SUBBATCHES=5 at context creation would)
+    ctx.set_option("zero_copy", 2)
+    with ctx.options(subbatches=2, zero_copy="auto", traceback="host"):
+        assert (ctx.get_option("subbatches"), ctx.get_option("zero_copy"), ctx.get_option("traceback")) == ("2", "auto", "host")
+    assert (ctx.get_option("subbatches"), ctx.get_option("zero_copy"), ctx.get_option("traceback")) == ("5", "2", "device")
+    ctx.set_option("subbatches", 0)
+    ctx.set_option("zero_copy", "auto")
+
+
 def test_device_level_calls_report_too(ctx):
     sc = S.make_scoring({"preset": "default"})
     batch = uniform(32, 90, 90, 4)
