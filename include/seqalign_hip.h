@@ -348,6 +348,9 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *                                           pairs of EQUAL shape share a wave: a chunk of one shape, or a ragged chunk whose pairs
  *                                           are paired up by shape on the host (the others: one per wave in the same launch, NW;
  *                                           a wave to themselves, SW): for chunks of >= 2 048 pairs | never | whatever the size
+ *   quad            0 | 1 | 2               the NW and the SW best-hit fill with FOUR pairs per wave (32 lanes a couple of pairs; chunks of
+ *                                           one shape, rows up to 192 columns): for chunks of >= 4 096 (NW) / 16 384 (SW) pairs | never |
+ *                                           whatever the size
  *   walk_overlap    1 | 0                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills
  *   nw_moves        1 | 0                   the walks on direction bytes send home two bits per alignment column (which string has
  *                                           a gap there) and the host expands them against the caller's sequences, instead of the
@@ -389,13 +392,15 @@ enum {
   SEQALIGN_K_SWEEP_LDS,            /* ... winners of two rows in LDS (wide pairs)                                  */
   SEQALIGN_K_SWEEP_STRIPS,         /* ... one wave per strip (few wide pairs)                                      */
   SEQALIGN_K_SWEEP_DIRS,           /* multi-hit sweep on match_scores + direction bytes, one pair per wave         */
-  SEQALIGN_K_SWEEP_DIRS_X2,        /* ... two pairs per wave                                                       */
+  SEQALIGN_K_SWEEP_DIRS_X2,        /* (reserved: two pairs per wave measured slower, never launched)               */
   SEQALIGN_K_WALK_LANE,            /* traceback on three matrices, one lane per walk (items: walks)                */
   SEQALIGN_K_WALK_WAVE,            /* ... one wave per walk, LDS tiles                                             */
   SEQALIGN_K_WALK_DIRS_LANE,       /* traceback on direction bytes, strings out, one lane per walk                 */
   SEQALIGN_K_WALK_DIRS_TILE,       /* ... one wave per walk, LDS tiles                                             */
   SEQALIGN_K_WALK_MOVES_LANE,      /* traceback on direction bytes, two bits per column out (host/sa_moves.c)      */
   SEQALIGN_K_WALK_MOVES_TILE,      /* ... one wave per walk                                                        */
+  SEQALIGN_K_FILL_NW_DIRS_X4,      /* NW, direction bytes only, FOUR pairs per wave (32 lanes a couple of pairs)   */
+  SEQALIGN_K_FILL_SW_BEST_X4,      /* SW best hit: direction bytes + the best cell, four pairs per wave            */
   SEQALIGN_K_COUNT
 };
 #define SEQALIGN_K_MAX 32

@@ -77,7 +77,7 @@ extern "C" const char *seqalign_kernel_kind_name(int kind) {
       "fill_wavefront", "fill_rowscan", "fill_stream", "fill_strips", "fill_wgstream", "fill_nw_dirs", "fill_nw_dirs_x2",
       "fill_sw_dirs", "fill_sw_dirs_x2", "fill_sw_best_x2", "sw_reduce", "sw_box", "sweep_regs", "sweep_lds", "sweep_strips",
       "sweep_dirs", "sweep_dirs_x2", "walk_lane", "walk_wave", "walk_dirs_lane", "walk_dirs_tile", "walk_moves_lane",
-      "walk_moves_tile"};
+      "walk_moves_tile", "fill_nw_dirs_x4", "fill_sw_best_x4"};
   return kind >= 0 && kind < SEQALIGN_K_COUNT ? names[kind] : nullptr;
 }
 
@@ -209,6 +209,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("sweep_dirs")) return flag(&o.sweep_dirs);
   if (is("nw_dirs")) return flag(&o.nw_dirs);
   if (is("pack16")) { if (!number(0, 2, &num)) return false; o.pack16 = (int)num; return true; }
+  if (is("quad")) { if (!number(0, 2, &num)) return false; o.quad = (uint32_t)num; return true; }
   if (is("walk_overlap")) return flag(&o.walk_overlap);
   if (is("nw_moves")) return flag(&o.nw_moves);
   if (is("zero_copy")) { if (eq("auto")) { o.zero_copy = 4; return true; } if (!number(0, 3, &num)) return false; o.zero_copy = (uint32_t)num; return true; }
@@ -251,6 +252,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("sweep_dirs")) return n(o.sweep_dirs);
   if (is("nw_dirs")) return n(o.nw_dirs);
   if (is("pack16")) return n(o.pack16);
+  if (is("quad")) return n(o.quad);
   if (is("walk_overlap")) return n(o.walk_overlap);
   if (is("nw_moves")) return n(o.nw_moves);
   if (is("zero_copy")) { if (o.zero_copy == 4) { *out = "auto"; return true; } return n(o.zero_copy); }
@@ -267,7 +269,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -396,7 +398,7 @@ extern "C" void seqalign_scoring_release(seqalign_ctx_t *ctx, seqalign_dev_scori
 // --------------------------------------------------------------- hot path ---
 static SaFillParams make_params(const seqalign_ctx *ctx, const seqalign_dev_scoring_t *s, const seqalign_dev_batch_t *b) {
   SaFillParams p;
-  p.tune_cpl = ctx->opt.cpl; p.tune_wpb = ctx->opt.wpb; p.tune_lds_pad = ctx->opt.lds_pad;
+  p.tune_cpl = ctx->opt.cpl; p.tune_wpb = ctx->opt.wpb; p.tune_lds_pad = ctx->opt.lds_pad; p.tune_quad = ctx->opt.quad;
   p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
   p.mat_off = b->mat_off; p.M = b->match_scores; p.A = b->gap_a_scores; p.B = b->gap_b_scores;
   p.status = b->status; p.code = s->d_code; p.table = s->d_table;

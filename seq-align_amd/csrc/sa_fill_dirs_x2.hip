@@ -86,6 +86,57 @@ __device__ __forceinline__ pk16 pk_wave_scan_max_excl(pk16 v) {
   return pk_from(dpp_mov0<0x138>(u) ^ 0x80008000u);   // wave_shr:1
 }
 
+// The same over each HALF of the wave separately (lanes 0-31, lanes 32-63: four pairs per wave, see LANES below): one step
+// fewer -- row_bcast:15 into rows 1 and 3 only (row_mask 0xA; the other rows keep the 0 = identity), no row_bcast:31 -- and
+// lane 32, which the last shift hands lane 31's value, gets the identity as lane 0 does.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0_rows(uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ pk16 pk_half_scan_max_excl(pk16 v, bool first_lane) {
+  uint32_t u = pk_bits(v) ^ 0x80008000u;
+  u = pk_max_u16(u, dpp_mov0<0x111>(u));   // row_shr:1
+  u = pk_max_u16(u, dpp_mov0<0x112>(u));   // row_shr:2
+  u = pk_max_u16(u, dpp_mov0<0x114>(u));   // row_shr:4
+  u = pk_max_u16(u, dpp_mov0<0x118>(u));   // row_shr:8
+  u = pk_max_u16(u, dpp_mov0_rows<0x142, 0xA>(u));   // row_bcast:15 -> rows 1, 3
+  const uint32_t r = dpp_mov0<0x138>(u);   // wave_shr:1
+  return pk_from((first_lane ? 0u : r) ^ 0x80008000u);
+}
+template <int LANES>
+__device__ __forceinline__ pk16 pk_scan_max_excl(pk16 v, bool first_lane) {
+  if constexpr (LANES == 64) return pk_wave_scan_max_excl(v);
+  else return pk_half_scan_max_excl(v, first_lane);
+}
+// lane l <- lane l - 1, the first lane of a span of LANES lanes <- 0
+template <int LANES>
+__device__ __forceinline__ pk16 pk_shr1_zero_in(pk16 src, bool first_lane) {
+  const uint32_t r = dpp_mov0<0x138>(pk_bits(src));
+  if constexpr (LANES == 64) return pk_from(r);
+  else return pk_from(first_lane ? 0u : r);
+}
+
+// lane l <- lane l - 1, the first lane of a span <- `first`
+template <int LANES>
+__device__ __forceinline__ pk16 pk_shr1_in(pk16 src, pk16 first, bool first_lane) {
+  if constexpr (LANES == 64) return pk_shr1(src, first);
+  else {
+    // (the shift first, with every lane active -- a lane that is masked out is no source for its neighbour -- then the choice)
+    const uint32_t r = dpp_mov0<0x138>(pk_bits(src));
+    return pk_from(first_lane ? pk_bits(first) : r);
+  }
+}
+// this row's characters of seq_b (code of the low pair | code of the high pair << 16) out of the chunk a span's lanes hold
+template <int LANES>
+__device__ __forceinline__ uint32_t row_codes(uint32_t chunk_code, int q, uint32_t span) {
+  if constexpr (LANES == 64) {
+    return (uint32_t)read_lane((int)chunk_code, q);
+  } else {
+    const uint32_t r0 = (uint32_t)read_lane((int)chunk_code, q), r1 = (uint32_t)read_lane((int)chunk_code, q + 32);
+    return span ? r1 : r0;
+  }
+}
+
 constexpr uint32_t kBoth = 0x00010001u;   // a 1 in each half
 
 // The substitution score of my columns against this row's character, both pairs at once.
@@ -147,35 +198,55 @@ __device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tb
 }
 
 // ---- Needleman-Wunsch, directions only (the packed form of fill_nw_dirs_kernel)
-// one wave's work: the directions-only NW fill of pairs pair0 (low halves) and pair1 (high halves; `two` = there is one)
-template <int CPL, int SUBST, int R>
-__device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair0,
-                                                const uint32_t pair1, const bool two, const int lane, uint8_t *ring0,
-                                                const uint32_t tbl_lds) {
-  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;   // (the same for every pair: the launcher checked)
-  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
-  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
-  uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
+// LANES = 64: one wave's work is the directions-only NW fill of two pairs, pair_lo in the low halves of every register and
+// pair_hi in the high halves (has_hi = there is one), CPL columns per lane.
+// LANES = 32 (round 4): FOUR pairs per wave -- lanes 0-31 carry one such couple of pairs, lanes 32-63 another (pair_lo /
+// pair_hi / has_* differ between the two spans of lanes), CPL columns per lane of a span.  A 151-column row (BASELINE
+// configs 2, 3, 5) takes 3 x 64 = 192 cell slots of a wave one way and 5 x 32 = 160 the other, and the per-row work that
+// does not depend on the row's width (scan, lane shifts, this row's character, the loop) serves four rows instead of two.
+// All pairs of a wave have the same shape: one set of stream positions, one row counter; the spans never exchange anything
+// (the lane shifts' hand-over at lane 32 is cut: first_lane).
+template <int CPL, int SUBST, int R, int LANES>
+__device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair_lo,
+                                                const uint32_t pair_hi, const bool has_lo, const bool has_hi, const int lane,
+                                                uint8_t *ring_wave, const uint32_t tbl_lds) {
+  static_assert(LANES == 64 || LANES == 32, "a span of lanes is the wave or half of it");
+  constexpr int kBytes = 256 / LANES;      // of a 256-byte block that a lane moves from a ring to HBM: 4 or 8
+  const int sl = LANES == 64 ? lane : (lane & 31);
+  const uint32_t span = LANES == 64 ? 0u : (uint32_t)lane >> 5;
+  const bool first_lane = sl == 0;
+  const uint32_t la = p.len_a[pair_lo], lb = p.len_b[pair_lo], W = la + 1;   // (the same for every pair: the launcher checked)
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair_lo], *__restrict__ sa1 = p.arena + p.off_a[pair_hi];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
+  uint8_t *const gd0 = dirs_arena + p.mat_off[pair_lo], *const gd1 = dirs_arena + p.mat_off[pair_hi];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
   SubstX2<SUBST, CPL> sub;
   sub.init(p);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
-  uint8_t *ring1 = ring0 + R;
+  uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;   // my span's rings: low halves, high halves
   uint32_t wv = 0, rv = 0;   // stream positions = cell indices: written up to wv, flushed up to rv
   auto flush_block = [&]() __attribute__((always_inline)) {
-    const uint32_t o = (rv & (R - 1)) + 4 * lane;
-    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
-    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
-    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
-    if (two) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    const uint32_t o = (rv & (R - 1)) + kBytes * sl;
+    if constexpr (LANES == 64) {
+      const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
+      const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
+      if (has_lo) __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + kBytes * sl));
+    } else {
+      typedef uint32_t v2u_a __attribute__((ext_vector_type(2)));
+      const v2u_a d0 = *reinterpret_cast<const v2u_a *>(ring0 + o);
+      const v2u_a d1 = *reinterpret_cast<const v2u_a *>(ring1 + o);
+      if (has_lo) __builtin_nontemporal_store(d0, reinterpret_cast<v2u_a *>(gd0 + rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(d1, reinterpret_cast<v2u_a *>(gd1 + rv + kBytes * sl));
+    }
     rv += 256;
   };
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
-    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+    static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      const uint32_t o = (wv + sl * CPL + c) & (R - 1);
       ring0[o] = (uint8_t)dv[c];             // ds_write_b8
       ring1[o] = (uint8_t)(dv[c] >> 16);     // ds_write_b8_d16_hi
     }
@@ -191,7 +262,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   pk16 mv[CPL], av[CPL], bv[CPL];         // the row just computed (after the loop: the last row, for the end cell)
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    const uint32_t g = lane * CPL + c;
+    const uint32_t g = sl * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
     sub.set_column(c, code0, code1, p.K, tbl_lds);
@@ -205,11 +276,12 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     const int g_ext = (int)g * p.ext;
     c1[c] = pk_splat(p.open1 - g_ext); c3[c] = pk_splat(g_ext);
   }
-  // The border column (lane 0, my column 0; alignment.c:72-80) comes out of the recurrence by itself, no selects in the loop:
+  // The border column (the span's first lane, my column 0; alignment.c:72-80) comes out of the recurrence by itself, no selects
+  // in the loop:
   //   gap_a(0, j) = gap_open + j * ext = gap_a(0, j - 1) + ext if the chain starts at "gap_a(0, 0) = gap_open" (max(M, B) of the
   //   cell above is the floor from row 1 on, and 0 + open1 = the same value on row 1);
-  //   gap_b(0, j) = the floor: the cell "to the left" is the 0 the lane shift gives lane 0, plus a constant that is the floor.
-  if (lane == 0) { Ap[0] = pk_splat(p.gap_open); c1[0] = floor_; }
+  //   gap_b(0, j) = the floor: the cell "to the left" is the 0 the lane shift gives that lane, plus a constant that is the floor.
+  if (first_lane) { Ap[0] = pk_splat(p.gap_open); c1[0] = floor_; }
   __builtin_amdgcn_s_waitcnt(kWaitVm0);
   {
     uint32_t dv[CPL];
@@ -220,14 +292,20 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
 
   uint32_t chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
-    const int q = (j - 1) & (kWave - 1);
+    const int q = (j - 1) & (LANES - 1);
     if (q == 0) {
-      const uint32_t r = j + lane;
+      const uint32_t r = j + sl;
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    sub.set_row((uint32_t)read_lane((int)chunk_code, q));   // this row's characters of seq_b (uniform)
-    const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (lane 0: the border column, overridden below)
+    // this row's characters of seq_b: uniform over the wave, or over each span
+    if constexpr (LANES == 64) {
+      sub.set_row((uint32_t)read_lane((int)chunk_code, q));
+    } else {
+      const uint32_t r0 = (uint32_t)read_lane((int)chunk_code, q), r1 = (uint32_t)read_lane((int)chunk_code, q + 32);
+      sub.set_row(span ? r1 : r0);
+    }
+    const pk16 x_ul = pk_shr1_zero(X[CPL - 1]);      // (a span's first lane: the border column, overridden below)
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     pk16 z[CPL];
     uint32_t dv[CPL], dvA[CPL];
@@ -240,7 +318,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       pk16 m = pk_adds(xd, s);                                                             // alignment.c:101-116
       const pk16 ae = pk_adds(Ap[c], ext);
       pk16 a = pk_max(pk_adds(Yp[c], open1), ae);                                          // alignment.c:128-135
-      if (c == 0) m = lane == 0 ? floor_ : m;                                              // the border column's match score
+      if (c == 0) m = first_lane ? floor_ : m;                                             // the border column's match score
       const uint32_t opened = pk_lt(ae, a);                                                // gap_a + ext is NOT the max
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);                                 // GAP_A (1) first, else B >= M ? 2 : 0
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
@@ -249,7 +327,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     pk16 Pm[CPL];                         // de-trended gap_b: prefix max up to and including my column
     pk16 e;                               //                   prefix max of the lanes to my left
     {
-      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      const pk16 zin = pk_shr1_zero_in<LANES>(z[CPL - 1], first_lane);
       pk16 P[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -257,12 +335,12 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
         pk16 w = pk_adds(zl, c1[c]);
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
-      e = pk_wave_scan_max_excl(P[CPL - 1]);
+      e = pk_scan_max_excl<LANES>(P[CPL - 1], first_lane);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
     }
     {
-      const pk16 al = pk_shr1_zero(av[CPL - 1]);
+      const pk16 al = pk_shr1_zero(av[CPL - 1]);     // (a span's first lane: only the border cell's byte reads it, overridden below)
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
@@ -284,7 +362,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     // the border cell (0, j): never stood on with a move to make, but byte for byte what fill_nw_dirs_kernel stores
     // there -- GAP_A continues down the column (its first step only if gap_open is 0), else max(M, B) = B
-    dv[0] = lane == 0 ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
+    dv[0] = first_lane ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
     append_row(dv);
   }
   while (rv < wv) flush_block();
@@ -294,16 +372,16 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   pk16 em = pk_splat(0), ea = em, eb = em;
 #pragma unroll
   for (int c = 0; c < CPL; ++c) { if (c == oc) { em = mv[c]; ea = av[c]; eb = bv[c]; } }
-  if (lane == owner) {
+  if (sl == owner) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 1 && !two) break;
+      if (!(h ? has_hi : has_lo)) continue;
       const int m = h ? em.y : em.x, a = h ? ea.y : ea.x, b = h ? eb.y : eb.x;
       int score = m;
       uint32_t st = 0;                                // MATCH
       if (b >= score) { st = 2; score = b; }          // GAP_B
       if (a >= score) { st = 1; score = a; }          // GAP_A
-      const uint32_t pr = h ? pair1 : pair0;
+      const uint32_t pr = h ? pair_hi : pair_lo;
       p.best_score[pr] = score;
       p.best_index[pr] = st;
       p.status[pr] = ~0ull;
@@ -325,7 +403,25 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
   const uint32_t pair1 = two ? (p.pair_list ? p.pair_list[2 * unit + 1] : 2 * unit + 1) : pair0;
 
-  nw_dirs_x2_wave<CPL, SUBST, R>(p, dirs_arena, pair0, pair1, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+  nw_dirs_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+}
+
+// four pairs per wave: pairs 4 unit .. 4 unit + 3 of the launch (all of one shape, no pair list); the pairs a short last wave
+// does not have shadow its first one
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (4 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (4 * unit >= p.n_pairs) return;
+  const uint32_t lo = 4 * unit + 2 * ((uint32_t)lane >> 5), hi = lo + 1;
+  const bool has_lo = lo < p.n_pairs, has_hi = hi < p.n_pairs;
+  nw_dirs_x2_wave<CPL, SUBST, R, 32>(p, dirs_arena, has_lo ? lo : 4 * unit, has_hi ? hi : 4 * unit, has_lo, has_hi, lane,
+                                     reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
 // The same for a chunk whose pairs are MOSTLY of one shape, in ONE grid: the first x2_blocks workgroups take the n_modal
@@ -347,7 +443,7 @@ fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena
     if (2 * unit >= n_modal) return;
     const bool two = 2 * unit + 1 < n_modal;
     const uint32_t pair0 = p.pair_list[2 * unit], pair1 = two ? p.pair_list[2 * unit + 1] : pair0;
-    nw_dirs_x2_wave<CPL, SUBST, R>(p, dirs_arena, pair0, pair1, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+    nw_dirs_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
   } else {
     const int32_t *table = p.table;
     if constexpr (SUBST == SA_SUBST_LDS) {
@@ -363,62 +459,59 @@ fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena
 }
 
 // ---- Smith-Waterman, match_scores + directions (the packed form of fill_dirs_kernel)
-// Same outputs as fill_dirs_kernel for both pairs of the wave: match_scores (int32 in HBM; the rings hold them as the
+// Same outputs as fill_dirs_kernel for every pair of the wave: match_scores (int32 in HBM; the rings hold them as the
 // int16 they are computed in, the flush widens them), the direction byte, the candidates' count / box / columns per row.
 // Floor 0: max(x, 0) is a real instruction here, and a state whose score is 0 gets the code 3 ("the walk ends").
+// (Two pairs per wave only: with four -- LANES = 32 as in nw_dirs_x2_wave -- this kernel, which also moves 2 B of scores per
+// cell through LDS and 4 B to HBM, measured 20-30 % SLOWER at every batch size: profiles/r04/r04_quad_fills.txt.)
 template <int CPL, int SUBST, int R>
-__global__ void __launch_bounds__(kWave * 4)
-fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const uint32_t tbl_lds = (blockDim.x >> 6) * (6 * R);   // the table sits behind the rings
-  load_table_x2<SUBST>(p, tbl_lds);
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-  // pairs 2 unit, 2 unit + 1 of the launch -- or, with a pair list (ragged chunks: sa_batch.hip pairs up the pairs of equal
-  // shape), the pairs pair_list[2 unit], pair_list[2 unit + 1] of the descriptor arrays; an entry repeated = a pair that
-  // found no partner and has the wave to itself
-  if (2 * unit >= p.n_pairs) return;
-  const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
-  const uint32_t pair1_ = p.pair_list ? p.pair_list[2 * unit + 1] : (2 * unit + 1 < p.n_pairs ? 2 * unit + 1 : pair0);
-  const bool two = pair1_ != pair0;
-  const uint32_t pair1 = pair1_;
-
-  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
-  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
-  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
-  const uint64_t mo0 = p.mat_off[pair0], mo1 = p.mat_off[pair1];   // multiples of 256 cells
+__device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair_lo,
+                                                const uint32_t pair_hi, const bool has_lo, const bool has_hi, const int lane,
+                                                uint8_t *ring_wave, const uint32_t tbl_lds) {
+  constexpr int LANES = 64;
+  constexpr int kCells = 256 / LANES;      // of a 256-cell block that a lane moves from the rings to HBM
+  const int sl = LANES == 64 ? lane : (lane & 31);
+  const uint32_t span = LANES == 64 ? 0u : (uint32_t)lane >> 5;
+  const bool first_lane = sl == 0;
+  const uint32_t la = p.len_a[pair_lo], lb = p.len_b[pair_lo], W = la + 1;
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair_lo], *__restrict__ sa1 = p.arena + p.off_a[pair_hi];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
+  const uint64_t mo0 = p.mat_off[pair_lo], mo1 = p.mat_off[pair_hi];   // multiples of 256 cells
   int32_t *const gm0 = p.M + mo0, *const gm1 = p.M + mo1;
   uint8_t *const gd0 = dirs_arena + mo0, *const gd1 = dirs_arena + mo1;
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
   SubstX2<SUBST, CPL> sub;
   sub.init(p);
 
-  // LDS per wave: two rings of R int16 scores, two rings of R direction bytes
-  uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (6 * R);
+  // LDS per span: two rings of R int16 scores, two rings of R direction bytes
+  uint8_t *ring = ring_wave + span * (6 * R);
   uint16_t *rm0 = reinterpret_cast<uint16_t *>(ring), *rm1 = rm0 + R;
   uint8_t *rd0 = ring + 4 * R, *rd1 = rd0 + R;
   uint32_t wv = 0, rv = 0;
   auto flush_block = [&]() __attribute__((always_inline)) {
     typedef int v4i_a __attribute__((ext_vector_type(4)));
-    const uint32_t o = (rv & (R - 1)) + 4 * lane;
-    const uint2 q0 = *reinterpret_cast<const uint2 *>(rm0 + o), q1 = *reinterpret_cast<const uint2 *>(rm1 + o);
-    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(rd0 + o), d1 = *reinterpret_cast<const uint32_t *>(rd1 + o);
-    const v4i_a m0 = {(int)(q0.x & 0xffffu), (int)(q0.x >> 16), (int)(q0.y & 0xffffu), (int)(q0.y >> 16)};   // scores are >= 0
-    __builtin_nontemporal_store(m0, reinterpret_cast<v4i_a *>(gm0 + rv + 4 * lane));
-    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
-    if (two) {
-      const v4i_a m1 = {(int)(q1.x & 0xffffu), (int)(q1.x >> 16), (int)(q1.y & 0xffffu), (int)(q1.y >> 16)};
-      __builtin_nontemporal_store(m1, reinterpret_cast<v4i_a *>(gm1 + rv + 4 * lane));
-      __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    const uint32_t o = (rv & (R - 1)) + kCells * sl;
+    {
+      const uint2 q0 = *reinterpret_cast<const uint2 *>(rm0 + o), q1 = *reinterpret_cast<const uint2 *>(rm1 + o);
+      const uint32_t d0 = *reinterpret_cast<const uint32_t *>(rd0 + o), d1 = *reinterpret_cast<const uint32_t *>(rd1 + o);
+      if (has_lo) {
+        const v4i_a m0 = {(int)(q0.x & 0xffffu), (int)(q0.x >> 16), (int)(q0.y & 0xffffu), (int)(q0.y >> 16)};   // scores are >= 0
+        __builtin_nontemporal_store(m0, reinterpret_cast<v4i_a *>(gm0 + rv + kCells * sl));
+        __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + kCells * sl));
+      }
+      if (has_hi) {
+        const v4i_a m1 = {(int)(q1.x & 0xffffu), (int)(q1.x >> 16), (int)(q1.y & 0xffffu), (int)(q1.y >> 16)};
+        __builtin_nontemporal_store(m1, reinterpret_cast<v4i_a *>(gm1 + rv + kCells * sl));
+        __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + kCells * sl));
+      }
     }
     rv += 256;
   };
   auto append_row = [&](const pk16 (&mv)[CPL], const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
-    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+    static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      const uint32_t o = (wv + sl * CPL + c) & (R - 1);
       const uint32_t mb = pk_bits(mv[c]);
       rm0[o] = (uint16_t)mb; rm1[o] = (uint16_t)(mb >> 16);         // ds_write_b16 / ds_write_b16_d16_hi
       rd0[o] = (uint8_t)dv[c]; rd1[o] = (uint8_t)(dv[c] >> 16);     // ds_write_b8 / ds_write_b8_d16_hi
@@ -435,7 +528,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   uint32_t T[CPL], TY4[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    const uint32_t g = lane * CPL + c;
+    const uint32_t g = sl * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
     sub.set_column(c, code0, code1, p.K, tbl_lds);
@@ -451,7 +544,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   // (sw_sweep_dirs*_kernel: whole rows in registers) wants to know; the per-row columns and the box's columns that the
   // three-matrix fills report serve the LDS / strip forms of the sweep, which never run behind a direction fill.  Kept per
   // lane (no ballots, no scalar code in the row loop: ~12 instead of ~45 instructions per row) and reduced at the end.
-  const pk16 thr = pk16{(short)min(max(p.cand_min[pair0], 1), 32767), (short)min(max(p.cand_min[pair1], 1), 32767)};
+  const pk16 thr = pk16{(short)min(max(p.cand_min[pair_lo], 1), 32767), (short)min(max(p.cand_min[pair_hi], 1), 32767)};
   uint32_t first_row[2] = {0xffffffffu, 0xffffffffu}, last_row[2] = {0, 0};
 
   {  // row 0: scores 0, every state ends
@@ -464,16 +557,16 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 
   uint32_t chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
-    const int q = (j - 1) & (kWave - 1);
+    const int q = (j - 1) & (LANES - 1);
     if (q == 0) {
-      const uint32_t r = j + lane;
+      const uint32_t r = j + sl;
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    sub.set_row((uint32_t)read_lane((int)chunk_code, q));
-    // up-left of my first column: the left lane's last column on the previous row; lane 0 (the border column): far
+    sub.set_row(row_codes<LANES>(chunk_code, q, span));
+    // up-left of my first column: the left lane's last column on the previous row; a span's first lane (the border column): far
     // enough below zero that M = max(.., 0) = 0
-    const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
+    const pk16 x_ul = pk_shr1_in<LANES>(X[CPL - 1], pk_splat(-16384), first_lane);
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
     uint32_t dv[CPL], dvA[CPL];
@@ -493,21 +586,21 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     }
     pk16 Pm[CPL], e;
     {
-      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      const pk16 zin = pk_shr1_zero_in<LANES>(z[CPL - 1], first_lane);
       pk16 P[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const pk16 zl = (c == 0) ? zin : z[c - 1];
         pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
-        // (lane 0, column 0: the lane shift gives 0 for the cell to the left, and max(0 + open1, 0) = 0 = gap_b of the border)
+        // (a span's first lane, column 0: the lane shift gives 0 for the cell to the left, and max(0 + open1, 0) = 0 = gap_b of the border)
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
-      e = pk_wave_scan_max_excl(P[CPL - 1]);
+      e = pk_scan_max_excl<LANES>(P[CPL - 1], first_lane);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
     }
     {
-      const pk16 al = pk_shr1_zero(av[CPL - 1]);
+      const pk16 al = pk_shr1_zero(av[CPL - 1]);   // (a span's first lane: gap_b of the border is 0, its byte does not depend on this)
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
@@ -544,16 +637,16 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LANES / 2; o > 0; o >>= 1) {
       first_row[h] = min(first_row[h], (uint32_t)__shfl_xor((int)first_row[h], o));
       last_row[h] = max(last_row[h], (uint32_t)__shfl_xor((int)last_row[h], o));
     }
   }
-  if (lane == 0) {
+  if (first_lane) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 1 && !two) break;
-      const uint32_t pr = h ? pair1 : pair0;
+      if (!(h ? has_hi : has_lo)) continue;
+      const uint32_t pr = h ? pair_hi : pair_lo;
       p.cand_count[pr] = first_row[h] != 0xffffffffu;
       uint32_t *box = p.cand_box + 4ull * pr;
       box[0] = first_row[h]; box[1] = last_row[h]; box[2] = 0; box[3] = W - 1;   // (columns: the whole row; see above)
@@ -562,53 +655,83 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   }
 }
 
+// pairs 2 unit, 2 unit + 1 of the launch -- or, with a pair list (ragged chunks: sa_batch.hip pairs up the pairs of equal
+// shape), the pairs pair_list[2 unit], pair_list[2 unit + 1] of the descriptor arrays; an entry repeated = a pair that
+// found no partner and has the wave to itself
+__device__ __forceinline__ bool x2_pairs_of(const SaFillParams &p, uint32_t unit, uint32_t *pair0, uint32_t *pair1) {
+  *pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
+  *pair1 = p.pair_list ? p.pair_list[2 * unit + 1] : (2 * unit + 1 < p.n_pairs ? 2 * unit + 1 : *pair0);
+  return *pair1 != *pair0;
+}
+// pairs 4 unit .. 4 unit + 3 of the launch (all of one shape, no pair list): my span's couple; the pairs a short last wave does
+// not have shadow its first one
+__device__ __forceinline__ void x4_pairs_of(const SaFillParams &p, uint32_t unit, int lane, uint32_t *lo, uint32_t *hi, bool *has_lo,
+                                            bool *has_hi) {
+  const uint32_t l = 4 * unit + 2 * ((uint32_t)lane >> 5), h = l + 1;
+  *has_lo = l < p.n_pairs; *has_hi = h < p.n_pairs;
+  *lo = *has_lo ? l : 4 * unit; *hi = *has_hi ? h : 4 * unit;
+}
+
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (6 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (2 * unit >= p.n_pairs) return;
+  uint32_t pair0, pair1;
+  const bool two = x2_pairs_of(p, unit, &pair0, &pair1);
+  sw_dirs_x2_wave<CPL, SUBST, R>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (6 * R), tbl_lds);
+}
+
 // ---- Smith-Waterman, best hit only (seqalign_sw_batch with max_hits = 1): directions + the best cell, no match_scores
 // The best-hit path needs from the matrices what seqalign_nw_batch needs -- where a walk goes -- plus where it starts:
 // the best match_scores cell in the reference's hit order (score descending, then column, then row ascending:
 // smith_waterman.c:71-86).  So this fill writes the direction byte only (1 B per cell, as fill_nw_dirs_x2_kernel) and
 // tracks, per column, the highest score and the first row that reached it; the pair's best cell and score go to
 // best_index / best_score (index 0, score 0: no cell above 0).
-template <int CPL, int SUBST, int R>
-__global__ void __launch_bounds__(kWave * 4)
-fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
-  load_table_x2<SUBST>(p, tbl_lds);
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-  // pairs 2 unit, 2 unit + 1 of the launch -- or, with a pair list (ragged chunks: sa_batch.hip pairs up the pairs of equal
-  // shape), the pairs pair_list[2 unit], pair_list[2 unit + 1] of the descriptor arrays; an entry repeated = a pair that
-  // found no partner and has the wave to itself
-  if (2 * unit >= p.n_pairs) return;
-  const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
-  const uint32_t pair1_ = p.pair_list ? p.pair_list[2 * unit + 1] : (2 * unit + 1 < p.n_pairs ? 2 * unit + 1 : pair0);
-  const bool two = pair1_ != pair0;
-  const uint32_t pair1 = pair1_;
-
-  const uint32_t la = p.len_a[pair0], lb = p.len_b[pair0], W = la + 1;
-  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair0], *__restrict__ sa1 = p.arena + p.off_a[pair1];
-  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair0], *__restrict__ sb1 = p.arena + p.off_b[pair1];
-  uint8_t *const gd0 = dirs_arena + p.mat_off[pair0], *const gd1 = dirs_arena + p.mat_off[pair1];   // 256-byte aligned
+template <int CPL, int SUBST, int R, int LANES>
+__device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair_lo,
+                                                const uint32_t pair_hi, const bool has_lo, const bool has_hi, const int lane,
+                                                uint8_t *ring_wave, const uint32_t tbl_lds) {
+  constexpr int kBytes = 256 / LANES;
+  const int sl = LANES == 64 ? lane : (lane & 31);
+  const uint32_t span = LANES == 64 ? 0u : (uint32_t)lane >> 5;
+  const bool first_lane = sl == 0;
+  const uint32_t la = p.len_a[pair_lo], lb = p.len_b[pair_lo], W = la + 1;
+  const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair_lo], *__restrict__ sa1 = p.arena + p.off_a[pair_hi];
+  const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
+  uint8_t *const gd0 = dirs_arena + p.mat_off[pair_lo], *const gd1 = dirs_arena + p.mat_off[pair_hi];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
   SubstX2<SUBST, CPL> sub;
   sub.init(p);
 
-  uint8_t *ring0 = reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), *ring1 = ring0 + R;
+  uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;
   auto flush_block = [&]() __attribute__((always_inline)) {
-    const uint32_t o = (rv & (R - 1)) + 4 * lane;
-    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
-    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
-    __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + 4 * lane));
-    if (two) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + 4 * lane));
+    const uint32_t o = (rv & (R - 1)) + kBytes * sl;
+    if constexpr (LANES == 64) {
+      const uint32_t d0 = *reinterpret_cast<const uint32_t *>(ring0 + o);
+      const uint32_t d1 = *reinterpret_cast<const uint32_t *>(ring1 + o);
+      if (has_lo) __builtin_nontemporal_store(d0, reinterpret_cast<uint32_t *>(gd0 + rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(d1, reinterpret_cast<uint32_t *>(gd1 + rv + kBytes * sl));
+    } else {
+      typedef uint32_t v2u_a __attribute__((ext_vector_type(2)));
+      const v2u_a d0 = *reinterpret_cast<const v2u_a *>(ring0 + o);
+      const v2u_a d1 = *reinterpret_cast<const v2u_a *>(ring1 + o);
+      if (has_lo) __builtin_nontemporal_store(d0, reinterpret_cast<v2u_a *>(gd0 + rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(d1, reinterpret_cast<v2u_a *>(gd1 + rv + kBytes * sl));
+    }
     rv += 256;
   };
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
-    static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+    static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const uint32_t o = (wv + lane * CPL + c) & (R - 1);
+      const uint32_t o = (wv + sl * CPL + c) & (R - 1);
       ring0[o] = (uint8_t)dv[c];
       ring1[o] = (uint8_t)(dv[c] >> 16);
     }
@@ -625,7 +748,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   uint32_t best_r[CPL];                   // ... and the first row that reached it (one pair per half)
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
-    const uint32_t g = lane * CPL + c;
+    const uint32_t g = sl * CPL + c;
     const uint32_t code0 = (g >= 1 && g <= la) ? p.code[sa0[g - 1]] : 0u;
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
     sub.set_column(c, code0, code1, p.K, tbl_lds);
@@ -646,14 +769,14 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 
   uint32_t chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
-    const int q = (j - 1) & (kWave - 1);
+    const int q = (j - 1) & (LANES - 1);
     if (q == 0) {
-      const uint32_t r = j + lane;
+      const uint32_t r = j + sl;
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    sub.set_row((uint32_t)read_lane((int)chunk_code, q));
-    const pk16 x_ul = pk_shr1(X[CPL - 1], pk_splat(-16384));
+    sub.set_row(row_codes<LANES>(chunk_code, q, span));
+    const pk16 x_ul = pk_shr1_in<LANES>(X[CPL - 1], pk_splat(-16384), first_lane);
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     const uint32_t row_pk = j * kBoth;    // (rows < 32 768: the launcher's score bound implies it)
     pk16 mv[CPL], av[CPL], bv[CPL], z[CPL];
@@ -678,7 +801,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
     }
     pk16 Pm[CPL], e;
     {
-      const pk16 zin = pk_shr1_zero(z[CPL - 1]);
+      const pk16 zin = pk_shr1_zero_in<LANES>(z[CPL - 1], first_lane);
       pk16 P[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
@@ -686,7 +809,7 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
         pk16 w = pk_max(pk_adds(zl, c1[c]), c2[c]);
         P[c] = (c == 0) ? w : pk_max(P[c - 1], w);
       }
-      e = pk_wave_scan_max_excl(P[CPL - 1]);
+      e = pk_scan_max_excl<LANES>(P[CPL - 1], first_lane);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
     }
@@ -716,30 +839,60 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   // the pair's best cell: highest score, then lowest column, then lowest row (per column: the first row above)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (h == 1 && !two) break;
     int b = 0;
     uint32_t tie = 0;   // (column << 16) | row
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int sc_ = h ? (int)best_s[c].y : (int)best_s[c].x;
       const uint32_t row = h ? best_r[c] >> 16 : best_r[c] & 0xffffu;
-      if (sc_ > b) { b = sc_; tie = ((uint32_t)(lane * CPL + c) << 16) | row; }
+      if (sc_ > b) { b = sc_; tie = ((uint32_t)(sl * CPL + c) << 16) | row; }
     }
     unsigned long long key = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)~tie;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LANES / 2; o > 0; o >>= 1) {
       const unsigned long long other = __shfl_xor(key, o);
       key = other > key ? other : key;
     }
-    if (lane == 0) {
+    if (first_lane && (h ? has_hi : has_lo)) {
       const uint32_t t = ~(uint32_t)key, col = t >> 16, row = t & 0xffffu;
       const int score = (int)(key >> 32);
-      const uint32_t pr = h ? pair1 : pair0;
+      const uint32_t pr = h ? pair_hi : pair_lo;
       p.best_score[pr] = score;
       p.best_index[pr] = score > 0 ? (uint64_t)row * W + col : 0;
       p.status[pr] = ~0ull;
     }
   }
+}
+
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (2 * unit >= p.n_pairs) return;
+  uint32_t pair0, pair1;
+  const bool two = x2_pairs_of(p, unit, &pair0, &pair1);
+  sw_best_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+}
+
+template <int CPL, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_sw_best_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t tbl_lds = (blockDim.x >> 6) * (4 * R);
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (4 * unit >= p.n_pairs) return;
+  uint32_t lo, hi;
+  bool has_lo, has_hi;
+  x4_pairs_of(p, unit, lane, &lo, &hi, &has_lo, &has_hi);
+  sw_best_x2_wave<CPL, SUBST, R, 32>(p, dirs_arena, lo, hi, has_lo, has_hi, lane, reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
 template <int CPL, int R>
@@ -772,6 +925,28 @@ static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   return hipGetLastError();
 }
 
+template <int CPL>
+static hipError_t launch_sw_best_x4_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  constexpr int R = 512;
+  const int wpb = 4;
+  const uint32_t units = (p.n_pairs + 3) / 4;
+  const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  return hipGetLastError();
+}
+
+template <int CPL>
+static hipError_t launch_nw_dirs_x4_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  constexpr int R = 512;   // (255 + 32 * 8 columns fit)
+  const int wpb = 4;
+  const uint32_t units = (p.n_pairs + 3) / 4;
+  const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  return hipGetLastError();
+}
+
 template <int CPL, int R>
 static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest, hipStream_t stream) {
   const int wpb = 4;
@@ -799,8 +974,33 @@ bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
   return sa_x2_scores_fit(p, max_len_a, max_len_b);
 }
 
+// Four pairs per wave (32 lanes a couple) instead of two: every pair of the launch one shape (no pair list), rows up to 192
+// columns (six columns per lane of a span: beyond that the registers cost more than the lanes save), and pairs enough that
+// half as many waves still fill the chip (min_pairs: NW 4 096 -- measured 3-7 % faster from there to 40 000 pairs of 150 x 150;
+// SW best hit 16 384 -- 150 x 1000: 1 % at 10 000 pairs, where 2 500 waves leave some SIMDs with three and some with two,
+// 8-9 % from 16 000 on; profiles/r04/r04_quad_fills.txt) -- or whenever the shape allows (option quad = 2: tests), or never
+// (quad = 1).  Returns the columns per lane of a span, 0 = two pairs per wave.
+static int sa_x4_columns(const SaFillParams &p, uint32_t max_len_a, uint32_t min_pairs) {
+  if (p.pair_list || p.tune_quad == 1 || p.tune_cpl) return 0;
+  const uint32_t need = (max_len_a + 1 + 31u) / 32u;
+  if (need > 6) return 0;
+  if (p.tune_quad != 2 && p.n_pairs < min_pairs) return 0;
+  return (int)need;
+}
+
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (const int c4 = sa_x4_columns(p, max_len_a, 4096u)) {
+    sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X4, p.n_pairs);
+    switch (c4) {
+      case 1: return sa::launch_nw_dirs_x4_cpl<1>(p, dirs, stream);
+      case 2: return sa::launch_nw_dirs_x4_cpl<2>(p, dirs, stream);
+      case 3: return sa::launch_nw_dirs_x4_cpl<3>(p, dirs, stream);
+      case 4: return sa::launch_nw_dirs_x4_cpl<4>(p, dirs, stream);
+      case 5: return sa::launch_nw_dirs_x4_cpl<5>(p, dirs, stream);
+      default: return sa::launch_nw_dirs_x4_cpl<6>(p, dirs, stream);
+    }
+  }
   sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_nw_dirs_x2_cpl<1, 512>(p, dirs, stream);
@@ -842,6 +1042,17 @@ bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  if (const int c4 = sa_x4_columns(p, max_len_a, 16384u)) {
+    sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X4, p.n_pairs);
+    switch (c4) {
+      case 1: return sa::launch_sw_best_x4_cpl<1>(p, dirs, stream);
+      case 2: return sa::launch_sw_best_x4_cpl<2>(p, dirs, stream);
+      case 3: return sa::launch_sw_best_x4_cpl<3>(p, dirs, stream);
+      case 4: return sa::launch_sw_best_x4_cpl<4>(p, dirs, stream);
+      case 5: return sa::launch_sw_best_x4_cpl<5>(p, dirs, stream);
+      default: return sa::launch_sw_best_x4_cpl<6>(p, dirs, stream);
+    }
+  }
   sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X2, p.n_pairs);
   const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
   if (need <= 1) return sa::launch_sw_best_x2_cpl<1, 512>(p, dirs, stream);

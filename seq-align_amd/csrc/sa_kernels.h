@@ -43,6 +43,7 @@ struct SaFillParams {
   const uint64_t *cand_rows_off; /* [n] where pair p's part starts, in uint64 (SaSweepParams::hit_off)                    */
   /* launch tuning (host side only; the context's options, sa_ctx.hpp SaOptions): 0 = the launcher's own choice */
   uint32_t tune_cpl, tune_wpb, tune_lds_pad;
+  uint32_t tune_quad = 0;   /* host side only: the packed fills with four pairs per wave: 0 = by shape and size, 1 = never, 2 = whenever the shape allows (option quad) */
   /* != 0: every pair of the launch has the same len_a and len_b and pair k's cells start at mat_off[0] + k * uniform_stride
    * (>= its cell count); the packed two-pairs-per-wave fills (sa_fill_dirs_x2.hip) need a multiple of 256 */
   uint64_t uniform_stride;

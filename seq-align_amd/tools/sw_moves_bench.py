@@ -19,7 +19,7 @@ from bench import WORKLOADS  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 variants = sys.argv[2:] or ["nw_moves=0", "nw_moves=1"]
-DEFAULTS = {"nw_moves": "1", "trace_kernel": "auto", "pack16": "1", "sweep_dirs": "1", "timing": "0", "sweep_ev": "1", "subbatches": "0"}
+DEFAULTS = {"nw_moves": "1", "trace_kernel": "auto", "pack16": "1", "sweep_dirs": "1", "timing": "0", "sweep_ev": "1", "subbatches": "0", "quad": "0"}
 with S.Context(0) as ctx:
     for name in (["C3", "C4"] if which == "both" else [which]):
         gen, kwargs, n, is_sw, spec, _ = WORKLOADS[name]

@@ -64,7 +64,7 @@ def near_bound_spec(la, lb, v):
 
 
 t_end = time.time() + seconds
-trials = pairs = oracle_pairs = 0
+trials = pairs = oracle_pairs = quad_batches = 0
 shapes = [(1, 1), (1, 7), (7, 1), (3, 5), (63, 64), (64, 64), (64, 10), (127, 130), (128, 128), (150, 150), (151, 149), (191, 40),
           (192, 33), (200, 37), (255, 256), (300, 100), (383, 20), (400, 60), (511, 70)]
 while time.time() < t_end:
@@ -86,7 +86,9 @@ while time.time() < t_end:
     r0 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
     ctx._nw_buffers = None
     ctx.set_option("pack16", 2)
+    ctx.set_option("quad", 2 if trials % 2 else 1)      # every other batch: four pairs per wave where the shape allows (rows <= 192 columns)
     r1 = [x.copy() for x in ctx.nw_batch(batch, sc, raw=True)]
+    quad_batches += "fill_nw_dirs_x4" in ctx.last_call()
     ctx._nw_buffers = None
     if not same(r0, r1):
         bad = np.nonzero(r0[4] != r1[4])[0]
@@ -109,7 +111,8 @@ while time.time() < t_end:
             oracle_pairs += 1
     trials += 1
     pairs += n
-print(f"x2_check: {trials} uniform batches, {pairs} pairs: packed (pack16 = 2) identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
+print(f"x2_check: {trials} uniform batches ({quad_batches} of them four pairs per wave), {pairs} pairs: packed (pack16 = 2) identical to pack16 = 0; {oracle_pairs} pairs against the oracle", flush=True)
+ctx.set_option("quad", 0)
 
 # ---- NW, chunks that are MOSTLY of one shape: the modal shape's pairs two per wave, the others one per wave, in one grid
 t_end = time.time() + seconds / 2
@@ -158,7 +161,7 @@ print(f"x2_check: NW mostly-one-shape: {mx_trials} batches, {mx_pairs} pairs: mi
 
 # ---- Smith-Waterman multi-hit: the packed fill of match_scores + directions (fill_dirs_x2_kernel)
 t_end = time.time() + seconds
-sw_trials = sw_pairs = sw_oracle = 0
+sw_trials = sw_pairs = sw_oracle = sw_quad = 0
 while time.time() < t_end:
     v = rng.below(1 << 20, 12).astype(int)
     la, lb = shapes[sw_trials % len(shapes)] if sw_trials < 2 * len(shapes) else (int(1 + v[0] % 511), int(1 + v[1] % 300))
@@ -176,11 +179,13 @@ while time.time() < t_end:
     sc = S.make_scoring(spec)
     batch = uniform_batch(n, la, lb, bool(v[8] & 1), alpha)
     thr = int(1 + v[9] % max(2, match * min(la, lb) // 2))
-    max_hits = int(1 + v[10] % 8)
+    max_hits = int(1 + v[10] % 8) if sw_trials % 3 else 1      # a third: the best hit only (its own fill; every other one four pairs per wave)
     ctx.set_option("pack16", 0)
     r0 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
     ctx.set_option("pack16", 2)
+    ctx.set_option("quad", 2 if sw_trials % 2 else 1)
     r1 = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=8 * n + 8)
+    sw_quad += "fill_sw_best_x4" in ctx.last_call()
     if r0 != r1:
         bad = [p for p in range(n) if r0[p] != r1[p]]
         print("SW MISMATCH pack16 0 vs 1:", la, lb, n, spec, "thr", thr, "max_hits", max_hits, "pairs", bad[:6], flush=True)
@@ -196,7 +201,8 @@ while time.time() < t_end:
             sw_oracle += 1
     sw_trials += 1
     sw_pairs += n
-print(f"x2_check: SW multi-hit: {sw_trials} uniform batches, {sw_pairs} pairs: packed (pack16 = 2) hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
+ctx.set_option("quad", 0)
+print(f"x2_check: SW multi-hit / best hit: {sw_trials} uniform batches ({sw_quad} of them the best-hit fill with four pairs per wave), {sw_pairs} pairs: packed (pack16 = 2) hit lists identical to pack16 = 0; {sw_oracle} pairs against the oracle", flush=True)
 
 # ---- ragged batches: pairs of MANY shapes, paired up by shape on the host (NW: mixed grid; SW: pair lists), against pack16 = 0
 t_end = time.time() + seconds / 2

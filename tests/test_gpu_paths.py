@@ -134,6 +134,91 @@ def test_sw_batch_reports_its_kernels(ctx, opts):
     assert "fill_stream" in got and "sweep_regs" in got and not any("dirs" in k for k in got)
 
 
+def gap_rich(n, la, lb, seed, alpha=b"ACGT"):
+    """n pairs of one shape: seq_b = seq_a with ~8 % deletions, ~8 % insertions, ~8 % substitutions, cut / padded to lb"""
+    rng = W.Rng(seed)
+    pairs = []
+    for _ in range(n):
+        a = bytes(alpha[v] for v in rng.below(len(alpha), la))
+        u = rng.unit(3 * la + 3).reshape(-1, 3)
+        r = rng.below(len(alpha), 2 * la + lb + 2)
+        b = bytearray()
+        for i, ch in enumerate(a):
+            if u[i][0] < 0.08:
+                continue
+            if u[i][1] < 0.08:
+                b.append(alpha[r[2 * i]])
+            b.append(alpha[r[2 * i + 1]] if u[i][2] < 0.08 else ch)
+        b = (bytes(b) + bytes(alpha[v] for v in r[2 * la:]))[:lb]
+        pairs.append((a, b))
+    return W.from_pairs(pairs), pairs
+
+
+@pytest.mark.parametrize("la,lb", [(150, 150), (31, 40), (32, 33), (95, 120), (96, 64), (159, 70), (160, 35), (191, 150), (1, 1), (5, 0)])
+def test_four_pairs_per_wave(ctx, opts, la, lb):
+    """The packed fills with FOUR pairs per wave (sa_fill_dirs_x2.hip, LANES = 32: lanes 0-31 one couple of pairs in the 16-bit
+    halves, lanes 32-63 another) -- seqalign_nw_batch and the SW best hit, gap-rich pairs, pair counts that leave the last wave
+    with one, two or three pairs, shapes at the edges of the columns-per-lane classes (32 k and 32 k - 1 columns).  Strings and
+    hits equal the two-pairs-per-wave form's and the oracle's (the arithmetic: src/alignment.c:101-155), and the kernel that
+    ran is the one asked for."""
+    sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    o_nw, o_sw = osc_of(sc_nw), osc_of(sc_sw)
+    for n in (1, 2, 3, 4, 5, 7, 42):
+        batch, pairs = gap_rich(n, la, lb, 1000 * la + lb + n)
+        opts(pack16=2, quad=2)
+        nw4 = ctx.nw_batch(batch, sc_nw)
+        assert ctx.last_call()["fill_nw_dirs_x4"] == (1, n) and "fill_nw_dirs_x2" not in ctx.last_call()
+        sw4 = ctx.sw_batch(batch, sc_sw, 8, max_hits=1)
+        assert ctx.last_call()["fill_sw_best_x4"] == (1, n) and "fill_sw_best_x2" not in ctx.last_call()
+        opts(quad=1)
+        nw2 = ctx.nw_batch(batch, sc_nw)
+        assert ctx.last_call()["fill_nw_dirs_x2"] == (1, n) and "fill_nw_dirs_x4" not in ctx.last_call()
+        sw2 = ctx.sw_batch(batch, sc_sw, 8, max_hits=1)
+        assert "fill_sw_best_x2" in ctx.last_call()
+        assert nw4 == nw2 and sw4 == sw2
+        for p, (a, b) in enumerate(pairs):
+            rc, s_, ra, rb = O.oracle_nw(o_nw, a, b)
+            assert rc == 0 and nw4[p] == (s_, ra, rb), (n, p)
+            rc, want = O.oracle_sw(o_sw, a, b, 8, 1)
+            assert rc == 0 and sw4[p] == want, (n, p)
+
+
+def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
+    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 16 384, rows up to 192 columns; ragged
+    chunks (a pair list) and the multi-hit fill stay two per wave; a substitution table (BLOSUM62) goes four per wave too."""
+    sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    opts(pack16=1, quad=0)
+    ctx.nw_batch(uniform(4095, 60, 50, 1), sc_nw)
+    assert "fill_nw_dirs_x2" in ctx.last_call() and "fill_nw_dirs_x4" not in ctx.last_call()
+    big = uniform(4096, 60, 50, 2)
+    got = ctx.nw_batch(big, sc_nw)
+    assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 4096)
+    opts(quad=1)
+    assert got == ctx.nw_batch(big, sc_nw)
+    opts(quad=0)
+    ctx.nw_batch(uniform(4096, 192, 20, 3), sc_nw)           # 193 columns: seven per lane of a span -- two pairs per wave
+    assert "fill_nw_dirs_x2" in ctx.last_call() and "fill_nw_dirs_x4" not in ctx.last_call()
+    sw = uniform(16384, 40, 30, 4)
+    got = ctx.sw_batch(sw, sc_sw, 10, max_hits=1)
+    assert ctx.last_call()["fill_sw_best_x4"] == (1, 16384)
+    opts(quad=1)
+    assert got == ctx.sw_batch(sw, sc_sw, 10, max_hits=1)
+    opts(quad=2, pack16=2)
+    ctx.sw_batch(uniform(64, 40, 30, 5), sc_sw, 10, max_hits=4)      # the multi-hit fill has no such form
+    assert "fill_sw_dirs_x2" in ctx.last_call()
+    prot = uniform(67, 90, 110, 6, alpha=b"ARNDCQEGHILKMFPSTWYV", related=1.0)
+    bl = S.make_scoring({"preset": "BLOSUM62"})
+    four = (ctx.nw_batch(prot, bl), ctx.last_call())
+    four_sw = (ctx.sw_batch(prot, bl, 15, max_hits=1), ctx.last_call())
+    assert "fill_nw_dirs_x4" in four[1] and "fill_sw_best_x4" in four_sw[1]
+    o_bl = osc_of(bl)
+    for p in range(prot.n_pairs):
+        rc, s_, ra, rb = O.oracle_nw(o_bl, prot.seq_a(p), prot.seq_b(p))
+        assert rc == 0 and four[0][p] == (s_, ra, rb), p
+        rc, want = O.oracle_sw(o_bl, prot.seq_a(p), prot.seq_b(p), 15, 1)
+        assert rc == 0 and four_sw[0][p] == want, p
+
+
 def test_ragged_batches_take_the_packed_fills(ctx, opts):
     """"for variable-length batches, sort / bucket by W x H first" -- chunks of reads of many lengths: the pairs of
     equal shape are paired up on the host and go two per wave (NW: the others one per wave in the same grid; SW: a pair without
