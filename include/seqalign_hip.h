@@ -351,7 +351,8 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *   quad            0 | 1 | 2               the NW and the SW best-hit fill with FOUR pairs per wave (32 lanes a couple of pairs; chunks of
  *                                           one shape, rows up to 192 columns): for chunks of >= 4 096 (NW) / 16 384 (SW) pairs | never |
  *                                           whatever the size
- *   walk_overlap    1 | 0                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills
+ *   walk_overlap    0 | 1                   seqalign_nw_batch (direction bytes): walks on their own stream beside the next fills (round 4:
+ *                                           off -- beside the four-pairs-per-wave fills the walks cost more than they hide)
  *   nw_moves        1 | 0                   the walks on direction bytes send home two bits per alignment column (which string has
  *                                           a gap there) and the host expands them against the caller's sequences, instead of the
  *                                           gapped strings (seqalign_nw_batch; seqalign_sw_batch: also ONE launch + wait for all

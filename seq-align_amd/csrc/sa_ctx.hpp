@@ -253,7 +253,7 @@ struct SaOptions {
                                   //                   never | chunks of >= 2 048 pairs | whatever the chunk's size (tests)
   uint32_t quad = 0;              // quad              0|1|2: the NW / SW best-hit packed fills take FOUR pairs per wave (32 lanes a couple; uniform chunks, rows
                                   //                   up to 192 columns): chunks of >= 4 096 / 16 384 pairs | never | whatever the chunk's size (tests)
-  bool walk_overlap = true;       // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
+  bool walk_overlap = false;      // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
                                   //                   while the next group fills (a VALU-bound fill next to a latency-bound walk)
   bool nw_moves = true;           // nw_moves          0|1: seqalign_nw_batch's direction-byte path sends home two bits per alignment column (which of
                                   //                   the two strings has a gap there) and the host expands them against the sequences it still

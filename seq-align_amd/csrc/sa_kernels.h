@@ -209,6 +209,8 @@ struct SaTraceParams {
   uint32_t walks_per_pair;
   const uint32_t *hit_count, *sweep_status;
 };
+/* direction-byte walks: one wave per walk (LDS tiles) below this many walks per launch, one lane per walk from there on (sa_traceback.hip) */
+#define SA_WALK_TILE_MAX 24576u
 #define SA_MOVES_ERR 0xFFFFFFF0u
 
 /* ---- which kernels a call launched (seqalign_ctx_last_call_info, include/seqalign_hip.h: SEQALIGN_K_*) ------------------

@@ -580,9 +580,11 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   if (p.dirs) {
     // walks on direction bytes: one wave per walk from LDS tiles while the walks do not fill the chip several times over
-    // (issue-bound: ~9 us of instructions per 300-step walk and wave), one lane per walk beyond (bound by scattered
-    // sectors; 125 k walks: 0.42 ms per 40 k).  The option trace_kernel = lane | wave forces one.
-    const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < 32768;
+    // (issue-bound: ~9 ns per 300-step walk once the chip is full -- 10 000 walks 0.085 ms, 31 250 walks 0.283 ms), one lane
+    // per walk beyond (latency-bound and flat: 0.17 ms for anything up to ~65 k walks when nothing runs beside it).  The
+    // two cross near 19 k walks; the tile form also writes its moves coalesced (in place over PCIe, sa_batch.hip), which is
+    // worth ~0.04 ms more: SA_WALK_TILE_MAX.  The option trace_kernel = lane | wave forces one.
+    const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < SA_WALK_TILE_MAX;
     if (p.nw_state) {   // NW behind the directions-only fill
       if (!p.nw_score) return hipErrorInvalidValue;
       if (p.moves) {    // ... sending home moves instead of strings
@@ -599,7 +601,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_meta4) return hipErrorInvalidValue;
       if (p.walks_per_pair && !(p.hit_keys && p.hit_count && p.sweep_status)) return hipErrorInvalidValue;
       // (walks_per_pair: most of the launch's walks return at once -- the choice follows the pairs, not the slots)
-      const bool wtiles = p.tune_walker ? p.tune_walker == 2 : (p.walks_per_pair ? p.n_pairs / p.walks_per_pair < 32768 : p.n_pairs < 32768);
+      const bool wtiles = p.tune_walker ? p.tune_walker == 2 : (p.walks_per_pair ? p.n_pairs / p.walks_per_pair < SA_WALK_TILE_MAX : p.n_pairs < SA_WALK_TILE_MAX);
       sa_record_launch(wtiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;

@@ -19,7 +19,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 variants = sys.argv[2:] or ["nw_moves=0", "nw_moves=1,zero_copy=0", "nw_moves=1,zero_copy=1", "nw_moves=1,zero_copy=2",
                             "nw_moves=1,zero_copy=3", "nw_moves=1,zero_copy=3,trace_kernel=lane",
                             "nw_moves=1,zero_copy=3,trace_kernel=wave"]
-DEFAULTS = {"nw_moves": "1", "zero_copy": "auto", "trace_kernel": "auto", "subbatches": "0", "walk_overlap": "1", "quad": "0"}
+DEFAULTS = {"nw_moves": "1", "zero_copy": "auto", "trace_kernel": "auto", "subbatches": "0", "walk_overlap": "0", "quad": "0"}
 batches = []
 if which in ("C2", "both"):
     batches.append(("C2", W.dna_nw_150(10000, seed=1)))
