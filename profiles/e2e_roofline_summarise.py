@@ -7,6 +7,7 @@ out, root, tag = sys.argv[1:4]   # <collected directory> <repo root> <tag of pro
 mix = json.load(open(os.path.join(root, "profiles", "r04", "r04_valu_mix.json")))
 N_SIMD, CLOCK = 1024, 2.4e9
 res = {}
+pmc_all = {}   # every counter of the --pmc passes, per workload and kernel: mean per launch -> <out>/e2e_pmc_insts.json
 for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C4_4000_hits4"):
     dur = defaultdict(list)
     f = os.path.join(out, key + "_kernel_trace.csv")
@@ -22,8 +23,12 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
     for db in glob.glob(os.path.join(out, key + ".pmc", "**", "*.db"), recursive=True):
         con = sqlite3.connect(db)
         for name, cname, val in con.execute("select kernel_name, counter_name, value from counters_collection"):
-            if cname == "SQ_INSTS_VALU" and "sa::" in name:
-                insts[name.split("(")[0].replace("void ", "").strip()].append(float(val))
+            if "sa::" not in name:
+                continue
+            kn = name.split("(")[0].replace("void ", "").strip()
+            pmc_all.setdefault(key, {}).setdefault(kn, {}).setdefault(cname, []).append(float(val))
+            if cname == "SQ_INSTS_VALU":
+                insts[kn].append(float(val))
     kernels = {}
     for k, v in dur.items():
         v = v[len(v) // 3:]          # the first call sizes buffers: later launches only
@@ -49,4 +54,6 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
                         "weighted by the static mix of the kernel's row loop (profiles/r04/r04_valu_mix.json)",
                 "source": f"profiles/{tag}/: rocprofv3 --kernel-trace (durations) and --pmc SQ_INSTS_VALU (own pass) over the host-level call",
                 "kernels_of_the_call": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in e.items()} for k, e in kernels.items()}}
+json.dump({k: {kn: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()} for kn, cs in ks.items()} for k, ks in pmc_all.items()},
+          open(os.path.join(out, "e2e_pmc_insts.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -5,8 +5,7 @@ instruction issue instead of HBM (the direction-byte fills, the sweep, the walke
     python valu_mix.py csrc/sa_fill_dirs_x2.hip fill_nw_dirs_x2_kernel 'ILi3E' [--loop largest|innermost]
 
 Compiles the file for gfx950 to assembly (device side only), finds the kernel whose mangled name contains every given
-substring, takes its hot loop (by default the backward branch that encloses the most instructions and contains no
-barrier-free inner loop larger than half of it -- the row loop) and counts its vector ALU instructions in the two rate
+substring, takes its hot loop (by default the backward branch that encloses the most vector ALU instructions -- the row loop) and counts its vector ALU instructions in the two rate
 classes tools/probes/valu_rate_probe.hip measured on MI355X (profiles/r03/r03_valu_rate_probe.txt, cycles per wave64
 instruction per SIMD at 2.4 GHz):
     half : 2.1-2.4 cycles  v_add_u32 / v_sub_u32 / v_and / v_or / v_xor / v_lshrrev / v_ashrrev / v_mov / v_bitop3 /
@@ -99,8 +98,8 @@ def main():
     size = lambda lp: lp[1] - lp[0]
     if which == "innermost":
         lp = max((l for l in lps if not any(o != l and o[0] >= l[0] and o[1] <= l[1] for o in lps)), key=size)
-    else:
-        lp = max(lps, key=size)
+    else:   # (the loop with the most vector ALU instructions: a setup loop full of scalar code and loads may be longer)
+        lp = max(lps, key=lambda l: (sum(1 for t in insts[l[0]:l[1] + 1] if classify(t)), size(l)))
     counts = {"half": 0, "full": 0}
     other = {"salu": 0, "lds": 0, "vmem": 0}
     for t in insts[lp[0]:lp[1] + 1]:
