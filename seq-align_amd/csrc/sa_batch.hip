@@ -953,6 +953,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         t.arena = d.arena; t.off_a = d.off_a; t.len_a = d.len_a; t.off_b = d.off_b; t.len_b = d.len_b; t.mat_off = d.mat_off;
         t.code = sc->d_code; t.table = sc->d_table;
         t.str_off = dv_slot + g0;
+        t.stage_words = (c.max_a + c.max_b + 31u) >> 5;
         t.moves = dv_moves + 2 * g0;        // walk w of the launch is pair g0 + w: words 2 ((slot >> 5) + g0 + w)
         t.out_meta2 = dv_meta + 2 * g0;
         t.fill_status = d.status;

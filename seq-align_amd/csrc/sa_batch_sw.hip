@@ -250,6 +250,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.str_off = dd.off_a;                       // (run_chunk packs a, b, a, b, ...: off_a IS the prefix of len_a + len_b)
     // walk w of the launch is hit w % max_hits of the slice's pair w / max_hits = the chunk's pair k0 + that: its slot is
     // 2 max_hits ((off_a >> 5) + chunk pair) + ..., so the bases move by the slice's first pair
+    t.stage_words = (c.max_a + c.max_b + 31u) >> 5;
     t.moves = ctx->h_ta.dev_as<uint32_t>() + 2ull * max_hits * k0; t.out_meta4 = ctx->h_B.dev_as<uint32_t>() + 4ull * max_hits * k0;
     t.walks_per_pair = max_hits; t.hit_count = r.hit_count; t.sweep_status = r.status;
     t.hit_keys = r.hit_keys; t.hit_off = r.hit_off; t.layout = layout; t.fill_status = dd.status;
@@ -631,6 +632,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     memset(&tp, 0, sizeof(tp));
     tp.arena = d.arena; tp.off_a = d.off_a; tp.len_a = d.len_a; tp.off_b = d.off_b; tp.len_b = d.len_b; tp.mat_off = d.mat_off;
     tp.code = sc->d_code; tp.table = sc->d_table; tp.str_off = d.off_a;
+    tp.stage_words = (c.max_a + c.max_b + 31u) >> 5;
     tp.moves = ctx->h_ta.dev_as<uint32_t>(); tp.out_meta4 = ctx->h_B.dev_as<uint32_t>();
     tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
     tp.dirs = ctx->dirs.as<uint8_t>(); tp.fill_status = d.status;

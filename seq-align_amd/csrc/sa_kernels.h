@@ -201,6 +201,8 @@ struct SaTraceParams {
    * words of walk w go to out_meta2[2w..]: score, then the number of walked columns -- or 0xFFFFFFF0 | SEQALIGN_E_* .
    * SW walks also need out_pos for nothing: the host derives the hit's position from the planes (sa_expand_sw_moves). */
   uint32_t *moves;
+  uint32_t stage_words = 0;    /* >= (len_a + len_b + 31) >> 5 of every walk of the launch (0 = unknown): the one-lane-per-walk kernel keeps a walk's
+                                  finished words in LDS until it is over (up to 96 words: 3 040 columns) */
   uint32_t *out_meta2;
   /* SW walks that send home moves: out_meta4[4w..] = score, walked columns, end cell x, y.  walks_per_pair = k > 0: the launch has
    * k walks per pair, walk w = hit w % k of pair w / k (its key in hit_keys), in the slot 2 k ((str_off[pair] >> 5) + pair) +
@@ -210,7 +212,7 @@ struct SaTraceParams {
   const uint32_t *hit_count, *sweep_status;
 };
 /* direction-byte walks: one wave per walk (LDS tiles) below this many walks per launch, one lane per walk from there on (sa_traceback.hip) */
-#define SA_WALK_TILE_MAX 24576u
+#define SA_WALK_TILE_MAX 11264u
 #define SA_MOVES_ERR 0xFFFFFFF0u
 
 /* ---- which kernels a call launched (seqalign_ctx_last_call_info, include/seqalign_hip.h: SEQALIGN_K_*) ------------------

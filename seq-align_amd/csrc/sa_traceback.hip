@@ -357,6 +357,67 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_kernel(const SaTraceP
   write_moves_meta<NW>(p, w, m, m.x, m.y, k);
 }
 
+// The same walk with the NEXT cell's byte on its way before this cell's byte is looked at (walks of up to 32 stage_words columns).
+// A step is bound by the latency of its one-byte load (scattered: 64 walks, 64 cache lines; ~0.55 us), but WHERE the walk goes
+// next does not wait for that byte: it follows from the state the walk stands in (alignment.c:311-327 -- MATCH: up-left,
+// GAP_A: up, GAP_B: left); the byte only says in which state it ARRIVES.  So two loads are in flight per lane, in two
+// registers that take turns.  For the compiler to leave them in flight -- it waits for EVERY load before it touches a loaded
+// register as soon as a younger load, or a store, MAY or MAY NOT have been issued on the way -- the loop has no branch but its
+// own: the wave runs until its longest walk is over, a walk that is over holds its position, every choice is a select, the
+// load is unconditional (a cell outside the matrix, asked for ahead of a walk about to end, reads cell 0 and is answered "every
+// state ends here"), and the words of the planes wait in LDS (word j of lane l at [plane][j][l], rewritten every step until
+// complete; row stage_words is where walks that are over write) and leave when the wave is done.
+template <bool NW>
+__global__ void __launch_bounds__(64) traceback_moves_lane_ahead_kernel(const SaTraceParams p) {
+  extern __shared__ uint32_t stage[];   // [2][stage_words + 1][64]
+  const uint32_t lane = threadIdx.x, rows = p.stage_words + 1u;
+  const uint32_t w_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool exists = w_raw < p.n_pairs;
+  const uint32_t w = exists ? w_raw : p.n_pairs - 1;      // (a lane without a walk shadows the last one and delivers nothing)
+  const MoveWalk m = move_walk<NW>(p, w);
+  const uint32_t la = p.len_a[m.pair], lb = p.len_b[m.pair], W = la + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+  const MoveSlot s = m.slot;
+  uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0;
+  bool alive = exists && m.valid;
+  if constexpr (NW) alive = alive && x != 0 && y != 0;
+  struct Ahead { uint32_t raw; bool inside; };
+  auto ask = [&](uint32_t cx, uint32_t cy) __attribute__((always_inline)) -> Ahead {
+    const bool inside = cx <= la && cy <= lb;
+    return Ahead{(uint32_t)Dg[inside ? cy * W + cx : 0u], inside};
+  };
+  Ahead b0 = ask(x, y);
+  uint32_t nx = x - (st != MAT_GAP_A), ny = y - (st != MAT_GAP_B);   // (may wrap below 0: `inside` answers, nobody stands there)
+  Ahead b1 = ask(nx, ny);
+  // one step on the byte `cur` of the cell the walk stands on; afterwards the walk stands on (nx, ny), whose byte is the OTHER
+  // register, and `cur` is loaded again with the cell after that
+  auto step = [&](Ahead &cur) __attribute__((always_inline)) {
+    const uint32_t f = cur.inside ? (cur.raw >> (2u * st)) & 3u : 3u;
+    const bool go = NW ? alive : (alive && f != 3u);   // (SW: this state's score is 0 -- the hit starts here, smith_waterman.c:192)
+    const uint32_t bit = go ? 0x80000000u >> (k & 31u) : 0u;   // the walk runs backwards: a word's columns arrive last first
+    acc_a |= st == MAT_GAP_A ? bit : 0u;
+    acc_b |= st == MAT_GAP_B ? bit : 0u;
+    const uint32_t row = go ? (uint32_t)s.nw - 1u - (k >> 5) : p.stage_words;   // the word column k belongs to
+    stage[row * 64u + lane] = acc_a; stage[(rows + row) * 64u + lane] = acc_b;
+    k += go;
+    const bool full = go && (k & 31u) == 0;
+    acc_a = full ? 0u : acc_a; acc_b = full ? 0u : acc_b;
+    x = go ? nx : x; y = go ? ny : y; st = go ? f : st;
+    alive = NW ? (go && x != 0 && y != 0) : go;
+    nx = x - (st != MAT_GAP_A); ny = y - (st != MAT_GAP_B);
+    cur = ask(nx, ny);
+  };
+  while (__any(alive)) {
+    step(b0);
+    step(b1);
+  }
+  if (!exists || !m.valid) return;
+  for (int j = s.nw - (int)((k + 31u) >> 5); j < s.nw; ++j) {   // the words the walk touched: the last ceil(k / 32) of its slot
+    s.plane_a[j] = stage[(uint32_t)j * 64u + lane]; s.plane_b[j] = stage[(rows + (uint32_t)j) * 64u + lane];
+  }
+  write_moves_meta<NW>(p, w, m, m.x, m.y, k);
+}
+
 // one wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk); lane l keeps word l of the current block
 // of 64 words per plane in a register, a block leaves as one coalesced store per plane
 // (walks_per_pair: one WAVE per pair walks the pair's hits one after the other -- nearly every pair has one; launched as one
@@ -579,11 +640,12 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   if (p.dirs) {
-    // walks on direction bytes: one wave per walk from LDS tiles while the walks do not fill the chip several times over
-    // (issue-bound: ~9 ns per 300-step walk once the chip is full -- 10 000 walks 0.085 ms, 31 250 walks 0.283 ms), one lane
-    // per walk beyond (latency-bound and flat: 0.17 ms for anything up to ~65 k walks when nothing runs beside it).  The
-    // two cross near 19 k walks; the tile form also writes its moves coalesced (in place over PCIe, sa_batch.hip), which is
-    // worth ~0.04 ms more: SA_WALK_TILE_MAX.  The option trace_kernel = lane | wave forces one.
+    // walks on direction bytes: one wave per walk from LDS tiles for small launches (issue-bound: ~9 ns per 300-step walk once
+    // the chip is full -- 10 000 walks 0.085 ms, 31 250 walks 0.283 ms; its moves leave coalesced, in place over PCIe:
+    // sa_batch.hip), one lane per walk with the next cell's byte asked for ahead beyond (bound by the sectors its scattered
+    // bytes pull in: ~3.3 ns per walk -- 31 250 walks 0.104 ms, 46 875 walks 0.158 ms; without the look-ahead 0.147 / 0.172).
+    // seqalign_nw_batch end to end, 150 x 150: equal at 10 000 pairs, the lane form 5 % ahead from 12 288 on
+    // (profiles/r04/r04_walkers.txt): SA_WALK_TILE_MAX.  The option trace_kernel = lane | wave forces one.
     const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < SA_WALK_TILE_MAX;
     if (p.nw_state) {   // NW behind the directions-only fill
       if (!p.nw_score) return hipErrorInvalidValue;
@@ -591,6 +653,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
         if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
+        else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
@@ -606,6 +669,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;
       if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
+      else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
