@@ -415,6 +415,20 @@ bool sa_host::traceback_on_host(const seqalign_ctx *ctx) { return ctx->opt.trace
 // Same kernels, same buffers (a sub-batch is a pair range of the chunk's descriptor arrays and arenas), same results.
 // Per group the device sends back ONE block of characters (out_a | out_b of its pairs) and one of per-pair words
 // (head, len, score, status interleaved: SaTraceParams::out_meta4; the fill's status is folded in by the walker).
+// The descriptor arrays of a chunk whose pairs all have ONE shape are arithmetic progressions: written on the device (a few
+// microseconds) instead of sent over PCIe (44 B per pair: 5.5 MB for a 125 k-pair share, 0.1 ms in front of the first fill
+// and 15 % on top of the sequences' bytes).  Layout of the block: off_a[n] | off_b[n] | mat_off[n] | slot[n + 1] | len_a[n] | len_b[n].
+__global__ void __launch_bounds__(256) uniform_descriptors_kernel(uint64_t *desc, uint64_t n, uint32_t la, uint32_t lb, uint64_t stride) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n) return;
+  uint64_t *off_a = desc, *off_b = off_a + n, *mat = off_b + n, *slot = mat + n;
+  uint32_t *len_a = reinterpret_cast<uint32_t *>(slot + n + 1), *len_b = len_a + n;
+  const uint64_t pos = k * ((uint64_t)la + lb);
+  slot[k] = pos;
+  if (k == n) return;
+  off_a[k] = pos; off_b[k] = pos + la; mat[k] = k * stride; len_a[k] = la; len_b[k] = lb;
+}
+
 static uint32_t pick_subbatches(const seqalign_ctx *ctx, const Chunk &c) {
   if (ctx->opt.subbatches) return (uint32_t)std::min<uint64_t>(ctx->opt.subbatches, std::max<uint64_t>(c.count, 1));
   // by size, measured (profiles/r03/r03_nw_pipeline.md): C2 (10 k pairs) gains nothing from 2 or 4 sub-batches (1.28 ->
@@ -827,7 +841,8 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
       bcut[s] = std::max(bi, bcut[s - 1]);
     } }
   auto pair_at = [&](uint64_t bi) { return std::min(n, bi * kHostBlk); };
-  constexpr uint64_t kGroupPairs = 32768;   // (measured, C5 share, walks in stream order: 2 groups 3.49 ms, 3 groups 3.31, 4 groups 3.44)
+  constexpr uint64_t kGroupPairs = 32768;   // (measured, C5 share, walks in stream order: 2 groups 3.49 ms, 3 groups 3.31, 4 groups 3.44;
+                                            //  with the lane walker's look-ahead 3 / 4 / 8 groups and a short last group: 3.12-3.27, no order)
   std::vector<uint32_t> gcut{0};
   for (uint32_t s = 1; s < n_sub; ++s)
     if (pair_at(bcut[s]) - pair_at(bcut[gcut.back()]) >= kGroupPairs && n - pair_at(bcut[s]) >= kGroupPairs / 2) gcut.push_back(s);
@@ -877,7 +892,16 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
 
   EventList ev;   // [0, n_sub): upload of s done; then per group: walk done / results home / fills done; last: descriptors up
   for (uint32_t k = 0; k < n_sub + 3 * n_grp + 1; ++k) HIP_TRY(ev.add(hipEventDisableTiming));
-  if (!zc_in) {
+  if (!zc_in && layout == kUniform) {
+    // one shape: the device writes them itself, in the fills' stream (uniform_descriptors_kernel)
+    hipLaunchKernelGGL(uniform_descriptors_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, sf, ctx->off_a.as<uint64_t>(),
+                       n, c.max_a, c.max_b, stride);
+    HIP_TRY(hipGetLastError());
+    if (sw != sf) {
+      HIP_TRY(hipEventRecord(ev.ev[n_sub + 3 * n_grp], sf));
+      HIP_TRY(hipStreamWaitEvent(sw, ev.ev[n_sub + 3 * n_grp], 0));
+    }
+  } else if (!zc_in) {
     // the descriptor arrays (44 B per pair: C5's share 5.5 MB, more than a sub-batch's sequences) go up on the download
     // stream, which has nothing to do yet, beside the first sub-batch's sequences on the upload stream: two copy engines
     // (C5's share 4.2 -> 4.05 ms against the same copy ahead of the sequences on the upload stream)
