@@ -398,7 +398,9 @@ def run(args) -> int:
         # ~30 % slower for 1.4-4.4 s after that (profiles/r03/r03_after_placement_transient.txt) and this loop waited 6 s; with
         # round 4's host path (moves home, no blit kernel, a worker pool sized to the CPU quota) the same experiment shows no
         # transient at all (tools/placement_pressure.py, profiles/r04/r04_placement_pressure.txt: 0.49 ms from the first 250 ms
-        # after walks of 24, 64 and 160 GiB).  `cold_ms` above is measured without any wait; this keeps calling for a second.
+        # after walks of 24, 64 and 160 GiB).  What remains is paid by the FIRST call when it allocates gigabytes right after a walk that
+        # used its whole budget: the driver clears what the walk handed back (first_call_ms 4 s for C5 / C3 after 165 GiB, 20-75 ms
+        # after shorter walks).  `cold_ms` above is measured without any wait; this keeps calling for a second.
         while time.perf_counter() - t_placed < args.e2e_after:
             fn()
         settle(fn)
