@@ -424,6 +424,35 @@ fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
                                      reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
+// Four AND two pairs per wave in one grid, for a launch whose last round of four-per-wave waves would be less than half full:
+// the first q_blocks workgroups take pairs [0, pairs_q) four per wave (pairs_q: a whole number of rounds of 1 024 waves), the
+// others the remaining pairs two per wave.  C2's 10 000 pairs are 2 500 four-per-wave waves: 452 SIMDs get three of them and
+// the rest wait with two (0.56 of the issue peak); as 2 048 four-per-wave + 904 two-per-wave waves every SIMD has two of the
+// former and at most one of the latter, ~12 % less work on the busiest SIMD (sa_launch_fill_nw_dirs_x2 decides).
+template <int CPL4, int SUBST, int R>
+__global__ void __launch_bounds__(kWave * 4)
+fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t q_blocks, const uint32_t pairs_q) {
+  constexpr int CPL2 = (CPL4 + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t tbl_lds = waves * (4 * R);   // the table sits behind the rings (the two-per-wave waves use half of theirs)
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (4 * R);
+  if (blockIdx.x < q_blocks) {   // (uniform per workgroup)
+    const uint32_t unit = blockIdx.x * waves + wave;
+    if (4 * unit >= pairs_q) return;
+    const uint32_t lo = 4 * unit + 2 * ((uint32_t)lane >> 5);
+    nw_dirs_x2_wave<CPL4, SUBST, R, 32>(p, dirs_arena, lo, lo + 1, true, true, lane, ring, tbl_lds);
+  } else {
+    const uint32_t pair0 = pairs_q + 2 * ((blockIdx.x - q_blocks) * waves + wave);
+    if (pair0 >= p.n_pairs) return;
+    const bool two = pair0 + 1 < p.n_pairs;
+    nw_dirs_x2_wave<CPL2, SUBST, R, 64>(p, dirs_arena, pair0, two ? pair0 + 1 : pair0, true, two, lane, ring, tbl_lds);
+  }
+}
+
 // The same for a chunk whose pairs are MOSTLY of one shape, in ONE grid: the first x2_blocks workgroups take the n_modal
 // pairs of the modal shape two per wave (p.pair_list[0 .. n_modal)), the others the n_rest remaining pairs one per wave
 // (p.pair_list[n_modal ..), fill_nw_dirs_kernel's body).  Two launches would run one after the other, and a launch of a
@@ -947,6 +976,17 @@ static hipError_t launch_nw_dirs_x4_cpl(const SaFillParams &p, uint8_t *dirs, hi
   return hipGetLastError();
 }
 
+template <int CPL4>
+static hipError_t launch_nw_dirs_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t pairs_q, hipStream_t stream) {
+  constexpr int R = 512;
+  const int wpb = 4;
+  const uint32_t q_blocks = (pairs_q / 4 + wpb - 1) / wpb, x2_blocks = ((p.n_pairs - pairs_q + 1) / 2 + wpb - 1) / wpb;
+  const dim3 grid(q_blocks + x2_blocks), block(kWave * wpb);
+  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
+  else hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
+  return hipGetLastError();
+}
+
 template <int CPL, int R>
 static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest, hipStream_t stream) {
   const int wpb = 4;
@@ -991,6 +1031,20 @@ static int sa_x4_columns(const SaFillParams &p, uint32_t max_len_a, uint32_t min
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   if (const int c4 = sa_x4_columns(p, max_len_a, 4096u)) {
+    // the last round of four-per-wave waves less than half full (and the choice left to the library): those pairs two per wave
+    const uint32_t pairs_q = p.n_pairs / 4096u * 4096u, rest = p.n_pairs - pairs_q;
+    if (p.tune_quad == 0 && pairs_q && rest && rest <= 2048u) {
+      sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X4, pairs_q);
+      sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, rest);
+      switch (c4) {
+        case 1: return sa::launch_nw_dirs_x4x2_cpl<1>(p, dirs, pairs_q, stream);
+        case 2: return sa::launch_nw_dirs_x4x2_cpl<2>(p, dirs, pairs_q, stream);
+        case 3: return sa::launch_nw_dirs_x4x2_cpl<3>(p, dirs, pairs_q, stream);
+        case 4: return sa::launch_nw_dirs_x4x2_cpl<4>(p, dirs, pairs_q, stream);
+        case 5: return sa::launch_nw_dirs_x4x2_cpl<5>(p, dirs, pairs_q, stream);
+        default: return sa::launch_nw_dirs_x4x2_cpl<6>(p, dirs, pairs_q, stream);
+      }
+    }
     sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X4, p.n_pairs);
     switch (c4) {
       case 1: return sa::launch_nw_dirs_x4_cpl<1>(p, dirs, stream);

@@ -196,6 +196,20 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
     opts(quad=1)
     assert got == ctx.nw_batch(big, sc_nw)
     opts(quad=0)
+    # a last round of four-per-wave waves that would be less than half full goes two per wave, in the same grid (gap-rich pairs)
+    mixed, pairs = gap_rich(4096 + 101, 70, 64, 77)
+    got = ctx.nw_batch(mixed, sc_nw)
+    info = ctx.last_call()
+    assert info["fill_nw_dirs_x4"] == (1, 4096) and info["fill_nw_dirs_x2"] == (1, 101), info
+    opts(quad=1)
+    assert got == ctx.nw_batch(mixed, sc_nw)
+    o_nw = osc_of(sc_nw)
+    for p in list(range(0, 4096, 257)) + list(range(4090, 4197)):
+        rc, s_, ra, rb = O.oracle_nw(o_nw, *pairs[p])
+        assert rc == 0 and got[p] == (s_, ra, rb), p
+    opts(quad=0)
+    ctx.nw_batch(uniform(4096 + 2049, 60, 50, 8), sc_nw)     # more than half a round left: four per wave throughout
+    assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 4096 + 2049) and "fill_nw_dirs_x2" not in ctx.last_call()
     ctx.nw_batch(uniform(4096, 192, 20, 3), sc_nw)           # 193 columns: seven per lane of a span -- two pairs per wave
     assert "fill_nw_dirs_x2" in ctx.last_call() and "fill_nw_dirs_x4" not in ctx.last_call()
     sw = uniform(16384, 40, 30, 4)
