@@ -16,6 +16,7 @@ emit() { # file function mangled-args demangled
 }
 emit sa_fill_dirs_x2.hip fill_nw_dirs_x2_kernel ILi3ELi0ELi512E "fill_nw_dirs_x2_kernel<3, 0, 512>"
 emit sa_fill_dirs_x2.hip fill_nw_dirs_x4_kernel ILi5ELi0ELi512E "fill_nw_dirs_x4_kernel<5, 0, 512>"
+emit sa_fill_dirs_x2.hip fill_nw_dirs_x4x2_kernel ILi5ELi0ELi512E "fill_nw_dirs_x4x2_kernel<5, 0, 512>"
 emit sa_fill_dirs_x2.hip fill_sw_best_x4_kernel ILi5ELi0ELi512E "fill_sw_best_x4_kernel<5, 0, 512>"
 emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi3ELi0ELi512E "fill_sw_best_x2_kernel<3, 0, 512>"
 emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi5ELi1ELi1024E "fill_sw_best_x2_kernel<5, 1, 1024>"
