@@ -464,7 +464,27 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
         __builtin_amdgcn_s_waitcnt(0);
         loaded = true;
       }
-      const uint32_t f = ((uint32_t)tile[(y - oy) * kT + (x - ox)] >> (2u * st)) & 3u;
+      const uint32_t at = (y - oy) * kT + (x - ox);
+      // Four cells up the diagonal at once: a walk spends most of its steps in MATCH going up-left (a mismatch is such a step too),
+      // and a step is ~230 ns of dependent latency -- an LDS read, the scalar bookkeeping, the loop -- whatever it decides.  While
+      // the walk stands in MATCH and the next four cells all say "arrive in MATCH" (four independent LDS reads), they are taken
+      // in one go: no gap bits to record, only the column count and, now and then, a finished word.  (10 000 walks of C2: 108 ->
+      // 91 us; reading eight cells and taking as many as stay in MATCH: 95 us -- the bookkeeping eats what the longer jumps save.)
+      if (st == MAT_MATCH && x >= ox + 4 && y >= oy + 4) {
+        const uint32_t four = (uint32_t)tile[at] | (uint32_t)tile[at - (kT + 1)] | (uint32_t)tile[at - 2 * (kT + 1)] | (uint32_t)tile[at - 3 * (kT + 1)];
+        if ((four & 3u) == 0) {
+          const uint32_t k4 = k + 4;
+          if ((k >> 5) != (k4 >> 5)) {   // the word the walk was in is complete (its remaining columns are not gaps)
+            const int jw = (int)(k4 >> 5) - 1;
+            if (lane == 63 - (jw & 63)) { reg_a = acc_a; reg_b = acc_b; }
+            acc_a = acc_b = 0;
+            if ((jw & 63) == 63) flush(jw >> 6, 0);
+          }
+          k = k4; x -= 4; y -= 4;
+          continue;
+        }
+      }
+      const uint32_t f = ((uint32_t)tile[at] >> (2u * st)) & 3u;
       if constexpr (!NW) { if (f == 3u) break; }
       const uint32_t bit = 0x80000000u >> (k & 31u);
       acc_a |= st == MAT_GAP_A ? bit : 0u;
