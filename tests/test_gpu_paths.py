@@ -208,6 +208,17 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
         rc, s_, ra, rb = O.oracle_nw(o_nw, *pairs[p])
         assert rc == 0 and got[p] == (s_, ra, rb), p
     opts(quad=0)
+    # ... the same with a substitution table (BLOSUM62: the table in LDS behind rings of two sizes) and a scoring with gap_extend 0
+    for spec, alpha in (({"preset": "BLOSUM62"}, b"ARNDCQEGHILKMFPSTWYV"), ({"init": [3, -2, -5, 0, 0, 0, 0, 0, 0, 0]}, b"ACGT")):
+        scx = S.make_scoring(spec)
+        mixed, pairs = gap_rich(4096 + 37, 45, 52, 78, alpha=alpha)
+        got = ctx.nw_batch(mixed, scx)
+        info = ctx.last_call()
+        assert info["fill_nw_dirs_x4"] == (1, 4096) and info["fill_nw_dirs_x2"] == (1, 37), info
+        ox = osc_of(scx)
+        for p in list(range(0, 4096, 311)) + list(range(4092, 4133)):
+            rc, s_, ra, rb = O.oracle_nw(ox, *pairs[p])
+            assert rc == 0 and got[p] == (s_, ra, rb), (spec, p)
     ctx.nw_batch(uniform(4096 + 2049, 60, 50, 8), sc_nw)     # more than half a round left: four per wave throughout
     assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 4096 + 2049) and "fill_nw_dirs_x2" not in ctx.last_call()
     ctx.nw_batch(uniform(4096, 192, 20, 3), sc_nw)           # 193 columns: seven per lane of a span -- two pairs per wave
