@@ -84,7 +84,10 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
   // the five descriptor arrays travel as the one block they are on the host (off_a: the device copy)
   if ((rc = ctx->off_a.reserve(desc_bytes)) || (rc = ctx->status.reserve(n * 8))) return rc;
   const bool no_matrices = cand && cand->best_only;   // direction bytes + the best cell only (the caller's cand->dirs)
-  if (!no_matrices && (rc = reserve_arenas(ctx, mat_total * 4))) return rc;
+  // (a caller that laid the chunk out for the packed direction-byte fill has reserved unplaced arenas: sa_batch_sw.hip -- asking for
+  // placed ones here would replace the set it already points into)
+  const bool packed_dirs = cand && cand->dirs && (bucket || uniform_stride);
+  if (!no_matrices && (rc = reserve_arenas(ctx, mat_total * 4, !packed_dirs))) return rc;
   hipStream_t st = ctx->stream;
   uint32_t list_len[2] = {0, 0};   // (bucket) entries of the first slice's list and of the second's
   if (bucket) {

@@ -190,9 +190,10 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   uint64_t cells256 = 0;
   if (stride == kBucketShapes)
     for (uint64_t k = 0; k < n; ++k) cells256 += (((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1) + 255u) & ~(uint64_t)255u;
-  if ((rc = reserve_arenas(ctx, (stride == kBucketShapes ? cells256 : stride ? n * stride : c.cells) * 4))) return rc;
   // (only when the sweep will run in its rows-in-registers form: not with the strip / LDS forms forced by an option)
   const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0;
+  // (the packed direction-byte fill is bound by instruction issue: its arenas need no placement walk)
+  if ((rc = reserve_arenas(ctx, (stride == kBucketShapes ? cells256 : stride ? n * stride : c.cells) * 4, !(allow_dirs && stride != 0)))) return rc;
   cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
   if (!allow_dirs) stride = 0;
   cand.uniform_stride = stride == kBucketShapes ? 256 : stride;

@@ -289,6 +289,7 @@ struct seqalign_ctx {
   sa_host::DevBuf arena, off_a, pair_list, status;   // (off_a holds all five descriptor arrays; pair_list: nw_chunk_pipelined's mixed chunks)
   sa_host::DevBuf M, A, B;           // views of arena_set (sa_host::reserve_arenas); never reserved / released on their own
   SaArenaSet *arena_set = nullptr;   // the three matrix arenas, placed (sa_placement.hip)
+  bool arena_placed = false;         // the set in arena_set went through the placement walk (reserve_arenas(.., placed = true))
   uint32_t arena_walks = 0;          // how often reserve_arenas has placed them (the first walk is the full one)
   sa_host::HostBuf h_one;            // the legacy single-pair call: descriptor + sequences + three matrices + status of ONE pair,
   void *one_dev = nullptr;           // pinned, read and written in place by the GPU (sa_fill_one_pair); its device address
@@ -320,7 +321,7 @@ struct CallScope {
 };
 
 // grow the context's three matrix arenas together (spread placement, sa_placement.hip)
-int reserve_arenas(seqalign_ctx *ctx, size_t bytes);
+int reserve_arenas(seqalign_ctx *ctx, size_t bytes, bool placed = true);
 
 // The uploaded form of `scoring` for the host-level entry points: the context keeps the last one it flattened and
 // uploaded (per NW / SW), keyed by a fingerprint of everything scoring_lookup can see, so that a caller who aligns

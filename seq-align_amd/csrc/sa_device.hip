@@ -98,8 +98,12 @@ static SaPlacementOpts placement_opts(const seqalign_ctx *ctx, bool explicit_cal
   return o;
 }
 
-int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
-  if (ctx->arena_set && bytes <= ctx->M.cap) return SEQALIGN_OK;
+// placed = false: the caller's kernels are bound by instruction issue, not by HBM (the multi-hit path's packed fill writes
+// match_scores + direction bytes at under half the HBM peak: profiles/r04, C3 the same with and without the walk) -- plain
+// allocations, no walk (0.1-0.3 s and up to a quarter of the free memory held for that long, then cleared by the driver).
+// A set made that way is replaced by a placed one as soon as somebody asks for placed arenas.
+int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes, bool placed) {
+  if (ctx->arena_set && bytes <= ctx->M.cap && (ctx->arena_placed || !placed)) return SEQALIGN_OK;
   if (ctx->arena_set) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -110,9 +114,12 @@ int sa_host::reserve_arenas(seqalign_ctx *ctx, size_t bytes) {
   ctx->M = DevBuf(); ctx->A = DevBuf(); ctx->B = DevBuf();   // views of the set, never freed on their own
   const size_t want = bytes + (ctx->arena_walks ? bytes / 2 : bytes / 8) + 4096;
   SaArenaSet *set = nullptr;
-  hipError_t e = sa_arenas_create(ctx->device, want, ctx->stream, placement_opts(ctx, false), &set);
+  SaPlacementOpts po = placement_opts(ctx, false);
+  if (!placed) po.scan_bytes = 0;
+  hipError_t e = sa_arenas_create(ctx->device, want, ctx->stream, po, &set);
   if (e != hipSuccess) return fail_hip(e, "matrix arenas");
-  ctx->arena_walks++;
+  if (placed) ctx->arena_walks++;
+  ctx->arena_placed = placed;
   ctx->arena_set = set;
   void *const *a = sa_arenas_base(set);
   ctx->M.p = a[0]; ctx->A.p = a[1]; ctx->B.p = a[2];
