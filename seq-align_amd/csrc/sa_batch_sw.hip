@@ -338,7 +338,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
       // where every hit goes in the caller's buffers: hits and string bytes per block of pairs (parallel), a prefix over the
       // blocks, then every block places and expands its own hits
-      constexpr uint64_t kBlk = 256;
+      constexpr uint64_t kBlk = 64;    // (pairs per task: C3's 10 000 pairs are 157 tasks for 16-32 threads; 256 left some threads a third more than others)
       const uint64_t nblk = (n + kBlk - 1) / kBlk;
       std::vector<uint64_t> blk_hits(nblk + 1, 0), blk_bytes(nblk + 1, 0);
       std::atomic<int> bad{SEQALIGN_OK};
