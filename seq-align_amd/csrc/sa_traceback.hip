@@ -418,11 +418,28 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_ahead_kernel(const Sa
   write_moves_meta<NW>(p, w, m, m.x, m.y, k);
 }
 
-// one wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk); lane l keeps word l of the current block
-// of 64 words per plane in a register, a block leaves as one coalesced store per plane
+// One wave per walk from 64 x 64-byte LDS tiles (traceback_dirs_tile_kernel's walk), all 64 lanes walking the same walk: the
+// state is wave-uniform and the compiler keeps it in scalar registers.  With ~10 such waves taking turns on a SIMD the time of
+// this kernel is its INSTRUCTION COUNT PER STEP (10 000 walks of 300 steps: ~28 instructions per step 108 us; with four cells
+// of a diagonal run taken at once 91 us; this form, 16 instructions per step, 65 us -- profiles/r04/r04_walkers.txt; the LDS
+// read's latency is not it: a read-ahead form with more bookkeeping was slower).  Inside a tile a walk cannot reach the tile's
+// edge, nor the matrix border, in fewer than min(tx, ty) steps, and it completes a 32-column word every 32 steps: so the steps
+// run in BURSTS of min(tx, ty, 32 - k % 32) with nothing in the loop but the byte, the state it says the walk arrives in, the
+// place in the tile, and two bits of "which state" shifted into a 64-bit word -- gap-in-a is the low bit of GAP_A = 1, gap-in-b
+// the high bit of GAP_B = 2, so the two planes' words are the even and the odd bits of that word, pulled apart once per 32
+// steps.  Lane l keeps word l of the current block of 64 words per plane in a register; a block leaves as one coalesced store
+// per plane.
 // (walks_per_pair: one WAVE per pair walks the pair's hits one after the other -- nearly every pair has one; launched as one
 // workgroup per walk slot, the 30 000 of C3's 40 000 slots that return at once cost 0.2 ms of workgroup dispatch, and as one
 // workgroup per pair with a wave per slot, four times the LDS per workgroup held for waves that had nothing to do)
+__device__ __forceinline__ uint32_t even_bits(unsigned long long v) {   // bits 0, 2, 4, ... of v as a 32-bit word
+  v &= 0x5555555555555555ull;
+  v = (v | (v >> 1)) & 0x3333333333333333ull;
+  v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  v = (v | (v >> 4)) & 0x00ff00ff00ff00ffull;
+  v = (v | (v >> 8)) & 0x0000ffff0000ffffull;
+  return (uint32_t)(v | (v >> 16));
+}
 template <bool NW>
 __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceParams p) {
   constexpr int kT = 64;
@@ -430,29 +447,28 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
   const int lane = threadIdx.x;
   const uint32_t reps = (!NW && p.walks_per_pair) ? p.walks_per_pair : 1u;
   typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   for (uint32_t rep = 0; rep < reps; ++rep) {
     const uint32_t w = blockIdx.x * reps + rep;
     if (w >= p.n_pairs) return;
     const MoveWalk m = move_walk<NW>(p, w);
-    if (!m.valid) return;   // (wave-uniform; a pair's hits are its first ranks: nothing behind an invalid one)
+    if (!m.valid) return;
     const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
     const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
     const MoveSlot s = m.slot;
-    uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0, reg_a = 0, reg_b = 0;
-    uint32_t ox = 0, oy = 0;
-    bool loaded = false;
-    // block q = the walk's words 64 q .. 64 q + 63 counted from the end; slot 63 - (j & 63) of the block holds word j, and slot t
-    // of block q is plane word nw - 64 (q + 1) + t
+    uint32_t x = uni(m.x), y = uni(m.y), st = uni(m.st), k = 0, reg_a = 0, reg_b = 0;
+    unsigned long long codes = 0;   // the states of the current word's steps, two bits each, the first step on top
     auto flush = [&](int q, int first_slot) {
       const int at = s.nw - 64 * (q + 1) + lane;
       if (lane >= first_slot) { s.plane_a[at] = reg_a; s.plane_b[at] = reg_b; }
     };
-    for (;;) {
+    bool over = false;
+    while (!over) {
       if constexpr (NW) { if (x == 0 || y == 0) break; }
-      if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
-        ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
-        oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      // ---- the tile whose bottom-right cell is (x, y)
+      const uint32_t ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0, oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      {
         const uint32_t r = oy + lane;
         if (r <= lb) {
           const uint8_t *src = Dg + (uint64_t)r * W + ox;
@@ -460,52 +476,60 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0);
-        loaded = true;
       }
-      const uint32_t at = (y - oy) * kT + (x - ox);
-      // Four cells up the diagonal at once: a walk spends most of its steps in MATCH going up-left (a mismatch is such a step too),
-      // and a step is ~230 ns of dependent latency -- an LDS read, the scalar bookkeeping, the loop -- whatever it decides.  While
-      // the walk stands in MATCH and the next four cells all say "arrive in MATCH" (four independent LDS reads), they are taken
-      // in one go: no gap bits to record, only the column count and, now and then, a finished word.  (10 000 walks of C2: 108 ->
-      // 91 us; reading eight cells and taking as many as stay in MATCH: 95 us -- the bookkeeping eats what the longer jumps save.)
-      if (st == MAT_MATCH && x >= ox + 4 && y >= oy + 4) {
-        const uint32_t four = (uint32_t)tile[at] | (uint32_t)tile[at - (kT + 1)] | (uint32_t)tile[at - 2 * (kT + 1)] | (uint32_t)tile[at - 3 * (kT + 1)];
-        if ((four & 3u) == 0) {
-          const uint32_t k4 = k + 4;
-          if ((k >> 5) != (k4 >> 5)) {   // the word the walk was in is complete (its remaining columns are not gaps)
-            const int jw = (int)(k4 >> 5) - 1;
-            if (lane == 63 - (jw & 63)) { reg_a = acc_a; reg_b = acc_b; }
-            acc_a = acc_b = 0;
-            if ((jw & 63) == 63) flush(jw >> 6, 0);
-          }
-          k = k4; x -= 4; y -= 4;
-          continue;
-        }
-      }
-      const uint32_t f = ((uint32_t)tile[at] >> (2u * st)) & 3u;
-      if constexpr (!NW) { if (f == 3u) break; }
-      const uint32_t bit = 0x80000000u >> (k & 31u);
-      acc_a |= st == MAT_GAP_A ? bit : 0u;
-      acc_b |= st == MAT_GAP_B ? bit : 0u;
-      if ((++k & 31u) == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);
+      uint32_t at = (y - oy) * kT + (x - ox);   // the place of the cell the walk stands on: ty * 64 + tx
+      auto word_done = [&]() __attribute__((always_inline)) {   // after a step: the 32nd column of a word?
+        if ((k & 31u) != 0) return;
         const int j = (int)(k >> 5) - 1;
-        if (lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
-        acc_a = acc_b = 0;
+        const uint32_t wa = even_bits(codes), wb = even_bits(codes >> 1);
+        if (lane == 63 - (j & 63)) { reg_a = wa; reg_b = wb; }
+        codes = 0;
         if ((j & 63) == 63) flush(j >> 6, 0);
+      };
+      for (;;) {
+        const uint32_t tx = at & (kT - 1), ty = at >> 6;
+        // a burst: steps that can neither leave the tile (nor reach the matrix border before its last step) nor pass the end of a word
+        uint32_t n = min(min(tx, ty), 32u - (k & 31u));
+        if (n == 0) {
+          // on the tile's first row or column: one step with the coordinates spelled out, then the next tile
+          const uint32_t f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
+          if constexpr (!NW) { if (f == 3u) { over = true; break; } }
+          codes = (codes << 2) | st;
+          x = ox + tx - (st != MAT_GAP_A); y = oy + ty - (st != MAT_GAP_B);
+          st = f;
+          ++k;
+          word_done();
+          break;
+        }
+        bool ended = false;
+        do {
+          const uint32_t f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
+          if constexpr (!NW) { if (f == 3u) { ended = true; break; } }
+          codes = (codes << 2) | st;
+          at -= (0x00014041u >> (8u * st)) & 0xffu;   // MATCH: one row and one column back (65), GAP_A: a row (64), GAP_B: a column (1)
+          st = f;
+          ++k;
+        } while (--n);
+        if (ended) { over = true; break; }
+        word_done();
+        x = ox + (at & (kT - 1)); y = oy + (at >> 6);
+        if constexpr (NW) { if (x == 0 || y == 0) { over = true; break; } }
       }
-      x -= (st != MAT_GAP_A);
-      y -= (st != MAT_GAP_B);
-      st = f;
+    }
+    if (k & 31u) {   // the unfinished word: its columns on top
+      const int j = (int)(k >> 5);
+      const unsigned long long top = codes << (2u * (32u - (k & 31u)));
+      const uint32_t wa = even_bits(top), wb = even_bits(top >> 1);
+      if (lane == 63 - (j & 63)) { reg_a = wa; reg_b = wb; }
     }
     if (k) {
-      const int j = (int)((k - 1) >> 5);   // the last word the walk touched
-      if ((k & 31u) && lane == 63 - (j & 63)) { reg_a = acc_a; reg_b = acc_b; }
+      const int j = (int)((k - 1) >> 5);
       flush(j >> 6, 63 - (j & 63));
     }
     if (lane == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, k);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the next walk's tile loads behind this walk's LDS reads)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 }
 
