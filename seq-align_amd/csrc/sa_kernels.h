@@ -212,7 +212,7 @@ struct SaTraceParams {
   const uint32_t *hit_count, *sweep_status;
 };
 /* direction-byte walks: one wave per walk (LDS tiles) below this many walks per launch, one lane per walk from there on (sa_traceback.hip) */
-#define SA_WALK_TILE_MAX 11264u
+#define SA_WALK_TILE_MAX 24576u
 #define SA_MOVES_ERR 0xFFFFFFF0u
 
 /* ---- which kernels a call launched (seqalign_ctx_last_call_info, include/seqalign_hip.h: SEQALIGN_K_*) ------------------

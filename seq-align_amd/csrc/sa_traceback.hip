@@ -684,11 +684,11 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) traceback_wave_kernel(c
 hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   if (p.dirs) {
-    // walks on direction bytes: one wave per walk from LDS tiles for small launches (issue-bound: ~9 ns per 300-step walk once
-    // the chip is full -- 10 000 walks 0.085 ms, 31 250 walks 0.283 ms; its moves leave coalesced, in place over PCIe:
+    // walks on direction bytes: one wave per walk from LDS tiles for small launches (bound by its instruction count per step:
+    // ~6.5 ns per 300-step walk once the chip is full -- 10 000 walks 0.065 ms; its moves leave coalesced, in place over PCIe:
     // sa_batch.hip), one lane per walk with the next cell's byte asked for ahead beyond (bound by the sectors its scattered
-    // bytes pull in: ~3.3 ns per walk -- 31 250 walks 0.104 ms, 46 875 walks 0.158 ms; without the look-ahead 0.147 / 0.172).
-    // seqalign_nw_batch end to end, 150 x 150: equal at 10 000 pairs, the lane form 5 % ahead from 12 288 on
+    // bytes pull in: ~3.3 ns per walk -- 31 250 walks 0.104 ms, 46 875 walks 0.158 ms -- behind a device buffer and a copy).
+    // seqalign_nw_batch end to end, 150 x 150: the tile form 8 % ahead at 10 000 pairs, 4 % at 24 576, equal at 32 768
     // (profiles/r04/r04_walkers.txt): SA_WALK_TILE_MAX.  The option trace_kernel = lane | wave forces one.
     const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < SA_WALK_TILE_MAX;
     if (p.nw_state) {   // NW behind the directions-only fill
