@@ -503,15 +503,21 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
           word_done();
           break;
         }
-        bool ended = false;
-        do {
+        // (two steps per turn of the loop: its counter and branch are 3 of a step's 16 instructions)
+        auto one = [&]() __attribute__((always_inline)) -> bool {
           const uint32_t f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
-          if constexpr (!NW) { if (f == 3u) { ended = true; break; } }
+          if constexpr (!NW) { if (f == 3u) return true; }
           codes = (codes << 2) | st;
           at -= (0x00014041u >> (8u * st)) & 0xffu;   // MATCH: one row and one column back (65), GAP_A: a row (64), GAP_B: a column (1)
           st = f;
           ++k;
-        } while (--n);
+          return false;
+        };
+        bool ended = false;
+        for (; n >= 2u; n -= 2u) {
+          if (one() || one()) { ended = true; break; }
+        }
+        if (!ended && n) ended = one();
         if (ended) { over = true; break; }
         word_done();
         x = ox + (at & (kT - 1)); y = oy + (at >> 6);
