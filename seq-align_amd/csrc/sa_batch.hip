@@ -837,12 +837,19 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   const uint32_t n_sub = (uint32_t)std::min<uint64_t>(pick_subbatches(ctx, c), nb);
   std::vector<uint64_t> bcut(n_sub + 1, nb);
   bcut[0] = 0;
-  { uint64_t bi = 0;
+  if (layout == kUniform && n_sub > 1 && n / n_sub >= 8192 && kHostBlk <= 4096 && 4096 % kHostBlk == 0) {
+    // one shape, four pairs per wave: sub-batches of whole ROUNDS of waves (4 096 pairs = 1 024 waves, one per SIMD) -- C5's
+    // share as 7 x 16 384 + 10 312 pairs is 31 rounds where 8 x 15 625 are 32
+    const uint64_t per = (((n + n_sub - 1) / n_sub + 4095u) & ~(uint64_t)4095u) / kHostBlk;
+    for (uint32_t s = 1; s < n_sub; ++s) bcut[s] = std::min<uint64_t>(nb, s * per);
+  } else {
+    uint64_t bi = 0;
     for (uint32_t s = 1; s < n_sub; ++s) {
       const uint64_t want = mat_total / n_sub * s;
       while (bi < nb && cells_at[bi] < want) ++bi;
       bcut[s] = std::max(bi, bcut[s - 1]);
-    } }
+    }
+  }
   auto pair_at = [&](uint64_t bi) { return std::min(n, bi * kHostBlk); };
   constexpr uint64_t kGroupPairs = 32768;   // (measured, C5 share, walks in stream order: 2 groups 3.49 ms, 3 groups 3.31, 4 groups 3.44;
                                             //  with the lane walker's look-ahead 3 / 4 / 8 groups and a short last group: 3.12-3.27, no order)
