@@ -20,8 +20,15 @@
 //   * both pairs' rows have the same length, so ONE set of stream positions serves both rings; the caller lays the
 //     direction bytes out with every pair starting on a 256-byte boundary (SaFillParams::uniform_stride), so every
 //     global store is a whole aligned 256 B block and the last one may run into the pair's own padding.
-// Domain: what sa_fill_dirs.hip takes, AND every pair of the launch has the same len_a and len_b, AND match /
-// mismatch scoring (K <= 1), AND the score bound above.  Anything else takes the one-pair-per-wave kernels.
+// Domain: what sa_fill_dirs.hip takes, AND the pairs that share a wave have the same len_a and len_b (a uniform launch, or a
+// pair list that the host has paired up by shape), AND scores inside the bound above (match / mismatch scoring, or a
+// substitution table of up to SA_LDS_TABLE_MAX_K classes held in LDS as int16).  Anything else takes the one-pair-per-wave
+// kernels.
+// Round 4: the wave functions take LANES = 64 (two pairs per wave, as above) or 32 -- FOUR pairs per wave, a couple of pairs in
+// the halves of lanes 0-31 and another in lanes 32-63 (a 151-column row: 160 cell slots instead of 192, and the per-row work
+// that does not depend on the width serves four rows; NW and the SW best-hit fill: nw_dirs_x2_wave / sw_best_x2_wave) -- and a
+// launch whose last round of four-per-wave waves would be less than half full runs that round two per wave in the same grid
+// (fill_nw_dirs_x4x2_kernel).  DESIGN.md 3.5f; profiles/r04/r04_quad_fills.txt.
 #include <algorithm>
 
 #include "sa_rowsweep.hpp"
