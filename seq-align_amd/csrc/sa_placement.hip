@@ -320,7 +320,8 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   //   walk 2: A = pool[pos, pos + per) with that B -- finds a THIRD class.  tools/probes/grade_probe.hip times the whole
   //           (A, B) grid: one class 0.52 ms, two classes 0.403-0.416, three classes 0.387-0.395 -- the "best grade",
   //           what a memset of the same bytes takes (profiles/r03/r03_grade_probe.txt).
-  // Either walk ends early at `quality_stop` (a three-class placement; walk 2 is skipped when walk 1 already got there).
+  //   walk 3 (below, round 4): M = pool[pos, pos + per) with that A and B, only when neither of them reached the target.
+  // Every walk ends early at `quality_stop` (a three-class placement; a later walk is skipped when an earlier one got there).
   const size_t step = std::max<size_t>(per, 8);
   auto probe = [&](void *x0, void *x1, void *x2) {
     void *trio[3] = {x0, x1, x2};
