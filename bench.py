@@ -32,7 +32,10 @@ Prints ONE JSON line (rank 0).  `value` = all ranks' cells / max-rank seconds.
 `cpu_baseline`: the reference itself (oracle/_ref, built from /root/reference in the
                 authoring container) or, if absent, our C restatement (oracle/), timed
                 on this box's host cores by a pthread harness (oracle/cpu_bench.c) on a
-                bounded sample: 1 pinned thread, and one thread per physical core.
+                bounded sample: 1 pinned thread, and as many threads as the container is granted
+                (min of physical cores, affinity mask, cgroup CPU quota -- all three in the line,
+                with the all-cores / (one thread x threads) ratio); fill only, and fill + traceback
+                (`cpu_baseline.e2e`: needleman_wunsch_align2 of the compiled reference) beside `e2e`.
 """
 from __future__ import annotations
 
@@ -222,49 +225,94 @@ def host_cpu_info() -> dict:
     return info
 
 
-def cpu_baseline(batch, spec, is_sw, budget_s=18.0):
-    """Reference CPU path on THIS host, bounded sample.  Checker code (oracle/): allowed here, and only here
-    plus the out-of-timed-region spot check."""
+def cpu_threads(cpu: dict) -> tuple[int, dict]:
+    """Threads the all-cores leg may use = min(physical cores, CPUs in the affinity mask, the cgroup's CPU quota):
+    what the scheduler will actually run side by side.  (Rounds 1-4 started one thread per physical core the box SHOWS --
+    128 -- on a 16-CPU quota and called the result "128 cores".)"""
+    limits = {"physical_cores": cpu.get("physical_cores"), "affinity_cpus": cpu.get("affinity_cpus"),
+              "cgroup_cpu_quota": cgroup_cpu_quota()}
+    known = [v for v in limits.values() if v]
+    return (min(known) if known else (cpu.get("logical_cpus") or 1)), limits
+
+
+def cpu_baseline(batch, spec, is_sw, budget_s=20.0, min_score=0):
+    """Reference CPU path on THIS host, bounded sample: fill only (the metric) and fill + traceback (beside `e2e`), each on one
+    pinned thread and on every core the container is granted.  Checker code (oracle/): allowed here, and only here plus the
+    out-of-timed-region spot check."""
     import orclib as O
     lib_path = ROOT / "oracle" / "libcpubench.so"
-    if not lib_path.exists():
+    src = ROOT / "oracle" / "cpu_bench.c"
+    if not lib_path.exists() or (src.exists() and lib_path.stat().st_mtime < src.stat().st_mtime):
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "libcpubench.so"], check=True, stdout=subprocess.DEVNULL)
     hb = C.CDLL(str(lib_path))
-    hb.cpubench_run.restype = C.c_double
-    ref = O.ref()
+    hb.cpubench_run_aux.restype = C.c_double
+    ref, orc = O.ref(), O.oracle()
+    vp = lambda f: C.cast(f, C.c_void_p)
+    import seqalign_amd
+    osc = O.Scoring.from_buffer_copy(bytes(seqalign_amd.make_scoring(spec)))
     if ref is not None:
         kind, mode = "reference", 0
         sc = O.build_scoring(spec, "ref")
-        fn, destroy = C.cast(ref.aligner_align, C.c_void_p), C.cast(ref.aligner_destroy, C.c_void_p)
+        fn, destroy = vp(ref.aligner_align), vp(ref.aligner_destroy)
         what = "aligner_align of the compiled reference (oracle/_ref, src/alignment.c:170-193)"
     else:
-        kind, mode = "port", 1
-        import seqalign_amd
-        sc = O.Scoring.from_buffer_copy(bytes(seqalign_amd.make_scoring(spec)))
-        fn, destroy = C.cast(O.oracle().orc_fill, C.c_void_p), C.c_void_p(0)
+        kind, mode, sc = "port", 1, osc
+        fn, destroy = vp(orc.orc_fill), C.c_void_p(0)
         what = "orc_fill of the C restatement (oracle/seqalign_oracle.c)"
+    # fill + traceback: the reference's own NW front-end when it was compiled; the restatement for SW (smith_waterman.c
+    # needs the un-vendored sort_r: not in _ref) and wherever _ref is absent
+    aux_t = C.c_void_p * 4
+    if not is_sw and ref is not None:
+        ref.needleman_wunsch_new.restype = C.c_void_p
+        ref.alignment_create.restype = C.c_void_p
+        e_kind, e_mode, e_sc, e_fn = "reference", 2, sc, vp(ref.needleman_wunsch_align2)
+        e_aux = aux_t(vp(ref.needleman_wunsch_new).value, vp(ref.needleman_wunsch_free).value,
+                      vp(ref.alignment_create).value, vp(ref.alignment_free).value)
+        e_what = ("needleman_wunsch_align2 of the compiled reference (src/needleman_wunsch.c:34-146): fill + end-cell pick + "
+                  "traceback into an alignment_t")
+    elif not is_sw:
+        e_kind, e_mode, e_sc, e_fn, e_aux = "port", 3, osc, vp(orc.orc_nw_align), aux_t()
+        e_what = "orc_nw_align of the C restatement: fill + traceback into strings"
+    else:
+        e_kind, e_mode, e_sc, e_fn = "port", 4, osc, vp(orc.orc_fill)
+        e_aux = aux_t(vp(orc.orc_sw_hits).value, None, None, None)
+        e_what = (f"orc_fill + orc_sw_hits(min_score={min_score}, max_hits=1) of the C restatement (the reference's SW front-end, "
+                  "src/smith_waterman.c:137-277, needs the absent sort_r and is not in oracle/_ref): fill + candidate sort + best hit")
     n = min(batch.n_pairs, 20000)     # the sample the threads cycle over
 
-    def run(threads, seconds):
+    def run(fn_, destroy_, aux_, mode_, sc_, threads, seconds):
         cells, pairs = C.c_uint64(0), C.c_uint64(0)
-        dt = hb.cpubench_run(fn, destroy, C.c_int(mode), C.byref(sc), batch.arena.ctypes.data_as(C.c_char_p),
-                             batch.off_a.ctypes.data_as(C.c_void_p), batch.len_a.ctypes.data_as(C.c_void_p),
-                             batch.off_b.ctypes.data_as(C.c_void_p), batch.len_b.ctypes.data_as(C.c_void_p),
-                             C.c_size_t(n), C.c_int(is_sw), C.c_int(threads), C.c_double(seconds),
-                             C.byref(cells), C.byref(pairs))
+        dt = hb.cpubench_run_aux(fn_, destroy_, aux_, C.c_int(mode_), C.byref(sc_), batch.arena.ctypes.data_as(C.c_char_p),
+                                 batch.off_a.ctypes.data_as(C.c_void_p), batch.len_a.ctypes.data_as(C.c_void_p),
+                                 batch.off_b.ctypes.data_as(C.c_void_p), batch.len_b.ctypes.data_as(C.c_void_p),
+                                 C.c_size_t(n), C.c_int(is_sw), C.c_int32(min_score), C.c_int(threads), C.c_double(seconds),
+                                 C.byref(cells), C.byref(pairs))
+        if dt <= 0:
+            raise RuntimeError("cpubench_run_aux failed")
         return cells.value / dt / 1e9, pairs.value, dt
 
     cpu = host_cpu_info()
-    v1, p1, d1 = run(1, budget_s * 0.45)
-    out = dict(value=v1, unit="GCUPS", cores=1, kind=kind,
-               sample=f"{p1} pairs through {what}, fill only, 1 pinned thread, {d1:.1f} s (pthread harness oracle/cpu_bench.c)",
-               host=cpu)
-    cores = cpu["physical_cores"] or cpu["logical_cpus"]
-    if cpu.get("affinity_cpus"):
-        cores = min(cores, cpu["affinity_cpus"])
-    vn, pn, dn = run(cores, budget_s * 0.35)
-    out["all_cores"] = dict(value=vn, unit="GCUPS", cores=cores,
-                            sample=f"{pn} pairs, one aligner per thread, {cores} pinned threads (one per physical core), {dn:.1f} s")
+    threads, limits = cpu_threads(cpu)
+    cpu["cgroup_cpu_quota"] = limits["cgroup_cpu_quota"]
+    how = ("one per physical core" if threads == limits["physical_cores"] else
+           f"the container's CPU grant: min of physical cores {limits['physical_cores']}, affinity mask {limits['affinity_cpus']}, "
+           f"cgroup CPU quota {limits['cgroup_cpu_quota']}")
+
+    def leg(fn_, destroy_, aux_, mode_, sc_, kind_, what_, t1, tn, note):
+        v1, p1, d1 = run(fn_, destroy_, aux_, mode_, sc_, 1, t1)
+        out = dict(value=v1, unit="GCUPS", cores=1, kind=kind_,
+                   sample=f"{p1} pairs through {what_}, {note}, 1 pinned thread, {d1:.1f} s (pthread harness oracle/cpu_bench.c)")
+        vn, pn, dn = run(fn_, destroy_, aux_, mode_, sc_, threads, tn)
+        out["all_cores"] = dict(value=vn, unit="GCUPS", cores=threads, threads=threads,
+                                cgroup_cpu_quota=limits["cgroup_cpu_quota"],
+                                scaling_vs_one_thread=vn / (v1 * threads) if v1 > 0 else None,
+                                sample=f"{pn} pairs, one aligner per thread, {threads} pinned threads ({how}), {dn:.1f} s")
+        return out
+
+    out = leg(fn, destroy, None, mode, sc, kind, what, budget_s * 0.30, budget_s * 0.25, "fill only")
+    out["host"] = cpu
+    out["e2e"] = leg(e_fn, C.c_void_p(0), e_aux, e_mode, e_sc, e_kind, e_what, budget_s * 0.25, budget_s * 0.20,
+                     "fill + traceback")
     return out
 
 
@@ -338,6 +386,18 @@ def run(args) -> int:
     ctx = S.Context(local)
     sc = S.make_scoring(spec)
     h = ctx.upload_scoring(sc, is_sw)
+    # What the SAME kernel does on arenas nobody placed (one plain allocation, the three arenas back to back): a few steps,
+    # before the walk, so that the line states what the placement contributes instead of implying it (roofline.frac_unplaced).
+    unplaced = None
+    if args.placement == "spread" and not args.no_unplaced and world == 1:
+        dbp = S.DeviceBatch(batch, local, placement="packed", ctx=ctx)
+        kp = S.KERNEL_STREAM if args.kernel == "auto" else {v: k for k, v in S.KERNEL_NAMES.items()}[args.kernel]
+        ms = dbp.time_fill_ms(ctx, h, kp, 5)[2:]
+        unplaced = {"kernel_ms": float(np.mean(ms)), "steps": len(ms), "kernel": S.KERNEL_NAMES[kp],
+                    "arenas": "one plain allocation (torch.empty), three arenas back to back; no walk"}
+        del dbp
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     db = S.DeviceBatch(batch, local, placement=args.placement, ctx=ctx)   # arenas from seqalign_arenas_alloc
     t_placed = time.perf_counter()
 
@@ -522,6 +582,9 @@ def run(args) -> int:
                          "kernel_ms": kern_ms, "kernel_ms_slowest_rank": kern_ms_max,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if unplaced:
+            out["roofline"]["frac_unplaced"] = alg_bytes / (unplaced["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["unplaced"] = unplaced
         if e2e:
             e2e.pop("ms_this_rank", None)
             rec = ROOT / "profiles" / "e2e_roofline.json"
@@ -529,11 +592,14 @@ def run(args) -> int:
                 try:
                     table = json.loads(rec.read_text())
                     r = table.get(f"{workload}:{batch.n_pairs}")
+                    #  these come from a committed rocprofv3 record, not from this run: say so in the line
+                    tag = {"measured_in_this_run": False,
+                           "pre_recorded": f"profiles/e2e_roofline.json (rocprofv3 kernel trace + PMC passes, {table.get('_recorded', 'round 4')})"}
                     if r:
-                        e2e["roofline"] = r     # bound, kernel, kernel_ms, instructions, frac + where they come from
+                        e2e["roofline"] = {**r, **tag}     # bound, kernel, kernel_ms, instructions, frac + where they come from
                     r4 = table.get(f"{workload}:{batch.n_pairs}:hits4")
                     if r4 and "up_to_4_hits" in e2e:
-                        e2e["up_to_4_hits"]["roofline"] = r4
+                        e2e["up_to_4_hits"]["roofline"] = {**r4, **tag}
                 except Exception:
                     pass
             out["e2e"] = e2e
@@ -560,7 +626,8 @@ def run(args) -> int:
                                 "frac": rbytes / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "algorithmic_bytes_per_launch": rbytes}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw)
+            out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw, min_score=(
+                W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0])) if is_sw else 0))
         print(json.dumps(out), flush=True)
 
     grp.barrier()
@@ -586,6 +653,8 @@ def main() -> int:
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-unplaced", action="store_true",
+                    help="skip the few steps of the same kernel on unplaced arenas (roofline.frac_unplaced)")
     ap.add_argument("--e2e-after", type=float, default=2.0,
                     help="seconds after the arena placement before `e2e` is measured (the driver's transient after the placement walk)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to its GPU's NUMA node")

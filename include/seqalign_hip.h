@@ -328,9 +328,20 @@ typedef struct {
   uint32_t second_walk_from; /* try_*[second_walk_from ..] belong to the second walk         */
   float try_quality[SEQALIGN_ARENA_MAX_TRIES];    /* their ratios, in order                  */
   float try_depth_gib[SEQALIGN_ARENA_MAX_TRIES];
+  float kept_gib;       /* what the process's chunk pool of this device holds after the walk  */
 } seqalign_arena_info_t;
 /* How the arenas returned by seqalign_arenas_alloc were placed (arenas[0] identifies them). */
 int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_arena_info_t *info);
+
+/* The chunk pool.  A placement walk creates up to arena_scan_gib of 512 MiB chunks and uses three arenas' worth; the driver
+ * clears released VRAM before it hands it out again, so a process whose walk had just given back 160 GiB waited seconds at
+ * its next large allocation (round 4: the first seqalign_nw_batch of BASELINE configs[4]'s share 3.7 s).  Up to
+ * arena_keep_gib (option, default 16) of the unused chunks therefore stay with the process, per device, and the contexts'
+ * large scratch buffers (direction bytes, staging, unplaced arena sets) are mapped from them; chunks of freed buffers and
+ * arenas return to the pool.  The pool is emptied when the device's last context is destroyed.
+ * seqalign_pool_trim releases everything beyond keep_bytes now (and lowers the cap to it; the next walk raises it again);
+ * keep_bytes = UINT64_MAX only queries.  *held_bytes, if not NULL, receives what the pool holds afterwards. */
+int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_bytes);
 
 /* ---- context options ----------------------------------------------------------- */
 /* Everything that steers a context's choices is an option of THAT context.  The defaults are read once, in
@@ -361,6 +372,7 @@ int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_ar
  *                                           memory in place; auto: moves in place when the walks run one wave each
  *   sweep_ev        1 | 0                   the direction-byte sweep carries a walk as one word key << 2 | state
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
+ *   arena_keep_gib  0 .. 1024               (the chunk pool, seqalign_pool_trim)
  *   cpl, wpb, lds_pad, reduce_depth, sweep_trace, timing   tuning experiments / development aids
  * Numbers are integers and nothing else ("abc", "1x", "" are refused, not read as 0); switches take 1 / 0, true / false, on / off,
  * yes / no.  Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */

@@ -307,7 +307,7 @@ int orc_nw_align(const orc_scoring_t *sc, const char *a, size_t len_a,
 /* ---------------------------------------------------------------- SW hits */
 
 typedef struct { const int32_t *M; size_t W; } hit_order_t;
-static hit_order_t g_order; /* qsort has no context argument in C99 */
+static __thread hit_order_t g_order; /* qsort has no context argument in C99; per thread: the CPU baseline runs one aligner per thread */
 
 /* smith_waterman.c:71-86: score descending, then column ascending; the
  * remaining tie (upstream comparator returns 0) is fixed as index ascending. */

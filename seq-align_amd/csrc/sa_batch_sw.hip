@@ -645,13 +645,16 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
     std::vector<uint64_t> hit_pair, hit_out;
     hit_pair.reserve(n); hit_out.reserve(n);
+    bool out_of_room = false;
     for (uint64_t k = 0; k < n; ++k) {
       const uint64_t p = c.first + k;
       const int32_t score = (int32_t)h_w[4 * k];
       const uint32_t len = h_w[4 * k + 1];
       if (len >= SA_MOVES_ERR) return (int)(len & 15u);
       if (score <= 0 || score < min_score[p]) continue;
-      if (found + hit_pair.size() >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
+      // out of room: the hits of this chunk that DID fit are still delivered (as the string path below and the one-trip
+      // multi-hit path do), then SEQALIGN_E_NOMEM
+      if (found + hit_pair.size() >= hit_cap || used_str + len + 1 > str_cap) { out_of_room = true; break; }
       hit_pair.push_back(k); hit_out.push_back(used_str);
       used_str += len + 1;
     }
@@ -674,6 +677,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     });
     if (bad.load()) return bad.load();
     found += n_out;
+    if (out_of_room) { *n_hits = found; return SEQALIGN_E_NOMEM; }
     return SEQALIGN_OK;
   }
   if (dirs_used) rc = sw_traceback_dirs(ctx, sc, &d, &t, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), st);

@@ -47,15 +47,29 @@ class HostPool {
     if (workers_.empty() || n == 1) { for (uint64_t k = 0; k < n; ++k) fn(k); return; }
     std::lock_guard<std::mutex> one_job(job_mu_);
     fn_ = &fn; n_ = n; next_.store(0, std::memory_order_relaxed);
-    pending_.store((unsigned)workers_.size(), std::memory_order_relaxed);
-    generation_.fetch_add(1);                       // (seq_cst: ordered against the sleepers' count below)
+    const uint64_t g = generation_.load(std::memory_order_relaxed) + 1;
+    open_.store(g);                                 // the job workers may check in to ...
+    generation_.store(g);                           // ... and the word they watch (seq_cst: ordered against the sleepers' count below)
     if (sleepers_.load() > 0) { { std::lock_guard<std::mutex> lk(mu_); } cv_.notify_all(); }
     for (uint64_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k);
-    // the workers are at most one task behind: spin, politely after a while
-    for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) {
-      if (spins < 20000) __builtin_ia32_pause(); else sched_yield();
+    // Every task has been taken.  Close the job -- a worker that wakes up from here on finds it closed and takes nothing -- and
+    // wait only for the workers that DID check in: they are at most one task behind.  (Round 4 waited for every worker to
+    // check in; a worker the scheduler had taken off its CPU -- other processes on the same cores, a cgroup quota -- stalled
+    // the caller for a time slice after all the work was done.)
+    open_.store(0);
+    for (unsigned spins = 0; active_.load() != 0; ++spins) {
+      if (spins < 20000) cpu_relax(); else sched_yield();
     }
     fn_ = nullptr;
+  }
+  static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    sched_yield();
+#endif
   }
 
  private:
@@ -106,7 +120,7 @@ class HostPool {
     for (;;) {
       const long long t0 = now_ns();
       for (unsigned spins = 1; generation_.load(std::memory_order_acquire) == seen; ++spins) {
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 255u) == 0 && now_ns() - t0 > kSpinNs) {
           std::unique_lock<std::mutex> lk(mu_);
           sleepers_.fetch_add(1);
@@ -117,10 +131,15 @@ class HostPool {
       }
       seen = generation_.load(std::memory_order_acquire);
       if (stop_.load()) return;
-      const std::function<void(uint64_t)> *fn = fn_;
-      const uint64_t n = n_;
-      for (uint64_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*fn)(k);
-      pending_.fetch_sub(1, std::memory_order_release);
+      // check in, THEN look whether the job this worker woke up for is still open (seq_cst on both sides: either this worker
+      // sees the job closed and touches nothing of it, or the caller sees the check-in and waits for it)
+      active_.fetch_add(1);
+      if (open_.load() == seen) {
+        const std::function<void(uint64_t)> *fn = fn_;
+        const uint64_t n = n_;
+        for (uint64_t k; (k = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*fn)(k);
+      }
+      active_.fetch_sub(1);
     }
   }
   std::vector<std::thread> workers_;
@@ -128,8 +147,8 @@ class HostPool {
   std::condition_variable cv_;
   const std::function<void(uint64_t)> *fn_ = nullptr;
   uint64_t n_ = 0;
-  std::atomic<uint64_t> generation_{0}, next_{0};
-  std::atomic<unsigned> pending_{0}, sleepers_{0};
+  std::atomic<uint64_t> generation_{0}, next_{0}, open_{0};   // open_: the generation whose tasks may still be taken (0: none)
+  std::atomic<unsigned> active_{0}, sleepers_{0};              // active_: workers checked in to a job
   std::atomic<bool> stop_{false};
 };
 
@@ -190,15 +209,22 @@ struct DevBuf {   // grow-only device scratch
   size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return SEQALIGN_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
+    release();
     size_t want = bytes + bytes / 8 + 256;
+    // large buffers (direction bytes, staging): from the chunks the arena placement's walk left with the process, when there
+    // are any -- VRAM that never went back to the driver needs no clearing (sa_placement.hip: the chunk pool)
+    int dev = -1;
+    if (want >= kPoolFrom && hipGetDevice(&dev) == hipSuccess && (p = sa_pool_alloc(dev, want))) {
+      cap = (want + kPoolChunk - 1) / kPoolChunk * kPoolChunk;
+      return SEQALIGN_OK;
+    }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; return fail_hip(e, "hipMalloc"); }
     cap = want;
     return SEQALIGN_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !sa_pool_free(p)) (void)hipFree(p); p = nullptr; cap = 0; }
+  static constexpr size_t kPoolFrom = (size_t)128 << 20, kPoolChunk = (size_t)512 << 20;
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -268,6 +294,8 @@ struct SaOptions {
   uint32_t arena_scan_gib = 160;  // arena_scan_gib    how much HBM the arena placement may hold transiently while it looks
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
+  uint32_t arena_keep_gib = 16;   // arena_keep_gib    how much of a walk's unused chunks stays with the process (the chunk pool: large scratch
+                                  //                   buffers are mapped from it instead of freshly released, not yet cleared VRAM); 0: none
 };
 
 struct seqalign_dev_scoring {

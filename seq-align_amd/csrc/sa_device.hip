@@ -90,6 +90,7 @@ static SaPlacementOpts placement_opts(const seqalign_ctx *ctx, bool explicit_cal
   SaPlacementOpts o;
   o.scan_bytes = (size_t)ctx->opt.arena_scan_gib << 30;
   o.quality_stop = ctx->opt.arena_quality;
+  o.keep_bytes = (size_t)ctx->opt.arena_keep_gib << 30;
   o.free_fraction = 0.6f;
   if (!explicit_call) {
     o.free_fraction = 0.25f;
@@ -230,6 +231,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   }
   if (is("subbatches")) { if (!number(0, 256, &num)) return false; o.subbatches = (uint32_t)num; return true; }
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
+  if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
   if (is("arena_quality")) {
     char *end = nullptr;
     const double q = strtod(val, &end);
@@ -268,6 +270,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("chunk_bytes")) return n((long long)o.chunk_bytes);
   if (is("subbatches")) return n(o.subbatches);
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
+  if (is("arena_keep_gib")) return n(o.arena_keep_gib);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
   return false;
 }
@@ -276,7 +279,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -325,6 +328,7 @@ extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
   ctx->device = device;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return fail_hip(e, "hipStreamCreate"); }
+  sa_pool_ref(device);   // the device's chunk pool lives as long as one context of it does
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   // one chunk of a host-level batch may use up to 40 % of what is free now
@@ -358,7 +362,16 @@ extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (hipStream_t t : ctx->copy_streams) if (t) (void)hipStreamDestroy(t);
   (void)hipStreamDestroy(ctx->stream);
+  sa_pool_unref(ctx->device);
   delete ctx;
+}
+
+extern "C" int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_bytes) {
+  if (!ctx) return SEQALIGN_E_ARG;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (keep_bytes != UINT64_MAX) sa_pool_trim(ctx->device, (size_t)keep_bytes);
+  if (held_bytes) *held_bytes = sa_pool_bytes(ctx->device);
+  return SEQALIGN_OK;
 }
 
 extern "C" int seqalign_ctx_device(const seqalign_ctx_t *ctx) { return ctx ? ctx->device : -1; }

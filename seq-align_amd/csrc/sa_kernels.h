@@ -334,12 +334,21 @@ struct SaArenaInfo {   /* = seqalign_arena_info_t (include/seqalign_hip.h) */
   float depth_gib, scanned_gib, depth_a_gib;
   uint32_t tries, second_walk_from;
   float try_quality[SA_ARENA_MAX_TRIES], try_depth_gib[SA_ARENA_MAX_TRIES];
+  float kept_gib;
 };
 struct SaPlacementOpts {
   size_t scan_bytes;     /* device memory the walk may hold transiently besides the arenas; 0 = allocate plainly */
   float quality_stop;    /* probe ratio that ends the walk */
   float free_fraction;   /* ... and never more than this share of the memory free at its start (0: the default, 0.6) */
+  size_t keep_bytes;     /* how much of the walk's unused chunks stays with the process (the chunk pool) instead of going back */
 };
+/* the per-device chunk pool (sa_placement.hip): large scratch buffers mapped from chunks a walk left behind */
+void *sa_pool_alloc(int device, size_t bytes);   /* NULL: the pool cannot serve it (allocate plainly) */
+bool sa_pool_free(void *ptr);                    /* false: not a pool buffer (hipFree it) */
+size_t sa_pool_bytes(int device);
+void sa_pool_trim(int device, size_t keep_bytes);
+void sa_pool_ref(int device);
+void sa_pool_unref(int device);
 struct SaArenaSet;
 hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out);
 void sa_arenas_destroy(SaArenaSet *s);

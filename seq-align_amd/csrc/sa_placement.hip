@@ -43,6 +43,15 @@
 // (hipMemAddressFree would let it hand the range out again): address space is the one resource a 64-bit process
 // has plenty of -- a C2-sized walk uses <= 42 GiB of it, a context allocates its arenas a few times in its life --
 // and past 32 TiB of retired ranges the allocator simply stops placing and allocates plainly.
+//
+// THE CHUNK POOL (round 5).  The chunks a walk created and did not use used to go straight back to the driver, which
+// clears released VRAM before it hands it out again: after a walk that had used its whole budget (160 GiB) the process's
+// next LARGE allocation waited for that -- the first seqalign_nw_batch of C5's share (2.9 GB of direction bytes) 3.7 s,
+// C3's first seqalign_sw_batch 4.6 s (profiles/r04/r04_bench_C{3,5}.json: first_call_ms).  Now up to `keep_bytes`
+// (option arena_keep_gib, default 16) of those chunks stay with the process, in a per-device pool, and the contexts'
+// large scratch buffers (DevBuf: direction bytes, staging; the unplaced arena sets) are mapped from it (sa_pool_alloc):
+// memory that never went back needs no clearing.  Buffers freed return their chunks to the pool; the pool is emptied
+// when the last context of the device is destroyed (sa_pool_unref) or on seqalign_pool_trim.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -185,6 +194,108 @@ struct Mapping {
   }
 };
 
+
+// ------------------------------------------------------------------ the chunk pool ---
+struct ChunkPool {
+  std::mutex mu;
+  std::vector<Handle> free;      // 512 MiB chunks kept from walks (and from pool buffers freed)
+  size_t cap_chunks = 0;         // what may stay (set by the walk that feeds it: option arena_keep_gib)
+  int contexts = 0;              // live contexts of the device (sa_pool_ref / sa_pool_unref)
+};
+ChunkPool g_pool[64];
+constexpr size_t kPoolChunk = (size_t)512 << 20;
+
+struct PoolBuf { Mapping map; std::vector<Handle> handles; int device; };
+std::mutex g_pool_bufs_mu;
+std::map<void *, PoolBuf *> g_pool_bufs;
+
+// hand `h` to the pool, or back to the driver when the pool is full
+void pool_put(int device, Handle h) {
+  ChunkPool &p = g_pool[device];
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.free.size() < p.cap_chunks) { p.free.push_back(h); return; }
+  }
+  (void)hipMemRelease(h);
+}
+
+}  // namespace
+
+void *sa_pool_alloc(int device, size_t bytes) {
+  if (device < 0 || device >= 64 || !bytes || g_retired_va.load() >= kRetiredVaLimit) return nullptr;
+  const size_t n = (bytes + kPoolChunk - 1) / kPoolChunk;
+  ChunkPool &p = g_pool[device];
+  PoolBuf *b = new (std::nothrow) PoolBuf();
+  if (!b) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.free.size() < n) { delete b; return nullptr; }
+    b->handles.assign(p.free.end() - n, p.free.end());
+    p.free.resize(p.free.size() - n);
+  }
+  b->device = device;
+  const VmmEnv env = vmm_env(device);
+  if (!env.ok || b->map.map(env, b->handles.data(), n, kPoolChunk) != hipSuccess) {
+    (void)hipGetLastError();
+    for (Handle h : b->handles) pool_put(device, h);
+    delete b;
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pool_bufs_mu);
+  g_pool_bufs[b->map.va] = b;
+  return b->map.va;
+}
+
+bool sa_pool_free(void *ptr) {
+  PoolBuf *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_bufs_mu);
+    auto it = g_pool_bufs.find(ptr);
+    if (it == g_pool_bufs.end()) return false;
+    b = it->second;
+    g_pool_bufs.erase(it);
+  }
+  b->map.unmap();
+  for (Handle h : b->handles) pool_put(b->device, h);
+  delete b;
+  return true;
+}
+
+size_t sa_pool_bytes(int device) {
+  if (device < 0 || device >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_pool[device].mu);
+  return g_pool[device].free.size() * kPoolChunk;
+}
+
+void sa_pool_trim(int device, size_t keep_bytes) {
+  if (device < 0 || device >= 64) return;
+  std::vector<Handle> out;
+  {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    std::vector<Handle> &f = g_pool[device].free;
+    const size_t keep = keep_bytes / kPoolChunk;
+    g_pool[device].cap_chunks = std::min(g_pool[device].cap_chunks, keep);
+    while (f.size() > keep) { out.push_back(f.back()); f.pop_back(); }
+  }
+  for (Handle h : out) (void)hipMemRelease(h);
+}
+
+void sa_pool_ref(int device) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_pool[device].mu);
+  g_pool[device].contexts++;
+}
+void sa_pool_unref(int device) {
+  if (device < 0 || device >= 64) return;
+  bool last;
+  {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    last = --g_pool[device].contexts <= 0;
+  }
+  if (last) sa_pool_trim(device, 0);   // nobody left to use it: the memory goes back
+}
+
+namespace {
 }  // namespace
 
 // what seqalign_arenas_alloc hands out, and what seqalign_arenas_free needs to take it back
@@ -192,6 +303,7 @@ struct SaArenaSet {
   void *base[3] = {nullptr, nullptr, nullptr};
   size_t bytes = 0;                 // usable bytes per arena
   bool vmm = false;
+  int device = 0;
   Mapping map[3];
   std::vector<Handle> handles[3];
   SaArenaInfo info;
@@ -229,11 +341,15 @@ float quality_of(void *const a[3], size_t bytes, hipStream_t st, int iters = 5) 
   return 3.f * t1 / t3;
 }
 
-hipError_t plain_set(size_t bytes, hipStream_t st, bool probe, SaArenaSet *s) {
+hipError_t plain_set(int device, size_t bytes, hipStream_t st, bool probe, SaArenaSet *s) {
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc(&s->base[k], bytes);
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+    // (large ones from the process's chunk pool when it has them: no freshly released VRAM for the driver to clear)
+    if (bytes >= ((size_t)128 << 20) && (s->base[k] = sa_pool_alloc(device, bytes))) continue;
+    e = hipMalloc(&s->base[k], bytes);
+  }
   if (e != hipSuccess) {
-    for (int k = 0; k < 3; ++k) { if (s->base[k]) (void)hipFree(s->base[k]); s->base[k] = nullptr; }
+    for (int k = 0; k < 3; ++k) { if (s->base[k] && !sa_pool_free(s->base[k])) (void)hipFree(s->base[k]); s->base[k] = nullptr; }
     return e;
   }
   s->bytes = bytes;
@@ -249,6 +365,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   SaArenaSet *s = new (std::nothrow) SaArenaSet();
   if (!s) return hipErrorOutOfMemory;
   s->info = SaArenaInfo();
+  s->device = device;
   s->info.quality = -1.f;
   s->info.depth_a_gib = -1.f;
   s->info.target = opt.quality_stop;
@@ -258,7 +375,7 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   std::unique_lock<std::mutex> one_walk;
   if (opt.scan_bytes && device >= 0 && device < kMaxDevices) one_walk = std::unique_lock<std::mutex>(g_walk_mu[device]);
   // small arenas are not bandwidth-bound; without the VMM API, or without room to look around, allocate plainly
-  const bool place = opt.scan_bytes && bytes >= ((size_t)256 << 20) && env.ok && g_retired_va.load() < kRetiredVaLimit &&
+  const bool place = opt.scan_bytes && device >= 0 && device < 64 && bytes >= ((size_t)256 << 20) && env.ok && g_retired_va.load() < kRetiredVaLimit &&
                      hipMemGetInfo(&free_b, &total_b) == hipSuccess;
   const size_t per = (bytes + chunk - 1) / chunk;                       // chunks per arena
   // what the walk may hold at its peak: the arenas + scan_bytes, and never more than `free_fraction` of what is free NOW --
@@ -270,13 +387,17 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   // the way out whenever placing is not possible (any more): three plain allocations, probed if large enough to matter
   auto plain = [&]() -> hipError_t {
     (void)hipGetLastError();
-    const hipError_t pe = plain_set(bytes, stream, bytes >= ((size_t)256 << 20), s);
+    const hipError_t pe = plain_set(device, bytes, stream, bytes >= ((size_t)256 << 20), s);
     if (pe != hipSuccess) { delete s; return pe; }
     register_set(s);
     *out = s;
     return hipSuccess;
   };
   if (!place || pool_max < 3 * per) return plain();
+  {
+    std::lock_guard<std::mutex> lk(g_pool[device].mu);
+    g_pool[device].cap_chunks = std::max(g_pool[device].cap_chunks, opt.keep_bytes / kPoolChunk);
+  }
 
   // ---- the pool: uniform chunks in allocation order; [0, per) = M, [per, 2 per) = A
   std::vector<Handle> pool;
@@ -298,8 +419,9 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
     for (size_t i = keep_first; i < pool.size(); ++i) {
       bool keep = false;
       for (size_t r : keep_runs) keep = keep || (i >= r && i < r + per);
-      if (!keep) (void)hipMemRelease(pool[i]);
+      if (!keep) pool_put(device, pool[i]);   // the first `keep_bytes` stay with the process (the chunk pool), the rest goes back
     }
+    s->info.kept_gib = (float)((double)sa_pool_bytes(device) / 1073741824.0);
   };
   if (!grow_to(3 * per)) {
     release_from(0, {});
@@ -443,10 +565,10 @@ void sa_arenas_destroy(SaArenaSet *s) {
   if (s->vmm) {
     for (int k = 0; k < 3; ++k) {
       s->map[k].unmap();
-      for (Handle h : s->handles[k]) (void)hipMemRelease(h);
+      for (Handle h : s->handles[k]) pool_put(s->device, h);
     }
   } else {
-    for (int k = 0; k < 3; ++k) if (s->base[k]) (void)hipFree(s->base[k]);
+    for (int k = 0; k < 3; ++k) if (s->base[k] && !sa_pool_free(s->base[k])) (void)hipFree(s->base[k]);
   }
   delete s;
 }

@@ -278,7 +278,7 @@ struct MoveWalk {
 };
 template <bool NW>
 __device__ __forceinline__ MoveWalk move_walk(const SaTraceParams &p, uint32_t w) {
-  MoveWalk m;
+  MoveWalk m{};   // (an invalid walk returns early: the look-ahead kernel reads x / y / st / slot.nw before it looks at `valid`)
   m.valid = true;
   uint32_t rank = 0, wpp = 1;
   if constexpr (NW) {

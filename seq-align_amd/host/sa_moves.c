@@ -44,6 +44,16 @@ static inline uint64_t plane_popcount(const uint32_t *plane, uint32_t n_words, u
   return n;
 }
 
+/* does any column in [first_bit, 32 * n_words) have BOTH planes set?  No walk produces that (a column is a gap in at most
+ * one of the strings); corrupt or stale plane words could, and the expansion would then write past len_a + len_b columns */
+static inline int planes_overlap(const uint32_t *pa, const uint32_t *pb, uint32_t n_words, uint64_t first_bit) {
+  uint64_t w = first_bit >> 5;
+  if (w >= n_words) return 0;
+  uint32_t any = (pa[w] & pb[w]) >> (first_bit & 31);
+  for (++w; w < n_words; ++w) any |= pa[w] & pb[w];
+  return any != 0;
+}
+
 typedef void (*expand_fn)(const char *src, const uint32_t *plane, uint32_t n_words, uint64_t first_bit, uint64_t n_cols,
                           char *dst);
 
@@ -113,8 +123,11 @@ int sa_expand_nw_moves(const char *a, uint32_t len_a, const char *b, uint32_t le
   const uint64_t gaps_a = plane_popcount(plane_a, n_words, first), gaps_b = plane_popcount(plane_b, n_words, first);
   /* a walked column consumes a character of seq_a unless it is a gap in a, of seq_b unless it is a gap in b */
   const uint64_t used_a = n_moves - gaps_a, used_b = n_moves - gaps_b;
-  if (used_a > len_a || used_b > len_b) return SEQALIGN_E_TRACEBACK;
+  if (used_a > len_a || used_b > len_b || planes_overlap(plane_a, plane_b, n_words, first)) return SEQALIGN_E_TRACEBACK;
   const uint64_t rest_a = len_a - used_a, rest_b = len_b - used_b;   /* where the walk stopped: (x, y) */
+  /* a global walk stops at the first row OR the first column (src/needleman_wunsch.c:82-115): one of the rests is 0; and the
+   * columns must fit the caller's len_a + len_b + 1 bytes (they do whenever the planes are disjoint: checked for corrupt words) */
+  if ((rest_a && rest_b) || rest_a + rest_b + n_moves > (uint64_t)len_a + len_b) return SEQALIGN_E_TRACEBACK;
   uint64_t col = 0;
   /* src/needleman_wunsch.c:117-132 emits, backwards, the rest of b against gaps and then the rest of a: forwards the
    * other way round */
@@ -138,7 +151,7 @@ int sa_expand_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t en
   const uint64_t first = 32ull * n_words - n_moves;
   const uint64_t used_a = n_moves - plane_popcount(plane_a, n_words, first);
   const uint64_t used_b = n_moves - plane_popcount(plane_b, n_words, first);
-  if (used_a > end_x || used_b > end_y) return SEQALIGN_E_TRACEBACK;
+  if (used_a > end_x || used_b > end_y || planes_overlap(plane_a, plane_b, n_words, first)) return SEQALIGN_E_TRACEBACK;
   pos[0] = (uint32_t)(end_x - used_a); pos[1] = (uint32_t)(end_y - used_b);   /* smith_waterman.c:251-255 */
   pos[2] = (uint32_t)used_a; pos[3] = (uint32_t)used_b;
   g_expand(a + pos[0], plane_a, n_words, first, n_moves, out_a);

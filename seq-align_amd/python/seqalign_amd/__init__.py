@@ -152,7 +152,7 @@ def batch_desc(batch: "workloads.Batch") -> BatchDesc:
 
 OPTION_DEFAULTS = {"kernel": "auto", "cpl": 0, "wpb": 0, "lds_pad": 0, "traceback": "device", "trace_kernel": "auto",
                    "sweep_mode": "auto", "sweep_strip": 0, "sweep_cpl": 0, "sweep_trace": 0, "sweep_dirs": 1, "nw_dirs": 1, "pack16": 1, "quad": 0, "walk_overlap": 0, "timing": 0, "chunk_bytes": 0,
-                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0}
+                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "arena_keep_gib": 16, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0}
 
 
 K_MAX = 32
@@ -166,14 +166,15 @@ class CallInfo(C.Structure):
 class ArenaInfo(C.Structure):
     _fields_ = [("quality", C.c_float), ("target", C.c_float), ("vmm", C.c_int32), ("chunk_mib", C.c_uint32),
                 ("depth_gib", C.c_float), ("scanned_gib", C.c_float), ("depth_a_gib", C.c_float), ("tries", C.c_uint32),
-                ("second_walk_from", C.c_uint32), ("try_quality", C.c_float * 96), ("try_depth_gib", C.c_float * 96)]
+                ("second_walk_from", C.c_uint32), ("try_quality", C.c_float * 96), ("try_depth_gib", C.c_float * 96),
+                ("kept_gib", C.c_float)]
 
     def as_dict(self):
         n = int(self.tries)
         return {"quality": round(float(self.quality), 3), "target": round(float(self.target), 3), "vmm": bool(self.vmm),
                 "chunk_mib": int(self.chunk_mib), "depth_gib": round(float(self.depth_gib), 1),
                 "scanned_gib": round(float(self.scanned_gib), 1), "depth_a_gib": round(float(self.depth_a_gib), 1),
-                "tries": n, "second_walk_from": int(self.second_walk_from),
+                "tries": n, "second_walk_from": int(self.second_walk_from), "kept_gib": round(float(self.kept_gib), 1),
                 "try_quality": [round(float(self.try_quality[i]), 3) for i in range(n)],
                 "try_depth_gib": [round(float(self.try_depth_gib[i]), 1) for i in range(n)]}
 
@@ -196,6 +197,13 @@ class Context:
 
     def __exit__(self, *exc):
         self.close()
+
+    def pool_trim(self, keep_bytes=None) -> int:
+        """seqalign_pool_trim: release the device's chunk pool down to keep_bytes (None: only ask); returns what it holds."""
+        held = C.c_uint64(0)
+        keep = C.c_uint64(0xFFFFFFFFFFFFFFFF if keep_bytes is None else int(keep_bytes))
+        _check(lib().seqalign_pool_trim(self._h, keep, C.byref(held)), "seqalign_pool_trim")
+        return int(held.value)
 
     # ---- options (seqalign_ctx_set_option: key = SEQALIGN_<KEY> in lower case) -----------------
     def set_option(self, key: str, value) -> None:
@@ -535,7 +543,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_ctx_destroy", "seqalign_ctx_device", "seqalign_scoring_upload", "seqalign_scoring_release",
     "seqalign_fill_batch_device", "seqalign_sw_reduce_device", "seqalign_nw_traceback_device", "seqalign_sw_traceback_device", "seqalign_fill_batch", "seqalign_nw_batch",
     "seqalign_sw_batch", "seqalign_time_fill_ms", "seqalign_arenas_alloc", "seqalign_arenas_free",
-    "seqalign_arenas_info", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
+    "seqalign_arenas_info", "seqalign_pool_trim", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
     "seqalign_kernel_kind_name", "seqalign_host_legs_nw", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
     # include/seqalign_io.h

@@ -938,6 +938,11 @@ def test_arena_allocator(ctx):
         assert not any(ptrs)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    # round 5: up to arena_keep_gib of a walk's unused chunks (and the freed arenas' own) stay with the process -- the chunk pool
+    held = ctx.pool_trim()
+    assert held % (512 << 20) == 0 and held <= int(ctx.get_option("arena_keep_gib")) << 30
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - held - (64 << 20)
+    assert ctx.pool_trim(0) == 0
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)      # spacer chunks and arenas all returned
     with S.Context(0) as plain:
         plain.set_option("arena_scan_gib", 0)

@@ -317,7 +317,47 @@ def test_arena_placement_when_the_device_is_half_full(ctx, opts):
     del hog
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    ctx.pool_trim(0)          # (what the walks left in the process's chunk pool)
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (256 << 20)
+
+
+def test_scratch_comes_from_the_chunk_pool(opts):
+    """Round 5: the chunks a placement walk created and did not use stay with the process (<= arena_keep_gib), and a context's
+    large scratch buffers -- here seqalign_nw_batch's direction bytes for 30 000 pairs, 0.7 GB -- are mapped from them instead of
+    from freshly released VRAM the driver has to clear first (round 4: the first call after a full walk waited 3.7 s).
+    Results are the oracle's whatever memory holds the bytes; the pool shrinks by what the buffers took, gets it back when the
+    context goes, and is emptied with the device's last context."""
+    import ctypes as C
+    import torch
+    torch.cuda.empty_cache()
+    sc = S.make_scoring({"preset": "default"})
+    osc = osc_of(sc)
+    batch = W.dna_nw_150(30000, seed=11)
+    with S.Context(0) as keeper:              # keeps the pool alive while `c` comes and goes
+        keeper.pool_trim(0)                   # (whatever earlier tests of this process left; also resets the pool's cap)
+        keeper.set_option("arena_keep_gib", 4)
+        keeper.set_option("arena_scan_gib", 12)
+        keeper.set_option("arena_quality", 9.0)      # unreachable: the walk uses its whole 12 GiB
+        ptrs, q = (C.c_void_p * 3)(), C.c_float(-1)
+        assert S.lib().seqalign_arenas_alloc(keeper._h, C.c_uint64(600 << 20), ptrs, C.byref(q)) == 0
+        info = S.ArenaInfo()
+        assert S.lib().seqalign_arenas_info(keeper._h, ptrs, C.byref(info)) == 0
+        held0 = keeper.pool_trim()
+        assert held0 == 4 << 30 and abs(info.as_dict()["kept_gib"] - 4.0) < 0.01
+        with S.Context(0) as c:
+            res = c.nw_batch(batch, sc)
+            assert any(k.startswith("fill_nw_dirs") for k in c.last_call())
+            held1 = c.pool_trim()
+            assert held1 <= held0 - (512 << 20)            # at least the direction bytes came from the pool
+            for p in range(0, batch.n_pairs, 997):
+                rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+                assert rc == 0 and res[p] == (s_, ra, rb), p
+        assert keeper.pool_trim() == held0                 # the buffers' chunks are back
+        assert S.lib().seqalign_arenas_free(keeper._h, ptrs) == 0
+        assert keeper.pool_trim() == held0                 # full: the arenas' own chunks went to the driver
+        assert keeper.pool_trim(1 << 30) == 1 << 30
+    with S.Context(0) as again:
+        assert again.pool_trim() == 0                      # emptied with the last context
 
 
 @pytest.mark.parametrize("walker", ["wave", "lane"])

@@ -96,6 +96,17 @@ def test_nw_moves_reject_planes_that_are_no_walk():
     assert rc == S.E_TRACEBACK
     rc, *_ = expand_nw(lib, a, b, pa, pb, n_words, 40)     # more moves than the slot holds
     assert rc == S.E_TRACEBACK
+    # a column with BOTH planes set (stale or corrupt words): no walk has one, and expanding it would overrun len_a + len_b
+    pa[0] = pb[0] = np.uint32(1 << 31)
+    rc, *_ = expand_nw(lib, a, b, pa, pb, n_words, 2)
+    assert rc == S.E_TRACEBACK
+    oa, ob, pos = C.create_string_buffer(8), C.create_string_buffer(8), (C.c_uint32 * 4)()
+    assert lib.sa_expand_sw_moves(a, b, C.c_uint32(4), C.c_uint32(2), pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p),
+                                  C.c_uint32(1), C.c_uint32(2), oa, ob, pos) == S.E_TRACEBACK
+    # a walk that stopped inside the matrix (both sequences have characters left): not a global alignment
+    pa[0] = pb[0] = 0
+    rc, *_ = expand_nw(lib, a, b, pa, pb, n_words, 1)
+    assert rc == S.E_TRACEBACK
 
 
 @pytest.mark.parametrize("scalar", [0, 1])
