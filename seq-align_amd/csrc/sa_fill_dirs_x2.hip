@@ -151,21 +151,42 @@ constexpr uint32_t kBoth = 0x00010001u;   // a 1 in each half
 //   SA_SUBST_LDS: the K x K table (int16 in LDS, behind the rings), row = class of the seq_a character; the two pairs'
 //   scores are two 16-bit LDS reads into the two halves of one register.  Class 0 x class 0 holds the "equal" score of
 //   characters outside the table: different characters get gen_ne (subst_score in sa_fill_common.hpp).
-template <int SUBST, int CPL>
+//   PROFILE (round 5; SA_SUBST_LDS, two pairs per wave): the row's scores come from a ROW PROFILE instead of the table itself.
+//   The two table reads per cell went to addresses all over the K x K table -- 64 lanes x 2 B at random: SQ_LDS_BANK_CONFLICT was
+//   39 % of the LDS cycles of fill_dirs_x2_kernel<5,1,1024> (profiles/r05/r05a_sweep_pmc_C4_before.json), each with its own
+//   address add, then a pack and the class-0 fix-up: the BLOSUM62 fills ran at 0.55-0.59 of the VALU issue peak where the DNA
+//   instantiations of the same code reach 0.66-0.71.  Now lane k < K builds, once per row,
+//       prof[k] = table[k][class of pair 0's character] | table[k][class of pair 1's character] << 16
+//   (the striped-profile idea, one row at a time: K words per wave, double-buffered -- the next row's profile is written while
+//   this row is worked on), and a cell reads prof[class of its seq_a character]: pair 0's word for the low half, pair 1's for the
+//   high half, one bit-select.  Addresses are constant per column (no adds), K <= 64 consecutive words never collide in a bank
+//   (equal addresses broadcast), and the class-0 fix-up (characters outside the table) runs only on rows whose seq_b character
+//   is outside it (wave-uniform test).  Reference: scoring_lookup, src/alignment_scoring.c:133-182; table :268-292.
+constexpr uint32_t kProfBytes = 512;      // per wave: two buffers of 64 words
+template <int SUBST, int CPL, bool PROFILE = false>
 struct SubstX2 {
+  static_assert(!PROFILE || SUBST == SA_SUBST_LDS, "a row profile is a view of the LDS table");
   uint32_t fa[CPL];                                   // folded characters of seq_a, one pair per half
   uint32_t ar0[SUBST == SA_SUBST_LDS ? CPL : 1];      // LDS byte address of the table row of pair 0's / pair 1's character
-  uint32_t ar1[SUBST == SA_SUBST_LDS ? CPL : 1];
+  uint32_t ar1[SUBST == SA_SUBST_LDS ? CPL : 1];      //   (PROFILE: of the profile word of its class, within a buffer)
   uint32_t a0[SUBST == SA_SUBST_LDS ? CPL : 1];       // 0xFFFF per half where the seq_a character is of class 0
   pk16 s_eq, s_delta, s_ne;
   uint32_t fb = 0, kb0 = 0, kb1 = 0, b0 = 0;          // this row (wave-uniform): characters, table columns * 2, class-0 mask
-  __device__ __forceinline__ void init(const SaFillParams &p) {
+  uint32_t prof = 0, bld_src = 0, bld_dst = 0;        // PROFILE: the wave's two buffers; this lane's table row / profile word
+  pk16 sc[PROFILE ? CPL : 1];                         // PROFILE: this row's scores of my columns
+  __device__ __forceinline__ void init(const SaFillParams &p, uint32_t tbl_lds = 0, int lane = 0) {
     s_eq = pk_splat(p.gen_eq); s_ne = pk_splat(p.gen_ne); s_delta = pk_splat(p.gen_ne - p.gen_eq);
+    if constexpr (PROFILE) {
+      const uint32_t k = min((uint32_t)lane, p.K - 1u);   // (lanes beyond the table repeat its last row: same word, same value)
+      prof = tbl_lds + ((p.K * p.K * 2u + 15u) & ~15u) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kProfBytes;
+      bld_src = tbl_lds + k * p.K * 2u; bld_dst = k * 4u;
+    }
   }
   __device__ __forceinline__ void set_column(int c, uint32_t code0, uint32_t code1, uint32_t K, uint32_t tbl_lds) {
     fa[c] = (code0 & 0xffu) | (code1 & 0xffu) << 16;
     if constexpr (SUBST == SA_SUBST_LDS) {
-      ar0[c] = tbl_lds + (code0 >> 8) * K * 2u; ar1[c] = tbl_lds + (code1 >> 8) * K * 2u;
+      if constexpr (PROFILE) { ar0[c] = (code0 >> 8) * 4u; ar1[c] = (code1 >> 8) * 4u; }
+      else { ar0[c] = tbl_lds + (code0 >> 8) * K * 2u; ar1[c] = tbl_lds + (code1 >> 8) * K * 2u; }
       a0[c] = ((code0 >> 8) ? 0u : 0xffffu) | ((code1 >> 8) ? 0u : 0xffff0000u);
     }
   }
@@ -176,7 +197,42 @@ struct SubstX2 {
       b0 = (kb0 ? 0u : 0xffffu) | (kb1 ? 0u : 0xffff0000u);
     }
   }
+  // PROFILE: the profile of a row whose characters are `codes` into buffer `buf` (0 / 1) -- every lane, no predicate
+  __device__ __forceinline__ void build_profile(uint32_t codes, uint32_t buf) const {
+    if constexpr (PROFILE) {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      char *l = reinterpret_cast<char *>(lds_base);
+      const uint32_t k0 = ((codes >> 8) & 0xffu) * 2u, k1 = (codes >> 24) * 2u;
+      const uint32_t v0 = *reinterpret_cast<const unsigned short *>(l + bld_src + k0);
+      const uint32_t v1 = *reinterpret_cast<const unsigned short *>(l + bld_src + k1);
+      *reinterpret_cast<uint32_t *>(l + prof + buf * (kProfBytes / 2) + bld_dst) = v0 | v1 << 16;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (one wave: program order; the compiler must keep it)
+    }
+  }
+  // PROFILE: this row's scores of my columns out of buffer `buf` (after set_row)
+  __device__ __forceinline__ void load_profile(uint32_t buf) {
+    if constexpr (PROFILE) {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      const char *l = reinterpret_cast<const char *>(lds_base) + prof + buf * (kProfBytes / 2);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(l + ar0[c]), w1 = *reinterpret_cast<const uint32_t *>(l + ar1[c]);
+        sc[c] = pk_from(bfi(0x0000ffffu, w0, w1));
+      }
+      if (b0) {   // (wave-uniform) a seq_b character outside the table: class 0 x class 0 means "equal" only for equal characters
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const uint32_t ne01 = pk_min_u16(fa[c] ^ fb, 0x00010001u);
+          const uint32_t differ = pk_bits(pk_splat(0) - pk_from(ne01));
+          sc[c] = pk_from(bfi(a0[c] & b0 & differ, pk_bits(s_ne), pk_bits(sc[c])));
+        }
+      }
+    }
+  }
   __device__ __forceinline__ pk16 score(int c) const {
+    if constexpr (PROFILE) {
+      return sc[c];
+    } else {
     const uint32_t ne01 = pk_min_u16(fa[c] ^ fb, 0x00010001u);
     if constexpr (SUBST == SA_SUBST_SIMPLE) {
       return pk_mad(ne01, s_delta, s_eq);
@@ -188,10 +244,12 @@ struct SubstX2 {
       const uint32_t differ = pk_bits(pk_splat(0) - pk_from(ne01));            // 0xFFFF where the characters differ
       return pk_from(bfi(a0[c] & b0 & differ, pk_bits(s_ne), pk_bits(pk16{v0, v1})));
     }
+    }
   }
 };
 
-static inline size_t table_lds_bytes(const SaFillParams &p) { return (((size_t)p.K * p.K * 2u) + 15u) & ~(size_t)15u; }
+// (behind the table: room for the row profiles of up to eight waves)
+static inline size_t table_lds_bytes(const SaFillParams &p) { return ((((size_t)p.K * p.K * 2u) + 15u) & ~(size_t)15u) + 8 * kProfBytes; }
 
 // the table into LDS as int16 (every thread of the workgroup, before anyone leaves)
 template <int SUBST>
@@ -227,8 +285,8 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
   uint8_t *const gd0 = dirs_arena + p.mat_off[pair_lo], *const gd1 = dirs_arena + p.mat_off[pair_hi];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
-  SubstX2<SUBST, CPL> sub;
-  sub.init(p);
+  SubstX2<SUBST, CPL, (SUBST == SA_SUBST_LDS && LANES == 64)> sub;
+  sub.init(p, tbl_lds, lane);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
   uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;   // my span's rings: low halves, high halves
@@ -307,7 +365,13 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     // this row's characters of seq_b: uniform over the wave, or over each span
     if constexpr (LANES == 64) {
-      sub.set_row((uint32_t)read_lane((int)chunk_code, q));
+      const uint32_t codes = (uint32_t)read_lane((int)chunk_code, q);
+      sub.set_row(codes);
+      // the row's profile (table scorings): built during the row before, or here at a chunk's first row; the next row's goes
+      // into the other buffer now, to be there when it is needed
+      if (q == 0) sub.build_profile(codes, j & 1u);
+      sub.load_profile(j & 1u);
+      if (q != LANES - 1 && j < lb) sub.build_profile((uint32_t)read_lane((int)chunk_code, q + 1), (j + 1u) & 1u);
     } else {
       const uint32_t r0 = (uint32_t)read_lane((int)chunk_code, q), r1 = (uint32_t)read_lane((int)chunk_code, q + 32);
       sub.set_row(span ? r1 : r0);
@@ -516,8 +580,8 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   int32_t *const gm0 = p.M + mo0, *const gm1 = p.M + mo1;
   uint8_t *const gd0 = dirs_arena + mo0, *const gd1 = dirs_arena + mo1;
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
-  SubstX2<SUBST, CPL> sub;
-  sub.init(p);
+  SubstX2<SUBST, CPL, (SUBST == SA_SUBST_LDS && LANES == 64)> sub;
+  sub.init(p, tbl_lds, lane);
 
   // LDS per span: two rings of R int16 scores, two rings of R direction bytes
   uint8_t *ring = ring_wave + span * (6 * R);
@@ -599,7 +663,15 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    sub.set_row(row_codes<LANES>(chunk_code, q, span));
+    {
+      const uint32_t codes = row_codes<LANES>(chunk_code, q, span);
+      sub.set_row(codes);
+      if constexpr (LANES == 64) {   // the row's profile (table scorings): see nw_dirs_x2_wave
+        if (q == 0) sub.build_profile(codes, j & 1u);
+        sub.load_profile(j & 1u);
+        if (q != LANES - 1 && j < lb) sub.build_profile(row_codes<LANES>(chunk_code, q + 1, span), (j + 1u) & 1u);
+      }
+    }
     // up-left of my first column: the left lane's last column on the previous row; a span's first lane (the border column): far
     // enough below zero that M = max(.., 0) = 0
     const pk16 x_ul = pk_shr1_in<LANES>(X[CPL - 1], pk_splat(-16384), first_lane);
@@ -742,8 +814,8 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
   uint8_t *const gd0 = dirs_arena + p.mat_off[pair_lo], *const gd1 = dirs_arena + p.mat_off[pair_hi];   // 256-byte aligned
   const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), zero = pk_splat(0);
-  SubstX2<SUBST, CPL> sub;
-  sub.init(p);
+  SubstX2<SUBST, CPL, (SUBST == SA_SUBST_LDS && LANES == 64)> sub;
+  sub.init(p, tbl_lds, lane);
 
   uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;
@@ -811,7 +883,15 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    sub.set_row(row_codes<LANES>(chunk_code, q, span));
+    {
+      const uint32_t codes = row_codes<LANES>(chunk_code, q, span);
+      sub.set_row(codes);
+      if constexpr (LANES == 64) {   // the row's profile (table scorings): see nw_dirs_x2_wave
+        if (q == 0) sub.build_profile(codes, j & 1u);
+        sub.load_profile(j & 1u);
+        if (q != LANES - 1 && j < lb) sub.build_profile(row_codes<LANES>(chunk_code, q + 1, span), (j + 1u) & 1u);
+      }
+    }
     const pk16 x_ul = pk_shr1_in<LANES>(X[CPL - 1], pk_splat(-16384), first_lane);
     const uint32_t t_ul = dpp_mov0<0x138>(T[CPL - 1]);
     const uint32_t row_pk = j * kBoth;    // (rows < 32 768: the launcher's score bound implies it)

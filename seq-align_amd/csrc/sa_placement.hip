@@ -387,7 +387,9 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   // the way out whenever placing is not possible (any more): three plain allocations, probed if large enough to matter
   auto plain = [&]() -> hipError_t {
     (void)hipGetLastError();
-    const hipError_t pe = plain_set(device, bytes, stream, bytes >= ((size_t)256 << 20), s);
+    // (probed when a walk had been asked for and could not be made; a caller that asked for plain arenas -- scan_bytes = 0: its
+    // kernels are not HBM-bound -- is not made to wait 3 ms for a figure it has no use for)
+    const hipError_t pe = plain_set(device, bytes, stream, opt.scan_bytes && bytes >= ((size_t)256 << 20), s);
     if (pe != hipSuccess) { delete s; return pe; }
     register_set(s);
     *out = s;

@@ -12,6 +12,7 @@
 // One wave per pair: the candidate counter lives in a wave-uniform register, no
 // atomics.  HBM-read bound: 4 B per cell.
 #include <algorithm>
+#include <type_traits>
 
 #include "sa_fill_common.hpp"
 
@@ -37,7 +38,8 @@ template <bool COMPACT, int kUnroll>
 __global__ void __launch_bounds__(kWave *kWavesPerBlock)
 sw_reduce_kernel(const SaReduceParams p) {
   const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t pair = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  // (wave-uniform, and SAID so: the pair's sizes and addresses then live in scalar registers)
+  const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
   if (pair >= p.n_pairs) return;
 
   const uint32_t W = p.len_a[pair] + 1, H = p.len_b[pair] + 1;
@@ -121,45 +123,132 @@ sw_reduce_kernel(const SaReduceParams p) {
       bidx = wins ? i0 + k : bidx;
     }
   };
-  int nxt[kUnroll][4];
-  load_step(0, nxt);
-  for (uint32_t base = 0; base < span; base += kStep) {
-    int v[kUnroll][4];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[u][k] = nxt[u][k];
-    if (base + kStep < span) load_step(base + kStep, nxt);
-    uint32_t cu = col_step0;
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t i0 = base + u * (kWave * 4) + lane * 4 - skew;   // the cell (wraps below 0 for masked cells: their value is 0)
-      uint32_t mine = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) mine += (v[u][k] >= min_score);
-      update_vector(v[u], i0, cu);
-      cu += r256; cu = cu >= W ? cu - W : cu;
-      if constexpr (!COMPACT) { count += mine; continue; }
-      // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
-      const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
-      if ((b0 | b1 | b2) == 0) continue;                // wave-uniform: no candidate in this KiB
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      uint32_t pos = count + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-      count += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-      if (mine) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (v[u][k] >= min_score) {
-            if (pos < cap) {
-              cidx[pos] = i0 + k;
-              if (cscore) cscore[pos] = v[u][k];
+  if constexpr (COMPACT) {
+    int nxt[kUnroll][4];
+    load_step(0, nxt);
+    for (uint32_t base = 0; base < span; base += kStep) {
+      int v[kUnroll][4];
+  #pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = nxt[u][k];
+      if (base + kStep < span) load_step(base + kStep, nxt);
+      uint32_t cu = col_step0;
+  #pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const uint32_t i0 = base + u * (kWave * 4) + lane * 4 - skew;   // the cell (wraps below 0 for masked cells: their value is 0)
+        uint32_t mine = 0;
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) mine += (v[u][k] >= min_score);
+        update_vector(v[u], i0, cu);
+        cu += r256; cu = cu >= W ? cu - W : cu;
+        if constexpr (!COMPACT) { count += mine; continue; }
+        // exclusive prefix of `mine` over lanes (mine <= 4: three ballots of its bits)
+        const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2), b2 = __ballot(mine & 4);
+        if ((b0 | b1 | b2) == 0) continue;                // wave-uniform: no candidate in this KiB
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t pos = count + __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        count += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        if (mine) {
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (v[u][k] >= min_score) {
+              if (pos < cap) {
+                cidx[pos] = i0 + k;
+                if (cscore) cscore[pos] = v[u][k];
+              }
+              ++pos;
             }
-            ++pos;
           }
         }
       }
+      col_step0 += r1024; col_step0 = col_step0 >= W ? col_step0 - W : col_step0;
     }
-    col_step0 += r1024; col_step0 = col_step0 >= W ? col_step0 - W : col_step0;
+  } else {
+    // Round 5: the stream as an explicit three-deep pipeline.  The loop above asks for step s + 1 before it works on step s
+    // (one step = kUnroll KiB in flight per wave, and none while the wave waits), its loads sit in branches (whole block /
+    // edge cells), and it hands `nxt` to `v` through 16 register moves behind a vmcnt(0): 125 VGPRs, 0.80 (C3) / 0.725 (C4: 4 000
+    // waves, four per SIMD) of the HBM peak where the bare access pattern reads 0.85.  Here every load is a whole aligned 1 KiB
+    // block, unconditionally -- a 1 KiB-aligned block that holds one of the pair's cells lies in the same 4 KiB page as that
+    // cell, so it is mapped whoever owns the rest of it; blocks past the pair's last are redirected to the last one and
+    // masked out by index -- issued by inline asm into NB rotating buffers and claimed with an in-order `s_waitcnt
+    // vmcnt((NB - 1) * kUnroll)`: two steps are always in flight while one is worked on (the compiler's own counting waits
+    // vmcnt(0) at every loop header, see sa_sw_sweep.hip).
+    constexpr int NB = 3;
+    typedef int v4i_r __attribute__((ext_vector_type(4)));
+    v4i_r buf[NB][kUnroll];
+    const uint32_t last_blk = (span - 1u) & ~255u;       // block-space index of the pair's last 1 KiB block
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    // (one asm statement per step: early-clobber outputs, and `s_nop 4` first -- a block address the compiler had to reload
+    // from a spilled SGPR with v_readlane would otherwise be read by the load inside the five wait states gfx9 asks for after a
+    // VALU write of an SGPR, and the compiler does not look into the statement: sa_sw_sweep.hip, SweepRow::request)
+    auto request = [&](uint32_t base, v4i_r (&b)[kUnroll]) __attribute__((always_inline)) {
+      static_assert(kUnroll == 4 || kUnroll == 8, "1 KiB blocks per step");
+#pragma unroll
+      for (int u = 0; u < kUnroll; u += 4) {
+        const int32_t *b0 = Mal + min(base + (uint32_t)u * 256u, last_blk);   // (wave-uniform: scalar address arithmetic)
+        const int32_t *b1 = Mal + min(base + (uint32_t)(u + 1) * 256u, last_blk);
+        const int32_t *b2 = Mal + min(base + (uint32_t)(u + 2) * 256u, last_blk);
+        const int32_t *b3 = Mal + min(base + (uint32_t)(u + 3) * 256u, last_blk);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 nt\n\tglobal_load_dwordx4 %1, %4, %6 nt\n\t"
+                     "global_load_dwordx4 %2, %4, %7 nt\n\tglobal_load_dwordx4 %3, %4, %8 nt"
+                     : "=&v"(b[u]), "=&v"(b[u + 1]), "=&v"(b[u + 2]), "=&v"(b[u + 3])
+                     : "v"(lane16), "s"(b0), "s"(b1), "s"(b2), "s"(b3));
+      }
+    };
+    auto claim = [&](v4i_r (&b)[kUnroll], auto younger) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(decltype(younger)::value) : "memory");
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) asm volatile("" : "+v"(b[u]));
+    };
+    auto work = [&](uint32_t base, const v4i_r (&b)[kUnroll]) __attribute__((always_inline)) {
+      const bool edge = base < skew || base + kStep > span;   // (wave-uniform) the step holds cells that are not the pair's
+      int q[kUnroll][4];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        q[u][0] = b[u].x; q[u][1] = b[u].y; q[u][2] = b[u].z; q[u][3] = b[u].w;
+        if (edge) {
+          const uint32_t v0 = base + u * (kWave * 4) + lane * 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q[u][k] = (v0 + k >= skew && v0 + k < span) ? q[u][k] : 0;
+        }
+      }
+      // cells >= min_score, and the step's largest score: straight-line
+      int top = q[0][0];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { count += (q[u][k] >= min_score); top = max(top, q[u][k]); }
+      // can any of the step's cells beat its lane's key (its best possible key: the largest score in column 0), or does a score
+      // not fit the key?  ONE test per step -- nearly always "no" once the lanes have seen a good cell -- where the first form
+      // asked twice per vector
+      const bool look = !keyed || top >= score_lim || (((uint32_t)top << col_bits) | col_mask) > bkey;
+      if (__any(look)) {
+        uint32_t cu = col_step0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          update_vector(q[u], base + u * (kWave * 4) + lane * 4 - skew, cu);
+          cu += r256; cu = cu >= W ? cu - W : cu;
+        }
+      }
+      col_step0 += r1024; col_step0 = col_step0 >= W ? col_step0 - W : col_step0;
+    };
+#pragma unroll
+    for (int b = 0; b < NB; ++b) request((uint32_t)b * kStep, buf[b]);
+    uint32_t base = 0;
+    bool done = false;
+    while (!done) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        claim(buf[b], std::integral_constant<int, (NB - 1) * kUnroll>());
+        work(base, buf[b]);
+        base += kStep;
+        if (base >= span) { done = true; break; }
+        request(base + (NB - 1) * kStep, buf[b]);   // (beyond the pair's last block: that block again, never looked at)
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) claim(buf[b], std::integral_constant<int, 0>());   // nothing may still be on its way into registers
   }
   // the lane's keyed best against what the division path may have found (both in hit order)
   if (bkey != 0) {

@@ -808,9 +808,97 @@ __global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6
 //     arrivals(c, y) = min3(own candidacy, up-left word of (c + 1, y + 1), up word of (c, y + 1))
 // ~34 instead of ~50 vector instructions per cell slot (the first form: compare + and + two selects per arrival and state).
 // Same hits, same order, same keys in the pair's list as sw_sweep_dirs_kernel (every sweep test runs both: option sweep_ev).
+//
+// Round 5: the rows' loads as a real pipeline.  Round 4's loop asked for row y - 1 before it worked on row y, but the compiler
+// had put `s_waitcnt vmcnt(0)` right behind the request (the loads sat in branches -- last row / lane beyond the row's end --
+// whose results merged at a join, and the first row's loads were still pending on loop entry): every row paid a full memory
+// latency, SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.56, VALU busy 0.42 (profiles/r05/r05a_sweep_pmc_C3_before.json).  Now
+//   * the loads are BRANCHLESS: a lane's run starts at min(its first column, W - 1) of the row -- always inside the pair's
+//     matrix; what it reads beyond the row's end is the next row (or, on the pair's last row, the <= 32 bytes behind the pair:
+//     the next pair, padding, or the arenas' slack -- sa_host::reserve_arenas adds >= 4 KiB; the first buffer's cells beyond
+//     column W - 1 are zeroed once, below).  Cells beyond the row's end can never win: no candidacy (thr_c) and no arrivals;
+//   * NB row buffers rotate through an NB-times unrolled row loop: while row y is worked on, the loads of rows y - 1 ..
+//     y - NB + 1 are in flight, and the only wait is the in-order vmcnt for the oldest of them -- written by hand (SweepRow:
+//     inline-asm loads + `s_waitcnt vmcnt((NB - 1) x loads per row)`), because the compiler's own counting gave up at the
+//     loop headers (a first version with plain loads still waited vmcnt(0) / vmcnt(1) where 6 was right);
+//   * a lane's direction bytes stay one word; the two bits of the winner's state come out of it with one v_bfe_u32.
+// One row of a lane's cells in flight: CPL match_scores (runs of 4 + a tail of 1..3) and the run's direction bytes as words,
+// requested with inline-asm loads the compiler does not track and claimed with an explicit in-order `s_waitcnt vmcnt(N)`
+// (below: why).  Between request and claim the registers are live (the claim takes them as "+v" operands) and nobody reads them.
+template <int T> struct SweepTail { typedef int type; };
+template <> struct SweepTail<2> { typedef int type __attribute__((ext_vector_type(2))); };
+template <> struct SweepTail<3> { typedef int type __attribute__((ext_vector_type(3))); };
+template <int CPL>
+struct SweepRow {
+  static constexpr int NV4 = CPL / 4, TAIL = CPL % 4, QW = (CPL + 3) / 4;
+  static constexpr int kLoads = NV4 + (TAIL ? 1 : 0) + QW;   // VMEM instructions per row
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  v4i_t m4[NV4 ? NV4 : 1];
+  typename SweepTail<TAIL>::type mt;
+  uint32_t q[QW];
+  // cell_off: the run's first cell, counted from the pair's first (bytes of directions = cells; match_scores: x 4).
+  // ONE asm statement per row: the compiler does not look into it, so (a) the outputs are early-clobber -- they must not share a
+  // register with an address a later load of the statement still reads -- and (b) the statement opens with `s_nop 4`: when the
+  // SGPRs holding Mg / Dg were spilled to a VGPR, the compiler reloads them with v_readlane right in front of the statement and
+  // cannot see that a VMEM instruction reads them within the five wait states gfx9 requires after a VALU write of an SGPR (a
+  // first version without the nop faulted on exactly that, eight columns per lane: a stale high word of Mg).
+  __device__ __forceinline__ void request(uint32_t cell_off, const int32_t *Mg, const uint8_t *Dg) {
+    const uint32_t mo = cell_off * 4u;
+    if constexpr (NV4 == 0 && TAIL == 2)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
+                   : "=&v"(mt), "=&v"(q[0]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 0 && TAIL == 3)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx3 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
+                   : "=&v"(mt), "=&v"(q[0]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 1 && TAIL == 0)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
+                   : "=&v"(m4[0]), "=&v"(q[0]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 1 && TAIL == 1)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dword %1, %4, %6 offset:16\n\t"
+                   "global_load_dword %2, %5, %7\n\tglobal_load_dword %3, %5, %7 offset:4"
+                   : "=&v"(m4[0]), "=&v"(mt), "=&v"(q[0]), "=&v"(q[1]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 1 && TAIL == 2)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx2 %1, %4, %6 offset:16\n\t"
+                   "global_load_dword %2, %5, %7\n\tglobal_load_dword %3, %5, %7 offset:4"
+                   : "=&v"(m4[0]), "=&v"(mt), "=&v"(q[0]), "=&v"(q[1]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 2 && TAIL == 0)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:16\n\t"
+                   "global_load_dword %2, %5, %7\n\tglobal_load_dword %3, %5, %7 offset:4"
+                   : "=&v"(m4[0]), "=&v"(m4[1]), "=&v"(q[0]), "=&v"(q[1]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else
+      static_assert(NV4 == 0 && TAIL == 2, "columns per lane: 2, 3, 4, 5, 6 or 8");
+  }
+  // the row is here once at most YOUNGER of the wave's VMEM instructions are outstanding (loads return in order)
+  template <int YOUNGER>
+  __device__ __forceinline__ void claim() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(YOUNGER) : "memory");
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) asm volatile("" : "+v"(m4[k]));
+    if constexpr (TAIL != 0) asm volatile("" : "+v"(mt));
+#pragma unroll
+    for (int k = 0; k < QW; ++k) asm volatile("" : "+v"(q[k]));
+  }
+  __device__ __forceinline__ int m(int c) const {
+    if (c < 4 * NV4) return m4[c >> 2][c & 3];
+    if constexpr (TAIL == 1) return mt; else if constexpr (TAIL != 0) return mt[c & 3]; else return 0;
+  }
+  __device__ __forceinline__ void set_m(int c, int v) {
+    if (c < 4 * NV4) m4[c >> 2][c & 3] = v;
+    else if constexpr (TAIL == 1) mt = v; else if constexpr (TAIL != 0) mt[c & 3] = v;
+  }
+};
+
+// waves per SIMD the kernel is compiled for (its register budget): the row buffers must stay in registers -- a spilled buffer is a
+// buffer stored while its load is still on its way (tools/check_inflight_loads.py fails the build on that)
+constexpr int sweep_ev_waves(int cpl, bool wide_keys) {
+  return wide_keys ? (cpl <= 2 ? 8 : cpl == 3 ? 6 : cpl == 4 ? 5 : cpl <= 6 ? 3 : 2) : (cpl <= 3 ? 8 : cpl == 4 ? 6 : cpl <= 6 ? 5 : 4);
+}
 template <int CPL, typename EvT>
-__global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6 ? 5 : 4)) sw_sweep_dirs_ev_kernel(const SaSweepParams p) {
+__global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) sw_sweep_dirs_ev_kernel(const SaSweepParams p) {
   constexpr EvT kNone = ~(EvT)0;
+  constexpr int NB = CPL <= 4 ? 4 : 3;   // row buffers
+  typedef SweepRow<CPL> Row;
+  constexpr int kYounger = (NB - 1) * Row::kLoads;   // VMEM instructions behind a row's own when its turn comes
   const int lane = threadIdx.x;
   const uint32_t pair = blockIdx.x;
   if (p.cand_count[pair] == 0) {
@@ -828,116 +916,114 @@ __global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6
   const uint32_t cshift = p.layout.row_bits + 2u, sshift = p.layout.row_bits + p.layout.col_bits + 2u;   // (of the ev word)
   const int cap = p.layout.cap;
 
-  int m[CPL], nm[CPL], thr_c[CPL];
-  uint32_t d[CPL], nd[CPL];
+  int thr_c[CPL];
+  Row rb[NB];
   EvT out_diag[CPL], out_up[CPL];          // what the cells of the row below send up-left / up (kNone: nothing)
   EvT col_row[CPL];                        // column << cshift | row << 2 of my cells on the current row
   uint32_t n_hits = 0;
   bool overflow = false;
   const int xl = lane * CPL;
+  const uint32_t xc = min((uint32_t)xl, W - 1u);   // where my run starts in memory (lanes beyond the row: its last cell)
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     thr_c[c] = (uint32_t)(xl + c) < W ? thr : INT32_MAX;
     out_diag[c] = kNone; out_up[c] = kNone;
     col_row[c] = ((EvT)(uint32_t)(xl + c) << cshift) | ((EvT)rmax << 2);
   }
-  auto load_row = [&](uint32_t y, int (&dm)[CPL], uint32_t (&dd)[CPL]) __attribute__((always_inline)) {
-    const uint32_t at = y * W + (uint32_t)xl;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) { dm[c] = 0; dd[c] = 0x3fu; }
-    if (y < lb) {   // a lane's run may reach past the row's end: that is the next row, still inside the pair's matrix
-      if ((uint32_t)xl < W) {
-        load_run<CPL>(Mg + at, dm);
-        if constexpr (CPL <= 4) {   // the run's direction bytes as one (unaligned) word: one load instead of CPL
-          typedef uint32_t u1_u __attribute__((aligned(1)));
-          const uint32_t q = *reinterpret_cast<const u1_u *>(Dg + at);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) dd[c] = (q >> (8 * c)) & 0xffu;
-        } else {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) dd[c] = Dg[at + c];
-        }
-      }
-    } else {        // the last row: cell by cell
-#pragma unroll
-      for (int c = 0; c < CPL; ++c)
-        if ((uint32_t)(xl + c) < W) { dm[c] = Mg[at + c]; dd[c] = Dg[at + c]; }
-    }
-  };
-
   uint32_t y = rmax;
-  load_row(y, m, d);
-  for (;; --y) {
-    if (y >= 1) load_row(y - 1, nm, nd);
-    bool live = false;
-    // ---- arrivals from below and the cell's own candidacy: one minimum
-    EvT arr[CPL];
-    bool any = false;
-    {
-      const EvT diag_edge = wave_shl1(out_diag[0], kNone);
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const EvT own = (m[c] >= thr_c[c]) ? (((EvT)(uint32_t)(cap - m[c]) << sshift) | col_row[c]) : kNone;   // (arrives in MATCH: 0)
-        const EvT dg = c + 1 < CPL ? out_diag[c + 1 < CPL ? c + 1 : c] : diag_edge;
-        arr[c] = min(own, min(dg, out_up[c]));
-        any |= arr[c] != kNone;
-      }
-    }
-    if (!__any(any)) {
+  for (int b = 0; b < NB; ++b) rb[b].request((y >= (uint32_t)b ? y - (uint32_t)b : 0u) * W + xc, Mg, Dg);
+  // rmax may be the pair's last row, and what lies behind that is not the pair's: the first row's cells beyond column W - 1 = 0
+  rb[0].template claim<kYounger>();
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) { out_diag[c] = kNone; out_up[c] = kNone; }
-    } else {
-      // ---- arrivals along the row: my columns right to left, then again while some lane's incoming walk changes
-      EvT in_ev = kNone, win[CPL];
-      uint32_t fdir[CPL];
-      for (;;) {
-        EvT h = in_ev;
+  for (int c = 0; c < CPL; ++c) rb[0].set_m(c, (uint32_t)(xl + c) < W ? rb[0].m(c) : 0);
+
+  bool done = false;
+  while (!done) {
 #pragma unroll
-        for (int c = CPL - 1; c >= 0; --c) {
-          const EvT w = min(h, arr[c]);
-          const uint32_t st = (uint32_t)w & 3u;
-          const uint32_t f = (d[c] >> (2u * st)) & 3u;
-          win[c] = w; fdir[c] = f;
-          // it goes on to the left iff it stands in GAP_B and its state's score is not 0 (f == 3: the walk ends here)
-          h = (w != kNone && st == MAT_GAP_B && f != 3u) ? ((w & ~(EvT)3) | f) : kNone;
-        }
-        const EvT nxt = wave_shl1(h, kNone);
-        const bool changed = nxt != in_ev;
-        in_ev = nxt;
-        if (!__any(changed)) break;
-      }
-      // ---- what every cell sends up-left / up; hits = winners whose state has score 0 (rare: one test for the whole row)
-      bool any_hit = false;
+    for (int b = 0; b < NB; ++b) {
+      Row &row = rb[b];
+      row.template claim<kYounger>();
+      int m[CPL];
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const EvT w = win[c];
-        const uint32_t st = (uint32_t)w & 3u, f = fdir[c];
-        const bool has = w != kNone, leaves = has && f != 3u;
-        const EvT on = (w & ~(EvT)3) | f;
-        out_diag[c] = (leaves && st == MAT_MATCH) ? on : kNone;
-        out_up[c] = (leaves && st == MAT_GAP_A) ? on : kNone;
-        live |= leaves;
-        any_hit |= has && f == 3u;
-      }
-      if (__any(any_hit)) {
+      for (int c = 0; c < CPL; ++c) m[c] = row.m(c);
+      bool live = false;
+      // ---- arrivals from below and the cell's own candidacy: one minimum
+      EvT arr[CPL];
+      bool any = false;
+      {
+        const EvT diag_edge = wave_shl1(out_diag[0], kNone);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const bool hit = win[c] != kNone && fdir[c] == 3u;
-          const unsigned long long bal = __ballot(hit);
-          if (bal) {
-            const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)(win[c] >> 2);
-            n_hits += (uint32_t)__popcll(bal);
-            if (n_hits > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
-          }
+          const EvT own = (m[c] >= thr_c[c]) ? (((EvT)(uint32_t)(cap - m[c]) << sshift) | col_row[c]) : kNone;   // (arrives in MATCH: 0)
+          const EvT dg = c + 1 < CPL ? out_diag[c + 1 < CPL ? c + 1 : c] : diag_edge;
+          arr[c] = min(own, min(dg, out_up[c]));
+          any |= arr[c] != kNone;
         }
       }
-    }
-    if (y == 0 || (!__any(live) && y <= rmin)) break;
+      if (!__any(any)) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { m[c] = nm[c]; d[c] = nd[c]; col_row[c] -= 4; }   // (the row field: y - 1)
+        for (int c = 0; c < CPL; ++c) { out_diag[c] = kNone; out_up[c] = kNone; }
+      } else {
+        // ---- arrivals along the row: my columns right to left, then again while some lane's incoming walk changes
+        EvT in_ev = kNone, win[CPL];
+        uint32_t fdir[CPL];
+        for (;;) {
+          EvT h = in_ev;
+#pragma unroll
+          for (int c = CPL - 1; c >= 0; --c) {
+            const EvT w = min(h, arr[c]);
+            const uint32_t st = (uint32_t)w & 3u;
+            const uint32_t f = __builtin_amdgcn_ubfe(row.q[c >> 2], 2u * st + 8u * (uint32_t)(c & 3), 2u);
+            win[c] = w; fdir[c] = f;
+            // it goes on to the left iff it stands in GAP_B and its state's score is not 0 (f == 3: the walk ends here)
+            h = (w != kNone && st == MAT_GAP_B && f != 3u) ? ((w & ~(EvT)3) | f) : kNone;
+          }
+          const EvT nxt = wave_shl1(h, kNone);
+          const bool changed = nxt != in_ev;
+          in_ev = nxt;
+          if (!__any(changed)) break;
+        }
+        // ---- what every cell sends up-left / up; hits = winners whose state has score 0 (rare: one test for the whole row)
+        bool any_hit = false;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const EvT w = win[c];
+          const uint32_t st = (uint32_t)w & 3u, f = fdir[c];
+          const bool has = w != kNone, leaves = has && f != 3u;
+          const EvT on = (w & ~(EvT)3) | f;
+          out_diag[c] = (leaves && st == MAT_MATCH) ? on : kNone;
+          out_up[c] = (leaves && st == MAT_GAP_A) ? on : kNone;
+          live |= leaves;
+          any_hit |= has && f == 3u;
+        }
+        if (__any(any_hit)) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const bool hit = win[c] != kNone && fdir[c] == 3u;
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+              const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+              if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)(win[c] >> 2);
+              n_hits += (uint32_t)__popcll(bal);
+              if (n_hits > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
+            }
+          }
+          // stores count in vmcnt too and need not return in order with loads: drain, so that the claims' counts hold
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      if (y == 0 || (!__any(live) && y <= rmin)) { done = true; break; }
+      row.request((y >= (uint32_t)NB ? y - (uint32_t)NB : 0u) * W + xc, Mg, Dg);   // this buffer's next row: NB rows up (above the first: row 0 again, never used)
+      --y;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) col_row[c] -= 4;   // (the row field: y - 1)
+    }
   }
 
+  // rows requested and never worked on are still on their way INTO registers: nothing below may start before they are in
+#pragma unroll
+  for (int b = 0; b < NB; ++b) rb[b].template claim<0>();
   // ---- the hits in key order (= the reference's order).  Up to 64: ranked here, one per lane.
   uint32_t status = overflow ? SA_SWEEP_OVERFLOW : 0u;
   if (n_hits > 1 && !overflow) {

@@ -30,6 +30,10 @@ DNAN = np.frombuffer(b"ACGTN", np.uint8)
 PROT = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVBZX", np.uint8)
 
 
+shapes = [(1, 1), (1, 7), (7, 1), (3, 5), (63, 64), (64, 64), (64, 10), (127, 130), (128, 128), (150, 150), (151, 149), (191, 40),
+          (192, 33), (200, 37), (255, 256), (300, 100), (383, 20), (400, 60), (511, 70)]
+
+
 def setup(seed=77, context=None):
     """(Re)seed the generator and bind the context the checks run on."""
     global rng, ctx
@@ -77,8 +81,6 @@ def check_uniform(seconds, max_trials=1 << 60):
     """NW on uniform batches: packed fills (pack16 = 2, two / four pairs per wave) vs the one-pair kernels and the oracle."""
     t_end = time.time() + seconds
     trials = pairs = oracle_pairs = quad_batches = 0
-    shapes = [(1, 1), (1, 7), (7, 1), (3, 5), (63, 64), (64, 64), (64, 10), (127, 130), (128, 128), (150, 150), (151, 149), (191, 40),
-              (192, 33), (200, 37), (255, 256), (300, 100), (383, 20), (400, 60), (511, 70)]
     while time.time() < t_end and trials < max_trials:
         v = rng.below(1 << 20, 12).astype(int)
         la, lb = shapes[trials % len(shapes)] if trials < 3 * len(shapes) else (int(1 + v[0] % 511), int(1 + v[1] % 300))

@@ -337,7 +337,7 @@ def test_scratch_comes_from_the_chunk_pool(opts):
         keeper.pool_trim(0)                   # (whatever earlier tests of this process left; also resets the pool's cap)
         keeper.set_option("arena_keep_gib", 4)
         keeper.set_option("arena_scan_gib", 12)
-        keeper.set_option("arena_quality", 9.0)      # unreachable: the walk uses its whole 12 GiB
+        keeper.set_option("arena_quality", 1.49)      # unreachable: the walk uses its whole 12 GiB
         ptrs, q = (C.c_void_p * 3)(), C.c_float(-1)
         assert S.lib().seqalign_arenas_alloc(keeper._h, C.c_uint64(600 << 20), ptrs, C.byref(q)) == 0
         info = S.ArenaInfo()
@@ -356,8 +356,9 @@ def test_scratch_comes_from_the_chunk_pool(opts):
         assert S.lib().seqalign_arenas_free(keeper._h, ptrs) == 0
         assert keeper.pool_trim() == held0                 # full: the arenas' own chunks went to the driver
         assert keeper.pool_trim(1 << 30) == 1 << 30
-    with S.Context(0) as again:
-        assert again.pool_trim() == 0                      # emptied with the last context
+        # (the pool is emptied when the device's LAST context goes; this process holds others -- the module's fixture, the
+        # DeviceBatch arena context -- so here it is emptied by hand)
+        assert keeper.pool_trim(0) == 0
 
 
 @pytest.mark.parametrize("walker", ["wave", "lane"])
