@@ -14,9 +14,19 @@
  * printed, as upstream does for non-interactive input).  Sequence files may be
  * gzip-compressed (zlib, like upstream's seq_file); --zam is provided for the global
  * tool.  --printmatrices uses the per-pair API (it needs the matrices on the host).
+ *
+ * Round 5: a PIPELINE of three threads over a ring of batches.  The reference's driver has one pair in flight
+ * (src/alignment_cmdline.c:578-640: read two records, align, print, repeat); rounds 3-4 here read 65 536 pairs, aligned
+ * them, printed them, one after the other, with four mallocs per record.  Now
+ *     reader  : parses records straight into the batch's ONE growing text arena (names and sequences, NUL-terminated;
+ *               the sequences' offsets / lengths are the seqalign_batch_t arrays) -- batch k + 1
+ *     aligner : seqalign_nw_batch / seqalign_sw_batch on the GPU                 -- batch k
+ *     printer : (the main thread) writes the reference's text                     -- batch k - 1
+ * run side by side; a batch's buffers are reused when it comes round again.  Output order is input order.
  */
 #define _POSIX_C_SOURCE 200809L
 #include <ctype.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,8 +48,7 @@ typedef struct {
   int n_files;
 } opts_t;
 
-typedef struct { char *name, *seq; size_t len; } rec_t;
-typedef struct { rec_t *a, *b; size_t n, cap; } pairs_t;
+typedef struct { const char *name, *seq; size_t len; } rec_t;   /* a view into a batch's text arena */
 
 static scoring_t scoring;   /* 271 KB */
 static opts_t opt;
@@ -48,11 +57,13 @@ static void die(const char *msg, const char *arg)
 {
   fprintf(stderr, "Error: ");
   fprintf(stderr, msg, arg);
-  fprintf(stderr, "\nusage: %s [OPTIONS] [seq1 seq2]   (options as in seq-align's %s)\n",
+  fprintf(stderr, "\nusage: %s [OPTIONS] [seq1 seq2]   (options as in seq-align's %s; --help lists them)\n",
           opt.tool == TOOL_NW ? "seqalign_nw" : "seqalign_sw",
           opt.tool == TOOL_NW ? "needleman_wunsch" : "smith_waterman");
   exit(EXIT_FAILURE);
 }
+
+static void oom(void) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
 
 static int parse_int(const char *s, int *out)
 {
@@ -63,34 +74,59 @@ static int parse_int(const char *s, int *out)
   return 1;
 }
 
-static char *dup_n(const char *s, size_t n)
-{
-  char *d = malloc(n + 1);
-  if(!d) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
-  memcpy(d, s, n);
-  d[n] = '\0';
-  return d;
-}
+/* One batch on its way through the pipeline.  Input: `text` holds, per pair, name_a\0 seq_a\0 name_b\0 seq_b\0 in reading
+ * order -- one growing arena instead of four mallocs per record -- and is the seqalign_batch_t's arena (off_a / off_b point
+ * at the sequences).  Results: the aligner's output buffers.  All arrays are kept and reused when the batch comes round. */
+typedef struct {
+  char *text; size_t text_len, text_cap;
+  size_t *name_a, *name_b;
+  uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
+  size_t n, cap;
+  int last;                               /* the reader's last batch: end of input */
+  /* results */
+  uint64_t *str_off; uint32_t *out_len; int32_t *score;     /* NW */
+  int32_t *min_score; seqalign_sw_hit_t *hits; uint64_t n_hits, hit_cap;   /* SW */
+  char *out_a, *out_b; size_t out_cap, res_cap;
+} batch_t;
 
-static void add_pair(pairs_t *ps, const char *na, const char *sa, size_t la, const char *nb, const char *sb, size_t lb)
+static void *grow(void *p, size_t bytes) { p = realloc(p, bytes); if(!p) oom(); return p; }
+
+static size_t text_add(batch_t *b, const char *s, size_t n)   /* appends s\0, returns its offset */
 {
-  if(ps->n == ps->cap) {
-    ps->cap = ps->cap ? 2 * ps->cap : 1024;
-    ps->a = realloc(ps->a, ps->cap * sizeof(rec_t));
-    ps->b = realloc(ps->b, ps->cap * sizeof(rec_t));
-    if(!ps->a || !ps->b) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
+  const size_t at = b->text_len;
+  if(at + n + 1 > b->text_cap) {
+    b->text_cap = b->text_cap ? 2 * b->text_cap : (size_t)1 << 20;
+    while(at + n + 1 > b->text_cap) b->text_cap *= 2;
+    b->text = grow(b->text, b->text_cap);
   }
-  ps->a[ps->n].name = dup_n(na, strlen(na)); ps->a[ps->n].seq = dup_n(sa, la); ps->a[ps->n].len = la;
-  ps->b[ps->n].name = dup_n(nb, strlen(nb)); ps->b[ps->n].seq = dup_n(sb, lb); ps->b[ps->n].len = lb;
-  ps->n++;
+  memcpy(b->text + at, s, n);
+  b->text[at + n] = '\0';
+  b->text_len = at + n + 1;
+  return at;
 }
 
-static void free_pairs(pairs_t *ps)
+/* the first record of a pair goes in when it is read (the reader's buffers are only valid until its next call) */
+static void batch_add_a(batch_t *b, const char *na, const char *sa, size_t la)
 {
-  size_t i;
-  for(i = 0; i < ps->n; i++) { free(ps->a[i].name); free(ps->a[i].seq); free(ps->b[i].name); free(ps->b[i].seq); }
-  ps->n = 0;
+  if(b->n == b->cap) {
+    b->cap = b->cap ? 2 * b->cap : 4096;
+    b->name_a = grow(b->name_a, b->cap * sizeof(size_t)); b->name_b = grow(b->name_b, b->cap * sizeof(size_t));
+    b->off_a = grow(b->off_a, b->cap * sizeof(uint64_t)); b->off_b = grow(b->off_b, b->cap * sizeof(uint64_t));
+    b->len_a = grow(b->len_a, b->cap * sizeof(uint32_t)); b->len_b = grow(b->len_b, b->cap * sizeof(uint32_t));
+  }
+  b->name_a[b->n] = text_add(b, na, strlen(na));
+  b->off_a[b->n] = text_add(b, sa, la); b->len_a[b->n] = (uint32_t)la;
 }
+static void batch_add_b(batch_t *b, const char *nb, const char *sb, size_t lb)
+{
+  b->name_b[b->n] = text_add(b, nb, strlen(nb));
+  b->off_b[b->n] = text_add(b, sb, lb); b->len_b[b->n] = (uint32_t)lb;
+  b->n++;
+}
+static void batch_drop_a(batch_t *b) { b->text_len = b->name_a[b->n]; }   /* an odd record at end of file */
+
+static rec_t rec_a(const batch_t *b, size_t i) { rec_t r = { b->text + b->name_a[i], b->text + b->off_a[i], b->len_a[i] }; return r; }
+static rec_t rec_b(const batch_t *b, size_t i) { rec_t r = { b->text + b->name_b[i], b->text + b->off_b[i], b->len_b[i] }; return r; }
 
 /* ---------------------------------------------------------------- options */
 
@@ -303,23 +339,6 @@ static void print_sw_hit(size_t index, size_t hit_index, const rec_t *ra, const 
 
 /* ---------------------------------------------------------------- batches */
 
-static void build_batch(const pairs_t *ps, size_t first, size_t n, seqalign_batch_t *b, char **arena,
-                        uint64_t **off_a, uint64_t **off_b, uint32_t **len_a, uint32_t **len_b)
-{
-  size_t i, total = 1, pos = 0;
-  for(i = 0; i < n; i++) total += ps->a[first+i].len + ps->b[first+i].len;
-  *arena = malloc(total);
-  *off_a = malloc(n * sizeof(uint64_t)); *off_b = malloc(n * sizeof(uint64_t));
-  *len_a = malloc(n * sizeof(uint32_t)); *len_b = malloc(n * sizeof(uint32_t));
-  for(i = 0; i < n; i++) {
-    const rec_t *ra = &ps->a[first+i], *rb = &ps->b[first+i];
-    (*off_a)[i] = pos; memcpy(*arena + pos, ra->seq, ra->len); pos += ra->len; (*len_a)[i] = (uint32_t)ra->len;
-    (*off_b)[i] = pos; memcpy(*arena + pos, rb->seq, rb->len); pos += rb->len; (*len_b)[i] = (uint32_t)rb->len;
-  }
-  b->n_pairs = n; b->arena = *arena; b->arena_bytes = total;
-  b->off_a = *off_a; b->len_a = *len_a; b->off_b = *off_b; b->len_b = *len_b;
-}
-
 static void check(int rc, const char *what)
 {
   if(rc != SEQALIGN_OK) {
@@ -333,72 +352,106 @@ static size_t g_alignment_index = 0;
 static seqalign_ctx_t *g_ctxs[64];
 static int g_nctx = 1;
 
-static void run_nw(seqalign_ctx_t *ctx, const pairs_t *ps)
+static void as_batch(const batch_t *bt, seqalign_batch_t *b)
 {
-  seqalign_batch_t b; char *arena; uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
-  size_t n = ps->n, i, total = 0;
-  uint64_t *str_off = malloc(n * sizeof(uint64_t));
-  uint32_t *out_len = malloc(n * sizeof(uint32_t));
-  int32_t *score = malloc(n * sizeof(int32_t));
-  char *out_a, *out_b;
-  if(!n) { free(str_off); free(out_len); free(score); return; }
-  build_batch(ps, 0, n, &b, &arena, &off_a, &off_b, &len_a, &len_b);
-  for(i = 0; i < n; i++) { str_off[i] = total; total += (size_t)len_a[i] + len_b[i] + 1; }
-  out_a = malloc(total + 1); out_b = malloc(total + 1);
-  if(g_nctx > 1) check(seqalign_nw_batch_multi(g_ctxs, g_nctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch_multi");
-  else check(seqalign_nw_batch(ctx, &b, &scoring, str_off, out_a, out_b, out_len, score), "seqalign_nw_batch");
+  b->n_pairs = bt->n; b->arena = bt->text; b->arena_bytes = bt->text_len;
+  b->off_a = bt->off_a; b->len_a = bt->len_a; b->off_b = bt->off_b; b->len_b = bt->len_b;
+}
+
+static void reserve_out(batch_t *bt, size_t bytes)
+{
+  if(bytes > bt->out_cap) {
+    bt->out_cap = bytes + bytes / 4;
+    free(bt->out_a); free(bt->out_b);
+    bt->out_a = malloc(bt->out_cap); bt->out_b = malloc(bt->out_cap);
+    if(!bt->out_a || !bt->out_b) oom();
+  }
+}
+
+/* ---- stage 2: the GPU */
+static void align_nw(batch_t *bt)
+{
+  seqalign_batch_t b;
+  size_t n = bt->n, i, total = 0;
+  if(!n) return;
+  if(n > bt->res_cap) {
+    bt->res_cap = n + n / 4;
+    bt->str_off = grow(bt->str_off, bt->res_cap * sizeof(uint64_t));
+    bt->out_len = grow(bt->out_len, bt->res_cap * sizeof(uint32_t));
+    bt->score = grow(bt->score, bt->res_cap * sizeof(int32_t));
+  }
+  as_batch(bt, &b);
+  for(i = 0; i < n; i++) { bt->str_off[i] = total; total += (size_t)bt->len_a[i] + bt->len_b[i] + 1; }
+  reserve_out(bt, total + 1);
+  if(g_nctx > 1) check(seqalign_nw_batch_multi(g_ctxs, g_nctx, &b, &scoring, bt->str_off, bt->out_a, bt->out_b, bt->out_len, bt->score), "seqalign_nw_batch_multi");
+  else check(seqalign_nw_batch(g_ctxs[0], &b, &scoring, bt->str_off, bt->out_a, bt->out_b, bt->out_len, bt->score), "seqalign_nw_batch");
+}
+
+static unsigned sw_cap(void) { return opt.max_hits_set ? opt.max_hits : 16; }   /* device path; see the re-run in print_sw */
+
+static void align_sw(batch_t *bt)
+{
+  seqalign_batch_t b;
+  size_t n = bt->n, i;
+  const unsigned cap = sw_cap();
+  uint64_t str_cap = 0, hit_cap;
+  bt->n_hits = 0;
+  if(!n) return;
+  if(n > bt->res_cap) {
+    bt->res_cap = n + n / 4;
+    bt->min_score = grow(bt->min_score, (bt->res_cap + 1) * sizeof(int32_t));
+  }
+  as_batch(bt, &b);
   for(i = 0; i < n; i++) {
+    /* sw_cmdline.c:192-197 */
+    bt->min_score[i] = opt.min_score_set ? opt.min_score
+                                         : (int)(scoring.match * MAX2(0.2 * MIN2(bt->len_a[i], bt->len_b[i]), 2));
+    str_cap += (uint64_t)(cap ? cap : 1) * ((uint64_t)bt->len_a[i] + bt->len_b[i] + 1);
+  }
+  hit_cap = (uint64_t)n * (cap ? cap : 1) + 16;
+  if(hit_cap > bt->hit_cap) { bt->hit_cap = hit_cap + hit_cap / 4; free(bt->hits); bt->hits = malloc(bt->hit_cap * sizeof(*bt->hits)); if(!bt->hits) oom(); }
+  reserve_out(bt, str_cap + 16);
+  if(cap && g_nctx > 1) check(seqalign_sw_batch_multi(g_ctxs, g_nctx, &b, &scoring, bt->min_score, cap, bt->hits, hit_cap, &bt->n_hits, bt->out_a, bt->out_b, str_cap + 16), "seqalign_sw_batch_multi");
+  else if(cap) check(seqalign_sw_batch(g_ctxs[0], &b, &scoring, bt->min_score, cap, bt->hits, hit_cap, &bt->n_hits, bt->out_a, bt->out_b, str_cap + 16), "seqalign_sw_batch");
+}
+
+/* ---- stage 3: the reference's text */
+static void print_nw_batch(const batch_t *bt)
+{
+  size_t i;
+  for(i = 0; i < bt->n; i++) {
+    const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
     if(opt.print_matrices) {   /* needs the matrices on the host: per-pair API */
       nw_aligner_t *nw = needleman_wunsch_new();
       alignment_t *r = alignment_create(256);
-      needleman_wunsch_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, nw, r);
+      needleman_wunsch_align2(ra.seq, rb.seq, ra.len, rb.len, &scoring, nw, r);
       alignment_print_matrices(nw);
       alignment_free(r); needleman_wunsch_free(nw);
     }
-    print_nw(&ps->a[i], &ps->b[i], out_a + str_off[i], out_b + str_off[i], score[i]);
+    print_nw(&ra, &rb, bt->out_a + bt->str_off[i], bt->out_b + bt->str_off[i], bt->score[i]);
   }
   fflush(stdout);
-  free(arena); free(off_a); free(off_b); free(len_a); free(len_b);
-  free(str_off); free(out_len); free(score); free(out_a); free(out_b);
 }
 
-static void run_sw(seqalign_ctx_t *ctx, const pairs_t *ps)
+static void print_sw_batch(const batch_t *bt)
 {
   /* pairs with an empty sequence are reported and skipped upstream (sw_cmdline.c:137-151) */
-  seqalign_batch_t b; char *arena; uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
-  size_t n = ps->n, i, h0;
-  int32_t *min_score = malloc((n + 1) * sizeof(int32_t));
-  const unsigned cap = opt.max_hits_set ? opt.max_hits : 16;   /* device path; see re-run below */
-  uint64_t hit_cap, n_hits = 0, str_cap = 0;
-  seqalign_sw_hit_t *hits;
-  char *out_a, *out_b;
-  if(!n) { free(min_score); return; }
-  build_batch(ps, 0, n, &b, &arena, &off_a, &off_b, &len_a, &len_b);
-  for(i = 0; i < n; i++) {
-    /* sw_cmdline.c:192-197 */
-    min_score[i] = opt.min_score_set ? opt.min_score
-                                     : (int)(scoring.match * MAX2(0.2 * MIN2(len_a[i], len_b[i]), 2));
-    str_cap += (uint64_t)(cap ? cap : 1) * ((uint64_t)len_a[i] + len_b[i] + 1);
-  }
-  hit_cap = (uint64_t)n * (cap ? cap : 1) + 16;
-  hits = malloc(hit_cap * sizeof(*hits));
-  out_a = malloc(str_cap + 16); out_b = malloc(str_cap + 16);
-  if(cap && g_nctx > 1) check(seqalign_sw_batch_multi(g_ctxs, g_nctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch_multi");
-  else if(cap) check(seqalign_sw_batch(ctx, &b, &scoring, min_score, cap, hits, hit_cap, &n_hits, out_a, out_b, str_cap + 16), "seqalign_sw_batch");
-
-  for(i = 0, h0 = 0; i < n; i++) {
+  const unsigned cap = sw_cap();
+  size_t i, h0;
+  for(i = 0, h0 = 0; i < bt->n; i++) {
+    const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
     size_t h1 = h0, k;
-    while(h1 < n_hits && hits[h1].pair == i) h1++;
-    if(ps->a[i].len == 0 || ps->b[i].len == 0) {
+    while(h1 < bt->n_hits && bt->hits[h1].pair == i) h1++;
+    if(ra.len == 0 || rb.len == 0) {
       fprintf(stderr, "Error: Sequences must have length > 0\n");
-      if(opt.print_fasta && ps->a[i].name[0] && ps->b[i].name[0]) fprintf(stderr, "%s\n%s\n", ps->a[i].name, ps->b[i].name);
+      if(opt.print_fasta && ra.name[0] && rb.name[0]) fprintf(stderr, "%s\n%s\n", ra.name, rb.name);
       h0 = h1;
       continue;
     }
-    print_sw_heading(g_alignment_index, &ps->a[i], &ps->b[i]);
+    print_sw_heading(g_alignment_index, &ra, &rb);
     if(opt.print_matrices) {
       sw_aligner_t *sw = smith_waterman_new();
-      smith_waterman_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, sw);
+      smith_waterman_align2(ra.seq, rb.seq, ra.len, rb.len, &scoring, sw);
       alignment_print_matrices(smith_waterman_get_aligner(sw));
       smith_waterman_free(sw);
     }
@@ -408,49 +461,137 @@ static void run_sw(seqalign_ctx_t *ctx, const pairs_t *ps)
       sw_aligner_t *sw = smith_waterman_new();
       alignment_t *r = alignment_create(256);
       size_t hit_index = 0;
-      smith_waterman_align2(ps->a[i].seq, ps->b[i].seq, ps->a[i].len, ps->b[i].len, &scoring, sw);
-      while(smith_waterman_fetch(sw, r) && r->score >= min_score[i]) {
+      smith_waterman_align2(ra.seq, rb.seq, ra.len, rb.len, &scoring, sw);
+      while(smith_waterman_fetch(sw, r) && r->score >= bt->min_score[i]) {
         seqalign_sw_hit_t h;
         h.pair = i; h.score = r->score; h.pos_a = (uint32_t)r->pos_a; h.pos_b = (uint32_t)r->pos_b;
         h.len_a = (uint32_t)r->len_a; h.len_b = (uint32_t)r->len_b; h.length = (uint32_t)r->length; h.str_off = 0;
-        print_sw_hit(g_alignment_index, hit_index++, &ps->a[i], &ps->b[i], &h, r->result_a, r->result_b);
+        print_sw_hit(g_alignment_index, hit_index++, &ra, &rb, &h, r->result_a, r->result_b);
       }
       alignment_free(r); smith_waterman_free(sw);
     } else {
       for(k = h0; k < h1; k++)
-        print_sw_hit(g_alignment_index, k - h0, &ps->a[i], &ps->b[i], &hits[k], out_a + hits[k].str_off, out_b + hits[k].str_off);
+        print_sw_hit(g_alignment_index, k - h0, &ra, &rb, &bt->hits[k], bt->out_a + bt->hits[k].str_off, bt->out_b + bt->hits[k].str_off);
     }
     fputs("==\n", stdout);
     g_alignment_index++;
     h0 = h1;
   }
   fflush(stdout);
-  free(arena); free(off_a); free(off_b); free(len_a); free(len_b);
-  free(min_score); free(hits); free(out_a); free(out_b);
 }
 
-/* ------------------------------------------------------------------- main */
+/* ------------------------------------------------------------- the pipeline */
 
 #define BATCH_PAIRS 65536
+#define N_BATCHES 3          /* one being read, one on the GPU, one being printed */
 
-static void flush(seqalign_ctx_t *ctx, pairs_t *ps)
+typedef struct {             /* a FIFO of batches between two stages */
+  pthread_mutex_t mu; pthread_cond_t cv;
+  batch_t *q[N_BATCHES + 1]; int head, count;
+} fifo_t;
+
+static void fifo_init(fifo_t *f) { pthread_mutex_init(&f->mu, NULL); pthread_cond_init(&f->cv, NULL); f->head = f->count = 0; }
+static void fifo_put(fifo_t *f, batch_t *b)
 {
-  if(opt.tool == TOOL_NW) run_nw(ctx, ps); else run_sw(ctx, ps);
-  free_pairs(ps);
+  pthread_mutex_lock(&f->mu);
+  f->q[(f->head + f->count++) % (N_BATCHES + 1)] = b;    /* (never more than N_BATCHES in circulation) */
+  pthread_cond_signal(&f->cv);
+  pthread_mutex_unlock(&f->mu);
+}
+static batch_t *fifo_get(fifo_t *f)
+{
+  batch_t *b;
+  pthread_mutex_lock(&f->mu);
+  while(!f->count) pthread_cond_wait(&f->cv, &f->mu);
+  b = f->q[f->head]; f->head = (f->head + 1) % (N_BATCHES + 1); f->count--;
+  pthread_mutex_unlock(&f->mu);
+  return b;
+}
+
+static fifo_t g_free, g_read, g_aligned;
+
+/* stage 1: records into batches (two records at a time, alignment_cmdline.c:611-622) */
+static void *reader_main(void *arg)
+{
+  batch_t *bt = fifo_get(&g_free);
+  int f;
+  (void)arg;
+  bt->n = 0; bt->text_len = 0; bt->last = 0;
+  if(opt.seq1) { batch_add_a(bt, "", opt.seq1, strlen(opt.seq1)); batch_add_b(bt, "", opt.seq2, strlen(opt.seq2)); }
+  for(f = 0; f < opt.n_files; f++) {
+    seqalign_reader_t *r1 = seqalign_reader_open(opt.files1[f]), *r2 = NULL;
+    const char *n1, *s1, *n2, *s2;
+    size_t l1, l2;
+    if(!r1) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files1[f]); exit(EXIT_FAILURE); }
+    if(opt.files2[f] && !(r2 = seqalign_reader_open(opt.files2[f]))) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files2[f]); exit(EXIT_FAILURE); }
+    for(;;) {
+      if(!seqalign_reader_next(r1, &n1, &s1, &l1)) break;
+      batch_add_a(bt, n1, s1, l1);      /* (the reader's buffers are valid until its next call) */
+      if(!seqalign_reader_next(r2 ? r2 : r1, &n2, &s2, &l2)) {
+        fprintf(stderr, "Odd number of sequences - I read in pairs!\n");
+        batch_drop_a(bt);
+        break;
+      }
+      batch_add_b(bt, n2, s2, l2);
+      if(bt->n >= BATCH_PAIRS) {
+        fifo_put(&g_read, bt);
+        bt = fifo_get(&g_free);         /* blocks while all batches are downstream: bounded memory */
+        bt->n = 0; bt->text_len = 0; bt->last = 0;
+      }
+    }
+    seqalign_reader_close(r1);
+    if(r2) seqalign_reader_close(r2);
+  }
+  bt->last = 1;
+  fifo_put(&g_read, bt);
+  return NULL;
+}
+
+/* stage 2 */
+static void *aligner_main(void *arg)
+{
+  (void)arg;
+  for(;;) {
+    batch_t *bt = fifo_get(&g_read);
+    if(opt.tool == TOOL_NW) align_nw(bt); else align_sw(bt);
+    fifo_put(&g_aligned, bt);
+    if(bt->last) return NULL;
+  }
+}
+
+static void usage(void)
+{
+  const int nw = opt.tool == TOOL_NW;
+  printf("usage: %s [OPTIONS] [seq1 seq2]\n"
+         "  %s alignment of pairs of sequences on an MI355X -- the options and the output of seq-align's %s.\n"
+         "  Pairs are read two records at a time (FASTA, FASTQ or one sequence per line; gzip accepted) and aligned in batches.\n\n"
+         "  input:    --file <file> | --files <f1> <f2> | --stdin | seq1 seq2\n"
+         "  scoring:  --case_sensitive  --scoring PAM30|PAM70|BLOSUM80|BLOSUM62|DNA_HYBRIDIZATION\n"
+         "            --match <n> --mismatch <n> --gapopen <n> --gapextend <n>   (gap of length N: gapopen + N * gapextend)\n"
+         "            --substitution_matrix <file>  --substitution_pairs <file>  --wildcard <char> <score>\n"
+         "            --nogaps --nogapsin1 --nogapsin2 --nomismatches%s\n"
+         "  output:   --printfasta --pretty --colour --printmatrices%s\n"
+         "  environment: SEQALIGN_DEVICE=<gpu>  SEQALIGN_GPUS=<n> (split every batch over n GPUs)\n",
+         nw ? "seqalign_nw" : "seqalign_sw", nw ? "Global (Needleman-Wunsch)" : "Local (Smith-Waterman)",
+         nw ? "needleman_wunsch" : "smith_waterman",
+         nw ? " --freestartgap --freeendgap" : "",
+         nw ? " --printscores --zam" : " --printseq --minscore <n> --maxhits <n> --context <n>");
 }
 
 int main(int argc, char **argv)
 {
   const char *base = strrchr(argv[0], '/');
   seqalign_ctx_t *ctx = NULL;
-  pairs_t ps = {0};
-  int f, rc;
+  static batch_t batches[N_BATCHES];
+  pthread_t reader, aligner;
+  int k, rc;
   base = base ? base + 1 : argv[0];
   /* a command-line run is short: skip the ~0.1-0.2 s the library would spend looking for a good
      placement of its matrix arenas (seqalign_hip.h, seqalign_arenas_alloc) unless the user asks for it */
   setenv("SEQALIGN_ARENA_SCAN_GIB", "0", 0);
   memset(&opt, 0, sizeof opt);
   opt.tool = strstr(base, "sw") ? TOOL_SW : TOOL_NW;
+  for(k = 1; k < argc; k++) if(!strcasecmp(argv[k], "--help") || !strcmp(argv[k], "-h")) { usage(); return EXIT_SUCCESS; }
 
   scoring_system_default(&scoring);
   if(opt.tool == TOOL_SW) {   /* sw_cmdline.c:37-46 */
@@ -479,32 +620,21 @@ int main(int argc, char **argv)
     }
   }
 
-  if(opt.seq1) add_pair(&ps, "", opt.seq1, strlen(opt.seq1), "", opt.seq2, strlen(opt.seq2));
-  for(f = 0; f < opt.n_files; f++) {
-    seqalign_reader_t *r1 = seqalign_reader_open(opt.files1[f]), *r2 = NULL;
-    const char *n1, *s1, *n2, *s2;
-    size_t l1, l2;
-    if(!r1) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files1[f]); return EXIT_FAILURE; }
-    if(opt.files2[f] && !(r2 = seqalign_reader_open(opt.files2[f]))) { fprintf(stderr, "Error: Couldn't read file: %s\n", opt.files2[f]); return EXIT_FAILURE; }
-    for(;;) {   /* two records at a time (alignment_cmdline.c:611-622) */
-      char *n1c, *s1c;
-      if(!seqalign_reader_next(r1, &n1, &s1, &l1)) break;
-      n1c = dup_n(n1, strlen(n1)); s1c = dup_n(s1, l1);
-      if(!seqalign_reader_next(r2 ? r2 : r1, &n2, &s2, &l2)) {
-        fprintf(stderr, "Odd number of sequences - I read in pairs!\n");
-        free(n1c); free(s1c);
-        break;
-      }
-      add_pair(&ps, n1c, s1c, l1, n2, s2, l2);
-      free(n1c); free(s1c);
-      if(ps.n >= BATCH_PAIRS) flush(ctx, &ps);
-    }
-    seqalign_reader_close(r1);
-    if(r2) seqalign_reader_close(r2);
+  fifo_init(&g_free); fifo_init(&g_read); fifo_init(&g_aligned);
+  for(k = 0; k < N_BATCHES; k++) fifo_put(&g_free, &batches[k]);
+  if(pthread_create(&reader, NULL, reader_main, NULL) || pthread_create(&aligner, NULL, aligner_main, NULL)) {
+    fprintf(stderr, "seqalign: cannot start the pipeline's threads\n");
+    return EXIT_FAILURE;
   }
-  flush(ctx, &ps);
-  free(ps.a); free(ps.b);
-  for(f = 1; f < g_nctx; f++) seqalign_ctx_destroy(g_ctxs[f]);
+  for(;;) {   /* stage 3, here: in input order */
+    batch_t *bt = fifo_get(&g_aligned);
+    const int last = bt->last;
+    if(opt.tool == TOOL_NW) print_nw_batch(bt); else print_sw_batch(bt);
+    if(last) break;
+    fifo_put(&g_free, bt);
+  }
+  pthread_join(reader, NULL); pthread_join(aligner, NULL);
+  for(k = 1; k < g_nctx; k++) seqalign_ctx_destroy(g_ctxs[k]);
   seqalign_ctx_destroy(ctx);
   return EXIT_SUCCESS;
 }

@@ -290,3 +290,34 @@ def test_cli_substitution_pairs_file_vs_oracle(tmp_path):
         for (a, b), blk in zip(pairs, blocks):
             rc, score, ra, rb_ = O.oracle_nw(onw, a, b)
             assert rc == 0 and blk == f"{ra.decode()}\n{rb_.decode()}\nscore: {score}", (pf.name, a, b)
+
+
+def test_pipeline_keeps_input_order_across_batches(tmp_path):
+    """Round 5: the tools run as a pipeline (reader | GPU | printer) over a ring of three batches of 65 536 pairs.  150 000 short
+    pairs cross two batch boundaries and reuse the first batch's buffers: every alignment must come out in input order, with
+    its own FASTA name, and equal the oracle's (reference driver: src/alignment_cmdline.c:578-640, one pair at a time)."""
+    rng = W.Rng(515)
+    n = 150_000
+    lens = 8 + rng.below(12, 2 * n).astype(int)
+    bases = rng.below(4, int(lens.sum()))
+    seqs, at = [], 0
+    for ln in lens:
+        seqs.append(bytes(b"ACGT"[i] for i in bases[at:at + ln]).decode())
+        at += int(ln)
+    fa = tmp_path / "pairs.fa"
+    with open(fa, "w") as f:
+        for k, s in enumerate(seqs):
+            f.write(f">r{k}\n{s}\n")
+    out = run(NW, "--printfasta", "--printscores", "--file", str(fa))
+    recs = out.strip("\n").split("\n\n")
+    assert len(recs) == n
+    osc = O.build_scoring({"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    for p in list(range(0, n, 997)) + [65535, 65536, 131071, 131072, n - 1]:
+        name_a, ra, name_b, rb, sc_line = recs[p].split("\n")      # nw_cmdline.c:78-149 with --printfasta --printscores
+        assert (name_a, name_b) == (f">r{2 * p}", f">r{2 * p + 1}"), (p, name_a, name_b)
+        rc, s_, wa, wb = O.oracle_nw(osc, seqs[2 * p].encode(), seqs[2 * p + 1].encode())
+        assert rc == 0 and (ra, rb, sc_line) == (wa.decode(), wb.decode(), f"score: {s_}"), p
+    # the local tool through the same pipeline: hit headings count alignments in input order
+    out = run(SW, "--minscore", "12", "--maxhits", "1", "--file", str(fa))
+    idx = [int(m) for m in re.findall(r"^== Alignment (\d+) lengths", out, re.M)]
+    assert idx == list(range(n))
