@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 
 #include "seqalign_hip.h"
 #include "seqalign_io.h"
@@ -509,12 +510,16 @@ static batch_t *fifo_get(fifo_t *f)
 }
 
 static fifo_t g_free, g_read, g_aligned;
+/* SEQALIGN_CLI_TIMING=1: how long each stage WORKED (not waited), on stderr at the end: which one bounds the tool */
+static double g_busy[3];
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 /* stage 1: records into batches (two records at a time, alignment_cmdline.c:611-622) */
 static void *reader_main(void *arg)
 {
   batch_t *bt = fifo_get(&g_free);
   int f;
+  double t0 = now_s();
   (void)arg;
   bt->n = 0; bt->text_len = 0; bt->last = 0;
   if(opt.seq1) { batch_add_a(bt, "", opt.seq1, strlen(opt.seq1)); batch_add_b(bt, "", opt.seq2, strlen(opt.seq2)); }
@@ -534,8 +539,10 @@ static void *reader_main(void *arg)
       }
       batch_add_b(bt, n2, s2, l2);
       if(bt->n >= BATCH_PAIRS) {
+        g_busy[0] += now_s() - t0;
         fifo_put(&g_read, bt);
         bt = fifo_get(&g_free);         /* blocks while all batches are downstream: bounded memory */
+        t0 = now_s();
         bt->n = 0; bt->text_len = 0; bt->last = 0;
       }
     }
@@ -543,17 +550,44 @@ static void *reader_main(void *arg)
     if(r2) seqalign_reader_close(r2);
   }
   bt->last = 1;
+  g_busy[0] += now_s() - t0;
   fifo_put(&g_read, bt);
   return NULL;
 }
 
-/* stage 2 */
+/* stage 2.  Opening the GPU (runtime initialisation + context: 0.2-0.3 s) is this thread's first job, so that it runs beside
+ * the reader's first batch instead of in front of it. */
+static void open_gpus(void)
+{
+  int rc = seqalign_ctx_create(getenv("SEQALIGN_DEVICE") ? atoi(getenv("SEQALIGN_DEVICE")) : 0, &g_ctxs[0]);
+  if(rc != SEQALIGN_OK) {
+    fprintf(stderr, "seqalign: cannot open the GPU: %s (%s)\nseqalign: there is no CPU path; an MI355X (gfx950) is required\n",
+            seqalign_strerror(rc), seqalign_last_error());
+    exit(EXIT_FAILURE);
+  }
+  if(getenv("SEQALIGN_GPUS")) {
+    int want = atoi(getenv("SEQALIGN_GPUS")), have = seqalign_device_count(), g;
+    if(want > have) want = have;
+    if(want > 64) want = 64;
+    for(g = 1; g < want; g++) {
+      if(seqalign_ctx_create(g, &g_ctxs[g]) != SEQALIGN_OK) {
+        fprintf(stderr, "seqalign: cannot open GPU %i: %s\n", g, seqalign_last_error());
+        exit(EXIT_FAILURE);
+      }
+      g_nctx = g + 1;
+    }
+  }
+}
+
 static void *aligner_main(void *arg)
 {
   (void)arg;
+  open_gpus();
   for(;;) {
     batch_t *bt = fifo_get(&g_read);
+    const double t0 = now_s();
     if(opt.tool == TOOL_NW) align_nw(bt); else align_sw(bt);
+    g_busy[1] += now_s() - t0;
     fifo_put(&g_aligned, bt);
     if(bt->last) return NULL;
   }
@@ -581,10 +615,9 @@ static void usage(void)
 int main(int argc, char **argv)
 {
   const char *base = strrchr(argv[0], '/');
-  seqalign_ctx_t *ctx = NULL;
   static batch_t batches[N_BATCHES];
   pthread_t reader, aligner;
-  int k, rc;
+  int k;
   base = base ? base + 1 : argv[0];
   /* a command-line run is short: skip the ~0.1-0.2 s the library would spend looking for a good
      placement of its matrix arenas (seqalign_hip.h, seqalign_arenas_alloc) unless the user asks for it */
@@ -599,27 +632,7 @@ int main(int argc, char **argv)
   }
   parse_args(argc, argv);
 
-  rc = seqalign_ctx_create(getenv("SEQALIGN_DEVICE") ? atoi(getenv("SEQALIGN_DEVICE")) : 0, &ctx);
-  if(rc != SEQALIGN_OK) {
-    fprintf(stderr, "seqalign: cannot open the GPU: %s (%s)\nseqalign: there is no CPU path; an MI355X (gfx950) is required\n",
-            seqalign_strerror(rc), seqalign_last_error());
-    return EXIT_FAILURE;
-  }
-
-  g_ctxs[0] = ctx;
-  if(getenv("SEQALIGN_GPUS")) {
-    int want = atoi(getenv("SEQALIGN_GPUS")), have = seqalign_device_count(), g;
-    if(want > have) want = have;
-    if(want > 64) want = 64;
-    for(g = 1; g < want; g++) {
-      if(seqalign_ctx_create(g, &g_ctxs[g]) != SEQALIGN_OK) {
-        fprintf(stderr, "seqalign: cannot open GPU %i: %s\n", g, seqalign_last_error());
-        return EXIT_FAILURE;
-      }
-      g_nctx = g + 1;
-    }
-  }
-
+  setvbuf(stdout, NULL, _IOFBF, (size_t)4 << 20);   /* hundreds of MB of text: fewer, larger writes */
   fifo_init(&g_free); fifo_init(&g_read); fifo_init(&g_aligned);
   for(k = 0; k < N_BATCHES; k++) fifo_put(&g_free, &batches[k]);
   if(pthread_create(&reader, NULL, reader_main, NULL) || pthread_create(&aligner, NULL, aligner_main, NULL)) {
@@ -629,12 +642,15 @@ int main(int argc, char **argv)
   for(;;) {   /* stage 3, here: in input order */
     batch_t *bt = fifo_get(&g_aligned);
     const int last = bt->last;
+    const double t0 = now_s();
     if(opt.tool == TOOL_NW) print_nw_batch(bt); else print_sw_batch(bt);
+    g_busy[2] += now_s() - t0;
     if(last) break;
     fifo_put(&g_free, bt);
   }
   pthread_join(reader, NULL); pthread_join(aligner, NULL);
-  for(k = 1; k < g_nctx; k++) seqalign_ctx_destroy(g_ctxs[k]);
-  seqalign_ctx_destroy(ctx);
+  if(getenv("SEQALIGN_CLI_TIMING"))
+    fprintf(stderr, "seqalign: stages busy: read %.3f s, align %.3f s, print %.3f s\n", g_busy[0], g_busy[1], g_busy[2]);
+  for(k = 0; k < g_nctx; k++) seqalign_ctx_destroy(g_ctxs[k]);
   return EXIT_SUCCESS;
 }

@@ -30,12 +30,13 @@ with open(fa, "wb") as f:
             out.append(b">a%d\n%s\n>b%d\n%s\n" % (lo + p, b.seq_a(p), lo + p, b.seq_b(p)))
         f.write(b"".join(out))
 print(f"wrote {fa} ({fa.stat().st_size / 1e6:.0f} MB, {n} pairs) in {time.perf_counter() - t0:.1f} s", flush=True)
-exe = ROOT / "seq-align_amd" / "bin" / "seqalign_nw"
+import os
+exe = Path(os.environ.get("CLI_EXE") or (ROOT / "seq-align_amd" / "bin" / "seqalign_nw"))
 for rep in range(3):
     out = tmp / "out.txt"
     t0 = time.perf_counter()
     with open(out, "wb") as fo:
-        subprocess.run([str(exe), "--printscores", "--file", str(fa)], stdout=fo, check=True)
+        subprocess.run([str(exe), "--printscores", "--file", str(fa)], stdout=fo, check=True, env=dict(os.environ, SEQALIGN_CLI_TIMING="1"))
     dt = time.perf_counter() - t0
     print(f"seqalign_nw --printscores --file: {dt:.3f} s wall, {n / dt / 1e6:.3f} M pairs/s, {n * 22500 / dt / 1e9:.1f} GCUPS end to end "
           f"(output {out.stat().st_size / 1e6:.0f} MB)", flush=True)
