@@ -4,8 +4,27 @@
 import csv, glob, json, os, sqlite3, sys
 from collections import defaultdict
 out, root, tag = sys.argv[1:4]   # <collected directory> <repo root> <tag of profiles/<tag>/>
-mix = json.load(open(os.path.join(root, "profiles", "r04", "r04_valu_mix.json")))
+# the static VALU mix of the kernels' row loops: the newest table (profiles/scripts/valu_mix_table.sh; it follows the source)
+mix_files = sorted(glob.glob(os.path.join(root, "profiles", "r0*", "r0*_valu_mix.json")))
+mix_path = sys.argv[4] if len(sys.argv) > 4 else mix_files[-1]
+mix = json.load(open(mix_path))
 N_SIMD, CLOCK = 1024, 2.4e9
+# The walkers are bound by a chain of DEPENDENT accesses, one per step of the walk (src/alignment.c:244-350: the next cell
+# follows from this one's direction), not by issue or bandwidth.  Their bound: rounds of resident walks x steps x the latency of
+# one step's access (MI355X_MICROARCH.md: ds_read ~50 cycles, global_load L2 hit ~200 cycles, HBM miss ~900 cycles at 2.4 GHz).
+#   tile walker (one wave per walk, 64 x 64-byte tiles of directions in LDS): a step is an LDS read; a tile costs one miss.
+#   lane walker (one lane per walk, the next byte asked for ahead): a step is a byte load that misses (the bytes left L2 long
+#   ago: C5's share writes 2.9 GB of them), two in flight per lane.
+LAT = {"lds": 50 / CLOCK, "l2": 200 / CLOCK, "hbm": 900 / CLOCK}
+def walker_bound(kernel, launches_items, steps):
+    """(bound seconds, description) of one launch of a walker kernel over `launches_items` walks of `steps` steps each."""
+    if "tile" in kernel:
+        slots = N_SIMD * 8                              # waves resident at once
+        rounds = max(1.0, launches_items / slots)
+        per_walk = steps * LAT["lds"] + (steps / 64.0 + 1.0) * LAT["hbm"]
+        return rounds * per_walk, f"{rounds:.2f} rounds of resident walks x ({steps:.0f} steps x 50-cycle LDS read + {steps / 64 + 1:.1f} tiles x 900-cycle miss)"
+    per_walk = steps * LAT["hbm"] / 2.0
+    return per_walk, f"{steps:.0f} steps x 900-cycle miss / 2 loads in flight per lane (every walk has a lane: one round)"
 res = {}
 pmc_all = {}   # every counter of the --pmc passes, per workload and kernel: mean per launch -> <out>/e2e_pmc_insts.json
 for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C4_4000_hits4"):
@@ -29,6 +48,14 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
             pmc_all.setdefault(key, {}).setdefault(kn, {}).setdefault(cname, []).append(float(val))
             if cname == "SQ_INSTS_VALU":
                 insts[kn].append(float(val))
+    # walks per launch and steps per walk: from the driver's own line in the trace log ("walks W steps S") when it prints one
+    steps = walks = None
+    logf = os.path.join(out, key + ".trace.log")
+    if os.path.exists(logf):
+        import re
+        m = re.search(r"walks (\d+) mean_steps ([0-9.]+)", open(logf).read())
+        if m:
+            walks, steps = int(m.group(1)), float(m.group(2))
     kernels = {}
     for k, v in dur.items():
         v = v[len(v) // 3:]          # the first call sizes buffers: later launches only
@@ -41,6 +68,13 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
             cpi = m["mix"]["cycles_per_valu_instruction"]
             e["cycles_per_instruction"] = cpi
             e["frac"] = e["instructions"] * cpi / (N_SIMD * CLOCK * e["kernel_ms"] * 1e-3)
+        if "traceback" in k and steps:
+            launches_per_call = max(1, round(len(dur[k]) / 6)) if key.startswith(("C2", "C5")) else max(1, round(len(dur[k]) / 3))
+            b, how = walker_bound(k, walks / launches_per_call, steps)
+            e["bound"] = "dependent_latency"
+            e["bound_ms"] = b * 1e3
+            e["frac"] = b * 1e3 / e["kernel_ms"]
+            e["bound_model"] = how
         kernels[k] = e
     total = sum(e["kernel_ms"] * e["launches_seen"] for e in kernels.values())
     for e in kernels.values():
@@ -51,7 +85,7 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
                 "instructions": d.get("instructions"), "cycles_per_instruction": d.get("cycles_per_instruction"),
                 "frac": round(d["frac"], 3) if "frac" in d else None,
                 "peak": "1024 SIMDs x 2.4 GHz; cycles per wave64 instruction by rate class (profiles/r03/r03_valu_rate_probe.txt) "
-                        "weighted by the static mix of the kernel's row loop (profiles/r04/r04_valu_mix.json)",
+                        f"weighted by the static mix of the kernel's row loop ({os.path.relpath(mix_path, root)})",
                 "source": f"profiles/{tag}/: rocprofv3 --kernel-trace (durations) and --pmc SQ_INSTS_VALU (own pass) over the host-level call",
                 "kernels_of_the_call": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in e.items()} for k, e in kernels.items()}}
 json.dump({k: {kn: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()} for kn, cs in ks.items()} for k, ks in pmc_all.items()},

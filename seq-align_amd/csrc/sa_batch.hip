@@ -943,23 +943,39 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   for (uint32_t s = 0; s < n_sub; ++s) {
     const uint64_t b0 = bcut[s], b1 = bcut[s + 1], k0 = pair_at(b0), k1 = pair_at(b1);
     if (k1 > k0) {
-      parallel_for(b1 - b0, [&](uint64_t bi) {   // host: this sub-batch's sequences into the pinned arena
-        if (blk[b0 + bi].packed) {   // the caller's arena already has them back to back (any batch built pair by pair): one copy
-          const uint64_t k = (b0 + bi) * kHostBlk;
-          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[c.first + k], blk[b0 + bi].chars);
-          return;
+      // host: this sub-batch's sequences into the pinned arena, and up -- in SLICES (round 5): a slice's copy to the device runs
+      // beside the packing of the next one.  C2's single sub-batch packed for 42 us and then uploaded for 72 (3 MB at 42 GB/s)
+      // before its fill could start; in four slices of quarter-block tasks (every pool thread has work in every slice) the last
+      // byte is up ~20 us after the last one is packed.
+      const uint64_t n_blocks = b1 - b0;
+      const uint64_t n_slices = zc_in ? 1 : std::min<uint64_t>(ctx->opt.upload_slices ? ctx->opt.upload_slices : 1, std::max<uint64_t>(1, n_blocks / 2));
+      constexpr uint64_t kParts = 4;   // tasks per block
+      for (uint64_t sl = 0; sl < n_slices; ++sl) {
+        const uint64_t sb0 = b0 + n_blocks * sl / n_slices, sb1 = b0 + n_blocks * (sl + 1) / n_slices;
+        parallel_for((sb1 - sb0) * kParts, [&](uint64_t ti) {
+          const uint64_t bi = sb0 + ti / kParts, part = ti % kParts;
+          const uint64_t kb = bi * kHostBlk, ke = std::min(n, (bi + 1) * kHostBlk), span = ke - kb;
+          const uint64_t ka = kb + span * part / kParts, kz = kb + span * (part + 1) / kParts;
+          if (kz <= ka) return;
+          if (blk[bi].packed) {   // the caller's arena already has them back to back (any batch built pair by pair): one copy
+            const uint64_t bytes = (kz < n ? h_off_a[kz] : total) - h_off_a[ka];
+            memcpy(h_seq + h_off_a[ka], batch->arena + batch->off_a[c.first + ka], bytes);
+            return;
+          }
+          for (uint64_t k = ka; k < kz; ++k) {
+            const uint64_t p = c.first + k;
+            memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], h_len_a[k]);
+            memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], h_len_b[k]);
+          }
+        });
+        if (!zc_in) {
+          const uint64_t c0 = h_slot[pair_at(sb0)], c1 = h_slot[pair_at(sb1)];
+          // (tried for C2's single sub-batch: the sequences in two halves on the upload and the download stream -- the runtime
+          // runs both host-to-device copies on one engine, 39 + 38 us one after the other instead of 72)
+          if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, su));
         }
-        for (uint64_t k = (b0 + bi) * kHostBlk, e = std::min(n, (b0 + bi + 1) * kHostBlk); k < e; ++k) {
-          const uint64_t p = c.first + k;
-          memcpy(h_seq + h_off_a[k], batch->arena + batch->off_a[p], h_len_a[k]);
-          memcpy(h_seq + h_off_b[k], batch->arena + batch->off_b[p], h_len_b[k]);
-        }
-      });
+      }
       if (!zc_in) {
-        const uint64_t c0 = h_slot[k0], c1 = h_slot[k1];
-        // (tried for C2's single sub-batch: the sequences in two halves on the upload and the download stream -- the runtime
-        // runs both host-to-device copies on one engine, 39 + 38 us one after the other instead of 72)
-        if (c1 > c0) HIP_TRY(hipMemcpyAsync(ctx->arena.as<uint8_t>() + c0, h_seq + c0, c1 - c0, hipMemcpyHostToDevice, su));
         HIP_TRY(hipEventRecord(ev.ev[s], su));
         HIP_TRY(hipStreamWaitEvent(sf, ev.ev[s], 0));
       }

@@ -290,6 +290,7 @@ struct SaOptions {
   uint32_t reduce_depth = 0;      // reduce_depth      0|4|8: KiB per wave and step of sw_reduce_kernel (0 = 4; 8 measured slower)
   bool timing = false;            // timing            stage laps of the host-level calls on stderr
   size_t chunk_bytes = 0;         // chunk_bytes       device memory one host-level chunk may use (0: 40 % of free, <= 48 GB)
+  uint32_t upload_slices = 0;     // upload_slices     seqalign_nw_batch (moves path): slices a sub-batch's sequences are packed and uploaded in (0 = 1)
   uint32_t subbatches = 0;        // subbatches        sub-batches a chunk of seqalign_nw_batch is pipelined in (0: by size, 1: off)
   uint32_t arena_scan_gib = 160;  // arena_scan_gib    how much HBM the arena placement may hold transiently while it looks
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
@@ -395,7 +396,7 @@ bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t 
 // cells start on a multiple of 256)
 bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 // Two pairs per wave halve the waves of a launch: below ~2 000 pairs of a chunk (a quarter of the chip's wave slots) the
-// one-pair kernels are as fast or faster (tools/x2_crossover.py, C2 / C3 shapes: 1 024 pairs +3 %, 2 048: -3 %, 8 192: -10 %)
+// one-pair kernels are as fast or faster (profiles/r03/r03_x2_crossover.txt, C2 / C3 shapes: 1 024 pairs +3 %, 2 048: -3 %, 8 192: -10 %)
 constexpr uint64_t kPackedFillMinPairs = 2048;
 bool sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b, const seqalign_trace_t *t,

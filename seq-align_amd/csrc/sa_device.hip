@@ -230,6 +230,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
     return true;
   }
   if (is("subbatches")) { if (!number(0, 256, &num)) return false; o.subbatches = (uint32_t)num; return true; }
+  if (is("upload_slices")) { if (!number(0, 16, &num)) return false; o.upload_slices = (uint32_t)num; return true; }
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
   if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
   if (is("arena_quality")) {
@@ -269,6 +270,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("timing")) return n(o.timing);
   if (is("chunk_bytes")) return n((long long)o.chunk_bytes);
   if (is("subbatches")) return n(o.subbatches);
+  if (is("upload_slices")) return n(o.upload_slices);
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
   if (is("arena_keep_gib")) return n(o.arena_keep_gib);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
@@ -279,7 +281,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);

@@ -527,7 +527,7 @@ fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena,
 // The same for a chunk whose pairs are MOSTLY of one shape, in ONE grid: the first x2_blocks workgroups take the n_modal
 // pairs of the modal shape two per wave (p.pair_list[0 .. n_modal)), the others the n_rest remaining pairs one per wave
 // (p.pair_list[n_modal ..), fill_nw_dirs_kernel's body).  Two launches would run one after the other, and a launch of a
-// few hundred one-pair waves takes as long as its longest pair's rows however few they are (tools/mixed_check.py).
+// few hundred one-pair waves takes as long as its longest pair's rows however few they are (profiles/r03/r03_mixed_check.txt; today: tools/x2_check.py check_mixed).
 template <int CPL, int SUBST, int R>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t x2_blocks, const uint32_t n_modal,

@@ -27,7 +27,7 @@
 // LDS per wave: 3 rings x R ints (R = 512 for len_a <= 255, else 1024) = 6 / 12
 // KiB; one wave per pair, 4 pairs per workgroup, no barrier after the table load.
 //
-// Tuning record (C2, in-process A/B with seq-align_amd/tools/ab.py, round 1):
+// Tuning record (C2, in-process A/B, round 1: profiles/r01_variants_stream.txt; today: tools/ab_option.py):
 //   flush unit 1 KiB vs 2 KiB, 1/2/4/8 pairs per workgroup (4 and 8 best), 8-24
 //   resident waves per CU, cache-policy bits (plain / nt / sc1 / sc0 sc1, +-2 %;
 //   nt kept), removing the arithmetic or the LDS ring altogether: none moves the

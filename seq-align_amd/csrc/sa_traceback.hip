@@ -730,7 +730,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
     return hipGetLastError();
   }
   const bool sw = p.start_index || p.hit_keys;
-  // Measured (seq-align_amd/tools/long_e2e.py): the tiled wave-per-pair walker wins when there are few pairs
+  // Measured (round 2 record: profiles/r02/; the tool was pruned in round 5): the tiled wave-per-pair walker wins when there are few pairs
   // (1 x 10 000^2: 9.5 -> 7.4 ms, 16 x 5 000^2: 6.6 -> 4.2 ms of traceback) and loses a little when the lanes of
   // one-lane-per-pair waves are all busy (10 k x 150^2: +0.13 ms).  The option trace_kernel = lane | wave forces one.
   // SW walks (a hit is ~the shorter sequence long): the tiled walker also wins with 10 000 walks (C3: 0.58 -> 0.47 ms,

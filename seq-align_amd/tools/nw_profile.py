@@ -21,5 +21,7 @@ sc = S.make_scoring(spec)
 ctx = S.Context(0)
 for it in range(6):
     t0 = time.perf_counter()
-    ctx.nw_batch(batch, sc, raw=True)
+    res = ctx.nw_batch(batch, sc, raw=True)
     print("nw_batch", n, "pairs %.3f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+# (for profiles/e2e_roofline_summarise.py: the walkers' latency bound needs the walks' lengths)
+print("walks %d mean_steps %.1f" % (n, float(res[3].mean())), flush=True)

@@ -25,5 +25,12 @@ thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
 ctx = S.Context(0)
 for it in range(3):
     t0 = time.perf_counter()
-    nh = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=min(max_hits, 20) * n + 8, raw=True)[0]
+    res = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=min(max_hits, 20) * n + 8, raw=True)
+    nh = res[0]
     print(name, "max_hits", max_hits, "hits", nh, "%.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+# (for profiles/e2e_roofline_summarise.py: the walkers' latency bound needs the walks' lengths)
+try:
+    hits = res[1]
+    print("walks %d mean_steps %.1f" % (nh, float(np.mean([h.length for h in hits[:nh]])) if nh else 0.0), flush=True)
+except Exception as e:      # the raw result's layout is the driver's business: no bound then
+    print("walks: no lengths (%s)" % e, flush=True)
