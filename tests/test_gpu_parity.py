@@ -1088,6 +1088,36 @@ def test_sw_batch_output_capacity_is_respected(ctx):
         assert err.value.code == 4   # SEQALIGN_E_NOMEM
 
 
+@pytest.mark.parametrize("nw_moves", [1, 0])
+def test_sw_batch_out_of_room_delivers_what_fits(ctx, nw_moves):
+    """the best-hit path with the moves walkers returned SEQALIGN_E_NOMEM before expanding the hits of the chunk that
+    did fit, the string path after -- the same call gave different *n_hits by an internal option.  Both deliver the fitting
+    prefix (in pair order, equal to the uncapped call's first hits), then SEQALIGN_E_NOMEM."""
+    import ctypes as C
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    batch = W.dna_sw_read_vs_ref(40, seed=7, read_len=60, ref_len=200)
+    with S.Context(0) as c:
+        c.set_option("nw_moves", nw_moves)
+        full = c.sw_batch(batch, sc, 20, max_hits=1)
+        assert sum(len(h) for h in full) >= 30
+        hit_cap = 11
+        hits = (S.SwHit * hit_cap)()
+        str_cap = hit_cap * (60 + 200 + 2)
+        out_a, out_b = np.zeros(str_cap, np.uint8), np.zeros(str_cap, np.uint8)
+        n_hits = C.c_uint64(0)
+        ms = np.full(batch.n_pairs, 20, np.int32)
+        d = S.batch_desc(batch)
+        rc = S.lib().seqalign_sw_batch(c._h, C.byref(d), C.byref(sc), S._ptr(ms), C.c_uint32(1), hits, C.c_uint64(hit_cap),
+                                       C.byref(n_hits), S._ptr(out_a), S._ptr(out_b), C.c_uint64(str_cap))
+        assert rc == 4 and n_hits.value == hit_cap          # SEQALIGN_E_NOMEM, and every slot used
+        flat = [(p, h) for p, hs in enumerate(full) for h in hs]
+        for k in range(hit_cap):
+            h, (p, want) = hits[k], flat[k]
+            got = dict(score=h.score, pos_a=h.pos_a, pos_b=h.pos_b, len_a=h.len_a, len_b=h.len_b,
+                       a=out_a[h.str_off:h.str_off + h.length].tobytes().decode(), b=out_b[h.str_off:h.str_off + h.length].tobytes().decode())
+            assert h.pair == p and got == want, (k, p)
+
+
 def test_sw_batch_multi_hit_in_several_chunks(ctx):
     """seqalign_sw_batch(max_hits > 1) on a batch that does not fit one chunk (tiny chunk budget): the per-chunk
     scratch (hit keys, walker lists, string slots) is reused chunk after chunk; hits equal the one-chunk call's."""
