@@ -386,18 +386,6 @@ def run(args) -> int:
     ctx = S.Context(local)
     sc = S.make_scoring(spec)
     h = ctx.upload_scoring(sc, is_sw)
-    # What the SAME kernel does on arenas nobody placed (one plain allocation, the three arenas back to back): a few steps,
-    # before the walk, so that the line states what the placement contributes instead of implying it (roofline.frac_unplaced).
-    unplaced = None
-    if args.placement == "spread" and not args.no_unplaced and world == 1:
-        dbp = S.DeviceBatch(batch, local, placement="packed", ctx=ctx)
-        kp = S.KERNEL_STREAM if args.kernel == "auto" else {v: k for k, v in S.KERNEL_NAMES.items()}[args.kernel]
-        ms = dbp.time_fill_ms(ctx, h, kp, 5)[2:]
-        unplaced = {"kernel_ms": float(np.mean(ms)), "steps": len(ms), "kernel": S.KERNEL_NAMES[kp],
-                    "arenas": "one plain allocation (torch.empty), three arenas back to back; no walk"}
-        del dbp
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
     db = S.DeviceBatch(batch, local, placement=args.placement, ctx=ctx)   # arenas from seqalign_arenas_alloc
     t_placed = time.perf_counter()
 
@@ -543,6 +531,21 @@ def run(args) -> int:
         gM, gA, gB = db.pair_matrices(p)
         bit_exact &= rc == 0 and np.array_equal(M, gM) and np.array_equal(A, gA) and np.array_equal(B, gB)
     bit_exact = grp.sum_int(0 if bit_exact else 1) == 0
+
+    # What the SAME kernel does on arenas nobody placed: three plain arenas (option arena_scan_gib = 0: no walk), a few steps --
+    # so that the line states what the placement contributes instead of implying it (roofline.frac_unplaced).  Measured LAST:
+    # an allocation of gigabytes before the walk changes what the allocator hands the walk (one box of four ended at quality
+    # 1.012 / 0.815 with it in front).  The arenas come from the chunks the walk left with the process when there are any --
+    # consecutive 512 MiB chunks of the allocation order, which is what three hipMallocs in a row are too.
+    unplaced = None
+    if args.placement == "spread" and not args.no_unplaced and world == 1:
+        with ctx.options(arena_scan_gib=0):
+            dbp = S.DeviceBatch(batch, local, placement="spread", ctx=ctx)
+        ms = dbp.time_fill_ms(ctx, h, kernel, 6)[2:]
+        unplaced = {"kernel_ms": float(np.mean(ms)), "steps": len(ms), "kernel": S.KERNEL_NAMES[kernel],
+                    "arenas": "three plain arenas, no walk (seqalign_arenas_alloc with arena_scan_gib = 0), measured after the timed loop"}
+        del dbp
+        torch.cuda.synchronize()
 
     # per-rank figures for the report: a slow rank (placement, NUMA, a busy neighbour) must be visible, not averaged away
     per_rank = grp.gather_objects({"rank": rank, "device": local, "kernel_ms": round(kern_ms, 4),
