@@ -295,6 +295,7 @@ struct SaOptions {
   uint32_t arena_scan_gib = 160;  // arena_scan_gib    how much HBM the arena placement may hold transiently while it looks
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
+  uint32_t arena_free_pct = 60;   // arena_free_pct    share of the memory free at the start that an explicit placement walk may hold (10 .. 90)
   uint32_t arena_keep_gib = 16;   // arena_keep_gib    how much of a walk's unused chunks stays with the process (the chunk pool: large scratch
                                   //                   buffers are mapped from it instead of freshly released, not yet cleared VRAM); 0: none
 };

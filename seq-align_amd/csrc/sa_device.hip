@@ -91,7 +91,7 @@ static SaPlacementOpts placement_opts(const seqalign_ctx *ctx, bool explicit_cal
   o.scan_bytes = (size_t)ctx->opt.arena_scan_gib << 30;
   o.quality_stop = ctx->opt.arena_quality;
   o.keep_bytes = (size_t)ctx->opt.arena_keep_gib << 30;
-  o.free_fraction = 0.6f;
+  o.free_fraction = 0.01f * (float)ctx->opt.arena_free_pct;
   if (!explicit_call) {
     o.free_fraction = 0.25f;
     if (ctx->arena_walks > 0) o.scan_bytes = std::min<size_t>(o.scan_bytes, (size_t)16 << 30);
@@ -233,6 +233,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("upload_slices")) { if (!number(0, 16, &num)) return false; o.upload_slices = (uint32_t)num; return true; }
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
   if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
+  if (is("arena_free_pct")) { if (!number(10, 90, &num)) return false; o.arena_free_pct = (uint32_t)num; return true; }
   if (is("arena_quality")) {
     char *end = nullptr;
     const double q = strtod(val, &end);
@@ -273,6 +274,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("upload_slices")) return n(o.upload_slices);
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
   if (is("arena_keep_gib")) return n(o.arena_keep_gib);
+  if (is("arena_free_pct")) return n(o.arena_free_pct);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
   return false;
 }
@@ -281,7 +283,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
