@@ -562,6 +562,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   seqalign_dev_batch_t d;
   bool have_best = false;   // the stream kernel reports the best cell itself
   const uint64_t n = c.count;
+  StageTimer tm(ctx->opt.timing);
   // Every pair of the chunk the same shape, match / mismatch scoring, scores inside int16: the fill writes only a byte of
   // directions per cell and finds the best cell itself, two pairs per wave (sa_fill_dirs_x2.hip: fill_sw_best_x2_kernel);
   // the walk follows the bytes.  No match_scores, no gap matrices: they are not even allocated.
@@ -641,40 +642,74 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel;
     hipError_t e2 = sa_launch_nw_traceback(tp, st);
     if (e2 != hipSuccess) return fail_hip(e2, "sw best-hit traceback");
-    if ((rc = fetch_status(ctx, c, nullptr))) return rc;   // syncs
+    tm.lap("sw best hit: fill + walk enqueued");
+    // (no fetch_status here: a direction fill is only admitted for scorings in which every character pair has a score, and the
+    // walks carry a pair's fill status home in their own word anyway -- the copy and its scan were 20 us of nothing)
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.lap("sw best hit: wait (upload, fill, walk)");
     const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
-    std::vector<uint64_t> hit_pair, hit_out;
-    hit_pair.reserve(n); hit_out.reserve(n);
-    bool out_of_room = false;
-    for (uint64_t k = 0; k < n; ++k) {
-      const uint64_t p = c.first + k;
-      const int32_t score = (int32_t)h_w[4 * k];
-      const uint32_t len = h_w[4 * k + 1];
-      if (len >= SA_MOVES_ERR) return (int)(len & 15u);
-      if (score <= 0 || score < min_score[p]) continue;
-      // out of room: the hits of this chunk that DID fit are still delivered (as the string path below and the one-trip
-      // multi-hit path do), then SEQALIGN_E_NOMEM
-      if (found + hit_pair.size() >= hit_cap || used_str + len + 1 > str_cap) { out_of_room = true; break; }
-      hit_pair.push_back(k); hit_out.push_back(used_str);
-      used_str += len + 1;
-    }
-    const uint64_t first_hit = found, n_out = hit_pair.size();
+    // Where every hit goes in the caller's buffers: hits and string bytes per block of pairs (parallel -- round 4 counted in one
+    // serial pass over words the GPU had just written, every line of them a miss: 0.1 ms of C4's 0.89 ms call), a prefix over
+    // the blocks, then every block places and expands its own hits.
+    constexpr uint64_t kBlk = 64;
+    const uint64_t nblk = (n + kBlk - 1) / kBlk;
+    std::vector<uint64_t> blk_hits(nblk + 1, 0), blk_bytes(nblk + 1, 0);
+    std::atomic<uint64_t> first_err{~0ull};   // pair << 8 | code of the LOWEST failing pair
+    auto is_hit = [&](uint64_t k) { const int32_t sc_ = (int32_t)h_w[4 * k]; return sc_ > 0 && sc_ >= min_score[c.first + k]; };
+    parallel_for(nblk, [&](uint64_t bi) {
+      uint64_t hs = 0, bytes = 0;
+      for (uint64_t k = bi * kBlk, e3 = std::min(n, (bi + 1) * kBlk); k < e3; ++k) {
+        const uint32_t len = h_w[4 * k + 1];
+        if (len >= SA_MOVES_ERR) {
+          uint64_t seen = first_err.load(std::memory_order_relaxed);
+          const uint64_t mine = k << 8 | (len & 15u);
+          while (mine < seen && !first_err.compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {}
+          continue;
+        }
+        if (is_hit(k)) { ++hs; bytes += (uint64_t)len + 1; }
+      }
+      blk_hits[bi + 1] = hs; blk_bytes[bi + 1] = bytes;
+    });
+    if (first_err.load() != ~0ull) return (int)(first_err.load() & 255u);
+    for (uint64_t bi = 0; bi < nblk; ++bi) { blk_hits[bi + 1] += blk_hits[bi]; blk_bytes[bi + 1] += blk_bytes[bi]; }
+    // what fits: whole blocks while they do, the first that does not pair by pair; the call reports SEQALIGN_E_NOMEM AFTER
+    // delivering what fits (as the string path below and the one-trip multi-hit path do)
+    const uint64_t hit_room = hit_cap > found ? hit_cap - found : 0, str_room = str_cap > used_str ? str_cap - used_str : 0;
+    const bool out_of_room = blk_hits[nblk] > hit_room || blk_bytes[nblk] > str_room;
+    const uint64_t first_hit = found, first_str = used_str;
+    std::atomic<uint64_t> delivered_hits{0}, delivered_bytes{0};
     std::atomic<int> bad{SEQALIGN_OK};
-    constexpr uint64_t kPack = 128;
-    parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
-      for (uint64_t i = blk * kPack, e3 = std::min(n_out, (blk + 1) * kPack); i < e3; ++i) {
-        const uint64_t k = hit_pair[i], p = c.first + k;
+    parallel_for(nblk, [&](uint64_t bi) {
+      uint64_t hi = blk_hits[bi], at = blk_bytes[bi], done_h = 0, done_b = 0;
+      if (hi >= hit_room || at >= str_room) return;   // (everything from here on is beyond the caller's room)
+      for (uint64_t k = bi * kBlk, e3 = std::min(n, (bi + 1) * kBlk); k < e3; ++k) {
+        if (k + 6 < e3) {   // the GPU wrote these lines: every first touch is a miss -- have the pair six ahead on its way
+          const uint64_t kn = k + 6;
+          const uint32_t nwn = (batch->len_a[c.first + kn] + batch->len_b[c.first + kn] + 31u) >> 5;
+          const uint32_t *pn = h_moves + 2ull * ((h_off[kn] >> 5) + kn);
+          __builtin_prefetch(h_w + 4 * kn); __builtin_prefetch(pn + nwn - 1); __builtin_prefetch(pn + 2 * nwn - 1);
+          __builtin_prefetch(batch->arena + batch->off_a[c.first + kn]);
+        }
+        if (!is_hit(k)) continue;
+        const uint64_t p = c.first + k;
+        const uint32_t len = h_w[4 * k + 1];
+        if (hi >= hit_room || at + len + 1 > str_room) break;   // (out_of_room is set: the call reports it)
         const uint32_t la = batch->len_a[p], lb = batch->len_b[p], nwd = (la + lb + 31u) >> 5;
         const uint32_t *pa = h_moves + 2ull * ((h_off[k] >> 5) + k);
         uint32_t pos[4];
         const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3],
-                                           pa, pa + nwd, nwd, h_w[4 * k + 1], out_a + hit_out[i], out_b + hit_out[i], pos);
-        if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); continue; }
-        seqalign_sw_hit_t &h = hits[first_hit + i];
+                                           pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
+        if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); break; }
+        seqalign_sw_hit_t &h = hits[first_hit + hi];
         h.pair = p; h.score = (int32_t)h_w[4 * k]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
-        h.length = h_w[4 * k + 1]; h.str_off = hit_out[i];
+        h.length = len; h.str_off = first_str + at;
+        ++hi; at += (uint64_t)len + 1; ++done_h; done_b += (uint64_t)len + 1;
       }
+      delivered_hits.fetch_add(done_h, std::memory_order_relaxed); delivered_bytes.fetch_add(done_b, std::memory_order_relaxed);
     });
+    const uint64_t n_out = delivered_hits.load();
+    used_str += delivered_bytes.load();
+    tm.lap("sw best hit: hits collected + expanded");
     if (bad.load()) return bad.load();
     found += n_out;
     if (out_of_room) { *n_hits = found; return SEQALIGN_E_NOMEM; }

@@ -411,6 +411,22 @@ def test_nw_batch_pipelined_subbatches(ctx, opts, n_sub, dirs):
     assert err.value.code == S.E_UNKNOWN_PAIR
 
 
+@pytest.mark.parametrize("max_hits", [1, 4])
+def test_sw_batch_reports_an_unknown_character_pair(ctx, max_hits):
+    """A character pair without a score (use_match_mismatch = 0: the reference exits there, alignment_scoring.c:178-181) fails the
+    local call with SEQALIGN_E_UNKNOWN_PAIR whatever path the other pairs would take -- small and large (packed-fill sized)
+    batches, best hit and several hits."""
+    hyb = S.make_scoring({"preset": "DNA_hybridization"})
+    good = (b"ACGTACGTAC" * 6, b"TTACGTACGTACGA" * 5)
+    for n in (9, 2500):
+        pairs = [good] * n
+        assert all(len(h) >= 1 for h in ctx.sw_batch(W.from_pairs(pairs), hyb, 5, max_hits=max_hits))
+        pairs[n // 2] = (good[0], good[1][:20] + b"X" + good[1][21:])
+        with pytest.raises(S.SeqAlignError) as err:
+            ctx.sw_batch(W.from_pairs(pairs), hyb, 5, max_hits=max_hits)
+        assert err.value.code == S.E_UNKNOWN_PAIR
+
+
 @pytest.mark.parametrize("max_len", [40, 100, 180, 250, 300, 380, 500, 511, 512, 513, 700])
 def test_direction_byte_paths_every_width(ctx, max_len):
     """The direction-byte fills (sa_fill_dirs.hip) in every columns-per-lane instantiation and on both sides of their
