@@ -256,7 +256,7 @@ int sa_host::fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_ou
   if ((rc = ctx->h_misc.reserve(c.count * 8))) return rc;
   uint64_t *h = ctx->h_misc.as<uint64_t>();
   HIP_TRY(hipMemcpyAsync(h, ctx->status.p, c.count * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(stream_wait_spinning(ctx->stream));
   rc = SEQALIGN_OK;
   for (uint64_t k = 0; k < c.count; ++k) {
     if (status_out) status_out[c.first + k] = h[k];
@@ -741,20 +741,6 @@ void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, uint64_t
     }
     blk[bi] = s;
   });
-}
-hipError_t wait_event_spinning(hipEvent_t e) {
-  // a group is a fraction of a millisecond away: poll first (a blocking wait adds the wake-up of a sleeping thread)
-  timespec t0, t1;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
-  for (unsigned spins = 1;; ++spins) {
-    const hipError_t q = hipEventQuery(e);
-    if (q != hipErrorNotReady) return q;
-    __builtin_ia32_pause();
-    if ((spins & 63u) == 0) {
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipEventSynchronize(e);
-    }
-  }
 }
 }  // namespace
 

@@ -414,7 +414,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (trace) {
     std::vector<unsigned long long> t(8 * n);
     HIP_TRY(hipMemcpyAsync(t.data(), d_trace.p, n * 64, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait_spinning(st));
     double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hits_total = 0;
     for (uint64_t k = 0; k < n; ++k) {
       for (int j = 0; j < 8; ++j) sum[j] += (double)t[8 * k + j];
@@ -436,10 +436,10 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       // run on that stream, and it is a non-blocking one -- a null-stream hipMemcpy would not be ordered with it)
       big.resize(cnt);
       HIP_TRY(hipMemcpyAsync(big.data(), dev_keys, (size_t)cnt * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(stream_wait_spinning(st));
       std::sort(big.begin(), big.end());
       HIP_TRY(hipMemcpyAsync(dev_keys, big.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(stream_wait_spinning(st));
     }
     if (h_status[k] & SA_SWEEP_OVERFLOW) {
       set_last_error("seqalign_sw_batch: internal error: pair " + std::to_string(c.first + k) + " has more hits than its share of the scratch arena");
@@ -452,7 +452,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       if (cnt >= max_hits) {
         unsigned long long last;
         HIP_TRY(hipMemcpyAsync(&last, dev_keys + (max_hits - 1), 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait_spinning(st));
         moot = last < h_err_key[k];
       }
       if (!moot) return (int)err;
@@ -498,7 +498,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
     // ---- round trip 2: the hits (their lengths size the packing)
     HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, dv_meta, nw * 32, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait_spinning(st));
   }
   tm.lap("sw: hit tracebacks");
   dst_off.resize(nw);
@@ -519,7 +519,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
                                    d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_a.as<char>() + gath_b_at, (uint32_t)nw, st)) != hipSuccess)
       return fail_hip(e, "gather hits");
     HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gath_b_at + gathered, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait_spinning(st));
   }
   tm.lap("sw: gather + strings D2H");
   const char *ha = ctx->h_ta.as<char>(), *hb = ha + gath_b_at;
@@ -645,7 +645,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tm.lap("sw best hit: fill + walk enqueued");
     // (no fetch_status here: a direction fill is only admitted for scorings in which every character pair has a score, and the
     // walks carry a pair's fill status home in their own word anyway -- the copy and its scan were 20 us of nothing)
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait_spinning(st));
     tm.lap("sw best hit: wait (upload, fill, walk)");
     const uint32_t *h_w = ctx->h_B.as<uint32_t>(), *h_moves = ctx->h_ta.as<uint32_t>();
     // Where every hit goes in the caller's buffers: hits and string bytes per block of pairs (parallel -- round 4 counted in one
@@ -740,7 +740,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
                                        d_meta + n, d_dst.as<uint64_t>(), d_gath_a.as<char>(), d_gath_a.as<char>() + gath_b_at, (uint32_t)n, st);
   if (e != hipSuccess) return fail_hip(e, "gather hits");
   HIP_TRY(hipMemcpyAsync(ctx->h_ta.p, d_gath_a.p, gath_b_at + gathered, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(stream_wait_spinning(st));
   const char *ha = ctx->h_ta.as<char>(), *hb = ha + gath_b_at;
   for (uint64_t k = 0; k < n; ++k) {
     const uint64_t p = c.first + k;
@@ -799,7 +799,7 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
     if ((rc = ctx->h_misc.reserve(n * (4 + 8 + 4)))) break;
     uint32_t *h_count = ctx->h_misc.as<uint32_t>();
     HIP_TRY(hipMemcpyAsync(h_count, ctx->cand_count.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(stream_wait_spinning(ctx->stream));
     c_off.resize(n);
     c_cap.assign(h_count, h_count + n);
     uint64_t total = 0;

@@ -187,7 +187,7 @@ void set_last_error(const std::string &msg);
 struct StreamSyncOnExit {
   hipStream_t st;
   explicit StreamSyncOnExit(hipStream_t s) : st(s) {}
-  ~StreamSyncOnExit() { (void)hipStreamSynchronize(st); }
+  ~StreamSyncOnExit();
   StreamSyncOnExit(const StreamSyncOnExit &) = delete;
   StreamSyncOnExit &operator=(const StreamSyncOnExit &) = delete;
 };
@@ -203,6 +203,41 @@ struct EventList {
     return rc;
   }
 };
+
+// a result that is a fraction of a millisecond away: poll its event first (a blocking wait adds the wake-up of a sleeping thread)
+inline hipError_t wait_event_spinning(hipEvent_t e) {
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 1;; ++spins) {
+    const hipError_t q = hipEventQuery(e);
+    if (q != hipErrorNotReady) return q;
+    __builtin_ia32_pause();
+    if ((spins & 63u) == 0) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipEventSynchronize(e);
+    }
+  }
+}
+
+// ... and a stream whose work is: hipStreamSynchronize puts the caller to sleep after a short spin, and being woken costs
+// ~70 us on this stack -- measured in round 5 on seqalign_sw_batch's best-hit call (C4: 0.91-0.95 ms with hipStreamSynchronize,
+// 0.84-0.86 polling, same box, profiles/r05/r05_experiments.txt).  The host-level calls wait for fractions of a millisecond:
+// they poll, and fall back to the blocking wait after 3 ms.
+inline hipError_t stream_wait_spinning(hipStream_t st) {
+  timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 1;; ++spins) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q != hipErrorNotReady) return q;
+    __builtin_ia32_pause();
+    if ((spins & 63u) == 0) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipStreamSynchronize(st);
+    }
+  }
+}
+
+inline StreamSyncOnExit::~StreamSyncOnExit() { (void)stream_wait_spinning(st); }
 
 struct DevBuf {   // grow-only device scratch
   void *p = nullptr;
