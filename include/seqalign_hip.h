@@ -373,6 +373,9 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *   sweep_ev        1 | 0                   the direction-byte sweep carries a walk as one word key << 2 | state
  *   arena_scan_gib  0 .. 1024               arena_quality  0.5 .. 1.5    (seqalign_arenas_alloc)
  *   arena_keep_gib  0 .. 1024               (the chunk pool, seqalign_pool_trim)
+ *   arena_free_pct  10 .. 90                share of the memory free at its start that a walk of seqalign_arenas_alloc may hold (60)
+ *   upload_slices   0 .. 16                 seqalign_nw_batch: slices a sub-batch's sequences are packed and uploaded in (0 = 1: measured,
+ *                                           more slices cost what they overlap)
  *   cpl, wpb, lds_pad, reduce_depth, sweep_trace, timing   tuning experiments / development aids
  * Numbers are integers and nothing else ("abc", "1x", "" are refused, not read as 0); switches take 1 / 0, true / false, on / off,
  * yes / no.  Returns SEQALIGN_E_ARG for an unknown key or a value outside the key's range (nothing changes then). */
