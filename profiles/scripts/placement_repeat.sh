@@ -6,6 +6,6 @@ import sys, json
 r = json.loads(sys.stdin.readline())
 s = r['config']['arena_placement_search']
 q = s['try_quality']; w2 = s['second_walk_from']
-print('proc $i: frac %.3f quality %.3f tries %d depthB %.0f depthA %.0f | walk1 max %.3f | rest: %s' % (r['roofline']['frac'], s['quality'], s['tries'], s['depth_gib'], s['depth_a_gib'], max(q[:w2]) if w2 else -1, ' '.join('%.3f' % x for x in q[w2:])))
+print('proc $i: frac %.3f quality %.3f balanced %.3f tries %d depthB %.0f depthA %.0f | walk1 max %.3f | rest: %s' % (r['roofline']['frac'], s['quality'], s.get('balanced_quality', 0), s['tries'], s['depth_gib'], s['depth_a_gib'], max(q[:w2]) if w2 else -1, ' '.join('%.3f' % x for x in q[w2:])))
 "
 done
