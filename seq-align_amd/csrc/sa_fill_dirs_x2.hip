@@ -1096,7 +1096,7 @@ bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_le
 }
 
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
-  if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs)) return false;
+  if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs) || !sa_domain_dirs_row(max_len_a)) return false;   // (packed: rows up to 512 columns)
   if (p.K > SA_LDS_TABLE_MAX_K || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
   return sa_x2_scores_fit(p, max_len_a, max_len_b);
 }

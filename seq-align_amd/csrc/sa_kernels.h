@@ -241,9 +241,12 @@ inline bool sa_scoring_needs_general(const SaScoringTraits &t) {
 }
 /* rows the direction fills (and the sweep behind them) keep in one wave's registers: 8 columns per lane */
 inline bool sa_domain_dirs_row(uint32_t max_len_a) { return max_len_a + 1 <= 8 * 64; }
-/* NW, directions only: no flag at all, no sentinel, gap_open <= 0, gap_extend <= 0, a table that fits LDS */
+/* NW, directions only: no flag at all, no sentinel, gap_open <= 0, gap_extend <= 0, a table that fits LDS.  Rows up to 1 024
+ * columns (16 per lane; round 5 -- the walkers follow the bytes whatever the row's length, only the SW sweep behind the
+ * direction fills keeps a row in registers and stops at 512) */
+inline bool sa_domain_nw_dirs_row(uint32_t max_len_a) { return max_len_a + 1 <= 16 * 64; }
 inline bool sa_domain_nw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
-  return t.flags == 0 && !sa_scoring_needs_general(t) && t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_dirs_row(max_len_a);
+  return t.flags == 0 && !sa_scoring_needs_general(t) && t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_nw_dirs_row(max_len_a);
 }
 /* SW, match_scores + directions / directions + best cell: the same without the start-gap / mismatch flags */
 inline bool sa_domain_sw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
@@ -262,7 +265,7 @@ inline bool sa_domain_x2_scores_fit(const SaScoringTraits &t, uint32_t max_len_a
   return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(t.ext) <= 30000;
 }
 inline bool sa_domain_nw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
-  return sa_domain_nw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
+  return sa_domain_nw_dirs(t, la) && sa_domain_dirs_row(la) && sa_domain_x2_scores_fit(t, la, lb);   /* (packed: up to 8 columns per lane) */
 }
 inline bool sa_domain_sw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
   return sa_domain_sw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);

@@ -10,7 +10,8 @@ from seqalign_amd import workloads as W
 opt, vals = sys.argv[1], sys.argv[2].split(",")
 wl = sys.argv[3] if len(sys.argv) > 3 else "C2"
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
-batch = W.dna_nw_150(10000, seed=1) if wl == "C2" else W.dna_nw_indexed(0, 125000, seed=5)
+batch = (W.dna_nw_150(10000, seed=1) if wl == "C2" else W.dna_nw_150(1000, seed=4, length=1000) if wl == "L1000" else
+         W.dna_nw_150(4000, seed=4, length=700) if wl == "L700" else W.dna_nw_indexed(0, 125000, seed=5))
 sc = S.make_scoring({"preset": "default"})
 ctx = S.Context(0)
 for _ in range(5): ctx.nw_batch(batch, sc, raw=True)

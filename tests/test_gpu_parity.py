@@ -427,11 +427,11 @@ def test_sw_batch_reports_an_unknown_character_pair(ctx, max_hits):
         assert err.value.code == S.E_UNKNOWN_PAIR
 
 
-@pytest.mark.parametrize("max_len", [40, 100, 180, 250, 300, 380, 500, 511, 512, 513, 700])
+@pytest.mark.parametrize("max_len", [40, 100, 180, 250, 300, 380, 500, 511, 512, 513, 700, 767, 768, 1000, 1023, 1024, 1025])
 def test_direction_byte_paths_every_width(ctx, max_len):
     """The direction-byte fills (sa_fill_dirs.hip) in every columns-per-lane instantiation and on both sides of their
-    512-column limit (511: the widest row they take; 512 / 513 / 700: the three-matrix paths must take over without a
-    seam): seqalign_nw_batch strings and seqalign_sw_batch hit lists (max_hits 1 and 6) against the oracle, default
+    limits (SW: 511 is the widest row they take, 512 / 513 / 700 go through the three matrices; NW, round 5: rows up to 1 024
+    columns -- 12 and 16 columns per lane -- and the three matrices beyond; no seam anywhere): seqalign_nw_batch strings and seqalign_sw_batch hit lists (max_hits 1 and 6) against the oracle, default
     options, plain scorings incl. a substitution table (BLOSUM62 -> the LDS-table instantiation) and a wildcard."""
     rng = W.Rng(4000 + max_len)
 

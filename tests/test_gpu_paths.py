@@ -56,6 +56,22 @@ def uniform(n, la, lb, seed, alpha=b"ACGT", related=0.5):
 
 # ------------------------------------------------------------------ which kernels ran ---
 
+@pytest.mark.parametrize("la,expect_dirs", [(512, True), (700, True), (1023, True), (1024, False), (1500, False)])
+def test_nw_direction_fill_takes_rows_up_to_1024_columns(ctx, la, expect_dirs):
+    """Round 5: seqalign_nw_batch writes one byte of directions per cell for rows up to 1 024 columns (len_a <= 1 023; 12 / 16
+    columns per lane, one pair per wave) -- beyond that the three matrices; either way the oracle's strings
+    (needleman_wunsch.c:34-146)."""
+    sc = S.make_scoring({"preset": "default"})
+    batch = uniform(6, la, 300, seed=900 + la)
+    res = ctx.nw_batch(batch, sc)
+    launched = ctx.last_call()
+    assert any(k.startswith("fill_nw_dirs") for k in launched) == expect_dirs, launched
+    osc = osc_of(sc)
+    for p in range(batch.n_pairs):
+        rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+        assert rc == 0 and res[p] == (s_, ra, rb), (la, p)
+
+
 def test_nw_batch_reports_its_kernels(ctx, opts):
     sc = S.make_scoring({"preset": "default"})
     batch = uniform(64, 150, 150, 1)
