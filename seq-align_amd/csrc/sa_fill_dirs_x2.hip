@@ -1096,7 +1096,7 @@ bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_le
 }
 
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
-  if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs) || !sa_domain_dirs_row(max_len_a)) return false;   // (packed: rows up to 512 columns)
+  if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs)) return false;
   if (p.K > SA_LDS_TABLE_MAX_K || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
   return sa_x2_scores_fit(p, max_len_a, max_len_b);
 }
@@ -1150,7 +1150,9 @@ hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, 
   if (need <= 4) return sa::launch_nw_dirs_x2_cpl<4, 512>(p, dirs, stream);
   if (need <= 5) return sa::launch_nw_dirs_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_nw_dirs_x2_cpl<6, 1024>(p, dirs, stream);
-  return sa::launch_nw_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 8) return sa::launch_nw_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 12) return sa::launch_nw_dirs_x2_cpl<12, 1024>(p, dirs, stream);   // (rows of 513 .. 1 024 columns: round 5)
+  return sa::launch_nw_dirs_x2_cpl<16, 2048>(p, dirs, stream);
 }
 
 // ---- Smith-Waterman multi-hit: match_scores + directions, two pairs per wave
@@ -1220,5 +1222,7 @@ hipError_t sa_launch_fill_nw_dirs_mixed(const SaFillParams &p, uint32_t max_len_
   if (need <= 4) return sa::launch_nw_dirs_mixed_cpl<4, 512>(p, dirs, n_modal, n_rest, stream);
   if (need <= 5) return sa::launch_nw_dirs_mixed_cpl<5, 1024>(p, dirs, n_modal, n_rest, stream);
   if (need <= 6) return sa::launch_nw_dirs_mixed_cpl<6, 1024>(p, dirs, n_modal, n_rest, stream);
-  return sa::launch_nw_dirs_mixed_cpl<8, 1024>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 8) return sa::launch_nw_dirs_mixed_cpl<8, 1024>(p, dirs, n_modal, n_rest, stream);
+  if (need <= 12) return sa::launch_nw_dirs_mixed_cpl<12, 1024>(p, dirs, n_modal, n_rest, stream);
+  return sa::launch_nw_dirs_mixed_cpl<16, 2048>(p, dirs, n_modal, n_rest, stream);
 }

@@ -265,7 +265,7 @@ inline bool sa_domain_x2_scores_fit(const SaScoringTraits &t, uint32_t max_len_a
   return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(t.ext) <= 30000;
 }
 inline bool sa_domain_nw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
-  return sa_domain_nw_dirs(t, la) && sa_domain_dirs_row(la) && sa_domain_x2_scores_fit(t, la, lb);   /* (packed: up to 8 columns per lane) */
+  return sa_domain_nw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
 }
 inline bool sa_domain_sw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
   return sa_domain_sw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);

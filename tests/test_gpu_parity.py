@@ -464,7 +464,8 @@ def test_direction_byte_paths_every_width(ctx, max_len):
 
 
 @pytest.mark.parametrize("shape", [(0, 0), (0, 7), (7, 0), (1, 1), (1, 9), (9, 1), (5, 3), (63, 64), (64, 33), (127, 70), (128, 128), (150, 150),
-                                   (191, 40), (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45)])
+                                   (191, 40), (192, 25), (255, 130), (300, 60), (383, 20), (450, 30), (511, 45),
+                                   (512, 40), (600, 33), (767, 21), (768, 30), (1000, 25), (1023, 18)])
 def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
     """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
     int16 halves; option pack16 -- 2: also for chunks below the 2 048 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
