@@ -1204,7 +1204,9 @@ hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, 
   if (need <= 4) return sa::launch_sw_best_x2_cpl<4, 512>(p, dirs, stream);
   if (need <= 5) return sa::launch_sw_best_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_sw_best_x2_cpl<6, 1024>(p, dirs, stream);
-  return sa::launch_sw_best_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 8) return sa::launch_sw_best_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 12) return sa::launch_sw_best_x2_cpl<12, 1024>(p, dirs, stream);   // (rows of 513 .. 1 024 columns: round 5)
+  return sa::launch_sw_best_x2_cpl<16, 2048>(p, dirs, stream);
 }
 
 // ---- NW, a chunk whose pairs are mostly of one shape: both kinds of waves in one grid (p.pair_list: modal pairs, then the rest)

@@ -270,8 +270,10 @@ inline bool sa_domain_nw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t
 inline bool sa_domain_sw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
   return sa_domain_sw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
 }
+/* (the best-hit fill has no sweep behind it: like the NW fill it takes rows up to 1 024 columns -- round 5) */
 inline bool sa_domain_sw_best_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
-  return sa_domain_sw_dirs(t, la) && lb < 32768 && sa_domain_x2_scores_fit(t, la, lb);
+  return (t.flags & SA_F_IS_SW) && !sa_scoring_needs_general(t) && !(t.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH)) &&
+         t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_nw_dirs_row(la) && lb < 32768 && sa_domain_x2_scores_fit(t, la, lb);
 }
 
 /* returns hipSuccess or the launch error; never synchronises */

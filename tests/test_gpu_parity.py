@@ -551,7 +551,8 @@ def test_nw_batch_mostly_one_shape(ctx, opts, n_sub):
 
 
 @pytest.mark.parametrize("shape", [(0, 0), (0, 6), (6, 0), (1, 1), (9, 2), (5, 40), (63, 64), (64, 33), (127, 70), (150, 200), (191, 40),
-                                   (192, 25), (255, 90), (300, 60), (383, 20), (450, 30), (511, 45)])
+                                   (192, 25), (255, 90), (300, 60), (383, 20), (450, 30), (511, 45),
+                                   (512, 40), (600, 50), (768, 30), (1000, 40), (1023, 25)])   # (beyond 511: the best-hit fill only)
 def test_sw_batch_two_pairs_per_wave(ctx, opts, shape):
     """The SW multi-hit path on batches whose pairs all have one shape: the packed fill of match_scores + directions
     (sa_fill_dirs_x2.hip: fill_dirs_x2_kernel, two pairs per wave in int16 halves; the sweep and the hit walks read what

@@ -56,6 +56,23 @@ def uniform(n, la, lb, seed, alpha=b"ACGT", related=0.5):
 
 # ------------------------------------------------------------------ which kernels ran ---
 
+def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
+    """Round 5: the packed best-hit fill (direction bytes + the best cell, no matrices) has no sweep behind it and takes rows up
+    to 1 024 columns like the NW fill; the multi-hit fill stops at 512 (its sweep keeps a row in registers)."""
+    opts(pack16=2)
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = osc_of(sc)
+    for la, best_packed in ((700, True), (1023, True), (1024, False)):
+        batch = uniform(8, la, 200, seed=700 + la)
+        one = ctx.sw_batch(batch, sc, 30, max_hits=1)
+        assert ("fill_sw_best_x2" in ctx.last_call()) == best_packed, (la, ctx.last_call())
+        many = ctx.sw_batch(batch, sc, 30, max_hits=3)
+        assert "fill_sw_dirs_x2" not in ctx.last_call() and "fill_sw_dirs" not in ctx.last_call(), ctx.last_call()
+        for p in range(batch.n_pairs):
+            rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 3)
+            assert rc == 0 and many[p] == want and one[p] == want[:1], (la, p)
+
+
 @pytest.mark.parametrize("la,expect_dirs", [(512, True), (700, True), (1023, True), (1024, False), (1500, False)])
 def test_nw_direction_fill_takes_rows_up_to_1024_columns(ctx, la, expect_dirs):
     """Round 5: seqalign_nw_batch writes one byte of directions per cell for rows up to 1 024 columns (len_a <= 1 023; 12 / 16
