@@ -467,7 +467,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   }
   h_slot[n] = pos;
   const uint64_t total = pos;   // == c.seq_bytes
-  // Plain scorings, rows up to 512 columns: the fill writes ONE byte of directions per cell and nothing else
+  // Plain scorings, rows up to 1 024 columns: the fill writes ONE byte of directions per cell and nothing else
   // (sa_fill_dirs.hip) -- the three matrices are never needed, so they are not even allocated.
   const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a);
   // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
@@ -696,7 +696,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
 // 0.12): a serial pass over the pairs for the offsets, packing on 10 of 32 threads, a descriptor copy and a sequence copy
 // (two copy-engine latencies + 3 MB at 40 GB/s before the fill could start), 6 MB of gapped strings home through the
 // runtime's blit kernel, unpacking on 10 threads again -- and each of the pool's dispatches paid for waking 31 sleeping
-// threads.  Here, for chunks the direction-byte fill takes (plain scorings, rows <= 512 columns):
+// threads.  Here, for chunks the direction-byte fill takes (plain scorings, rows <= 1 024 columns):
 //   * the fill reads the packed sequences and the descriptor arrays IN PLACE from pinned host memory (300 B per pair over
 //     PCIe, hidden behind 0.2 ms of arithmetic), so the kernel is launched the moment the host has packed -- no copy, no
 //     event, no second stream on the way in (option zero_copy & 1);

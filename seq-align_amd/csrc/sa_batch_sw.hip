@@ -171,7 +171,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   SaCandBox cand{};
   cand.cand_count = ctx->cand_count.as<uint32_t>(); cand.cand_box = d_box.as<uint32_t>(); cand.cand_min = d_min.as<int32_t>();
   cand.cand_rows = d_keys.as<uint32_t>(); cand.hit_off = d_hitoff.as<uint64_t>();
-  // plain scorings, rows up to 512 columns: the fill writes match_scores + one byte of directions per cell instead of the
+  // plain scorings, rows up to 1 024 columns (513 and up: see wide_ok below): the fill writes match_scores + one byte of directions per cell instead of the
   // three matrices (sa_fill_dirs.hip); the directions go where gap_a_scores would have gone
   bool dirs_used = false;
   // every pair of the chunk the same shape (reads against windows of one length), match / mismatch scoring: the packed
@@ -191,7 +191,12 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if (stride == kBucketShapes)
     for (uint64_t k = 0; k < n; ++k) cells256 += (((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1) + 255u) & ~(uint64_t)255u;
   // (only when the sweep will run in its rows-in-registers form: not with the strip / LDS forms forced by an option)
-  const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0;
+  // and rows of 513 .. 1 024 columns only where the sweep's one-word form takes them (sa_launch_sw_sweep) and a wave per pair fills
+  // the chip (few wide pairs: strips, below, as before)
+  const bool wide_row = c.max_a + 1 > 512;
+  const bool wide_ok = ctx->opt.sweep_ev && layout.row_bits + layout.col_bits + layout.score_bits <= 62 &&
+                       (n >= 1024 || ctx->opt.sweep_mode == 1);
+  const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0 && (!wide_row || wide_ok);
   // (the packed direction-byte fill is bound by instruction issue: its arenas need no placement walk)
   if ((rc = reserve_arenas(ctx, (stride == kBucketShapes ? cells256 : stride ? n * stride : c.cells) * 4, !(allow_dirs && stride != 0)))) return rc;
   cand.dirs = allow_dirs ? ctx->A.as<uint8_t>() : nullptr; cand.dirs_used = &dirs_used;
@@ -213,7 +218,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   const bool trace = ctx->opt.sweep_trace;   // development aid: per-pair counters on stderr
   DevBuf &d_trace = ctx->e[12];
   const bool may_one_trip = allow_dirs && ctx->opt.sweep_mode == 0 && !trace && ctx->opt.nw_moves && max_hits <= 8 &&
-                            n * max_hits <= ((uint64_t)4 << 20) && c.max_a + 1 <= 512;
+                            n * max_hits <= ((uint64_t)4 << 20) && c.max_a + 1 <= 1024;
   SaSweepParams q;
   memset(&q, 0, sizeof(q));
   auto sweep_params = [&](const seqalign_dev_batch_t &dd, uint64_t k0, uint64_t k1, bool dirs) {
@@ -266,7 +271,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   if ((rc = run_chunk(ctx, batch, c, sc, &d, nullptr, &cand, &reported, stride))) return rc;
   // (behind ALL the fills: per slice -- a small first slice's sweep and walks, then the rest's -- C3 took 5.2 instead of 4.7 ms)
   if (may_one_trip && (rc = after_fill(0, n, d, dirs_used, reported))) return rc;
-  const bool strips_needed = c.max_a + 1 > 512 && (c.max_a + 1 > SA_SWEEP_LDS_COLUMNS || n < 1024);
+  const bool strips_needed = !dirs_used && c.max_a + 1 > 512 && (c.max_a + 1 > SA_SWEEP_LDS_COLUMNS || n < 1024);
   bool strips = false;
   if (piped && piped_any) {
     // everything is enqueued on the one stream: one wait for all of it

@@ -304,7 +304,9 @@ hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_
   if (need <= 4) return sa::launch_dirs_cpl<4, 512>(p, dirs, stream);
   if (need <= 5) return sa::launch_dirs_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_dirs_cpl<6, 1024>(p, dirs, stream);
-  return sa::launch_dirs_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 8) return sa::launch_dirs_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 12) return sa::launch_dirs_cpl<12, 1024>(p, dirs, stream);   // (rows of 513 .. 1 024 columns: round 5)
+  return sa::launch_dirs_cpl<16, 2048>(p, dirs, stream);
 }
 
 // ---- Needleman-Wunsch: directions only (seqalign_nw_batch)

@@ -1172,7 +1172,9 @@ hipError_t sa_launch_fill_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uin
   if (need <= 4) return sa::launch_dirs_x2_cpl<4, 512>(p, dirs, stream);
   if (need <= 5) return sa::launch_dirs_x2_cpl<5, 1024>(p, dirs, stream);
   if (need <= 6) return sa::launch_dirs_x2_cpl<6, 1024>(p, dirs, stream);
-  return sa::launch_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 8) return sa::launch_dirs_x2_cpl<8, 1024>(p, dirs, stream);
+  if (need <= 12) return sa::launch_dirs_x2_cpl<12, 1024>(p, dirs, stream);   // (rows of 513 .. 1 024 columns: round 5)
+  return sa::launch_dirs_x2_cpl<16, 2048>(p, dirs, stream);
 }
 
 // ---- Smith-Waterman best hit: directions + the best cell, two pairs per wave

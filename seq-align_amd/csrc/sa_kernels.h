@@ -239,11 +239,10 @@ inline SaScoringTraits sa_traits_of(const SaFillParams &p) {
 inline bool sa_scoring_needs_general(const SaScoringTraits &t) {
   return (t.flags & (SA_F_NO_END_GAP | SA_F_NO_GAPS_A | SA_F_NO_GAPS_B | SA_F_HAS_SENTINEL)) || t.open1 > t.ext;
 }
-/* rows the direction fills (and the sweep behind them) keep in one wave's registers: 8 columns per lane */
-inline bool sa_domain_dirs_row(uint32_t max_len_a) { return max_len_a + 1 <= 8 * 64; }
-/* NW, directions only: no flag at all, no sentinel, gap_open <= 0, gap_extend <= 0, a table that fits LDS.  Rows up to 1 024
- * columns (16 per lane; round 5 -- the walkers follow the bytes whatever the row's length, only the SW sweep behind the
- * direction fills keeps a row in registers and stops at 512) */
+/* rows the direction fills keep in one wave's registers: 16 columns per lane (round 5; 8 before).  The SW sweep behind them
+ * keeps a row in registers too: up to 512 columns in either of its forms, 513 .. 1 024 in the one-word form only
+ * (sw_sweep_dirs_ev_kernel, keys of <= 62 bits) -- the caller (sa_batch_sw.hip) offers a direction arena only when that holds */
+/* NW, directions only: no flag at all, no sentinel, gap_open <= 0, gap_extend <= 0, a table that fits LDS */
 inline bool sa_domain_nw_dirs_row(uint32_t max_len_a) { return max_len_a + 1 <= 16 * 64; }
 inline bool sa_domain_nw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
   return t.flags == 0 && !sa_scoring_needs_general(t) && t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_nw_dirs_row(max_len_a);
@@ -251,7 +250,7 @@ inline bool sa_domain_nw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
 /* SW, match_scores + directions / directions + best cell: the same without the start-gap / mismatch flags */
 inline bool sa_domain_sw_dirs(const SaScoringTraits &t, uint32_t max_len_a) {
   return (t.flags & SA_F_IS_SW) && !sa_scoring_needs_general(t) && !(t.flags & (SA_F_NO_START_GAP | SA_F_NO_MISMATCH)) &&
-         t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_dirs_row(max_len_a);
+         t.K <= SA_LDS_TABLE_MAX_K && t.ext <= 0 && sa_domain_nw_dirs_row(max_len_a);
 }
 /* two pairs per wave in packed int16: every score the recurrence can produce on pairs up to max_len_a x max_len_b, de-trended
  * or not, stays inside int16 */

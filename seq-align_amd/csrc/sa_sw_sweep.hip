@@ -865,8 +865,21 @@ struct SweepRow {
       asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %6 offset:16\n\t"
                    "global_load_dword %2, %5, %7\n\tglobal_load_dword %3, %5, %7 offset:4"
                    : "=&v"(m4[0]), "=&v"(m4[1]), "=&v"(q[0]), "=&v"(q[1]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 3 && TAIL == 0)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %6, %8\n\tglobal_load_dwordx4 %1, %6, %8 offset:16\n\t"
+                   "global_load_dwordx4 %2, %6, %8 offset:32\n\t"
+                   "global_load_dword %3, %7, %9\n\tglobal_load_dword %4, %7, %9 offset:4\n\tglobal_load_dword %5, %7, %9 offset:8"
+                   : "=&v"(m4[0]), "=&v"(m4[1]), "=&v"(m4[2]), "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2])
+                   : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
+    else if constexpr (NV4 == 4 && TAIL == 0)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %8, %10\n\tglobal_load_dwordx4 %1, %8, %10 offset:16\n\t"
+                   "global_load_dwordx4 %2, %8, %10 offset:32\n\tglobal_load_dwordx4 %3, %8, %10 offset:48\n\t"
+                   "global_load_dword %4, %9, %11\n\tglobal_load_dword %5, %9, %11 offset:4\n\t"
+                   "global_load_dword %6, %9, %11 offset:8\n\tglobal_load_dword %7, %9, %11 offset:12"
+                   : "=&v"(m4[0]), "=&v"(m4[1]), "=&v"(m4[2]), "=&v"(m4[3]), "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+                   : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
     else
-      static_assert(NV4 == 0 && TAIL == 2, "columns per lane: 2, 3, 4, 5, 6 or 8");
+      static_assert(NV4 == 0 && TAIL == 2, "columns per lane: 2, 3, 4, 5, 6, 8, 12 or 16");
   }
   // the row is here once at most YOUNGER of the wave's VMEM instructions are outstanding (loads return in order)
   template <int YOUNGER>
@@ -891,12 +904,13 @@ struct SweepRow {
 // waves per SIMD the kernel is compiled for (its register budget): the row buffers must stay in registers -- a spilled buffer is a
 // buffer stored while its load is still on its way (tools/check_inflight_loads.py fails the build on that)
 constexpr int sweep_ev_waves(int cpl, bool wide_keys) {
-  return wide_keys ? (cpl <= 2 ? 8 : cpl == 3 ? 6 : cpl == 4 ? 5 : cpl <= 6 ? 3 : 2) : (cpl <= 3 ? 8 : cpl == 4 ? 6 : cpl <= 6 ? 5 : 4);
+  return wide_keys ? (cpl <= 2 ? 8 : cpl == 3 ? 6 : cpl == 4 ? 5 : cpl <= 6 ? 3 : 2)
+                   : (cpl <= 3 ? 8 : cpl == 4 ? 6 : cpl <= 6 ? 5 : cpl <= 12 ? 4 : 3);
 }
 template <int CPL, typename EvT>
 __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) sw_sweep_dirs_ev_kernel(const SaSweepParams p) {
   constexpr EvT kNone = ~(EvT)0;
-  constexpr int NB = CPL <= 4 ? 4 : 3;   // row buffers
+  constexpr int NB = CPL <= 4 ? 4 : CPL <= 8 ? 3 : 2;   // row buffers (12 / 16 columns per lane: a row's work outlasts a load)
   typedef SweepRow<CPL> Row;
   constexpr int kYounger = (NB - 1) * Row::kLoads;   // VMEM instructions behind a row's own when its turn comes
   const int lane = threadIdx.x;
@@ -1121,20 +1135,29 @@ static void launch_sweep_dirs(const SaSweepParams &p, hipStream_t stream) {
   if (key32) hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
   else hipLaunchKernelGGL((sw_sweep_dirs_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
 }
+template <int CPL>
+static void launch_sweep_dirs_wide(const SaSweepParams &p, hipStream_t stream) {
+  const uint32_t bits = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits;
+  if (bits + 2 <= 32) hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+  else hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+}
 }  // namespace sa
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   if (p.dirs) {   // behind sa_fill_dirs.hip: match_scores + a byte of directions per cell (rows up to 512 columns)
     const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;
-    if (need > 8 || p.strip_progress) return hipErrorInvalidValue;
+    if (need > 16 || p.strip_progress) return hipErrorInvalidValue;
+    if (need > 8 && !(p.tune_ev && p.layout.row_bits + p.layout.col_bits + p.layout.score_bits + 2 <= 64)) return hipErrorInvalidValue;
     sa_record_launch(SEQALIGN_K_SWEEP_DIRS, p.n_pairs);
     if (need <= 2) sa::launch_sweep_dirs<2>(p, stream);
     else if (need <= 3) sa::launch_sweep_dirs<3>(p, stream);
     else if (need <= 4) sa::launch_sweep_dirs<4>(p, stream);
     else if (need <= 5) sa::launch_sweep_dirs<5>(p, stream);
     else if (need <= 6) sa::launch_sweep_dirs<6>(p, stream);
-    else sa::launch_sweep_dirs<8>(p, stream);
+    else if (need <= 8) sa::launch_sweep_dirs<8>(p, stream);
+    else if (need <= 12) sa::launch_sweep_dirs_wide<12>(p, stream);   // (rows of 513 .. 1 024 columns: the ev form only)
+    else sa::launch_sweep_dirs_wide<16>(p, stream);
     return hipGetLastError();
   }
   // Up to 512 columns a segment holds the whole row and the winners stay in registers (short sequences: the walks

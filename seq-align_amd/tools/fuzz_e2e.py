@@ -67,7 +67,7 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
         ctx.set_option("trace_kernel", ("lane", "wave")[int(v[0] >> 7) & 1])
         # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
         # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
-        for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs"):
+        for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "pack16"):
             ctx.set_option(key, S.OPTION_DEFAULTS[key])
         mode = int(v[0] >> 9) % 8
         if mode < 3:
@@ -78,6 +78,11 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
             ctx.set_option("kernel", "rowscan")
         elif mode == 5:
             ctx.set_option("kernel", "wgstream")   # (rows over 512 columns: reports the candidates itself; else falls back)
+        elif mode == 6:
+            # one wave per pair whatever the batch's size: rows of 513 .. 1 024 columns through the direction bytes and the
+            # one-word sweep (12 / 16 columns per lane); every other draw with the packed fills forced on
+            ctx.set_option("sweep_mode", "pair")
+            if int(v[0] >> 16) & 1: ctx.set_option("pack16", 2)
         ctx.set_option("subbatches", (0, 1, 2, 5)[int(v[0] >> 12) % 4])   # seqalign_nw_batch: pipelined sub-batches
         if int(v[0] >> 14) % 4 == 0:                  # a quarter of the draws through the three-matrix paths whatever the scoring
             ctx.set_option("nw_dirs", 0)
@@ -103,7 +108,7 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
     msg = (f"fuzz_e2e ok: {trials} random scorings x batches; {nw_checked} NW alignments, {sw_checked} SW hit lists identical "
            f"to the oracle (seed {seed})")
     print(msg, flush=True)
-    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "trace_kernel"):
+    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "trace_kernel", "pack16"):
         ctx.set_option(key, S.OPTION_DEFAULTS[key])
     return {"trials": trials, "nw_checked": nw_checked, "sw_checked": sw_checked}
 

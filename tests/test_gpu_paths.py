@@ -58,7 +58,7 @@ def uniform(n, la, lb, seed, alpha=b"ACGT", related=0.5):
 
 def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
     """Round 5: the packed best-hit fill (direction bytes + the best cell, no matrices) has no sweep behind it and takes rows up
-    to 1 024 columns like the NW fill; the multi-hit fill stops at 512 (its sweep keeps a row in registers)."""
+    to 1 024 columns like the NW fill; the multi-hit fill takes such rows only from 1 024 pairs up (next test)."""
     opts(pack16=2)
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     osc = osc_of(sc)
@@ -71,6 +71,50 @@ def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
         for p in range(batch.n_pairs):
             rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 3)
             assert rc == 0 and many[p] == want and one[p] == want[:1], (la, p)
+
+
+@pytest.mark.parametrize("pack16", [2, 0])
+@pytest.mark.parametrize("la,lb,wide_keys", [(512, 150, False), (700, 200, False), (767, 90, False), (768, 130, False), (1023, 200, False),
+                                             (640, 2500, True), (1000, 2100, True)])
+def test_sw_multi_hit_direction_path_takes_rows_up_to_1024_columns(ctx, opts, pack16, la, lb, wide_keys):
+    """Round 5: match_scores + direction bytes and the one-word sweep behind them (sw_sweep_dirs_ev_kernel, 12 / 16 columns per lane)
+    for rows of 513 .. 1 024 columns -- offered from 1 024 pairs up, or with sweep_mode = pair (here: few pairs, so that the oracle
+    finishes); with 32-bit and with 64-bit keys; through the one-trip call (max_hits <= 8) and the three-trip one; against the
+    three-matrix path (sweep_ev = 0 does not take wide rows) and the oracle (smith_waterman.c:137-277)."""
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = osc_of(sc)
+    n = 6 if wide_keys else 12
+    batch = uniform(n, la, lb, seed=1300 + la)
+    opts(pack16=pack16, sweep_mode="pair")
+    few = ctx.sw_batch(batch, sc, 24, max_hits=3)
+    launched = ctx.last_call()
+    assert ("fill_sw_dirs_x2" if pack16 else "fill_sw_dirs") in launched and "sweep_dirs" in launched, launched
+    many = ctx.sw_batch(batch, sc, 24, max_hits=40)
+    assert "sweep_dirs" in ctx.last_call(), ctx.last_call()
+    opts(sweep_ev=0)
+    ref = ctx.sw_batch(batch, sc, 24, max_hits=40)
+    assert ("sweep_dirs" in ctx.last_call()) == (la + 1 <= 512), ctx.last_call()
+    assert many == ref
+    for p in range(batch.n_pairs):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 24, 40)
+        assert rc == 0 and many[p] == want and few[p] == want[:3], (la, lb, p, len(want))
+
+
+def test_sw_multi_hit_wide_rows_from_1024_pairs(ctx):
+    """The same path as the default for a batch of 1 024 reads of 600 bp against 700-column windows (and not for 1 023 of them:
+    few wide pairs go to the strip sweep as before); hit lists against the oracle for a sample of the pairs."""
+    sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc = osc_of(sc)
+    batch = uniform(1024, 700, 120, seed=77)
+    res = ctx.sw_batch(batch, sc, 30, max_hits=4)
+    launched = ctx.last_call()
+    assert "fill_sw_dirs" in launched and "sweep_dirs" in launched, launched   # (packed two per wave from 2 048 pairs up)
+    for p in range(0, 1024, 37):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 4)
+        assert rc == 0 and res[p] == want, p
+    small = uniform(1023, 700, 120, seed=77)
+    ctx.sw_batch(small, sc, 30, max_hits=4)
+    assert "sweep_dirs" not in ctx.last_call(), ctx.last_call()
 
 
 @pytest.mark.parametrize("la,expect_dirs", [(512, True), (700, True), (1023, True), (1024, False), (1500, False)])
