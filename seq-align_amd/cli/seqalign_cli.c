@@ -32,6 +32,7 @@
 #include <string.h>
 #include <strings.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "seqalign_hip.h"
 #include "seqalign_io.h"
@@ -417,9 +418,50 @@ static void align_sw(batch_t *bt)
 }
 
 /* ---- stage 3: the reference's text */
+
+/* The plain form (no --pretty / --colour / --printfasta / --zam / --printmatrices): res_a \n res_b \n [score: N \n] \n per
+ * pair (nw_cmdline.c:78-149 with those options off), composed in 1 MiB pieces and written with one fwrite each -- the batch
+ * calls know every string's length, so nothing is scanned (a million pairs: 0.27 s of fputs / putc / printf before). */
+static void print_nw_batch_plain(const batch_t *bt)
+{
+  enum { PIECE = 1 << 20 };
+  static char *buf;
+  size_t i, at = 0;
+  if(!buf && !(buf = malloc(PIECE + 64))) oom();
+  for(i = 0; i < bt->n; i++) {
+    const size_t len = bt->out_len[i], need = 2 * len + 32;
+    const char *ra = bt->out_a + bt->str_off[i], *rb = bt->out_b + bt->str_off[i];
+    if(need > PIECE) {                       /* a pair longer than a piece: straight through stdio */
+      fwrite(buf, 1, at, stdout); at = 0;
+      fwrite(ra, 1, len, stdout); putc('\n', stdout); fwrite(rb, 1, len, stdout); putc('\n', stdout);
+      if(opt.print_scores) printf("score: %i\n", bt->score[i]);
+      putc('\n', stdout);
+      continue;
+    }
+    if(at + need > PIECE) { fwrite(buf, 1, at, stdout); at = 0; }
+    memcpy(buf + at, ra, len); at += len; buf[at++] = '\n';
+    memcpy(buf + at, rb, len); at += len; buf[at++] = '\n';
+    if(opt.print_scores) {
+      char digits[12];
+      long long v = bt->score[i];
+      unsigned long long u = v < 0 ? (unsigned long long)-v : (unsigned long long)v;
+      int nd = 0;
+      memcpy(buf + at, "score: ", 7); at += 7;
+      if(v < 0) buf[at++] = '-';
+      do { digits[nd++] = (char)('0' + u % 10); u /= 10; } while(u);
+      while(nd) buf[at++] = digits[--nd];
+      buf[at++] = '\n';
+    }
+    buf[at++] = '\n';
+  }
+  fwrite(buf, 1, at, stdout);
+  fflush(stdout);
+}
+
 static void print_nw_batch(const batch_t *bt)
 {
   size_t i;
+  if(!opt.print_matrices && !opt.zam && !opt.print_fasta && !opt.print_pretty && !opt.print_colour) { print_nw_batch_plain(bt); return; }
   for(i = 0; i < bt->n; i++) {
     const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
     if(opt.print_matrices) {   /* needs the matrices on the host: per-pair API */
@@ -484,7 +526,9 @@ static void print_sw_batch(const batch_t *bt)
 /* ------------------------------------------------------------- the pipeline */
 
 #define BATCH_PAIRS 65536
-#define N_BATCHES 3          /* one being read, one on the GPU, one being printed */
+#define N_BATCHES 8          /* one on the GPU, one being printed, the rest read ahead: opening the GPU takes as long as reading
+                                ~0.5 M pairs, and a reader that may only run two batches ahead sits out most of that (a batch's
+                                buffers are allocated when it is first used: short inputs touch one) */
 
 typedef struct {             /* a FIFO of batches between two stages */
   pthread_mutex_t mu; pthread_cond_t cv;
@@ -511,7 +555,7 @@ static batch_t *fifo_get(fifo_t *f)
 
 static fifo_t g_free, g_read, g_aligned;
 /* SEQALIGN_CLI_TIMING=1: how long each stage WORKED (not waited), on stderr at the end: which one bounds the tool */
-static double g_busy[3];
+static double g_busy[3], g_open_s;
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 /* stage 1: records into batches (two records at a time, alignment_cmdline.c:611-622) */
@@ -582,7 +626,7 @@ static void open_gpus(void)
 static void *aligner_main(void *arg)
 {
   (void)arg;
-  open_gpus();
+  { const double t0 = now_s(); open_gpus(); g_open_s = now_s() - t0; }
   for(;;) {
     batch_t *bt = fifo_get(&g_read);
     const double t0 = now_s();
@@ -618,6 +662,7 @@ int main(int argc, char **argv)
   static batch_t batches[N_BATCHES];
   pthread_t reader, aligner;
   int k;
+  const double t_main = now_s();
   base = base ? base + 1 : argv[0];
   /* a command-line run is short: skip the ~0.1-0.2 s the library would spend looking for a good
      placement of its matrix arenas (seqalign_hip.h, seqalign_arenas_alloc) unless the user asks for it */
@@ -649,8 +694,18 @@ int main(int argc, char **argv)
     fifo_put(&g_free, bt);
   }
   pthread_join(reader, NULL); pthread_join(aligner, NULL);
-  if(getenv("SEQALIGN_CLI_TIMING"))
-    fprintf(stderr, "seqalign: stages busy: read %.3f s, align %.3f s, print %.3f s\n", g_busy[0], g_busy[1], g_busy[2]);
-  for(k = 0; k < g_nctx; k++) seqalign_ctx_destroy(g_ctxs[k]);
+  {
+    const double t1 = now_s();
+    for(k = 0; k < g_nctx; k++) seqalign_ctx_destroy(g_ctxs[k]);
+    if(getenv("SEQALIGN_CLI_TIMING"))
+      fprintf(stderr, "seqalign: stages busy: read %.3f s, align %.3f s (GPU opened in %.3f s), print %.3f s; main() %.3f s to the last byte, "
+              "%.3f s closing the contexts\n", g_busy[0], g_busy[1], g_open_s, g_busy[2], t1 - t_main, now_s() - t1);
+  }
+  /* Everything is written and the contexts are closed: leave without the HIP runtime's exit handlers (0.15 s of a 0.3-0.5 s
+     run on a million pairs; SEQALIGN_CLI_EXIT=full runs them, for leak checkers) */
+  if(!getenv("SEQALIGN_CLI_EXIT") || strcmp(getenv("SEQALIGN_CLI_EXIT"), "full")) {
+    const int bad = fflush(NULL) != 0 || ferror(stdout);
+    _exit(bad ? EXIT_FAILURE : EXIT_SUCCESS);
+  }
   return EXIT_SUCCESS;
 }

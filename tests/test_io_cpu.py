@@ -144,3 +144,35 @@ def test_sequence_reader_fasta_fastq_plain(tmp_path):
     got = read_all(gz)
     assert got[:2] == [(">seqA", "ACAATAGAC", 9), (">seqB", "ACGAATAGAT", 10)]
     assert got[2][0] == ">long" and got[2][2] == 200000 and got[2][1] == "ACGT" * 50000
+
+
+def test_sequence_reader_lines_across_block_boundaries(tmp_path):
+    """The reader takes its lines out of 4 MiB blocks (host/sa_io.c: read_line_block): records whose lines straddle a block's
+    end, a line longer than a block, CR LF ends, blank lines and a last line without a newline -- against a parse in Python;
+    plain and gzip-compressed."""
+    import gzip
+    import random
+    rnd = random.Random(11)
+    recs, parts = [], []
+    big = "".join(rnd.choice("ACGT") for _ in range(1 << 16)) * 80          # 5 MiB in one line
+    for k in range(3000):
+        name = ">r%d %s" % (k, "x" * rnd.randrange(0, 40))
+        if k == 1500:
+            lines = [big]
+        else:
+            lines = ["".join(rnd.choice("ACGTN") for _ in range(rnd.randrange(1, 9000))) for _ in range(rnd.randrange(1, 4))]
+        eol = "\r\n" if k % 7 == 0 else "\n"
+        parts.append(name + eol + eol.join(lines) + eol + ("\n" if k % 11 == 0 else ""))
+        recs.append((name, "".join(lines)))
+    text = "".join(parts)
+    text = text[:-1] if text.endswith("\n") else text                       # no newline at the end of the file
+    assert len(text) > 3 * (4 << 20)
+    p = tmp_path / "big.fa"
+    p.write_text(text, newline="")
+    got = read_all(p)
+    assert len(got) == len(recs)
+    assert all(g == (n, s, len(s)) for g, (n, s) in zip(got, recs))
+    gz = tmp_path / "big.fa.gz"
+    with gzip.open(gz, "wt", newline="", compresslevel=1) as f:
+        f.write(text)
+    assert read_all(gz) == got
