@@ -25,3 +25,10 @@ for n in ("default", "C5", "C3", "C4"):
 PY
 bash profiles/scripts/e2e_roofline.sh $TAG > gpurun_out/$TAG/e2e_roofline.log 2>&1
 tail -3 gpurun_out/$TAG/e2e_roofline.log
+# the headline kernel under rocprofv3 (kernel trace + the PMC passes, each its own run) and the eight-rank launch folded onto this box's GPU
+cd $GRAFT_REPO_ROOT
+bash profiles/collect.sh ${TAG}_C2 > gpurun_out/$TAG/collect_C2.log 2>&1
+cp gpurun_out/prof_${TAG}_C2/summary.json gpurun_out/$TAG/${TAG}_C2.json; cp gpurun_out/prof_${TAG}_C2/kernel_stats.csv gpurun_out/$TAG/${TAG}_C2_kernel_stats.csv
+head -c 600 gpurun_out/$TAG/${TAG}_C2.json; echo
+python bench.py --gpus 8 --pairs 8000 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/${TAG}_bench_n8_folded.json 2> gpurun_out/$TAG/bench_n8.err
+head -c 400 gpurun_out/$TAG/${TAG}_bench_n8_folded.json; echo

@@ -649,7 +649,8 @@ static void usage(void)
          "            --substitution_matrix <file>  --substitution_pairs <file>  --wildcard <char> <score>\n"
          "            --nogaps --nogapsin1 --nogapsin2 --nomismatches%s\n"
          "  output:   --printfasta --pretty --colour --printmatrices%s\n"
-         "  environment: SEQALIGN_DEVICE=<gpu>  SEQALIGN_GPUS=<n> (split every batch over n GPUs)\n",
+         "  environment: SEQALIGN_DEVICE=<gpu>  SEQALIGN_GPUS=<n> (split every batch over n GPUs)\n"
+         "               SEQALIGN_CLI_TIMING=1 (the stages' busy times on stderr)  SEQALIGN_CLI_EXIT=full (run the runtime's exit handlers)\n",
          nw ? "seqalign_nw" : "seqalign_sw", nw ? "Global (Needleman-Wunsch)" : "Local (Smith-Waterman)",
          nw ? "needleman_wunsch" : "smith_waterman",
          nw ? " --freestartgap --freeendgap" : "",
