@@ -232,7 +232,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     r.hit_count = reinterpret_cast<uint32_t *>(d_meta.as<unsigned long long>() + n) + k0; r.status = r.hit_count + n;
     r.n_pairs = (uint32_t)(k1 - k0); r.K = sc->flat.n_classes; r.open1 = sc->flat.open1; r.ext = sc->flat.ext;
     r.gen_eq = sc->flat.gen_eq; r.gen_ne = sc->flat.gen_ne; r.flags = sc->flat.flags;
-    r.max_len_a = c.max_a; r.layout = layout; r.tune_cpl = ctx->opt.sweep_cpl; r.tune_ev = ctx->opt.sweep_ev;
+    r.max_len_a = c.max_a; r.max_len_b = c.max_b; r.layout = layout; r.tune_cpl = ctx->opt.sweep_cpl; r.tune_ev = ctx->opt.sweep_ev;
     r.dirs = dirs ? cand.dirs : nullptr;
     return r;
   };

@@ -141,6 +141,7 @@ struct SaSweepParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t max_len_a;            /* of the chunk: picks the kernel                                    */
+  uint32_t max_len_b;            /* of the chunk (0: unknown): with max_len_a the radices of the sweep's mixed-radix 32-bit word  */
   SaKeyLayout layout;
   unsigned long long *trace;     /* optional [8n]: cycles, rows, active row segments, rounds, cycles in active segments (option sweep_trace) */
   uint32_t tune_ev;              /* host side only: the direction-byte sweep's second form (walks as key << 2 | state words; option sweep_ev) */

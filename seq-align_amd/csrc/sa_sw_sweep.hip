@@ -907,8 +907,13 @@ constexpr int sweep_ev_waves(int cpl, bool wide_keys) {
   return wide_keys ? (cpl <= 2 ? 8 : cpl == 3 ? 6 : cpl == 4 ? 5 : cpl <= 6 ? 3 : 2)
                    : (cpl <= 3 ? 8 : cpl == 4 ? 6 : cpl <= 6 ? 5 : cpl <= 12 ? 4 : 3);
 }
-template <int CPL, typename EvT>
+// MIXED (32-bit words only): the key inside the word is not the layout's bit fields but the same three numbers in mixed radix,
+// ((cap - score) x W + column) x H + row with W, H = the chunk's longest sequences + 1 -- same order, up to three bits shorter,
+// which is what puts reads of 600-700 bp against 1 000-column windows (31 bits of fields) into a 32-bit word: one v_min3_u32 per
+// cell instead of two 64-bit compare-and-selects.  Hits (rare) are turned back into layout keys where they are stored.
+template <int CPL, typename EvT, bool MIXED = false>
 __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) sw_sweep_dirs_ev_kernel(const SaSweepParams p) {
+  static_assert(!MIXED || sizeof(EvT) == 4, "the mixed-radix word is the 32-bit one");
   constexpr EvT kNone = ~(EvT)0;
   constexpr int NB = CPL <= 4 ? 4 : CPL <= 8 ? 3 : 2;   // row buffers (12 / 16 columns per lane: a row's work outlasts a load)
   typedef SweepRow<CPL> Row;
@@ -928,6 +933,7 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
   const uint32_t rmin = p.cand_box[4ull * pair], rmax = p.cand_box[4ull * pair + 1];
   const int thr = max(p.min_score[pair], 1);
   const uint32_t cshift = p.layout.row_bits + 2u, sshift = p.layout.row_bits + p.layout.col_bits + 2u;   // (of the ev word)
+  const uint32_t mix_h = p.max_len_b + 1u, mix_wh = (p.max_len_a + 1u) * mix_h;   // (MIXED: the radices; mix_wh * 4 < 2^24)
   const int cap = p.layout.cap;
 
   int thr_c[CPL];
@@ -942,7 +948,8 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
   for (int c = 0; c < CPL; ++c) {
     thr_c[c] = (uint32_t)(xl + c) < W ? thr : INT32_MAX;
     out_diag[c] = kNone; out_up[c] = kNone;
-    col_row[c] = ((EvT)(uint32_t)(xl + c) << cshift) | ((EvT)rmax << 2);
+    if constexpr (MIXED) col_row[c] = (EvT)((((uint32_t)(xl + c) * mix_h) + rmax) << 2);
+    else col_row[c] = ((EvT)(uint32_t)(xl + c) << cshift) | ((EvT)rmax << 2);
   }
   uint32_t y = rmax;
 #pragma unroll
@@ -969,7 +976,10 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
         const EvT diag_edge = wave_shl1(out_diag[0], kNone);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const EvT own = (m[c] >= thr_c[c]) ? (((EvT)(uint32_t)(cap - m[c]) << sshift) | col_row[c]) : kNone;   // (arrives in MATCH: 0)
+          EvT own_key;
+          if constexpr (MIXED) own_key = (EvT)(__umul24((uint32_t)(cap - m[c]), mix_wh << 2) + (uint32_t)col_row[c]);
+          else own_key = ((EvT)(uint32_t)(cap - m[c]) << sshift) | col_row[c];
+          const EvT own = (m[c] >= thr_c[c]) ? own_key : kNone;   // (arrives in MATCH: 0)
           const EvT dg = c + 1 < CPL ? out_diag[c + 1 < CPL ? c + 1 : c] : diag_edge;
           arr[c] = min(own, min(dg, out_up[c]));
           any |= arr[c] != kNone;
@@ -1018,7 +1028,14 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
             const unsigned long long bal = __ballot(hit);
             if (bal) {
               const uint32_t pos = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-              if (hit && pos < hit_cap) hit_keys[pos] = (unsigned long long)(win[c] >> 2);
+              if (hit && pos < hit_cap) {
+                if constexpr (MIXED) {   // back to the layout's fields (the walkers and the host read those)
+                  const uint32_t k = (uint32_t)(win[c] >> 2), s = k / mix_wh, rem = k - s * mix_wh, col = rem / mix_h, row = rem - col * mix_h;
+                  hit_keys[pos] = ((unsigned long long)s << (sshift - 2u)) | ((unsigned long long)col << (cshift - 2u)) | row;
+                } else {
+                  hit_keys[pos] = (unsigned long long)(win[c] >> 2);
+                }
+              }
               n_hits += (uint32_t)__popcll(bal);
               if (n_hits > hit_cap) overflow = true;   // (cannot happen: SaSweepParams::hit_off)
             }
@@ -1124,11 +1141,19 @@ uint32_t sa_sweep_strip_blocks(uint32_t n_pairs, uint32_t max_len_a, uint32_t st
 }
 
 namespace sa {
+// the mixed-radix 32-bit word (sw_sweep_dirs_ev_kernel<.., true>): every key (cap - score, column, row) of the chunk below 2^30 - 1
+// (all ones = "no walk"), and the score's factor small enough for the 24-bit multiplier
+static bool sweep_mixed_fits(const SaSweepParams &p) {
+  if (!p.max_len_b || p.layout.cap <= 0) return false;
+  const uint64_t wh = ((uint64_t)p.max_len_a + 1) * ((uint64_t)p.max_len_b + 1);
+  return wh * 4 < ((uint64_t)1 << 24) && (uint64_t)p.layout.cap < ((uint64_t)1 << 24) && (uint64_t)p.layout.cap * wh < ((uint64_t)1 << 30) - 1;
+}
 template <int CPL>
 static void launch_sweep_dirs(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t bits = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits;
   if (p.tune_ev) {   // key << 2 | state in one word (62-bit keys at most: seqalign_sw_batch's layouts are <= 63 bits, the host path takes the rest)
     if (bits + 2 <= 32) { hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p); return; }
+    if (sweep_mixed_fits(p)) { hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t, true>), dim3(p.n_pairs), dim3(kWave), 0, stream, p); return; }
     if (bits + 2 <= 64) { hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p); return; }
   }
   const bool key32 = bits <= 31;
@@ -1139,6 +1164,7 @@ template <int CPL>
 static void launch_sweep_dirs_wide(const SaSweepParams &p, hipStream_t stream) {
   const uint32_t bits = p.layout.row_bits + p.layout.col_bits + p.layout.score_bits;
   if (bits + 2 <= 32) hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
+  else if (sweep_mixed_fits(p)) hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, uint32_t, true>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
   else hipLaunchKernelGGL((sw_sweep_dirs_ev_kernel<CPL, unsigned long long>), dim3(p.n_pairs), dim3(kWave), 0, stream, p);
 }
 }  // namespace sa

@@ -48,11 +48,14 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
         osc = O.Scoring.from_buffer_copy(bytes(sc))
         # pairs: random, related, and tandem repeats (many equal-score candidates, several hits)
         pairs = []
+        mode = int(v[0] >> 9) % 8                     # (which sweep form: below)
+        lb_max = 1500 if mode == 6 else 200           # mode 6: long second sequences too, so that the sweep's word is 32 bits of
+                                                      # fields, 32 bits in mixed radix or 64 bits from draw to draw
         for k in range(12):
             kind = int(v[7] + k) % 3
             la = int(2 + (v[8] * (k + 1)) % (260 if k % 4 else 900))
             if kind == 0:
-                a, b = rand(la), rand(int(2 + (v[9] * (k + 3)) % 200))
+                a, b = rand(la), rand(int(2 + (v[9] * (k + 3)) % lb_max))
             elif kind == 1:
                 a = rand(la)
                 cut = int(v[10] % max(1, len(a)))
@@ -69,7 +72,6 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
         # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
         for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "pack16"):
             ctx.set_option(key, S.OPTION_DEFAULTS[key])
-        mode = int(v[0] >> 9) % 8
         if mode < 3:
             ctx.set_option("sweep_cpl", (1, 2, 4)[mode])
         elif mode == 3:

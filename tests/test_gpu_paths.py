@@ -75,7 +75,9 @@ def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
 
 @pytest.mark.parametrize("pack16", [2, 0])
 @pytest.mark.parametrize("la,lb,wide_keys", [(512, 150, False), (700, 200, False), (767, 90, False), (768, 130, False), (1023, 200, False),
-                                             (640, 2500, True), (1000, 2100, True)])
+                                             (640, 2500, True), (1000, 2100, True),
+                                             # keys of 31 bits in the layout's fields, < 2^30 in mixed radix (sw_sweep_dirs_ev_kernel<.., true>)
+                                             (700, 1000, True), (600, 1000, True), (500, 2100, True), (767, 900, True)])
 def test_sw_multi_hit_direction_path_takes_rows_up_to_1024_columns(ctx, opts, pack16, la, lb, wide_keys):
     """Round 5: match_scores + direction bytes and the one-word sweep behind them (sw_sweep_dirs_ev_kernel, 12 / 16 columns per lane)
     for rows of 513 .. 1 024 columns -- offered from 1 024 pairs up, or with sweep_mode = pair (here: few pairs, so that the oracle
