@@ -13,7 +13,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e $*"
+CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-unplaced $*"
 echo "$CMD" > "$OUT/command.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
 # the same pass once more as CSV: the human-readable --stats table that gets committed
