@@ -84,6 +84,7 @@ typedef struct {
   size_t *name_a, *name_b;
   uint64_t *off_a, *off_b; uint32_t *len_a, *len_b;
   size_t n, cap;
+  uint64_t cells;                         /* sum of (len_a + 1)(len_b + 1): a batch also ends at BATCH_CELLS */
   int last;                               /* the reader's last batch: end of input */
   /* results */
   uint64_t *str_off; uint32_t *out_len; int32_t *score;     /* NW */
@@ -123,6 +124,7 @@ static void batch_add_b(batch_t *b, const char *nb, const char *sb, size_t lb)
 {
   b->name_b[b->n] = text_add(b, nb, strlen(nb));
   b->off_b[b->n] = text_add(b, sb, lb); b->len_b[b->n] = (uint32_t)lb;
+  b->cells += ((uint64_t)b->len_a[b->n] + 1) * ((uint64_t)lb + 1);
   b->n++;
 }
 static void batch_drop_a(batch_t *b) { b->text_len = b->name_a[b->n]; }   /* an odd record at end of file */
@@ -526,6 +528,10 @@ static void print_sw_batch(const batch_t *bt)
 /* ------------------------------------------------------------- the pipeline */
 
 #define BATCH_PAIRS 65536
+/* ... or this many DP cells, whichever comes first: the multi-hit SW path keeps 5 bytes per cell on the GPU (NW and --maxhits 1:
+ * one), and the first batch pays for allocating that -- 65 536 reads of 150 bp against 1 000 bp windows would ask for 50 GB at once
+ * (0.5-2 s in the driver); 2 G cells = 10 GB, taken once and reused by every later batch */
+#define BATCH_CELLS ((uint64_t)2 << 30)
 #define N_BATCHES 8          /* one on the GPU, one being printed, the rest read ahead: opening the GPU takes as long as reading
                                 ~0.5 M pairs, and a reader that may only run two batches ahead sits out most of that (a batch's
                                 buffers are allocated when it is first used: short inputs touch one) */
@@ -565,7 +571,7 @@ static void *reader_main(void *arg)
   int f;
   double t0 = now_s();
   (void)arg;
-  bt->n = 0; bt->text_len = 0; bt->last = 0;
+  bt->n = 0; bt->text_len = 0; bt->last = 0; bt->cells = 0;
   if(opt.seq1) { batch_add_a(bt, "", opt.seq1, strlen(opt.seq1)); batch_add_b(bt, "", opt.seq2, strlen(opt.seq2)); }
   for(f = 0; f < opt.n_files; f++) {
     seqalign_reader_t *r1 = seqalign_reader_open(opt.files1[f]), *r2 = NULL;
@@ -582,12 +588,12 @@ static void *reader_main(void *arg)
         break;
       }
       batch_add_b(bt, n2, s2, l2);
-      if(bt->n >= BATCH_PAIRS) {
+      if(bt->n >= BATCH_PAIRS || bt->cells >= BATCH_CELLS) {
         g_busy[0] += now_s() - t0;
         fifo_put(&g_read, bt);
         bt = fifo_get(&g_free);         /* blocks while all batches are downstream: bounded memory */
         t0 = now_s();
-        bt->n = 0; bt->text_len = 0; bt->last = 0;
+        bt->n = 0; bt->text_len = 0; bt->last = 0; bt->cells = 0;
       }
     }
     seqalign_reader_close(r1);

@@ -54,3 +54,23 @@ for _ in range(6):
     ctx.nw_batch(b, sc, raw=True)
     ts.append(time.perf_counter() - t0)
 print(f"seqalign_nw_batch on 125 000 of the pairs: {np.median(ts[1:]) * 1e3:.2f} ms -> {n / 125000 * np.median(ts[1:]):.3f} s for {n}", flush=True)
+
+# ---- the same for seqalign_sw: BASELINE configs[2]'s reads (150 bp against 1 000 bp windows) as a file, the tool's defaults
+# (--minscore from the lengths, every hit) and --maxhits 1
+ns = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
+fs = tmp / f"c3_{ns}.fa"
+with open(fs, "wb") as f:
+    for lo in range(0, ns, 20000):
+        b = W.dna_sw_read_vs_ref(min(20000, ns - lo), seed=2 + lo)
+        f.write(b"".join(b">r%d\n%s\n>w%d\n%s\n" % (lo + p, b.seq_a(p), lo + p, b.seq_b(p)) for p in range(b.n_pairs)))
+print(f"wrote {fs} ({fs.stat().st_size / 1e6:.0f} MB, {ns} read / window pairs)", flush=True)
+exe_sw = exe.with_name("seqalign_sw")
+for extra in ([], ["--maxhits", "1"]):
+    for rep in range(2):
+        out = tmp / "out_sw.txt"
+        t0 = time.perf_counter()
+        with open(out, "wb") as fo:
+            subprocess.run([str(exe_sw), *extra, "--file", str(fs)], stdout=fo, check=True, env=dict(os.environ, SEQALIGN_CLI_TIMING="1"))
+        dt = time.perf_counter() - t0
+        print(f"seqalign_sw {' '.join(extra)} --file: {dt:.3f} s wall, {ns / dt / 1e6:.3f} M pairs/s, {ns * 151 * 1001 / dt / 1e9:.1f} GCUPS end to end "
+              f"(output {out.stat().st_size / 1e6:.0f} MB)", flush=True)
