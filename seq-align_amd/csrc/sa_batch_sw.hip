@@ -287,7 +287,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
 
   // ---- the sweep: every hit of every pair
   q = sweep_params(d, 0, n, dirs_used);
-  // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows up to 512 columns in registers,
+  // How the pairs are laid over waves (sa_sw_sweep.hip): one wave per pair -- rows in registers (up to 512 columns on three matrices, up to 1 024 on direction bytes),
   // wider ones in segments with the winners of two rows in LDS -- or, for FEW wide pairs (a wave per pair would leave
   // the chip empty) and for rows too wide for LDS, one wave per 256-column strip.  The option sweep_mode = strips | pair
   // forces one (tests, experiments).

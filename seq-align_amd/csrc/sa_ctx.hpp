@@ -306,7 +306,7 @@ struct SaOptions {
   bool sweep_ev = true;           // sweep_ev          0|1: the direction-byte sweep carries a walk as one word key << 2 | state (one min3 per cell)
   bool sweep_trace = false;       // sweep_trace       per-pair counters of the sweep on stderr
   bool nw_dirs = true;            // nw_dirs           0|1: seqalign_nw_batch fills ONLY a byte of directions per cell (sa_fill_dirs.hip) where
-                                  //                   it applies (plain scorings, rows <= 512 columns), instead of the three matrices
+                                  //                   it applies (plain scorings, rows <= 1 024 columns), instead of the three matrices
   bool sweep_dirs = true;         // sweep_dirs        0|1: the multi-hit path fills match_scores + direction bytes (sa_fill_dirs.hip)
                                   //                   where it applies, instead of the three matrices
   int pack16 = 1;                 // pack16            0|1|2: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)

@@ -17,7 +17,7 @@
 // per row) as the stream kernel's SA_STREAM_CAND mode.
 //
 // Domain: Smith-Waterman, "plain" scorings (no free / forbidden gaps, no sentinel scores, gap_open <= 0 -- what every
-// BASELINE SW config is), rows up to 512 columns (the sweep's rows-in-registers form).  Everything else takes the
+// BASELINE SW config is), rows up to 1 024 columns (the sweep's rows-in-registers forms; 513 and up: round 5).  Everything else takes the
 // three-matrix path.  The decisions are the SAME expressions the sweep evaluated (sa_sw_sweep.hip, `plain`), on the
 // same int32 values; tests/test_gpu_parity.py runs every hit-list test through both paths.
 #include "sa_rowsweep.hpp"

@@ -300,11 +300,11 @@ hipError_t sa_launch_fill_wgstream(const SaFillParams &p, uint32_t max_len_a, hi
 bool sa_wgstream_kernel_reports_best(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b);
 bool sa_wgstream_kernel_emits_candidates(const SaFillParams &p, uint32_t max_len_a);
 /* the SW multi-hit path's own fill (sa_fill_dirs.hip): match_scores + one byte of directions per cell into `dirs`
- * (same cell offsets as the matrices), candidates reported as by the stream kernel; plain SW scorings, rows <= 512 columns */
+ * (same cell offsets as the matrices), candidates reported as by the stream kernel; plain SW scorings, rows <= 1 024 columns */
 bool sa_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
 hipError_t sa_launch_fill_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 /* seqalign_nw_batch's own fill: ONLY the directions (1 B per cell) + per pair the end cell's score (p.best_score) and state
- * (p.best_index); plain NW scorings (no flag), rows <= 512 columns */
+ * (p.best_index); plain NW scorings (no flag), rows <= 1 024 columns */
 bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const uint8_t *dirs);
 hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream);
 /* the same fills with two pairs per wave in packed int16 (sa_fill_dirs_x2.hip): uniform batches, match / mismatch scorings,

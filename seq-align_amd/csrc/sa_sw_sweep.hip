@@ -1171,7 +1171,7 @@ static void launch_sweep_dirs_wide(const SaSweepParams &p, hipStream_t stream) {
 
 hipError_t sa_launch_sw_sweep(const SaSweepParams &p, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  if (p.dirs) {   // behind sa_fill_dirs.hip: match_scores + a byte of directions per cell (rows up to 512 columns)
+  if (p.dirs) {   // behind sa_fill_dirs.hip: match_scores + a byte of directions per cell (rows up to 1 024 columns)
     const uint32_t need = (p.max_len_a + 1 + sa::kWave - 1) / sa::kWave;
     if (need > 16 || p.strip_progress) return hipErrorInvalidValue;
     if (need > 8 && !(p.tune_ev && p.layout.row_bits + p.layout.col_bits + p.layout.score_bits + 2 <= 64)) return hipErrorInvalidValue;
