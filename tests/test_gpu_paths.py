@@ -58,7 +58,7 @@ def uniform(n, la, lb, seed, alpha=b"ACGT", related=0.5):
 
 def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
     """Round 5: the packed best-hit fill (direction bytes + the best cell, no matrices) has no sweep behind it and takes rows up
-    to 1 024 columns like the NW fill; the multi-hit fill takes such rows only from 1 024 pairs up (next test)."""
+    to 1 024 columns like the NW fill; the multi-hit fill takes such rows only from 128 pairs up (next test)."""
     opts(pack16=2)
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     osc = osc_of(sc)
@@ -80,7 +80,7 @@ def test_sw_best_hit_fill_takes_rows_up_to_1024_columns(ctx, opts):
                                              (700, 1000, True), (600, 1000, True), (500, 2100, True), (767, 900, True)])
 def test_sw_multi_hit_direction_path_takes_rows_up_to_1024_columns(ctx, opts, pack16, la, lb, wide_keys):
     """Round 5: match_scores + direction bytes and the one-word sweep behind them (sw_sweep_dirs_ev_kernel, 12 / 16 columns per lane)
-    for rows of 513 .. 1 024 columns -- offered from 1 024 pairs up, or with sweep_mode = pair (here: few pairs, so that the oracle
+    for rows of 513 .. 1 024 columns -- offered from 128 pairs up, or with sweep_mode = pair (here: few pairs, so that the oracle
     finishes); with 32-bit and with 64-bit keys; through the one-trip call (max_hits <= 8) and the three-trip one; against the
     three-matrix path (sweep_ev = 0 does not take wide rows) and the oracle (smith_waterman.c:137-277)."""
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
@@ -102,19 +102,19 @@ def test_sw_multi_hit_direction_path_takes_rows_up_to_1024_columns(ctx, opts, pa
         assert rc == 0 and many[p] == want and few[p] == want[:3], (la, lb, p, len(want))
 
 
-def test_sw_multi_hit_wide_rows_from_1024_pairs(ctx):
-    """The same path as the default for a batch of 1 024 reads of 600 bp against 700-column windows (and not for 1 023 of them:
-    few wide pairs go to the strip sweep as before); hit lists against the oracle for a sample of the pairs."""
+def test_sw_multi_hit_wide_rows_from_128_pairs(ctx):
+    """The same path as the default for a batch of 128 reads of 700 bp against 120-row windows (and not for 127 of them: few wide
+    pairs go to the strip sweep as before); hit lists against the oracle."""
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     osc = osc_of(sc)
-    batch = uniform(1024, 700, 120, seed=77)
+    batch = uniform(128, 700, 120, seed=77)
     res = ctx.sw_batch(batch, sc, 30, max_hits=4)
     launched = ctx.last_call()
     assert "fill_sw_dirs" in launched and "sweep_dirs" in launched, launched   # (packed two per wave from 2 048 pairs up)
-    for p in range(0, 1024, 37):
+    for p in range(128):
         rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 4)
         assert rc == 0 and res[p] == want, p
-    small = uniform(1023, 700, 120, seed=77)
+    small = uniform(127, 700, 120, seed=77)
     ctx.sw_batch(small, sc, 30, max_hits=4)
     assert "sweep_dirs" not in ctx.last_call(), ctx.last_call()
 
