@@ -577,7 +577,13 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     bool same_shape = true;
     for (uint64_t k = 1; k < n && same_shape; ++k)
       same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
-    if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
+    // From how many pairs: what this fill competes with below that is not a one-pair direction fill (the NW / multi-hit paths'
+    // kPackedFillMinPairs) but three matrices and their walker.  tools/sw_best_few.py, same process, packed against not:
+    // BLOSUM62 300 x 300 -- ahead at every size (128 pairs 0.52 -> 0.46 ms, 2 047 pairs 0.92 -> 0.58); match / mismatch, 150 x 1 000 --
+    // level at ~1 400 pairs (1 024: 0.68 -> 0.76, 2 047: 0.99 -> 0.83); 700 x 1 000 -- at ~700 (512: 1.63 -> 1.94, 1 024: 2.25 -> 2.00,
+    // 2 047: 4.10 -> 2.11): a wave's row costs more with two pairs in it, which is what a launch too small to fill the chip pays.
+    const uint64_t best_min_pairs = sc->flat.n_classes > 1 ? 128 : c.max_a + 1 > 512 ? 1024 : 1536;
+    if (same_shape && (n >= best_min_pairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
     else if (!same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
              sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
