@@ -311,7 +311,7 @@ struct SaOptions {
                                   //                   where it applies, instead of the three matrices
   int pack16 = 1;                 // pack16            0|1|2: the direction-byte fills take two pairs per wave in packed int16 (sa_fill_dirs_x2.hip)
                                   //                   where they apply (every pair of the chunk the same shape, match / mismatch scoring):
-                                  //                   never | chunks of >= 2 048 pairs | whatever the chunk's size (tests)
+                                  //                   never | chunks of > 1 024 pairs | whatever the chunk's size (tests)
   uint32_t quad = 0;              // quad              0|1|2: the NW / SW best-hit packed fills take FOUR pairs per wave (32 lanes a couple; uniform chunks, rows
                                   //                   up to 192 columns): chunks of >= 4 096 / 16 384 pairs | never | whatever the chunk's size (tests)
   bool walk_overlap = false;      // walk_overlap      0|1: seqalign_nw_batch's direction-byte path walks a group of sub-batches on its own stream
@@ -431,9 +431,12 @@ bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t 
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
 // cells start on a multiple of 256)
 bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
-// Two pairs per wave halve the waves of a launch: below ~2 000 pairs of a chunk (a quarter of the chip's wave slots) the
-// one-pair kernels are as fast or faster (profiles/r03/r03_x2_crossover.txt, C2 / C3 shapes: 1 024 pairs +3 %, 2 048: -3 %, 8 192: -10 %)
-constexpr uint64_t kPackedFillMinPairs = 2048;
+// Two pairs per wave halve the waves of a launch.  Up to 1 024 pairs every wave of the one-pair kernels has a SIMD to itself and the
+// two forms take the same time; from the 1 025th pair on two of their waves share a SIMD and the packed fills are ahead
+// (tools/pack_by_batch_size.py, profiles/r05/r05_pack_by_batch_size.txt: 1 056 pairs -- NW C2's shape 0.228 -> 0.214 ms, SW up to 4
+// hits C3's 1.28 -> 1.12, C4's 0.92 -> 0.88; 1 024 pairs: 0.200 / 0.199, 1.10 / 1.09, 0.75 / 0.78).  (Rounds 3-4: 2 048, from a
+// record taken before the packed kernels' later gains.)
+constexpr uint64_t kPackedFillMinPairs = 1025;
 bool sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b, const seqalign_trace_t *t,
                       const uint8_t *dirs, const int32_t *start_score, void *stream);

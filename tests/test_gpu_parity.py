@@ -468,7 +468,7 @@ def test_direction_byte_paths_every_width(ctx, max_len):
                                    (512, 40), (600, 33), (767, 21), (768, 30), (1000, 25), (1023, 18)])
 def test_nw_batch_two_pairs_per_wave(ctx, opts, shape):
     """Batches whose pairs all have one shape take the packed direction fill (sa_fill_dirs_x2.hip: two pairs per wave,
-    int16 halves; option pack16 -- 2: also for chunks below the 2 048 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
+    int16 halves; option pack16 -- 2: also for chunks below the 1 025 pairs from which it pays): strings and scores equal the oracle's (needleman_wunsch.c:53-145) and the one-pair
     kernel's (pack16 = 0) for every columns-per-lane instantiation, odd and even pair counts (the last wave of an odd
     launch holds one pair), unrelated and related sequences, gap_open = 0, sub-batches cut at odd pairs, substitution
     tables -- and a scoring whose scores could leave int16 is NOT packed (same results through the 32-bit kernel)."""

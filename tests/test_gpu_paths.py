@@ -110,7 +110,7 @@ def test_sw_multi_hit_wide_rows_from_128_pairs(ctx):
     batch = uniform(128, 700, 120, seed=77)
     res = ctx.sw_batch(batch, sc, 30, max_hits=4)
     launched = ctx.last_call()
-    assert "fill_sw_dirs" in launched and "sweep_dirs" in launched, launched   # (packed two per wave from 2 048 pairs up)
+    assert "fill_sw_dirs" in launched and "sweep_dirs" in launched, launched   # (packed two per wave from 1 025 pairs up)
     for p in range(128):
         rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 4)
         assert rc == 0 and res[p] == want, p
