@@ -242,7 +242,7 @@ int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  *       the pair, in order -- follow from one pass over the rows, bottom to top, without
  *       the sequential procedure of smith_waterman.c:165-277 being run
  *       -> one GPU traceback per wanted hit.  Any max_hits; only the strings cross PCIe.
- *       Plain scorings, rows up to 1 024 columns (513 and up: batches of >= 128 pairs, keys
+ *       Plain scorings, rows up to 1 024 columns (513 and up: batches of >= 128 pairs, 769 and up: >= 640; keys
  *       of <= 62 bits): the fill writes match_scores + one byte of directions per cell
  *       instead of the three matrices, the sweep and the walks read those (option
  *       sweep_dirs=0: three matrices everywhere).

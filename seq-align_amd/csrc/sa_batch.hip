@@ -469,7 +469,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   const uint64_t total = pos;   // == c.seq_bytes
   // Plain scorings, rows up to 1 024 columns: the fill writes ONE byte of directions per cell and nothing else
   // (sa_fill_dirs.hip) -- the three matrices are never needed, so they are not even allocated.
-  const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a);
+  const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a, n);
   // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
   // (sa_fill_dirs_x2.hip); each pair's bytes then start on a 256-byte boundary
   uint64_t stride = 0, mat_total = c.cells;
@@ -1148,7 +1148,7 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   seqalign_dev_scoring *sc = nullptr;
   if ((rc = cached_scoring(ctx, scoring, 0, &sc))) return rc;
   const bool on_host = traceback_on_host(ctx);
-  if (!on_host && ctx->opt.nw_moves && nw_dirs_applicable(ctx, sc, whole.max_a)) {
+  if (!on_host && ctx->opt.nw_moves && nw_dirs_applicable(ctx, sc, whole.max_a, batch->n_pairs)) {
     // direction bytes (1 B per cell, every pair rounded up to 256 at most) + ~64 B per pair of descriptors and results:
     // C5's 1 M pairs are 23 GB -- one chunk, where 12 B per cell cut them into six
     if (cells256 + 64 * batch->n_pairs + whole.seq_bytes <= ctx->chunk_budget)

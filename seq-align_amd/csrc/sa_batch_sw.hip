@@ -195,7 +195,9 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   // the chip (few wide pairs: strips, below, as before)
   const bool wide_row = c.max_a + 1 > 512;
   const bool wide_ok = ctx->opt.sweep_ev && layout.row_bits + layout.col_bits + layout.score_bits <= 62 &&
-                       (n >= 128 || ctx->opt.sweep_mode == 1);   // (tools/sw_wide_few.py: 128 pairs 4.04 -> 3.69 ms, 64: 3.51 -> 3.67)
+                       (n >= (c.max_a + 1 > 768 ? 640u : 128u) || ctx->opt.sweep_mode == 1);
+  // (tools/sw_wide_few.py, 700 x 1000 -- 12 columns per lane: 128 pairs 4.04 -> 3.69 ms, 64: 3.51 -> 3.67; 900 x 1000 -- 16 per lane:
+  //  512 pairs 5.8 on strips / 6.3 here, 1 024 pairs 8.1 / 6.2)
   const bool allow_dirs = ctx->opt.sweep_mode != 2 && ctx->opt.sweep_cpl == 0 && (!wide_row || wide_ok);
   // (the packed direction-byte fill is bound by instruction issue: its arenas need no placement walk)
   if ((rc = reserve_arenas(ctx, (stride == kBucketShapes ? cells256 : stride ? n * stride : c.cells) * 4, !(allow_dirs && stride != 0)))) return rc;

@@ -427,7 +427,8 @@ int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, con
 int nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                        int32_t *end_score, uint64_t *end_state, void *stream, const uint32_t *list, uint32_t n_modal, uint32_t n_rest,
                        uint32_t modal_a, uint32_t modal_b);
-bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a);
+// (n_pairs: of the chunk -- FEW pairs with rows over 768 columns stay with three matrices, whose fills put several waves on a pair)
+bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a, uint64_t n_pairs = ~0ull);
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's
 // cells start on a multiple of 256)
 bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);

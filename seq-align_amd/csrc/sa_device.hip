@@ -602,7 +602,11 @@ static SaScoringTraits traits_of(const seqalign_dev_scoring_t *s) {
   return SaScoringTraits{s->flat.flags, s->flat.n_classes, s->flat.gap_open, s->flat.open1, s->flat.ext, s->flat.gen_eq, s->flat.gen_ne,
                          s->table_abs_max};
 }
-bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a) {
+bool sa_host::nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a, uint64_t n_pairs) {
+  // One wave walks a pair's rows one after the other; with 16 columns per lane (rows of 769 .. 1 024 columns) a row is long enough
+  // that a few pairs are done sooner by fills that put several waves on each (tools/nw_wide_few.py, 1 000 x 1 000: 8 pairs 1.29 ms
+  // on three matrices / 1.88 on direction bytes, 128: 1.82 / 1.94, 256: 1.95 / 1.98, 512: 2.25 / 2.03; 700 x 700: ahead at every size)
+  if (max_len_a + 1 > 12 * 64 && n_pairs < 384) return false;
   return ctx->opt.nw_dirs && ctx->opt.kernel == SEQALIGN_KERNEL_AUTO && sa_domain_nw_dirs(traits_of(scoring), max_len_a);
 }
 bool sa_host::nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b) {

@@ -102,30 +102,33 @@ def test_sw_multi_hit_direction_path_takes_rows_up_to_1024_columns(ctx, opts, pa
         assert rc == 0 and many[p] == want and few[p] == want[:3], (la, lb, p, len(want))
 
 
-def test_sw_multi_hit_wide_rows_from_128_pairs(ctx):
-    """The same path as the default for a batch of 128 reads of 700 bp against 120-row windows (and not for 127 of them: few wide
-    pairs go to the strip sweep as before); hit lists against the oracle."""
+@pytest.mark.parametrize("la,n_min", [(700, 128), (767, 128), (768, 640), (900, 640)])
+def test_sw_multi_hit_wide_rows_by_batch_size(ctx, la, n_min):
+    """The same path as the default from 128 pairs up for rows of 513 .. 768 columns, from 640 for 769 .. 1 024 (below that few wide
+    pairs go to the strip sweep as before: tools/sw_wide_few.py); hit lists against the oracle."""
     sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     osc = osc_of(sc)
-    batch = uniform(128, 700, 120, seed=77)
+    batch = uniform(n_min, la, 60, seed=77 + la)
     res = ctx.sw_batch(batch, sc, 30, max_hits=4)
     launched = ctx.last_call()
     assert "fill_sw_dirs" in launched and "sweep_dirs" in launched, launched   # (packed two per wave from 1 025 pairs up)
-    for p in range(128):
+    for p in range(0, n_min, 3):
         rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 30, 4)
         assert rc == 0 and res[p] == want, p
-    small = uniform(127, 700, 120, seed=77)
+    small = uniform(n_min - 1, la, 60, seed=77 + la)
     ctx.sw_batch(small, sc, 30, max_hits=4)
     assert "sweep_dirs" not in ctx.last_call(), ctx.last_call()
 
 
-@pytest.mark.parametrize("la,expect_dirs", [(512, True), (700, True), (1023, True), (1024, False), (1500, False)])
-def test_nw_direction_fill_takes_rows_up_to_1024_columns(ctx, la, expect_dirs):
+@pytest.mark.parametrize("la,n,expect_dirs", [(512, 6, True), (700, 6, True), (767, 6, True), (768, 6, False), (1023, 6, False),
+                                              (768, 384, True), (1023, 384, True), (1023, 383, False), (1024, 384, False), (1500, 6, False)])
+def test_nw_direction_fill_takes_rows_up_to_1024_columns(ctx, la, n, expect_dirs):
     """Round 5: seqalign_nw_batch writes one byte of directions per cell for rows up to 1 024 columns (len_a <= 1 023; 12 / 16
-    columns per lane, one pair per wave) -- beyond that the three matrices; either way the oracle's strings
+    columns per lane, one pair per wave; rows over 768 columns from 384 pairs up: fewer are done sooner by the three-matrix fills,
+    which put several waves on a pair) -- beyond that the three matrices; either way the oracle's strings
     (needleman_wunsch.c:34-146)."""
     sc = S.make_scoring({"preset": "default"})
-    batch = uniform(6, la, 300, seed=900 + la)
+    batch = uniform(n, la, 300 if n < 100 else 24, seed=900 + la)
     res = ctx.nw_batch(batch, sc)
     launched = ctx.last_call()
     assert any(k.startswith("fill_nw_dirs") for k in launched) == expect_dirs, launched
