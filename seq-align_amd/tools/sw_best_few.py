@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """seqalign_sw_batch(max_hits = 1) by batch size: what runs below the packed fills' 2 048 pairs (pack16 = 1, the default) against the
-packed best-hit fill forced on (pack16 = 2), alternating in one process.   sw_best_few.py [C3 | C4 | wide] [pairs ...]"""
+packed best-hit fill forced on (pack16 = 2), alternating in one process.   sw_best_few.py [C3 | C4 | wide | wide<read length>] [pairs ...]"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
@@ -15,7 +15,7 @@ for n in sizes:
     if kind == "C4":
         batch = W.protein_sw_300(n, seed=3); sc = S.make_scoring({"preset": "BLOSUM62"})
     else:
-        batch = W.dna_sw_read_vs_ref(n, seed=2, read_len=700 if kind == "wide" else 150, ref_len=1000)
+        batch = W.dna_sw_read_vs_ref(n, seed=2, read_len=int(kind[4:] or 700) if kind.startswith("wide") else 150, ref_len=1000)
         sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0]))
     res = {1: [], 2: []}
