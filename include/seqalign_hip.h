@@ -216,7 +216,7 @@ int seqalign_fill_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
  * on the device and only the strings cross PCIe; the option traceback=host copies
  * the matrices back and walks them on the host (north_star's literal split --
  * identical results, PCIe-bound).  For plain scorings (no free / forbidden gaps, no
- * sentinel scores, gap_open <= 0, gap_extend <= 0) and rows up to 1 024 columns (round 5) the
+ * sentinel scores, gap_open <= 0, gap_extend <= 0) and rows up to 1 024 columns (round 5; over 768: from 384 pairs) the
  * device path does not write the matrices at all: the fill leaves one byte of
  * directions per cell -- the answers to alignment_reverse_move's equality tests,
  * src/alignment.c:311-327, taken while the operands are in registers -- and the
