@@ -6,3 +6,6 @@ cp gpurun_out/e2e_roofline_$TAG/e2e_pmc_insts.json $D/${TAG}_e2e_pmc_insts.json
 cp gpurun_out/e2e_roofline_$TAG/e2e_roofline.json $D/${TAG}_e2e_roofline.json
 cp gpurun_out/e2e_roofline_$TAG/e2e_roofline.json profiles/e2e_roofline.json
 ls $D | grep "^$TAG" | wc -l
+# the bench line the rocprof'd process itself printed (its live HIP-event figure belongs beside that process's kernel trace: every
+# process finds its own placement, 0.82-0.86)
+grep -h '"metric"' gpurun_out/prof_${TAG}_C2/stats.log | sed 's/^[^{]*//' > $D/${TAG}_C2_bench_line_under_rocprof.json
