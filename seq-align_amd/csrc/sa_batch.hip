@@ -482,7 +482,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
     for (uint64_t k = 0; k < n; ++k) h_mat[k] = k * stride;
     mat_total = n * stride;
-  } else if (use_dirs && !same_shape && ctx->opt.pack16 && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2)) {
+  } else if (use_dirs && !same_shape && ctx->opt.pack16 && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2)) {
     // the majority shape, if there is one (Boyer-Moore vote, then an exact count: two passes of compares, no hashing --
     // a hash map over 125 000 pairs cost more host time than the packed kernel saves)
     uint64_t best_key = 0, votes = 0, best_count = 0;
@@ -492,7 +492,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
     }
     for (uint64_t k = 0; k < n; ++k) best_count += ((uint64_t)h_len_a[k] << 32 | h_len_b[k]) == best_key;
     modal_a = (uint32_t)(best_key >> 32); modal_b = (uint32_t)best_key;
-    if ((best_count >= kPackedFillMinPairs || (ctx->opt.pack16 == 2 && best_count >= 2)) && best_count * 2 >= n &&
+    if ((best_count >= kBucketedFillMinPairs || (ctx->opt.pack16 == 2 && best_count >= 2)) && best_count * 2 >= n &&
         nw_dirs_x2_applicable(ctx, sc, modal_a, modal_b)) {
       mixed = true;
       uint64_t at = 0;
@@ -770,7 +770,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   if (same_shape && may_pack && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     layout = kUniform;
     stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
-  } else if (!same_shape && may_pack && (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull) <= kShapeTableMax &&
+  } else if (!same_shape && may_pack && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2) && (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull) <= kShapeTableMax &&
              nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     // ragged (reads trimmed to various lengths): pairs of EQUAL shape are found per sub-batch and go two per wave, the ones
     // left over one per wave, all in one grid per sub-batch (below: pair_up)

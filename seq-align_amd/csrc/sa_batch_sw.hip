@@ -183,7 +183,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       same_shape = batch->len_a[c.first + k] == batch->len_a[c.first] && batch->len_b[c.first + k] == batch->len_b[c.first];
     if (same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
-    else if (!same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
+    else if (!same_shape && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
              sw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = kBucketShapes;   // ragged: run_chunk pairs up the pairs of equal shape, every pair on a multiple of 256 cells
   }
@@ -587,7 +587,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     const uint64_t best_min_pairs = sc->flat.n_classes > 1 ? 128 : c.max_a + 1 > 512 ? 1024 : 1536;
     if (same_shape && (n >= best_min_pairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
-    else if (!same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
+    else if (!same_shape && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
              sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = kBucketShapes;   // ragged: run_chunk pairs up the pairs of equal shape
   }

@@ -438,6 +438,10 @@ bool nw_dirs_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring
 // hits C3's 1.28 -> 1.12, C4's 0.92 -> 0.88; 1 024 pairs: 0.200 / 0.199, 1.10 / 1.09, 0.75 / 0.78).  (Rounds 3-4: 2 048, from a
 // record taken before the packed kernels' later gains.)
 constexpr uint64_t kPackedFillMinPairs = 1025;
+// ... and for RAGGED chunks (pairs bucketed by shape: the pairs that find a partner two per wave, the others one per wave, in two
+// launches or one mixed grid) the rounds-3/4 threshold stands: 1 100-2 047 pairs of 100..150 x 100..150 are 2-12 % SLOWER bucketed
+// (tools/ragged_bench.py 1600: 0.227 ms against 0.207 one pair per wave; 2 500: 0.254 / 0.250; 125 000: 3.6 / 4.6)
+constexpr uint64_t kBucketedFillMinPairs = 2048;
 bool sw_best_x2_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t len_a, uint32_t len_b);
 int sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sc, const seqalign_dev_batch_t *b, const seqalign_trace_t *t,
                       const uint8_t *dirs, const int32_t *start_score, void *stream);
