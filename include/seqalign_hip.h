@@ -359,7 +359,7 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where scores fit int16 --
  *                                           pairs of EQUAL shape share a wave: a chunk of one shape, or a ragged chunk whose pairs
  *                                           are paired up by shape on the host (the others: one per wave in the same launch, NW;
- *                                           a wave to themselves, SW): for chunks of > 1 024 pairs | never | whatever the size
+ *                                           a wave to themselves, SW): for chunks of > 1 024 pairs (ragged: >= 2 048) | never | whatever the size
  *   quad            0 | 1 | 2               the NW and the SW best-hit fill with FOUR pairs per wave (32 lanes a couple of pairs; chunks of
  *                                           one shape, rows up to 192 columns): for chunks of >= 4 096 (NW) / 16 384 (SW) pairs | never |
  *                                           whatever the size
