@@ -120,6 +120,51 @@ def test_sw_multi_hit_wide_rows_by_batch_size(ctx, la, n_min):
     assert "sweep_dirs" not in ctx.last_call(), ctx.last_call()
 
 
+@pytest.mark.parametrize("kind,la,lb,n_min", [("blosum", 60, 50, 128), ("dna", 100, 40, 1536), ("dna", 600, 30, 1024)])
+def test_sw_best_hit_packed_fill_by_batch_size(ctx, kind, la, lb, n_min):
+    """From how many pairs of one shape seqalign_sw_batch(max_hits = 1) takes the packed best-hit fill (sa_batch_sw.hip: it competes with
+    three matrices, not with a one-pair direction fill): 128 on table scorings, 1 536 on match / mismatch, 1 024 there for rows over 512
+    columns (tools/sw_best_few.py); either way the oracle's best hit (smith_waterman.c:137-277)."""
+    if kind == "blosum":
+        sc = S.make_scoring({"preset": "BLOSUM62"})
+        batch = uniform(n_min, la, lb, seed=31, alpha=b"ARNDCQEGHILKMFPSTWYV")
+    else:
+        sc = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+        batch = uniform(n_min, la, lb, seed=32 + la)
+    osc = osc_of(sc)
+    res = ctx.sw_batch(batch, sc, 12, max_hits=1)
+    assert "fill_sw_best_x2" in ctx.last_call() or "fill_sw_best_x4" in ctx.last_call(), ctx.last_call()
+    for p in range(0, n_min, 7):
+        rc, want = O.oracle_sw(osc, batch.seq_a(p), batch.seq_b(p), 12, 1)
+        assert rc == 0 and res[p] == want, p
+    fewer = W.from_pairs([(batch.seq_a(p), batch.seq_b(p)) for p in range(n_min - 1)])
+    res2 = ctx.sw_batch(fewer, sc, 12, max_hits=1)
+    assert "fill_sw_best_x2" not in ctx.last_call() and "fill_sw_best_x4" not in ctx.last_call(), ctx.last_call()
+    assert res2 == res[:n_min - 1]
+
+
+def test_packed_fills_from_1025_pairs_uniform_2048_ragged(ctx):
+    """seqalign_nw_batch: one shape -- two pairs per wave from the 1 025th pair on (every one-pair wave has a SIMD to itself up to 1 024);
+    ragged -- bucketed from 2 048 (tools/pack_by_batch_size.py, ragged_bench.py); the oracle's strings for a sample."""
+    sc = S.make_scoring({"preset": "default"})
+    osc = osc_of(sc)
+    for n, packed in ((1024, False), (1025, True)):
+        batch = uniform(n, 90, 40, seed=5 + n)
+        res = ctx.nw_batch(batch, sc)
+        assert any(k in ctx.last_call() for k in ("fill_nw_dirs_x2", "fill_nw_dirs_x4")) == packed, (n, ctx.last_call())
+        for p in range(0, n, 41):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and res[p] == (s_, ra, rb), (n, p)
+    for n, packed in ((2047, False), (2048, True)):
+        base = uniform(n, 90, 40, seed=9)
+        batch = W.from_pairs([(base.seq_a(p)[:60 + p % 31], base.seq_b(p)[:20 + p % 21]) for p in range(n)])
+        res = ctx.nw_batch(batch, sc)
+        assert any(k in ctx.last_call() for k in ("fill_nw_dirs_x2", "fill_nw_dirs_x4")) == packed, (n, ctx.last_call())
+        for p in range(0, n, 97):
+            rc, s_, ra, rb = O.oracle_nw(osc, batch.seq_a(p), batch.seq_b(p))
+            assert rc == 0 and res[p] == (s_, ra, rb), (n, p)
+
+
 @pytest.mark.parametrize("la,n,expect_dirs", [(512, 6, True), (700, 6, True), (767, 6, True), (768, 6, False), (1023, 6, False),
                                               (768, 384, True), (1023, 384, True), (1023, 383, False), (1024, 384, False), (1500, 6, False)])
 def test_nw_direction_fill_takes_rows_up_to_1024_columns(ctx, la, n, expect_dirs):
