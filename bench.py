@@ -347,6 +347,7 @@ def run(args) -> int:
     rank, local, world = env_world()
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    args.default_workload = args.workload is None
     workload = args.workload or ("C2" if world == 1 else "C5")
     args.workload = workload
     backend = os.environ.get("SEQALIGN_DIST_BACKEND", "store")
@@ -379,10 +380,56 @@ def run(args) -> int:
         pin["host_threads"] = int(os.environ["SEQALIGN_HOST_THREADS"])
         pin["cgroup_cpu_quota"] = quota
 
-    gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
-    batch, global_pairs, first_pair = make_shard(workload, rank, world, args.pairs, args.scaling)
+    S.lib()                                          # raises if the HIP library is missing: no fallback
+    env = dict(rank=rank, local=local, world=world, backend=backend, folded=folded, pin=pin)
+    out = measure(args, grp, env, workload, args.steps, args.warmup, args.pairs)
+    if rank == 0:
+        # Every other BASELINE config in the SAME driver-run line: configs[2] (C3), configs[3] (C4) and one GPU's
+        # share of configs[4] (C5: 125 000 of the 1 M pairs), each through the same measurement as the headline -- its own context,
+        # its own placed arenas, the fill timed with HIP events on the launch stream, the same kernel on unplaced arenas, the
+        # separate SW reduction, the host-level calls -- a few seconds each.  `value` stays C2's.
+        if world == 1 and args.default_workload and not args.no_configs:
+            out["configs"] = {}
+            for name, steps in (("C3", 30), ("C4", 100), ("C5", 20)):
+                t_cfg = time.perf_counter()
+                try:
+                    r = measure(args, grp, env, name, steps, min(args.warmup, 5), 0)
+                    entry = {"workload": r["config"]["workload"], "pairs": r["config"]["pairs_per_gpu"], "value": r["value"],
+                             "unit": "GCUPS", "steps": steps, "ms_per_step": r["ms_per_step"], "kernel": r["config"]["kernel"],
+                             "bit_exact_vs_oracle": r["bit_exact_vs_oracle"], "roofline": r["roofline"],
+                             "arena_placement_quality": r["config"]["arena_placement_quality"],
+                             "arena_placement_search": r["config"]["arena_placement_search"]}
+                    for k in ("sw_reduce", "e2e"):
+                        if k in r:
+                            entry[k] = r[k]
+                except Exception as ex:      # the headline must survive a failing extra: say what failed, in the line
+                    entry = {"error": f"{type(ex).__name__}: {ex}"}
+                entry["seconds_spent"] = round(time.perf_counter() - t_cfg, 2)
+                out["configs"]["C5_share" if name == "C5" else name] = entry
+        # north_star: the 1 / 2 / 4 / 8-GPU figures "next to the reference CPU path" -- rank 0 times it at every N (once, the same
+        # bounded leg; the other ranks wait in the barrier below with their GPUs idle: it is outside every timed region)
+        if not args.no_cpu_baseline:
+            gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
+            b0 = out.pop("_batch")
+            sc0 = S.make_scoring(spec)
+            out["cpu_baseline"] = cpu_baseline(b0, spec, is_sw, min_score=(
+                W.default_minscore(sc0.match, int(b0.len_a[0]), int(b0.len_b[0])) if is_sw else 0))
+        out.pop("_batch", None)
+        print(json.dumps(out), flush=True)
+    grp.barrier()
+    grp.close()
+    return 0
 
-    lib = S.lib()                                    # raises if the HIP library is missing: no fallback
+
+def measure(args, grp, env, workload, steps, warmup, pairs):
+    """One workload through the whole measurement (fill roofline with placed and unplaced arenas, the SW reduction, the host-level
+    calls): the headline's, and each entry of `configs`.  Returns the line's dict on rank 0 (None elsewhere)."""
+    import torch
+    import seqalign_amd as S
+    rank, local, world, backend, folded, pin = (env[k] for k in ("rank", "local", "world", "backend", "folded", "pin"))
+    gen, kwargs, _, is_sw, spec, desc = WORKLOADS[workload]
+    batch, global_pairs, first_pair = make_shard(workload, rank, world, pairs, args.scaling)
+
     ctx = S.Context(local)
     sc = S.make_scoring(spec)
     h = ctx.upload_scoring(sc, is_sw)
@@ -484,7 +531,7 @@ def run(args) -> int:
                                    "value": total_cells / wall4 / 1e9, "unit": "GCUPS"}
 
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         db.fill(ctx, h, kernel, order_after_current=False)
     torch.cuda.synchronize()
     grp.barrier()
@@ -506,11 +553,11 @@ def run(args) -> int:
                           "per_gpu_alone_gcups": batch.cells() * n_alone / dt / 1e9}
         grp.barrier()
 
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         starts[i].record(db.stream)  # the stream the kernel is launched on
         db.fill(ctx, h, kernel, order_after_current=False)
         ends[i].record(db.stream)
@@ -552,6 +599,7 @@ def run(args) -> int:
                                    "arena_placement_quality": round(db.placement_quality, 3),
                                    "arena_placement_tries": (db.placement_info or {}).get("tries"),
                                    "e2e_ms": round(e2e["ms_this_rank"], 3) if e2e else None, **pin})
+    out = None
     if rank == 0:
         alg_bytes = db.algorithmic_bytes()
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -568,9 +616,9 @@ def run(args) -> int:
             except Exception:
                 traffic = None
         out = {
-            "metric": "dp_cell_updates_per_sec", "value": total_cells * args.steps / elapsed / 1e9, "unit": "GCUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "metric": "dp_cell_updates_per_sec", "value": total_cells * steps / elapsed / 1e9, "unit": "GCUPS",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{workload}: {desc}", "pairs_per_gpu": batch.n_pairs,
                        "global_pairs": global_pairs, "kernel": S.KERNEL_NAMES[kernel],
@@ -597,7 +645,7 @@ def run(args) -> int:
                     r = table.get(f"{workload}:{batch.n_pairs}")
                     #  these come from a committed rocprofv3 record, not from this run: say so in the line
                     tag = {"measured_in_this_run": False,
-                           "pre_recorded": f"profiles/e2e_roofline.json (rocprofv3 kernel trace + PMC passes, {table.get('_recorded', 'round 4')})"}
+                           "pre_recorded": f"profiles/e2e_roofline.json (rocprofv3 kernel trace + PMC passes, {table.get('_recorded', 'round unknown')})"}
                     if r:
                         e2e["roofline"] = {**r, **tag}     # bound, kernel, kernel_ms, instructions, frac + where they come from
                     r4 = table.get(f"{workload}:{batch.n_pairs}:hits4")
@@ -628,17 +676,14 @@ def run(args) -> int:
                                 "achieved": rbytes / (rms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": rbytes / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "algorithmic_bytes_per_launch": rbytes}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, spec, is_sw, min_score=(
-                W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0])) if is_sw else 0))
-        print(json.dumps(out), flush=True)
+        out["_batch"] = batch     # (for the caller's cpu_baseline leg; popped before the line is printed)
 
     grp.barrier()
     ctx.release_scoring(h)
     del db
+    torch.cuda.synchronize()
     ctx.close()
-    grp.close()
-    return 0
+    return out if rank == 0 else None
 
 
 def main() -> int:
@@ -655,6 +700,8 @@ def main() -> int:
                     help="--kernel auto also times wavefront / rowscan / strips (correctness paths that have never won a configuration)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1, default workload: skip the `configs` block (C3, C4, C5's share measured beside the C2 headline)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-unplaced", action="store_true",
                     help="skip the few steps of the same kernel on unplaced arenas (roofline.frac_unplaced)")

@@ -257,6 +257,15 @@ typedef struct {
   uint64_t str_off;                    /* into out_a / out_b */
 } seqalign_sw_hit_t;
 
+/* Errors and what has been delivered when they are returned:
+ *   SEQALIGN_E_NOMEM   hit_cap or str_cap is too small: the hits that FIT have been delivered first -- a prefix of the
+ *                      result in pair order, *n_hits counts them -- then the call stops and reports it;
+ *   a pair's own error (SEQALIGN_E_UNKNOWN_PAIR: a character pair without a score, SEQALIGN_E_TRACEBACK): the lowest failing
+ *                      pair's code is returned, it takes precedence over E_NOMEM within its chunk, and nothing of that chunk
+ *                      is delivered (earlier chunks' hits stay, *n_hits says how many).
+ * The packed best-hit path (max_hits == 1, direction bytes) has no separate fill status to fetch: a direction fill is only
+ * admitted for scorings in which every character pair has a score, and each walk carries its pair's status home in its own
+ * word (sa_batch_sw.hip). */
 int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                       const scoring_t *scoring, const int32_t *min_score,
                       uint32_t max_hits, seqalign_sw_hit_t *hits,
@@ -330,6 +339,7 @@ typedef struct {
   float try_quality[SEQALIGN_ARENA_MAX_TRIES];    /* their ratios, in order                  */
   float try_depth_gib[SEQALIGN_ARENA_MAX_TRIES];
   float kept_gib;       /* what the process's chunk pool of this device holds after the walk  */
+  float seconds;        /* wall clock of seqalign_arenas_alloc: chunk creation, mappings, every timed candidate, releases */
 } seqalign_arena_info_t;
 /* How the arenas returned by seqalign_arenas_alloc were placed (arenas[0] identifies them). */
 int seqalign_arenas_info(seqalign_ctx_t *ctx, void *const arenas[3], seqalign_arena_info_t *info);

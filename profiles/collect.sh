@@ -13,12 +13,23 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-unplaced $*"
+CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-unplaced --no-configs $*"
 echo "$CMD" > "$OUT/command.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
 # the same pass once more as CSV: the human-readable --stats table that gets committed
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $CMD > "$OUT/stats.log" 2>&1
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+# PMC_SETS=traffic: only the two HBM-traffic passes (WRITE_SIZE, FETCH_SIZE; what bench.py's roofline.traffic quotes)
+if [ "${PMC_SETS:-all}" = traffic ]; then
+  i=0
+  for set in "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OUT/pmc$i" -o p -- $CMD > "$OUT/pmc$i.log" 2>&1
+  done
+  python "$REPO/profiles/summarise.py" "$OUT" > "$OUT/summary.json" 2> "$OUT/summarise.err"
+  cat "$OUT/summary.json"
+  exit 0
+fi
 i=0
 for set in "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "FETCH_SIZE" \

@@ -90,4 +90,5 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
                 "kernels_of_the_call": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in e.items()} for k, e in kernels.items()}}
 json.dump({k: {kn: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()} for kn, cs in ks.items()} for k, ks in pmc_all.items()},
           open(os.path.join(out, "e2e_pmc_insts.json"), "w"), indent=1)
+res["_recorded"] = f"tag {tag}" + (f", round {int(tag[1:3])}" if tag[:1] == "r" and tag[1:3].isdigit() else "")
 print(json.dumps(res, indent=1))

@@ -1,7 +1,7 @@
 # N processes in a row on one box: what placement each finds (quality, kernel roofline) and how its walks went
 N=${1:-6}
 for i in $(seq 1 $N); do
-python bench.py --no-cpu-baseline --no-e2e --no-unplaced --steps 100 2>/dev/null | python -c "
+python bench.py --no-cpu-baseline --no-e2e --no-unplaced --no-configs --steps 100 2>/dev/null | python -c "
 import sys, json
 r = json.loads(sys.stdin.readline())
 s = r['config']['arena_placement_search']

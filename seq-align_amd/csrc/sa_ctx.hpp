@@ -211,7 +211,7 @@ inline hipError_t wait_event_spinning(hipEvent_t e) {
   for (unsigned spins = 1;; ++spins) {
     const hipError_t q = hipEventQuery(e);
     if (q != hipErrorNotReady) return q;
-    __builtin_ia32_pause();
+    HostPool::cpu_relax();
     if ((spins & 63u) == 0) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipEventSynchronize(e);
@@ -223,21 +223,23 @@ inline hipError_t wait_event_spinning(hipEvent_t e) {
 // ~70 us on this stack -- measured in round 5 on seqalign_sw_batch's best-hit call (C4: 0.91-0.95 ms with hipStreamSynchronize,
 // 0.84-0.86 polling, same box, profiles/r05/r05_experiments.txt).  The host-level calls wait for fractions of a millisecond:
 // they poll, and fall back to the blocking wait after 3 ms.
-inline hipError_t stream_wait_spinning(hipStream_t st) {
+inline hipError_t stream_wait_spinning(hipStream_t st, long long budget_ns = 3000000ll) {
   timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (unsigned spins = 1;; ++spins) {
     const hipError_t q = hipStreamQuery(st);
     if (q != hipErrorNotReady) return q;
-    __builtin_ia32_pause();
+    HostPool::cpu_relax();
     if ((spins & 63u) == 0) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 3000000ll) return hipStreamSynchronize(st);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > budget_ns) return hipStreamSynchronize(st);
     }
   }
 }
 
-inline StreamSyncOnExit::~StreamSyncOnExit() { (void)stream_wait_spinning(st); }
+// (the guard of every exit path, the error paths included: on the common path the stream is already idle and the first query says
+// so; where it is not, poll briefly and then sleep -- a thread per GPU polling 3 ms each under a cgroup CPU quota is noticeable)
+inline StreamSyncOnExit::~StreamSyncOnExit() { (void)stream_wait_spinning(st, 200000ll); }
 
 struct DevBuf {   // grow-only device scratch
   void *p = nullptr;

@@ -111,7 +111,9 @@ struct SaSweepParams {
   const uint64_t *off_b;
   const uint32_t *len_b;
   const uint64_t *mat_off;
-  const int32_t *M, *A, *B;
+  const int32_t *M, *A, *B;      /* OVER-READ (sw_sweep_dirs_ev_kernel, branchless row loads): up to CPL * 4 <= 64 bytes of M and
+                                    CPL + 3 <= 19 bytes of `dirs` BEHIND the last pair's last cell are loaded (never used): the
+                                    caller's arenas must extend that far (sa_host::reserve_arenas and the dirs buffers add 4 KiB) */
   const uint16_t *code;
   const int32_t *table;
   const uint32_t *cand_count;    /* [n]                                                              */
@@ -340,6 +342,7 @@ struct SaArenaInfo {   /* = seqalign_arena_info_t (include/seqalign_hip.h) */
   uint32_t tries, second_walk_from;
   float try_quality[SA_ARENA_MAX_TRIES], try_depth_gib[SA_ARENA_MAX_TRIES];
   float kept_gib;
+  float seconds;
 };
 struct SaPlacementOpts {
   size_t scan_bytes;     /* device memory the walk may hold transiently besides the arenas; 0 = allocate plainly */

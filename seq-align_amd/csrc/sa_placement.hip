@@ -59,6 +59,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -255,6 +256,15 @@ bool sa_pool_free(void *ptr) {
     b = it->second;
     g_pool_bufs.erase(it);
   }
+  // hipFree waits for the device; hipMemUnmap + handing the chunks to the next mapping is not documented to.  Callers have
+  // synchronised their own stream by now (DevBuf::reserve runs between calls, reserve_arenas syncs), but a kernel of ANOTHER
+  // context's stream could still be writing through a view of this buffer only if its owner released it mid-flight -- make the
+  // precondition hold here instead of at every caller: freeing a >= 128 MiB buffer is rare and never on a timed path.
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (cur != b->device) (void)hipSetDevice(b->device);
+  (void)hipDeviceSynchronize();
+  if (cur >= 0 && cur != b->device) (void)hipSetDevice(cur);
   b->map.unmap();
   for (Handle h : b->handles) pool_put(b->device, h);
   delete b;
@@ -360,7 +370,7 @@ hipError_t plain_set(int device, size_t bytes, hipStream_t st, bool probe, SaAre
 
 }  // namespace
 
-hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out) {
+static hipError_t arenas_create_untimed(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out) {
   *out = nullptr;
   SaArenaSet *s = new (std::nothrow) SaArenaSet();
   if (!s) return hipErrorOutOfMemory;
@@ -563,6 +573,16 @@ hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const 
   register_set(s);
   *out = s;
   return hipSuccess;
+}
+
+// What the placement costs its caller, stated with the result (the bench line quotes a fraction that depends on a
+// walk -- its wall clock belongs beside it): chunk creation, mappings, every timed candidate, the releases.
+hipError_t sa_arenas_create(int device, size_t bytes, hipStream_t stream, const SaPlacementOpts &opt, SaArenaSet **out) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = arenas_create_untimed(device, bytes, stream, opt, out);
+  if (e == hipSuccess && *out)
+    (*out)->info.seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+  return e;
 }
 
 void sa_arenas_destroy(SaArenaSet *s) {

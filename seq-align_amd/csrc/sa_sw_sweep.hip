@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(kWave, (CPL <= 3 ? 8 : CPL == 4 ? 6 : CPL <= 6
 // whose results merged at a join, and the first row's loads were still pending on loop entry): every row paid a full memory
 // latency, SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.56, VALU busy 0.42 (profiles/r05/r05a_sweep_pmc_C3_before.json).  Now
 //   * the loads are BRANCHLESS: a lane's run starts at min(its first column, W - 1) of the row -- always inside the pair's
-//     matrix; what it reads beyond the row's end is the next row (or, on the pair's last row, the <= 32 bytes behind the pair:
+//     matrix; what it reads beyond the row's end is the next row (or, on the pair's last row, the <= CPL * 4 bytes of match_scores / CPL + 3 bytes of directions behind the pair (60 / 18 at 16 columns per lane):
 //     the next pair, padding, or the arenas' slack -- sa_host::reserve_arenas adds >= 4 KiB; the first buffer's cells beyond
 //     column W - 1 are zeroed once, below).  Cells beyond the row's end can never win: no candidacy (thr_c) and no arrivals;
 //   * NB row buffers rotate through an NB-times unrolled row loop: while row y is worked on, the loads of rows y - 1 ..
@@ -842,8 +842,14 @@ struct SweepRow {
   // SGPRs holding Mg / Dg were spilled to a VGPR, the compiler reloads them with v_readlane right in front of the statement and
   // cannot see that a VMEM instruction reads them within the five wait states gfx9 requires after a VALU write of an SGPR (a
   // first version without the nop faulted on exactly that, eight columns per lane: a stale high word of Mg).
-  __device__ __forceinline__ void request(uint32_t cell_off, const int32_t *Mg, const uint8_t *Dg) {
-    const uint32_t mo = cell_off * 4u;
+  //  The ROW's base goes into the scalar address (row and W are wave-uniform: 64-bit SALU arithmetic), the lane's
+  // column into the 32-bit VGPR offset: a pair of >= 2^30 cells (rows <= 1 024 columns, e.g. 500 x 2.2 M) used to wrap
+  // `cell_off * 4` and read match_scores of the wrong rows.  The VGPR offsets are now < 4 * 1 024 + 64 whatever the pair's size.
+  __device__ __forceinline__ void request(uint32_t row, uint32_t W, uint32_t xc, const int32_t *Mp, const uint8_t *Dp) {
+    const uint64_t row_cells = (uint64_t)__builtin_amdgcn_readfirstlane(row) * (uint64_t)W;
+    const int32_t *Mg = Mp + row_cells;
+    const uint8_t *Dg = Dp + row_cells;
+    const uint32_t cell_off = xc, mo = xc * 4u;
     if constexpr (NV4 == 0 && TAIL == 2)
       asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %2, %4\n\tglobal_load_dword %1, %3, %5"
                    : "=&v"(mt), "=&v"(q[0]) : "v"(mo), "v"(cell_off), "s"(Mg), "s"(Dg));
@@ -953,7 +959,7 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
   }
   uint32_t y = rmax;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) rb[b].request((y >= (uint32_t)b ? y - (uint32_t)b : 0u) * W + xc, Mg, Dg);
+  for (int b = 0; b < NB; ++b) rb[b].request(y >= (uint32_t)b ? y - (uint32_t)b : 0u, W, xc, Mg, Dg);
   // rmax may be the pair's last row, and what lies behind that is not the pair's: the first row's cells beyond column W - 1 = 0
   rb[0].template claim<kYounger>();
 #pragma unroll
@@ -1045,7 +1051,7 @@ __global__ void __launch_bounds__(kWave, sweep_ev_waves(CPL, sizeof(EvT) > 4)) s
         }
       }
       if (y == 0 || (!__any(live) && y <= rmin)) { done = true; break; }
-      row.request((y >= (uint32_t)NB ? y - (uint32_t)NB : 0u) * W + xc, Mg, Dg);   // this buffer's next row: NB rows up (above the first: row 0 again, never used)
+      row.request(y >= (uint32_t)NB ? y - (uint32_t)NB : 0u, W, xc, Mg, Dg);   // this buffer's next row: NB rows up (above the first: row 0 again, never used)
       --y;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) col_row[c] -= 4;   // (the row field: y - 1)

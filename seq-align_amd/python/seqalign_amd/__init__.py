@@ -167,14 +167,14 @@ class ArenaInfo(C.Structure):
     _fields_ = [("quality", C.c_float), ("target", C.c_float), ("vmm", C.c_int32), ("chunk_mib", C.c_uint32),
                 ("depth_gib", C.c_float), ("scanned_gib", C.c_float), ("depth_a_gib", C.c_float), ("tries", C.c_uint32),
                 ("second_walk_from", C.c_uint32), ("try_quality", C.c_float * 96), ("try_depth_gib", C.c_float * 96),
-                ("kept_gib", C.c_float)]
+                ("kept_gib", C.c_float), ("seconds", C.c_float)]
 
     def as_dict(self):
         n = int(self.tries)
         return {"quality": round(float(self.quality), 3), "target": round(float(self.target), 3), "vmm": bool(self.vmm),
                 "chunk_mib": int(self.chunk_mib), "depth_gib": round(float(self.depth_gib), 1),
                 "scanned_gib": round(float(self.scanned_gib), 1), "depth_a_gib": round(float(self.depth_a_gib), 1),
-                "tries": n, "second_walk_from": int(self.second_walk_from), "kept_gib": round(float(self.kept_gib), 1),
+                "tries": n, "second_walk_from": int(self.second_walk_from), "kept_gib": round(float(self.kept_gib), 1), "seconds": round(float(self.seconds), 3),
                 "try_quality": [round(float(self.try_quality[i]), 3) for i in range(n)],
                 "try_depth_gib": [round(float(self.try_depth_gib[i]), 1) for i in range(n)]}
 

@@ -269,3 +269,51 @@ def ref_lookup(sc: Scoring, a: int, b: int):
     s, m = C.c_int(0), C.c_bool(False)
     lib.scoring_lookup(C.byref(sc), C.c_char(bytes([a])), C.c_char(bytes([b])), C.byref(s), C.byref(m))
     return s.value, int(m.value)
+
+
+def ref_sw_hits(sc: Scoring, a: bytes, b: bytes, min_score: int, max_hits: int = 1 << 30):
+    """The reference's SW hit list with EVERY piece of arithmetic done by the compiled reference (oracle/_ref): the fill is its
+    aligner_align(is_sw = 1) (src/alignment.c:170-193), every step of every walk its alignment_reverse_move (:244-350).  Restated
+    here -- smith_waterman.c itself cannot be compiled (it needs the un-vendored sort_r) -- are only the two pieces that carry no
+    arithmetic: the candidate ORDER (smith_waterman.c:152-161 collects every pos with M > 0 in ascending pos; the comparator :71-86
+    orders by score descending, then column pos % W ascending, and returns 0 beyond that -- a stable sort leaves ascending pos,
+    SURVEY A.3-4) and the VISITED MASK of smith_waterman_fetch / _follow_hit (:165-277: a candidate already visited is skipped; a
+    walk marks each cell it stands on, is abandoned -- its marks stay -- at a cell somebody marked before, and is a hit when it
+    reaches score 0).  Fresh mask per pair.  Hits come out in descending score, so "score >= min_score" (the
+    command line's --minscore, sw_cmdline.c:214-217) is a prefix: candidates below it are never needed.
+    An enumeration independent of oracle/seqalign_oracle.c's orc_sw_hits: the two must agree on every hit."""
+    lib = ref()
+    al = Aligner()
+    C.memset(C.byref(al), 0, C.sizeof(al))
+    ba, bb = _buf(a), _buf(b)
+    lib.aligner_align(C.byref(al), ba, bb, C.c_size_t(len(a)), C.c_size_t(len(b)), C.byref(sc), C.c_char(b"\1"))
+    W_ = len(a) + 1
+    M = np.ctypeslib.as_array(al.match_scores, (W_ * (len(b) + 1),))
+    cand = np.flatnonzero(M >= max(int(min_score), 1))
+    order = cand[np.lexsort((cand, cand % W_, -M[cand].astype(np.int64)))]
+    visited = np.zeros(M.size, bool)
+    hits = []
+    mat, score, cx, cy, idx = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    for pos in order.tolist():
+        if len(hits) >= max_hits:
+            break
+        if visited[pos]:
+            continue
+        x0, y0 = pos % W_, pos // W_
+        mat.value, score.value, cx.value, cy.value, idx.value = MATCH, int(M[pos]), x0, y0, pos
+        ra, rb, alive = [], [], True
+        while True:
+            if visited[idx.value]:
+                alive = False
+                break
+            visited[idx.value] = True
+            if score.value == 0:
+                break
+            ra.append("-" if mat.value == GAP_A else chr(a[cx.value - 1]))
+            rb.append("-" if mat.value == GAP_B else chr(b[cy.value - 1]))
+            lib.alignment_reverse_move(C.byref(mat), C.byref(score), C.byref(cx), C.byref(cy), C.byref(idx), C.byref(al))
+        if alive:
+            hits.append(dict(score=int(M[pos]), pos_a=cx.value, pos_b=cy.value, len_a=x0 - cx.value, len_b=y0 - cy.value,
+                             a="".join(reversed(ra)), b="".join(reversed(rb))))
+    lib.aligner_destroy(C.byref(al))
+    return hits

@@ -737,6 +737,40 @@ def test_sw_batch_hit_lists_at_config_size(ctx, name, where, opts):
                 assert rc == 0 and live == want
 
 
+def _refwalk_sections():
+    g = load("sw_hits_refwalk.json")
+    for name in ("C3", "C4", "C3_low", "C4_low"):
+        e = g[name]
+        batch = W.make(e["gen"], e["of"], e["kwargs"])
+        yield name, e["scoring"], batch.slice(0, e["n"]), e["min_score"], e["hits"]
+    for k, r in enumerate(g["repeats"]):
+        yield f"repeats[{k}]", r["scoring"], W.from_pairs([(a.encode(), b.encode()) for a, b in r["pairs"]]), r["min_score"], r["hits"]
+
+
+@pytest.mark.parametrize("where", ["device", "device-three-matrices", "device-first-sweep-form"])
+def test_sw_batch_equals_the_reference_walked_hit_lists(ctx, where, opts):
+    """seqalign_sw_batch against tests/golden/sw_hits_refwalk.json -- hit lists in which every score, every
+    matrix cell and every traceback step was computed by the COMPILED REFERENCE (aligner_align + alignment_reverse_move; candidate
+    order and visited mask of smith_waterman.c:71-86,137-277 restated in Python, tests/orclib.py: ref_sw_hits), not by our own C
+    restatement: all hits >= 60 of the 64 C3 / C4 pairs, 24-58 hits per pair at threshold 15 (walks abandoned at marked cells,
+    marks left behind), and tandem repeats under twelve scorings with gap flags / wildcards / free end gaps (ties on score AND
+    column).  Unlimited max_hits and a cut-off of 3; the direction-byte path, the three-matrix path, the sweep's first form."""
+    if where == "device-three-matrices":
+        opts(sweep_dirs=0)
+    elif where == "device-first-sweep-form":
+        opts(sweep_ev=0)
+    total = 0
+    for label, spec, batch, thr, rows in _refwalk_sections():
+        sc = S.make_scoring(spec)
+        for max_hits in (1 << 20, 3):
+            got = ctx.sw_batch(batch, sc, thr, max_hits=max_hits, hit_cap=1 << 16)
+            for p in range(batch.n_pairs):
+                want = [dict(score=h[0], pos_a=h[1], pos_b=h[2], len_a=h[3], len_b=h[4], a=h[5], b=h[6]) for h in rows[p][:max_hits]]
+                assert got[p] == want, (label, where, max_hits, p, len(got[p]), len(want))
+                total += len(want)
+    assert total > 3000
+
+
 @pytest.mark.parametrize("name", ["C3", "C4"])
 def test_sw_batch_full_size_hit_list_properties(ctx, name):
     """seqalign_sw_batch with up to 4 hits per pair on the FULL config (10 000 x 150x1000 DNA / 4 000 x 300x300

@@ -631,3 +631,44 @@ def test_packed_fills_at_the_edge_of_int16(ctx, opts, la, lb, pen, ext, bound, p
             for p, (a, b) in enumerate(pairs):
                 rc, want = O.oracle_sw(osc, a, b, thr, max_hits)
                 assert rc == 0 and got_sw[p] == want, (spec, "sw", max_hits, p)
+
+
+# ------------------------------------------------------------------ one pair of more than 2^30 cells ---
+
+def test_sweep_reads_the_right_rows_beyond_2_30_cells(ctx):
+    """the one-word sweep formed a cell's byte offset as a 32-bit `cell * 4`, which wraps from cell 2^30 on --
+    a 500 x 2.2 M pair (1.1 G cells: admitted, the limit is 2^31) read match_scores of the wrong rows for its last 57 000 rows and
+    lost the hits there.  The row's base is now part of the 64-bit scalar address.  One such pair with the read planted three
+    times -- once in the first rows, twice BEHIND cell 2^30 -- against the oracle run on windows of seq_b around the copies (the
+    whole pair would need 13 GB of host matrices; with min_score 200 nothing outside the copies is a candidate)."""
+    la, lb = 500, 2_200_000
+    assert (la + 1) * (lb + 1) > 1 << 30 and (la + 1) * (lb + 1) < 1 << 31
+    rng = W.Rng(6001)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    a = acgt[rng.below(4, la).astype(np.int64)].copy()
+    b = acgt[rng.below(4, lb).astype(np.int64)].copy()
+    starts = (100_000, 2_160_000, 2_190_000)        # (2^30 / 501 = row 2 143 237)
+    for k, s in enumerate(starts):
+        copy = a.copy()
+        sub = rng.unit(la) < 0.03 * (k + 1)           # 3 %, 6 %, 9 % substitutions: three different scores
+        copy[sub] = acgt[(np.searchsorted(acgt, copy[sub]) + 1 + rng.below(3, int(sub.sum())).astype(np.int64)) % 4]
+        b[s:s + la] = copy
+    batch = W._fixed_batch(a.reshape(1, la), b.reshape(1, lb))
+    spec = {"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}
+    sc, osc = S.make_scoring(spec), O.build_scoring(spec, "oracle")
+    got = ctx.sw_batch(batch, sc, 200, max_hits=64, hit_cap=4096)[0]
+    ran = ctx.last_call()
+    assert "sweep_dirs" in ran and "fill_sw_dirs" in ran, ran     # the direction-byte path: the one the offset was wrong in
+    want = []
+    for s in starts:
+        lo, hi = s - 2000, s + la + 2000
+        rc, hits = O.oracle_sw(osc, a.tobytes(), b[lo:hi].tobytes(), 200, 64)
+        assert rc == 0 and hits
+        for h in hits:
+            assert h["pos_b"] > 500 and h["pos_b"] + h["len_b"] < hi - lo - 500     # the walk stayed inside the window
+            want.append(dict(h, pos_b=h["pos_b"] + lo))
+    # the reference's hit order (smith_waterman.c:71-86): score desc, end column asc, end cell index asc
+    want.sort(key=lambda h: (-h["score"], h["pos_a"] + h["len_a"], h["pos_b"] + h["len_b"]))
+    assert len({h["score"] for h in want[:3]}) == 3
+    assert got == want, (len(got), len(want), [h["score"] for h in got[:5]], [h["score"] for h in want[:5]])
+    assert sum(h["pos_b"] > 2_143_237 for h in got) >= 2

@@ -133,3 +133,33 @@ def test_oracle_derived_sw_hit_lists_are_current(name):
         rc, hits = O.oracle_sw(sc, batch.seq_a(p), batch.seq_b(p), g["min_score"])
         assert rc == 0
         assert [[h["score"], h["pos_a"], h["pos_b"], h["len_a"], h["len_b"], h["a"], h["b"]] for h in hits] == g["hits"][p]
+
+
+def _refwalk_cases():
+    """(label, oracle-side scoring spec, pairs as (a, b) bytes, min_score, expected hit rows per pair) of sw_hits_refwalk.json."""
+    g = load("sw_hits_refwalk.json")
+    for name in ("C3", "C4", "C3_low", "C4_low"):
+        e = g[name]
+        spec = load("presets.json")[e["scoring"]["preset"]]["spec"] if "preset" in e["scoring"] else e["scoring"]
+        batch = W.make(e["gen"], e["of"], e["kwargs"])
+        yield name, spec, [(batch.seq_a(p), batch.seq_b(p)) for p in range(e["n"])], e["min_score"], e["hits"]
+    for k, r in enumerate(g["repeats"]):
+        yield f"repeats[{k}]", r["scoring"], [(a.encode(), b.encode()) for a, b in r["pairs"]], r["min_score"], r["hits"]
+
+
+def test_oracle_hit_lists_equal_the_reference_walked_ones():
+    """the restatement's SW enumeration (orc_sw_hits) against tests/golden/sw_hits_refwalk.json -- hit lists whose
+    every number the COMPILED REFERENCE computed (aligner_align + alignment_reverse_move per step; only candidate order and visited
+    mask restated, in Python: orclib.ref_sw_hits).  Two independent enumerations of smith_waterman.c:137-277 must agree on every
+    hit of every pair: all hits >= 60 of the 64 C3 / C4 pairs, tens of hits per pair at a quarter of that threshold, and tandem
+    repeats under twelve scorings (ties on score AND column)."""
+    total = 0
+    for label, spec, pairs, thr, want in _refwalk_cases():
+        sc = O.build_scoring(spec, "oracle")
+        for p, (a, b) in enumerate(pairs):
+            rc, hits = O.oracle_sw(sc, a, b, thr)
+            assert rc == 0
+            got = [[h["score"], h["pos_a"], h["pos_b"], h["len_a"], h["len_b"], h["a"], h["b"]] for h in hits]
+            assert got == want[p], (label, p, len(got), len(want[p]))
+            total += len(got)
+    assert total > 3000

@@ -100,3 +100,42 @@ def test_sw_walk_uses_reference_reverse_move():
         assert ("".join(reversed(ra)), "".join(reversed(rb))) == (h["a"], h["b"])
         assert (cx.value, cy.value) == (h["pos_a"], h["pos_b"])
         lib.aligner_destroy(C.byref(al))
+
+
+def test_reference_walked_hit_lists_are_current_and_equal_the_oracle_live():
+    """(needs oracle/_ref) orclib.ref_sw_hits -- the reference's own fill and reverse moves under a restated candidate order +
+    visited mask -- (1) still produces tests/golden/sw_hits_refwalk.json, and (2) agrees with orc_sw_hits on fresh random draws:
+    random scorings with every flag, random / related / tandem-repeat pairs, thresholds from 1 up, max_hits cut-offs."""
+    import json
+    from pathlib import Path
+    g = json.loads((Path(__file__).parent / "golden" / "sw_hits_refwalk.json").read_text())
+    e = g["C3_low"]
+    sr = O.build_scoring(e["scoring"], "ref")
+    batch = W.make(e["gen"], e["of"], e["kwargs"])
+    for p in (0, 7):
+        hits = O.ref_sw_hits(sr, batch.seq_a(p), batch.seq_b(p), e["min_score"])
+        assert [[h["score"], h["pos_a"], h["pos_b"], h["len_a"], h["len_b"], h["a"], h["b"]] for h in hits] == e["hits"][p]
+    rng = W.Rng(606)
+
+    def rand(n, alpha=b"ACGT"):
+        return bytes(alpha[i] for i in rng.below(len(alpha), n)) if n else b""
+    checked = 0
+    for trial in range(40):
+        v = rng.below(1 << 20, 12).astype(int)
+        flags = [int(v[0] >> k) & 1 for k in range(5)]
+        match, mismatch, go, ge = int(1 + v[1] % 4), -int(v[2] % 5), -int(v[3] % 8), -int(v[4] % 3)
+        if flags[2] and flags[3]:
+            mismatch = min(mismatch, go + ge)
+        spec = {"init": [match, mismatch, go, ge, *flags, int(v[5] & 1)], "wildcards": [["N", int(v[6] % 3) - 1]] if v[6] & 1 else []}
+        so, sr = O.build_scoring(spec, "oracle"), O.build_scoring(spec, "ref")
+        unit = rand(int(2 + v[7] % 6))
+        a0 = rand(int(20 + v[8] % 60))
+        pairs = [(rand(int(2 + v[9] % 70)), rand(int(2 + v[10] % 90))),
+                 (a0, rand(int(v[11] % 20)) + a0[5:45] + rand(6) + a0[10:40]),
+                 (unit * int(2 + v[8] % 14), rand(2) + unit * int(2 + v[9] % 16) + b"N")]
+        thr, max_hits = int(1 + v[5] % (5 * match)), (1, 3, 1 << 20)[trial % 3]
+        for a, b in pairs:
+            rc, want = O.oracle_sw(so, a, b, thr, max_hits)
+            assert rc == 0 and O.ref_sw_hits(sr, a, b, thr, max_hits) == want, (spec, thr, max_hits, a, b)
+            checked += len(want)
+    assert checked > 200
