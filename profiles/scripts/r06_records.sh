@@ -15,8 +15,8 @@ tests)
   python -m pytest tests -m gpu -q > gpurun_out/$TAG/${TAG}_gputests.log 2>&1; echo "pytest rc $?" >> gpurun_out/$TAG/${TAG}_gputests.log
   grep -v amdgpu.ids gpurun_out/$TAG/${TAG}_gputests.log | tail -4 ;;
 bench)
-  /usr/bin/time -f "bench default wall %e s" python bench.py > gpurun_out/$TAG/${TAG}_bench_default.json 2> gpurun_out/$TAG/bench_default.err
-  tail -2 gpurun_out/$TAG/bench_default.err
+  T0=$SECONDS; python bench.py > gpurun_out/$TAG/${TAG}_bench_default.json 2> gpurun_out/$TAG/bench_default.err
+  echo "bench default wall $((SECONDS - T0)) s"; grep -v amdgpu.ids gpurun_out/$TAG/bench_default.err | tail -3
   python - $TAG <<'PY'
 import json, sys
 tag = sys.argv[1]

@@ -1047,8 +1047,13 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         } else {
           const uint32_t nw = (h_len_a[k] + h_len_b[k] + 31u) >> 5;
           const uint32_t *pa = h_moves + move_word(k);
-          prc = sa_expand_nw_moves(batch->arena + batch->off_a[p], h_len_a[k], batch->arena + batch->off_b[p], h_len_b[k], pa, pa + nw,
-                                   nw, n_moves, out_a + str_off[p], out_b + str_off[p], &out_len[p]);
+          if (ctx->cigar_format)   // seqalign_nw_batch_cigar: run lengths straight from the two planes, no strings (str_off has n + 1 entries: the slots)
+            prc = sa_cigar_nw_moves(batch->arena + batch->off_a[p], h_len_a[k], batch->arena + batch->off_b[p], h_len_b[k], pa, pa + nw,
+                                    nw, n_moves, ctx->cigar_format, ctx->cigar_fold, out_a + str_off[p], str_off[p + 1] - str_off[p],
+                                    &out_len[p], nullptr);
+          else
+            prc = sa_expand_nw_moves(batch->arena + batch->off_a[p], h_len_a[k], batch->arena + batch->off_b[p], h_len_b[k], pa, pa + nw,
+                                     nw, n_moves, out_a + str_off[p], out_b + str_off[p], &out_len[p]);
           out_score[p] = (int32_t)h_meta[2 * k];
         }
         if (prc != SEQALIGN_OK) {   // the LOWEST failing pair's code is the call's (whatever thread meets it first)
@@ -1123,11 +1128,12 @@ extern "C" int seqalign_host_legs_nw(const seqalign_batch_t *batch, const uint64
   return SEQALIGN_OK;
 }
 
-extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
-                                 const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
-                                 int32_t *out_score) {
-  if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
-  CallScope scope(ctx);
+// (CIGAR mode -- ctx->cigar_format, set by seqalign_nw_batch_cigar: only the direction-byte path, whose walks come home as bit
+// planes, delivers it; for every other path kNeedsStrings tells the caller to run the call for strings and convert them)
+static constexpr int kNeedsStrings = -1;
+static int nw_batch_impl(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                         const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                         int32_t *out_score) {
   const seqalign_batch_t *b = batch;
   if (!b || (b->n_pairs && (!b->arena || !b->off_a || !b->off_b || !b->len_a || !b->len_b))) return SEQALIGN_E_ARG;
   if (batch->n_pairs == 0) return SEQALIGN_OK;
@@ -1161,6 +1167,7 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
     }
     return SEQALIGN_OK;
   }
+  if (ctx->cigar_format) return kNeedsStrings;
   // host mode: matrices come back through pinned staging, so chunks are also bounded by host memory
   const size_t budget = on_host ? std::min<size_t>(ctx->chunk_budget, (size_t)6 << 30) : ctx->chunk_budget;
   for (const Chunk &c : plan_chunks(batch, budget)) {
@@ -1201,3 +1208,63 @@ extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
   return SEQALIGN_OK;
 }
 
+extern "C" int seqalign_nw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len,
+                                 int32_t *out_score) {
+  if (!ctx || !scoring || !str_off || !out_a || !out_b || !out_len || !out_score) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
+  return nw_batch_impl(ctx, batch, scoring, str_off, out_a, out_b, out_len, out_score);
+}
+
+uint64_t sa_host::put_alignment(const seqalign_ctx *ctx, const char *sa, const char *sb, uint32_t len, char *out_a, char *out_b,
+                                uint64_t at, uint64_t room) {
+  if (!ctx->cigar_format) {
+    if ((uint64_t)len + 1 > room) return 0;
+    memcpy(out_a + at, sa, len); memcpy(out_b + at, sb, len);
+    out_a[at + len] = out_b[at + len] = '\0';
+    return (uint64_t)len + 1;
+  }
+  if (!room) return 0;
+  const size_t n = seqalign_cigar(sa, sb, len, ctx->cigar_format == 2, ctx->cigar_fold, out_a + at, room);
+  return n == (size_t)-1 ? 0 : (uint64_t)n + 1;
+}
+
+// Global alignments as CIGAR (include/seqalign_hip.h).  On the direction-byte path the walks come home as two bit planes and the
+// host run-length encodes those (host/sa_moves.c: sa_cigar_nw_moves): no string is ever written.  The other paths (three
+// matrices, traceback = host) produce strings: the call runs for strings into its own buffers and encodes them.
+extern "C" int seqalign_nw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring, int format,
+                                       const uint64_t *cigar_off, char *cigar, uint32_t *cigar_len, int32_t *out_score) {
+  if (!ctx || !scoring || !cigar_off || !cigar || !cigar_len || !out_score || (format != SEQALIGN_CIGAR_M && format != SEQALIGN_CIGAR_EQX))
+    return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
+  if (!batch) return SEQALIGN_E_ARG;
+  for (uint64_t p = 0; p < batch->n_pairs; ++p)
+    if (cigar_off[p + 1] < cigar_off[p]) return SEQALIGN_E_ARG;
+  int rc;
+  {
+    CigarScope mode(ctx, format, !scoring->case_sensitive);
+    rc = nw_batch_impl(ctx, batch, scoring, cigar_off, cigar, cigar, cigar_len, out_score);
+  }
+  if (rc != kNeedsStrings) return rc;
+  const uint64_t n = batch->n_pairs;
+  std::vector<uint64_t> off(n + 1, 0);
+  for (uint64_t p = 0; p < n; ++p) off[p + 1] = off[p] + batch->len_a[p] + batch->len_b[p] + 1;
+  std::vector<char> sa(off[n] + 1), sb(off[n] + 1);
+  std::vector<uint32_t> len(n);
+  if ((rc = nw_batch_impl(ctx, batch, scoring, off.data(), sa.data(), sb.data(), len.data(), out_score))) return rc;
+  std::atomic<uint64_t> first_bad{~0ull};
+  parallel_for((n + 255) / 256, [&](uint64_t blk) {
+    for (uint64_t p = blk * 256, e = std::min(n, (blk + 1) * 256); p < e; ++p) {
+      const uint64_t cap = cigar_off[p + 1] - cigar_off[p];
+      const size_t got = cap ? seqalign_cigar(sa.data() + off[p], sb.data() + off[p], len[p], format == SEQALIGN_CIGAR_EQX,
+                                              !scoring->case_sensitive, cigar + cigar_off[p], cap) : (size_t)-1;
+      if (got == (size_t)-1) {
+        uint64_t seen = first_bad.load(std::memory_order_relaxed);
+        while (p < seen && !first_bad.compare_exchange_weak(seen, p, std::memory_order_relaxed)) {}
+      } else {
+        cigar_len[p] = (uint32_t)got;
+      }
+    }
+  });
+  return first_bad.load() == ~0ull ? SEQALIGN_OK : SEQALIGN_E_NOMEM;
+}

@@ -371,6 +371,10 @@ struct seqalign_ctx {
   int call_depth = 0;                    // entry points nest (seqalign_nw_batch -> seqalign_fill_batch_device): the outermost resets
   seqalign_dev_scoring *cached[2] = {nullptr, nullptr};
   uint64_t cached_fp[2] = {0, 0};
+  // what the host-level call in progress delivers per alignment (seqalign_*_batch_cigar set it for their duration; a context
+  // serves one host-level call at a time): 0 = the two gapped strings, 1 = CIGAR with M, 2 = CIGAR with = / X
+  int cigar_format = 0;
+  bool cigar_fold = false;      // format 2: letters compared case-folded (the scoring is case-insensitive)
 };
 
 
@@ -386,6 +390,19 @@ struct CallScope {
   CallScope(const CallScope &) = delete;
   CallScope &operator=(const CallScope &) = delete;
 };
+
+struct CigarScope {   // RAII: the call's output format, put back on every way out
+  seqalign_ctx *ctx;
+  CigarScope(seqalign_ctx *c, int format, bool fold) : ctx(c) { c->cigar_format = format; c->cigar_fold = fold; }
+  ~CigarScope() { ctx->cigar_format = 0; ctx->cigar_fold = false; }
+  CigarScope(const CigarScope &) = delete;
+  CigarScope &operator=(const CigarScope &) = delete;
+};
+
+// One alignment given as its two gapped strings (the paths whose walkers produce strings: three matrices, the host) into the
+// caller's buffer at out_a + at (and out_b + at): the strings, or in CIGAR mode the CIGAR of them (out_a only).  Returns the bytes
+// used with the NUL, or 0 when `room` bytes do not hold it.
+uint64_t put_alignment(const seqalign_ctx *ctx, const char *sa, const char *sb, uint32_t len, char *out_a, char *out_b, uint64_t at, uint64_t room);
 
 // grow the context's three matrix arenas together (spread placement, sa_placement.hip)
 int reserve_arenas(seqalign_ctx *ctx, size_t bytes, bool placed = true);

@@ -85,6 +85,16 @@ int sa_expand_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t en
                        uint32_t pos[4]);
 int sa_moves_uses_simd(void);
 void sa_moves_force_scalar(int on);
+/* CIGAR straight from the planes (seq_a = query, seq_b = reference: a gap in result_b is I, a gap in result_a is D; format 1: M / I / D,
+ * 2: = / X / I / D with the letters compared as they are or, fold != 0, case-folded) -- the same text seqalign_cigar makes of the expanded
+ * strings, without expanding them.  out == NULL: only the length.  Return SEQALIGN_OK, SEQALIGN_E_TRACEBACK (the planes describe no walk
+ * over these lengths) or SEQALIGN_E_NOMEM (cap, counted with the NUL, is too small); *out_len = strlen of the CIGAR. */
+int sa_cigar_nw_moves(const char *a, uint32_t len_a, const char *b, uint32_t len_b, const uint32_t *plane_a,
+                      const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, int format, int fold, char *out, uint64_t cap,
+                      uint32_t *out_len, uint32_t *out_columns);
+int sa_cigar_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t end_y, const uint32_t *plane_a,
+                      const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, int format, int fold, char *out, uint64_t cap,
+                      uint32_t pos[4], uint32_t *out_len);
 
 /* SW hit enumeration over candidate cells (index list, any order; sorted here).
  * `seen` is a caller-provided zeroed bitmap of W*H bits. */

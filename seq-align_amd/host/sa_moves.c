@@ -159,3 +159,114 @@ int sa_expand_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t en
   out_a[n_moves] = out_b[n_moves] = '\0';
   return SEQALIGN_OK;
 }
+
+/* ---- CIGAR straight from the planes (north_star: "identical CIGAR/alignment strings") -------------------
+ * The reference prints the two gapped strings (src/tools/nw_cmdline.c:78-149); CIGAR is the derived format, defined in
+ * include/seqalign_hip.h beside seqalign_cigar: seq_a is the query, seq_b the reference -- plane B bit ('-' in result_b) = I,
+ * plane A bit ('-' in result_a) = D, neither = M (or '=' / 'X').  A run-length encoder over the bits: 64 columns per step, a run's
+ * length is a count of trailing ones -- a 150-column read without gaps is three steps and the four bytes "150M", where the
+ * strings are 2 x 151 bytes written and then read again by whoever wants the CIGAR. */
+#include <ctype.h>
+
+typedef struct {
+  char *out;          /* NULL: count only */
+  uint64_t cap, used; /* used counts every byte the CIGAR needs, written or not */
+  char op;            /* the open run (0: none) */
+  uint64_t run;
+} cigar_sink;
+
+static inline void cigar_flush(cigar_sink *s) {
+  if (!s->op) return;
+  char tmp[24];
+  int n = 0;
+  uint64_t v = s->run;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  if (s->out && s->used + (uint64_t)n + 1 < s->cap) {   /* (+ 1 op, and the NUL must still fit behind it: <) */
+    for (int k = 0; k < n; ++k) s->out[s->used + k] = tmp[n - 1 - k];
+    s->out[s->used + n] = s->op;
+  }
+  s->used += (uint64_t)n + 1;
+  s->op = 0; s->run = 0;
+}
+
+static inline void cigar_push(cigar_sink *s, char op, uint64_t n) {
+  if (!n) return;
+  if (s->op != op) { cigar_flush(s); s->op = op; }
+  s->run += n;
+}
+
+/* the walked columns [first, first + n_cols) of the planes; a / b: the characters those columns consume, in order (format 2 only) */
+static void cigar_walked(cigar_sink *s, const uint32_t *plane_a, const uint32_t *plane_b, uint32_t n_words, uint64_t first, uint64_t n_cols,
+                         const char *a, const char *b, int format, int fold) {
+  for (uint64_t c = 0; c < n_cols; c += 64) {
+    const uint64_t m = n_cols - c < 64 ? n_cols - c : 64;
+    const uint64_t valid = m == 64 ? ~0ull : ((1ull << m) - 1);
+    const uint64_t ga = plane_bits64(plane_a, n_words, first + c) & valid, gb = plane_bits64(plane_b, n_words, first + c) & valid;
+    const uint64_t mm = ~(ga | gb) & valid;
+    uint64_t at = 0;
+    while (at < m) {
+      const uint64_t bit = 1ull << at;
+      const uint64_t same = (ga & bit) ? ga : (gb & bit) ? gb : mm;
+      const char op = (ga & bit) ? 'D' : (gb & bit) ? 'I' : 'M';
+      /* trailing ones of `same` from `at` on */
+      const uint64_t rest = ~(same >> at);
+      uint64_t run = rest ? (uint64_t)__builtin_ctzll(rest) : 64;
+      if (run > m - at) run = m - at;
+      if (op == 'D') b += run;
+      else if (op == 'I') a += run;
+      else if (format != 2) { a += run; b += run; }
+      if (op != 'M' || format != 2) cigar_push(s, op, run);
+      else {
+        for (uint64_t k = 0; k < run; ++k, ++a, ++b) {
+          const int eq = fold ? tolower((unsigned char)*a) == tolower((unsigned char)*b) : *a == *b;
+          cigar_push(s, eq ? '=' : 'X', 1);
+        }
+      }
+      at += run;
+    }
+  }
+}
+
+static int cigar_finish(cigar_sink *s, uint32_t *out_len) {
+  cigar_flush(s);
+  *out_len = (uint32_t)s->used;
+  if (!s->out) return SEQALIGN_OK;
+  if (s->used + 1 > s->cap) return SEQALIGN_E_NOMEM;
+  s->out[s->used] = '\0';
+  return SEQALIGN_OK;
+}
+
+int sa_cigar_nw_moves(const char *a, uint32_t len_a, const char *b, uint32_t len_b, const uint32_t *plane_a,
+                      const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, int format, int fold, char *out, uint64_t cap,
+                      uint32_t *out_len, uint32_t *out_columns) {
+  if ((uint64_t)n_moves > 32ull * n_words) return SEQALIGN_E_TRACEBACK;
+  const uint64_t first = 32ull * n_words - n_moves;
+  const uint64_t gaps_a = plane_popcount(plane_a, n_words, first), gaps_b = plane_popcount(plane_b, n_words, first);
+  const uint64_t used_a = n_moves - gaps_a, used_b = n_moves - gaps_b;
+  if (used_a > len_a || used_b > len_b || planes_overlap(plane_a, plane_b, n_words, first)) return SEQALIGN_E_TRACEBACK;
+  const uint64_t rest_a = len_a - used_a, rest_b = len_b - used_b;
+  if ((rest_a && rest_b) || rest_a + rest_b + n_moves > (uint64_t)len_a + len_b) return SEQALIGN_E_TRACEBACK;
+  cigar_sink s = {out, cap, 0, 0, 0};
+  /* forwards: the rest of seq_a against gaps (I), or the rest of seq_b against gaps (D) -- sa_expand_nw_moves,
+   * src/needleman_wunsch.c:117-132 -- then the walked columns */
+  cigar_push(&s, 'I', rest_a);
+  cigar_push(&s, 'D', rest_b);
+  cigar_walked(&s, plane_a, plane_b, n_words, first, n_moves, a + rest_a, b + rest_b, format, fold);
+  if (out_columns) *out_columns = (uint32_t)(rest_a + rest_b + n_moves);
+  return cigar_finish(&s, out_len);
+}
+
+int sa_cigar_sw_moves(const char *a, const char *b, uint32_t end_x, uint32_t end_y, const uint32_t *plane_a,
+                      const uint32_t *plane_b, uint32_t n_words, uint32_t n_moves, int format, int fold, char *out, uint64_t cap,
+                      uint32_t pos[4], uint32_t *out_len) {
+  if ((uint64_t)n_moves > 32ull * n_words) return SEQALIGN_E_TRACEBACK;
+  const uint64_t first = 32ull * n_words - n_moves;
+  const uint64_t used_a = n_moves - plane_popcount(plane_a, n_words, first);
+  const uint64_t used_b = n_moves - plane_popcount(plane_b, n_words, first);
+  if (used_a > end_x || used_b > end_y || planes_overlap(plane_a, plane_b, n_words, first)) return SEQALIGN_E_TRACEBACK;
+  pos[0] = (uint32_t)(end_x - used_a); pos[1] = (uint32_t)(end_y - used_b);
+  pos[2] = (uint32_t)used_a; pos[3] = (uint32_t)used_b;
+  cigar_sink s = {out, cap, 0, 0, 0};
+  cigar_walked(&s, plane_a, plane_b, n_words, first, n_moves, a + pos[0], b + pos[1], format, fold);
+  return cigar_finish(&s, out_len);
+}

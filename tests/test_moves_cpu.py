@@ -144,3 +144,106 @@ def test_sw_moves_expand_to_the_oracle_hits(scalar):
         assert done > 100
     finally:
         lib.sa_moves_force_scalar(C.c_int(0))
+
+
+# ------------------------------------------------------------------ CIGAR straight from the planes ---
+
+def cigar_of_strings(lib, ra: bytes, rb: bytes, extended: int, fold: int) -> bytes:
+    """seqalign_cigar (host/sa_alignment.c) over the two gapped strings: the definition the plane encoder must reproduce."""
+    lib.seqalign_cigar.restype = C.c_size_t
+    out = C.create_string_buffer(2 * len(ra) + 8)
+    n = lib.seqalign_cigar(ra, rb, C.c_size_t(len(ra)), C.c_int(extended), C.c_int(fold), out, C.c_size_t(len(out)))
+    assert n != C.c_size_t(-1).value
+    return out.value
+
+
+def py_cigar(ra: bytes, rb: bytes, extended: int, fold: int) -> bytes:
+    """The same definition once more, in Python (independent of both C encoders): seq_a = query, seq_b = reference."""
+    ops = []
+    for x, y in zip(ra, rb):
+        if x == 45: op = "D"
+        elif y == 45: op = "I"
+        elif not extended: op = "M"
+        else: op = "=" if (bytes([x]).lower() == bytes([y]).lower() if fold else x == y) else "X"
+        if ops and ops[-1][0] == op: ops[-1][1] += 1
+        else: ops.append([op, 1])
+    return "".join(f"{n}{op}" for op, n in ops).encode()
+
+
+def test_nw_cigar_from_planes_equals_cigar_of_the_strings():
+    lib = S.lib()
+    rng = random.Random(77)
+    specs = [{"init": [1, -2, -4, -1, 0, 0, 0, 0, 0, 0]}, {"init": [2, -3, -1, -1, 0, 0, 0, 0, 0, 0]}, {"init": [1, -1, 0, -2, 0, 0, 0, 0, 0, 0]}]
+    for trial in range(300):
+        osc = O.build_scoring(specs[trial % 3], "oracle")
+        la = rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 150, 151, 300, rng.randrange(0, 400)])
+        a = bytes(rng.choice(b"ACGTacgt") for _ in range(la))
+        if trial % 2:
+            b = bytearray(a.upper() if trial % 4 == 1 else a)
+            for _ in range(rng.randrange(0, 6)):
+                if b and rng.random() < 0.5:
+                    at = rng.randrange(len(b)); del b[at:at + rng.randrange(1, 9)]
+                else:
+                    at = rng.randrange(len(b) + 1); b[at:at] = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(1, 9)))
+            b = bytes(b)
+        else:
+            b = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 1, 5, 64, 127, 128, 150, rng.randrange(0, 500)])))
+        rc, score, ra, rb = O.oracle_nw(osc, a, b)
+        assert rc == 0
+        pa, pb, n_words, n_moves = planes_from_alignment(ra, rb, len(a), len(b), True)
+        if n_words:   # poison what the walk did not write
+            first = 32 * n_words - n_moves
+            for plane in (pa, pb):
+                for w in range(first // 32):
+                    plane[w] = 0xDEADBEEF
+                if first % 32:
+                    plane[first // 32] |= np.uint32((1 << (first % 32)) - 1)
+        for fmt, fold in ((1, 0), (2, 0), (2, 1)):
+            want = cigar_of_strings(lib, ra, rb, fmt == 2, fold)
+            assert want == py_cigar(ra, rb, fmt == 2, fold)
+            n, cols = C.c_uint32(0), C.c_uint32(0)
+            args = (a, C.c_uint32(len(a)), b, C.c_uint32(len(b)), pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p),
+                    C.c_uint32(n_words), C.c_uint32(n_moves), C.c_int(fmt), C.c_int(fold))
+            # length only, exact capacity, one byte short
+            assert lib.sa_cigar_nw_moves(*args, None, C.c_uint64(0), C.byref(n), C.byref(cols)) == 0
+            assert (n.value, cols.value) == (len(want), len(ra)), (trial, fmt)
+            out = C.create_string_buffer(b"\xff" * (len(want) + 9), len(want) + 9)
+            assert lib.sa_cigar_nw_moves(*args, out, C.c_uint64(len(want) + 1), C.byref(n), C.byref(cols)) == 0
+            assert out.raw[:len(want) + 1] == want + b"\0" and out.raw[len(want) + 1:] == b"\xff" * 8, (trial, fmt, want)
+            if want:
+                out = C.create_string_buffer(b"\xff" * (len(want) + 9), len(want) + 9)
+                assert lib.sa_cigar_nw_moves(*args, out, C.c_uint64(len(want)), C.byref(n), C.byref(cols)) == S.E_NOMEM
+                assert out.raw[len(want):] == b"\xff" * 9      # never past the capacity it was given
+
+
+def test_sw_cigar_from_planes_equals_cigar_of_the_hits():
+    lib = S.lib()
+    rng = random.Random(78)
+    osc = O.build_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, "oracle")
+    done = 0
+    for trial in range(150):
+        lb = rng.randrange(40, 400)
+        b = bytes(rng.choice(b"ACGT") for _ in range(lb))
+        o = rng.randrange(0, lb - 30)
+        a = bytearray(b[o:o + rng.randrange(30, 200)])
+        for _ in range(rng.randrange(0, 6)):
+            at = rng.randrange(len(a))
+            if rng.random() < 0.5: del a[at:at + rng.randrange(1, 4)]
+            else: a[at:at] = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(1, 4)))
+        a = bytes(a).lower() if trial % 3 == 0 else bytes(a)
+        rc, hits = O.oracle_sw(osc, a, b, 10, 3)
+        assert rc == 0
+        for h in hits:
+            ra, rb = h["a"].encode(), h["b"].encode()
+            pa, pb, n_words, n_moves = planes_from_alignment(ra, rb, len(a), len(b), False)
+            for fmt, fold in ((1, 0), (2, 0), (2, 1)):
+                want = py_cigar(ra, rb, fmt == 2, fold)
+                assert want == cigar_of_strings(lib, ra, rb, fmt == 2, fold)
+                out, pos, n = C.create_string_buffer(len(want) + 1), (C.c_uint32 * 4)(), C.c_uint32(0)
+                rc = lib.sa_cigar_sw_moves(a, b, C.c_uint32(h["pos_a"] + h["len_a"]), C.c_uint32(h["pos_b"] + h["len_b"]),
+                                           pa.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p), C.c_uint32(n_words),
+                                           C.c_uint32(n_moves), C.c_int(fmt), C.c_int(fold), out, C.c_uint64(len(want) + 1), pos, C.byref(n))
+                assert rc == 0 and out.value == want and n.value == len(want)
+                assert list(pos) == [h["pos_a"], h["pos_b"], h["len_a"], h["len_b"]]
+                done += 1
+    assert done > 300
