@@ -449,6 +449,31 @@ const char *seqalign_kernel_kind_name(int kind);
 size_t seqalign_cigar(const char *result_a, const char *result_b, size_t length, int extended,
                       int case_insensitive, char *out, size_t cap);
 
+/* The batch calls with CIGAR as their output (north_star: "identical CIGAR/alignment strings").  Same alignments, same order, same
+ * query convention as seqalign_cigar above -- seq_a is the QUERY, seq_b the REFERENCE: a column with '-' in result_b is I, with '-'
+ * in result_a is D.  format: SEQALIGN_CIGAR_M (M / I / D) or SEQALIGN_CIGAR_EQX (= / X / I / D; letters compared case-folded unless
+ * scoring->case_sensitive).  On plain scorings the device walks come home as two bits per alignment column and the
+ * host run-length encodes those bits: the gapped strings are never written, and a read's "150M" is 5 bytes where its strings are 302.
+ *   seqalign_nw_batch_cigar: pair p's CIGAR NUL-terminated at cigar + cigar_off[p], capacity cigar_off[p + 1] - cigar_off[p] (cigar_off
+ *     has n_pairs + 1 entries; SEQALIGN_E_NOMEM when a pair's does not fit: no CIGAR is longer than 2 (len_a + len_b) + 1 bytes),
+ *     cigar_len[p] = its strlen, out_score[p] as seqalign_nw_batch.  A global alignment's CIGAR covers both sequences completely
+ *     (leading / trailing gaps are I / D runs, as the reference's strings have them, src/needleman_wunsch.c:117-132).
+ *   seqalign_sw_batch_cigar: as seqalign_sw_batch; hit h's CIGAR NUL-terminated at cigar + hits[h].str_off, hits back to back;
+ *     hits[h].length stays the number of alignment columns, pos_a / pos_b / len_a / len_b say where the hit lies. */
+#define SEQALIGN_CIGAR_M 1
+#define SEQALIGN_CIGAR_EQX 2
+int seqalign_nw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring, int format,
+                            const uint64_t *cigar_off, char *cigar, uint32_t *cigar_len, int32_t *out_score);
+int seqalign_sw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                            const int32_t *min_score, uint32_t max_hits, int format, seqalign_sw_hit_t *hits,
+                            uint64_t hit_cap, uint64_t *n_hits, char *cigar, uint64_t cigar_cap);
+/* ... and over several contexts (GPUs), as seqalign_nw_batch_multi / seqalign_sw_batch_multi */
+int seqalign_nw_batch_cigar_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                  int format, const uint64_t *cigar_off, char *cigar, uint32_t *cigar_len, int32_t *out_score);
+int seqalign_sw_batch_cigar_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                  const int32_t *min_score, uint32_t max_hits, int format, seqalign_sw_hit_t *hits,
+                                  uint64_t hit_cap, uint64_t *n_hits, char *cigar, uint64_t cigar_cap);
+
 /* ---- diagnostics ---------------------------------------------------------------- */
 /* The host legs of seqalign_nw_batch's direction-byte path alone, no device involved: sizes, offsets and packing of the
  * sequences (pack_ms), then the expansion of synthetic all-MATCH moves into the caller's strings (expand_ms); averages

@@ -42,6 +42,7 @@ enum { TOOL_NW, TOOL_SW };
 typedef struct {
   int tool;
   int case_sensitive, print_scores, print_seq, print_matrices, print_fasta, print_pretty, print_colour, zam;
+  int cigar;   /* 0, SEQALIGN_CIGAR_M (--cigar) or SEQALIGN_CIGAR_EQX (--cigarx): an output of this tool only (the reference has no CIGAR) */
   int min_score, min_score_set;
   unsigned max_hits; int max_hits_set;
   unsigned context;
@@ -176,6 +177,8 @@ static void parse_args(int argc, char **argv)
     else if(!strcasecmp(a, "--printfasta")) opt.print_fasta = 1;
     else if(!strcasecmp(a, "--pretty")) opt.print_pretty = 1;
     else if(!strcasecmp(a, "--colour")) opt.print_colour = 1;
+    else if(!strcasecmp(a, "--cigar")) opt.cigar = SEQALIGN_CIGAR_M;
+    else if(!strcasecmp(a, "--cigarx")) opt.cigar = SEQALIGN_CIGAR_EQX;
     else if(!strcasecmp(a, "--zam")) { if(opt.tool != TOOL_NW) die("--zam only valid with Needleman-Wunsch%s", ""); opt.zam = 1; }
     else if(!strcasecmp(a, "--stdin")) { opt.files1[opt.n_files] = "-"; opt.files2[opt.n_files++] = NULL; }
     else if(i + 1 >= argc) die("%s takes an argument", a);
@@ -220,6 +223,8 @@ static void parse_args(int argc, char **argv)
   if(opt.tool == TOOL_NW && scoring.no_mismatches && (scoring.no_gaps_in_a || scoring.no_gaps_in_b))
     die("--nogaps.. --nomismatches cannot be used at together%s", "");
   if(!opt.seq1 && !opt.n_files) die("No input specified%s", "");
+  if(opt.cigar && (opt.zam || opt.print_pretty || opt.print_colour || opt.print_matrices || opt.print_seq || opt.context))
+    die("--cigar / --cigarx print one tab-separated line per alignment: not with --zam, --pretty, --colour, --printmatrices, --printseq or --context%s", "");
   if(opt.zam && (opt.print_pretty || opt.print_scores || opt.print_colour || opt.print_fasta))
     die("Cannot use --printscore, --printfasta, --pretty or --colour with --zam%s", "");
 
@@ -380,11 +385,26 @@ static void align_nw(batch_t *bt)
   if(!n) return;
   if(n > bt->res_cap) {
     bt->res_cap = n + n / 4;
-    bt->str_off = grow(bt->str_off, bt->res_cap * sizeof(uint64_t));
+    bt->str_off = grow(bt->str_off, (bt->res_cap + 1) * sizeof(uint64_t));
     bt->out_len = grow(bt->out_len, bt->res_cap * sizeof(uint32_t));
     bt->score = grow(bt->score, bt->res_cap * sizeof(int32_t));
   }
   as_batch(bt, &b);
+  if(opt.cigar) {
+    /* CIGAR straight from the walks' bit planes (seqalign_nw_batch_cigar): 64-byte slots -- a read's "150M" is 5 bytes -- and once
+     * more with worst-case slots (2 (len_a + len_b) + 2) for the rare batch in which some pair's does not fit */
+    int pass, rc = SEQALIGN_OK;
+    for(pass = 0; pass < 2; pass++) {
+      for(i = 0, total = 0; i < n; i++) { bt->str_off[i] = total; total += pass ? 2 * ((size_t)bt->len_a[i] + bt->len_b[i]) + 2 : 64; }
+      bt->str_off[n] = total;
+      reserve_out(bt, total + 1);
+      rc = g_nctx > 1 ? seqalign_nw_batch_cigar_multi(g_ctxs, g_nctx, &b, &scoring, opt.cigar, bt->str_off, bt->out_a, bt->out_len, bt->score)
+                      : seqalign_nw_batch_cigar(g_ctxs[0], &b, &scoring, opt.cigar, bt->str_off, bt->out_a, bt->out_len, bt->score);
+      if(rc != SEQALIGN_E_NOMEM) break;
+    }
+    check(rc, "seqalign_nw_batch_cigar");
+    return;
+  }
   for(i = 0; i < n; i++) { bt->str_off[i] = total; total += (size_t)bt->len_a[i] + bt->len_b[i] + 1; }
   reserve_out(bt, total + 1);
   if(g_nctx > 1) check(seqalign_nw_batch_multi(g_ctxs, g_nctx, &b, &scoring, bt->str_off, bt->out_a, bt->out_b, bt->out_len, bt->score), "seqalign_nw_batch_multi");
@@ -415,6 +435,11 @@ static void align_sw(batch_t *bt)
   hit_cap = (uint64_t)n * (cap ? cap : 1) + 16;
   if(hit_cap > bt->hit_cap) { bt->hit_cap = hit_cap + hit_cap / 4; free(bt->hits); bt->hits = malloc(bt->hit_cap * sizeof(*bt->hits)); if(!bt->hits) oom(); }
   reserve_out(bt, str_cap + 16);
+  if(opt.cigar) {   /* (no CIGAR is longer than 2 x its columns: the strings' room holds it twice over, out_a and out_b are one allocation each) */
+    if(cap && g_nctx > 1) check(seqalign_sw_batch_cigar_multi(g_ctxs, g_nctx, &b, &scoring, bt->min_score, cap, opt.cigar, bt->hits, hit_cap, &bt->n_hits, bt->out_a, str_cap + 16), "seqalign_sw_batch_cigar_multi");
+    else if(cap) check(seqalign_sw_batch_cigar(g_ctxs[0], &b, &scoring, bt->min_score, cap, opt.cigar, bt->hits, hit_cap, &bt->n_hits, bt->out_a, str_cap + 16), "seqalign_sw_batch_cigar");
+    return;
+  }
   if(cap && g_nctx > 1) check(seqalign_sw_batch_multi(g_ctxs, g_nctx, &b, &scoring, bt->min_score, cap, bt->hits, hit_cap, &bt->n_hits, bt->out_a, bt->out_b, str_cap + 16), "seqalign_sw_batch_multi");
   else if(cap) check(seqalign_sw_batch(g_ctxs[0], &b, &scoring, bt->min_score, cap, bt->hits, hit_cap, &bt->n_hits, bt->out_a, bt->out_b, str_cap + 16), "seqalign_sw_batch");
 }
@@ -460,9 +485,64 @@ static void print_nw_batch_plain(const batch_t *bt)
   fflush(stdout);
 }
 
+/* --cigar / --cigarx (this tool's own; the reference prints the gapped strings only): one line per pair,
+ *     <pair index>\t<name of seq 1 | *>\t<name of seq 2 | *>\t<score>\t<CIGAR>
+ * names without their '>' / '@'; seq 1 is the CIGAR's query, seq 2 its reference (include/seqalign_hip.h). */
+static const char *bare_name(const char *name) { return !name || !name[0] ? "*" : (name[0] == '>' || name[0] == '@') ? name + 1 : name; }
+static size_t g_pair_index;
+
+static void print_nw_batch_cigar(const batch_t *bt)
+{
+  size_t i;
+  for(i = 0; i < bt->n; i++, g_pair_index++) {
+    const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
+    printf("%zu\t%s\t%s\t%i\t", g_pair_index, bare_name(ra.name), bare_name(rb.name), bt->score[i]);
+    fwrite(bt->out_a + bt->str_off[i], 1, bt->out_len[i], stdout);
+    putc('\n', stdout);
+  }
+  fflush(stdout);
+}
+
+/* SW: one line per hit,  <pair index>\t<hit index>\t<score>\t<pos in seq 1>\t<len>\t<pos in seq 2>\t<len>\t<CIGAR>  (0-based positions, as the
+ * reference's "[pos: P; len: L]", sw_cmdline.c:82-124) */
+static void print_sw_batch_cigar(const batch_t *bt)
+{
+  const unsigned cap = sw_cap();
+  size_t k = 0;
+  while(k < bt->n_hits) {
+    const size_t pair = (size_t)bt->hits[k].pair;
+    size_t k1 = k, hit = 0;
+    while(k1 < bt->n_hits && bt->hits[k1].pair == pair) k1++;
+    if(!opt.max_hits_set && k1 - k == cap) {
+      /* the device path stopped at its cap but the user asked for "no limit": this one pair through the per-pair API (as print_sw_batch) */
+      const rec_t ra = rec_a(bt, pair), rb = rec_b(bt, pair);
+      sw_aligner_t *sw = smith_waterman_new();
+      alignment_t *r = alignment_create(256);
+      char *text = malloc(2 * (ra.len + rb.len) + 8);
+      if(!text) oom();
+      smith_waterman_align2(ra.seq, rb.seq, ra.len, rb.len, &scoring, sw);
+      while(smith_waterman_fetch(sw, r) && r->score >= bt->min_score[pair]) {
+        if(seqalign_cigar(r->result_a, r->result_b, r->length, opt.cigar == SEQALIGN_CIGAR_EQX, !scoring.case_sensitive, text, 2 * (ra.len + rb.len) + 8) == (size_t)-1)
+          die("internal error: CIGAR of a hit%s", "");
+        printf("%zu\t%zu\t%i\t%zu\t%zu\t%zu\t%zu\t%s\n", g_pair_index + pair, hit++, r->score, r->pos_a, r->len_a, r->pos_b, r->len_b, text);
+      }
+      free(text); alignment_free(r); smith_waterman_free(sw);
+    } else {
+      for(; k < k1; k++) {
+        const seqalign_sw_hit_t *h = &bt->hits[k];
+        printf("%zu\t%zu\t%i\t%u\t%u\t%u\t%u\t%s\n", g_pair_index + pair, hit++, h->score, h->pos_a, h->len_a, h->pos_b, h->len_b, bt->out_a + h->str_off);
+      }
+    }
+    k = k1;
+  }
+  g_pair_index += bt->n;
+  fflush(stdout);
+}
+
 static void print_nw_batch(const batch_t *bt)
 {
   size_t i;
+  if(opt.cigar) { print_nw_batch_cigar(bt); return; }
   if(!opt.print_matrices && !opt.zam && !opt.print_fasta && !opt.print_pretty && !opt.print_colour) { print_nw_batch_plain(bt); return; }
   for(i = 0; i < bt->n; i++) {
     const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
@@ -483,6 +563,7 @@ static void print_sw_batch(const batch_t *bt)
   /* pairs with an empty sequence are reported and skipped upstream (sw_cmdline.c:137-151) */
   const unsigned cap = sw_cap();
   size_t i, h0;
+  if(opt.cigar) { print_sw_batch_cigar(bt); return; }
   for(i = 0, h0 = 0; i < bt->n; i++) {
     const rec_t ra = rec_a(bt, i), rb = rec_b(bt, i);
     size_t h1 = h0, k;
@@ -655,6 +736,8 @@ static void usage(void)
          "            --substitution_matrix <file>  --substitution_pairs <file>  --wildcard <char> <score>\n"
          "            --nogaps --nogapsin1 --nogapsin2 --nomismatches%s\n"
          "  output:   --printfasta --pretty --colour --printmatrices%s\n"
+         "            --cigar | --cigarx   one tab-separated line per alignment with its CIGAR (M / I / D, or = / X / I / D; seq 1 is the\n"
+         "                                 query) instead of the gapped strings -- made from the GPU walks' bit planes, no strings expanded\n"
          "  environment: SEQALIGN_DEVICE=<gpu>  SEQALIGN_GPUS=<n> (split every batch over n GPUs)\n"
          "               SEQALIGN_CLI_TIMING=1 (the stages' busy times on stderr)  SEQALIGN_CLI_EXIT=full (run the runtime's exit handlers)\n",
          nw ? "seqalign_nw" : "seqalign_sw", nw ? "Global (Needleman-Wunsch)" : "Local (Smith-Waterman)",

@@ -349,6 +349,24 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
       const uint64_t nblk = (n + kBlk - 1) / kBlk;
       std::vector<uint64_t> blk_hits(nblk + 1, 0), blk_bytes(nblk + 1, 0);
       std::atomic<int> bad{SEQALIGN_OK};
+      // where hit j of pair k lies: its planes, and what it takes in the caller's string buffer -- its columns + NUL, or in CIGAR
+      // mode (seqalign_sw_batch_cigar) its CIGAR's length + NUL, counted from the planes (host/sa_moves.c)
+      auto planes_of = [&](uint64_t k, uint32_t j, uint32_t *nwd_out) {
+        const uint64_t pp = c.first + k;
+        const uint32_t nwd = (batch->len_a[pp] + batch->len_b[pp] + 31u) >> 5;
+        *nwd_out = nwd;
+        return h_moves + 2ull * max_hits * ((ctx->h_desc.as<uint64_t>()[k] >> 5) + k) + 2ull * j * nwd;
+      };
+      auto out_bytes = [&](uint64_t k, uint32_t j, uint32_t len) -> uint64_t {
+        if (!ctx->cigar_format) return (uint64_t)len + 1;
+        const uint64_t pp = c.first + k, w = k * max_hits + j;
+        uint32_t nwd, pos[4], clen = 0;
+        const uint32_t *pa = planes_of(k, j, &nwd);
+        if (sa_cigar_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3], pa, pa + nwd,
+                              nwd, len, ctx->cigar_format, ctx->cigar_fold, nullptr, 0, pos, &clen))
+          return 1;   // (the placement pass meets the same error and reports it)
+        return (uint64_t)clen + 1;
+      };
       parallel_for(nblk, [&](uint64_t bi) {
         uint64_t hs = 0, bytes = 0;
         for (uint64_t k = bi * kBlk, e2 = std::min(n, (bi + 1) * kBlk); k < e2; ++k) {
@@ -356,7 +374,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
           for (uint32_t j = 0; j < take; ++j) {
             const uint32_t len = h_w[4 * (k * max_hits + j) + 1];
             if (len >= SA_MOVES_ERR) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, (int)(len & 15u)); continue; }
-            ++hs; bytes += (uint64_t)len + 1;
+            ++hs; bytes += out_bytes(k, j, len);
           }
         }
         blk_hits[bi + 1] = hs; blk_bytes[bi + 1] = bytes;
@@ -388,16 +406,20 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
           for (uint32_t j = 0; j < take; ++j, ++hi) {
             const uint64_t w = k * max_hits + j;
             const uint32_t len = h_w[4 * w + 1];
-            if (hi >= hit_room || at + len + 1 > str_room) { stop = true; break; }   // (no_room is set: the call reports it)
+            const uint64_t need = out_bytes(k, j, len);
+            if (hi >= hit_room || at + need > str_room) { stop = true; break; }   // (no_room is set: the call reports it)
             const uint32_t *pa = h_moves + 2ull * max_hits * ((slot >> 5) + k) + 2ull * j * nwd;
             seqalign_sw_hit_t &h = hits[first_hit + hi];
-            uint32_t pos[4];
-            const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3],
-                                               pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
+            uint32_t pos[4], clen = 0;
+            const int prc = ctx->cigar_format
+              ? sa_cigar_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3], pa, pa + nwd,
+                                  nwd, len, ctx->cigar_format, ctx->cigar_fold, out_a + first_str + at, need, pos, &clen)
+              : sa_expand_sw_moves(batch->arena + batch->off_a[pp], batch->arena + batch->off_b[pp], h_w[4 * w + 2], h_w[4 * w + 3],
+                                   pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
             if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); stop = true; break; }
             h.pair = pp; h.score = (int32_t)h_w[4 * w]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
             h.length = len; h.str_off = first_str + at;
-            at += (uint64_t)len + 1; ++done_h; done_b += (uint64_t)len + 1;
+            at += need; ++done_h; done_b += need;
           }
         }
         delivered_hits.fetch_add(done_h); delivered_bytes.fetch_add(done_b);
@@ -536,7 +558,16 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   std::vector<uint64_t> out_off(nw);
   for (uint64_t w = 0; w < nw; ++w) {
     const uint32_t len = h_meta[nw + w];
-    if (*found + n_out >= hit_cap || *used_str + len + 1 > str_cap) { no_room = true; break; }
+    if (*found + n_out >= hit_cap) { no_room = true; break; }
+    if (ctx->cigar_format) {   // CIGAR mode on a path whose walkers write strings: encode them, one after the other (not the common kind)
+      const uint64_t took = put_alignment(ctx, ha + dst_off[w], hb + dst_off[w], len, out_a, out_b, *used_str, str_cap > *used_str ? str_cap - *used_str : 0);
+      if (!took) { no_room = true; break; }
+      out_off[w] = *used_str;
+      *used_str += took;
+      ++n_out;
+      continue;
+    }
+    if (*used_str + len + 1 > str_cap) { no_room = true; break; }
     out_off[w] = *used_str;
     *used_str += len + 1;
     ++n_out;
@@ -546,9 +577,11 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
   parallel_for((n_out + kPack - 1) / kPack, [&](uint64_t blk) {
     for (uint64_t w = blk * kPack, e2 = std::min(n_out, (blk + 1) * kPack); w < e2; ++w) {
       const uint32_t len = h_meta[nw + w], *pos = h_meta + 4 * nw + 4 * w;
-      memcpy(out_a + out_off[w], ha + dst_off[w], len);
-      memcpy(out_b + out_off[w], hb + dst_off[w], len);
-      out_a[out_off[w] + len] = out_b[out_off[w] + len] = '\0';
+      if (!ctx->cigar_format) {
+        memcpy(out_a + out_off[w], ha + dst_off[w], len);
+        memcpy(out_b + out_off[w], hb + dst_off[w], len);
+        out_a[out_off[w] + len] = out_b[out_off[w] + len] = '\0';
+      }
       seqalign_sw_hit_t &h = hits[first_hit + w];
       h.pair = c.first + walk_pair[w]; h.score = reinterpret_cast<const int32_t *>(h_meta)[2 * nw + w];
       h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3]; h.length = len; h.str_off = out_off[w];
@@ -669,6 +702,18 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     std::vector<uint64_t> blk_hits(nblk + 1, 0), blk_bytes(nblk + 1, 0);
     std::atomic<uint64_t> first_err{~0ull};   // pair << 8 | code of the LOWEST failing pair
     auto is_hit = [&](uint64_t k) { const int32_t sc_ = (int32_t)h_w[4 * k]; return sc_ > 0 && sc_ >= min_score[c.first + k]; };
+    // what pair k's hit takes in the caller's string buffer: its columns + NUL, or (seqalign_sw_batch_cigar) its CIGAR + NUL, counted from the planes
+    auto out_bytes = [&](uint64_t k, uint32_t len) -> uint64_t {
+      if (!ctx->cigar_format) return (uint64_t)len + 1;
+      const uint64_t p = c.first + k;
+      const uint32_t nwd = (batch->len_a[p] + batch->len_b[p] + 31u) >> 5;
+      const uint32_t *pa = h_moves + 2ull * ((h_off[k] >> 5) + k);
+      uint32_t pos[4], clen = 0;
+      if (sa_cigar_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3], pa, pa + nwd, nwd, len,
+                            ctx->cigar_format, ctx->cigar_fold, nullptr, 0, pos, &clen))
+        return 1;   // (the placement pass meets the same error and reports it)
+      return (uint64_t)clen + 1;
+    };
     parallel_for(nblk, [&](uint64_t bi) {
       uint64_t hs = 0, bytes = 0;
       for (uint64_t k = bi * kBlk, e3 = std::min(n, (bi + 1) * kBlk); k < e3; ++k) {
@@ -679,7 +724,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
           while (mine < seen && !first_err.compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {}
           continue;
         }
-        if (is_hit(k)) { ++hs; bytes += (uint64_t)len + 1; }
+        if (is_hit(k)) { ++hs; bytes += out_bytes(k, len); }
       }
       blk_hits[bi + 1] = hs; blk_bytes[bi + 1] = bytes;
     });
@@ -706,17 +751,21 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
         if (!is_hit(k)) continue;
         const uint64_t p = c.first + k;
         const uint32_t len = h_w[4 * k + 1];
-        if (hi >= hit_room || at + len + 1 > str_room) break;   // (out_of_room is set: the call reports it)
+        const uint64_t need = out_bytes(k, len);
+        if (hi >= hit_room || at + need > str_room) break;   // (out_of_room is set: the call reports it)
         const uint32_t la = batch->len_a[p], lb = batch->len_b[p], nwd = (la + lb + 31u) >> 5;
         const uint32_t *pa = h_moves + 2ull * ((h_off[k] >> 5) + k);
-        uint32_t pos[4];
-        const int prc = sa_expand_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3],
-                                           pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
+        uint32_t pos[4], clen = 0;
+        const int prc = ctx->cigar_format
+          ? sa_cigar_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3], pa, pa + nwd, nwd, len,
+                              ctx->cigar_format, ctx->cigar_fold, out_a + first_str + at, need, pos, &clen)
+          : sa_expand_sw_moves(batch->arena + batch->off_a[p], batch->arena + batch->off_b[p], h_w[4 * k + 2], h_w[4 * k + 3],
+                               pa, pa + nwd, nwd, len, out_a + first_str + at, out_b + first_str + at, pos);
         if (prc) { int expected = SEQALIGN_OK; bad.compare_exchange_strong(expected, prc); break; }
         seqalign_sw_hit_t &h = hits[first_hit + hi];
         h.pair = p; h.score = (int32_t)h_w[4 * k]; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
         h.length = len; h.str_off = first_str + at;
-        ++hi; at += (uint64_t)len + 1; ++done_h; done_b += (uint64_t)len + 1;
+        ++hi; at += need; ++done_h; done_b += need;
       }
       delivered_hits.fetch_add(done_h, std::memory_order_relaxed); delivered_bytes.fetch_add(done_b, std::memory_order_relaxed);
     });
@@ -760,15 +809,13 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     const uint32_t len = h_meta[n + k];
     const int32_t score = reinterpret_cast<const int32_t *>(h_meta)[2 * n + k];
     if (score <= 0 || score < min_score[p]) continue;
-    if (found >= hit_cap || used_str + len + 1 > str_cap) { *n_hits = found; return SEQALIGN_E_NOMEM; }
-    memcpy(out_a + used_str, ha + dst_off[k], len);
-    memcpy(out_b + used_str, hb + dst_off[k], len);
-    out_a[used_str + len] = out_b[used_str + len] = '\0';
+    const uint64_t took = found >= hit_cap ? 0 : put_alignment(ctx, ha + dst_off[k], hb + dst_off[k], len, out_a, out_b, used_str, str_cap > used_str ? str_cap - used_str : 0);
+    if (!took) { *n_hits = found; return SEQALIGN_E_NOMEM; }
     seqalign_sw_hit_t &h = hits[found++];
     const uint32_t *pos = h_meta + 4 * n + 4 * k;
     h.pair = p; h.score = score; h.pos_a = pos[0]; h.pos_b = pos[1]; h.len_a = pos[2]; h.len_b = pos[3];
     h.length = len; h.str_off = used_str;
-    used_str += len + 1;
+    used_str += took;
   }
   return SEQALIGN_OK;
 }
@@ -867,14 +914,14 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
       const PairHits &ph = per_pair[k];
       for (size_t i = 0; i < ph.hits.size(); ++i) {
         const seqalign_sw_hit_t &src = ph.hits[i];
-        if (found >= hit_cap || used_str + src.length + 1 > str_cap) { rc = SEQALIGN_E_NOMEM; break; }
-        memcpy(out_a + used_str, ph.str_a.data() + src.str_off, src.length + 1);
-        memcpy(out_b + used_str, ph.str_b.data() + src.str_off, src.length + 1);
+        const uint64_t took = found >= hit_cap ? 0 : put_alignment(ctx, ph.str_a.data() + src.str_off, ph.str_b.data() + src.str_off, src.length, out_a, out_b,
+                                                                   used_str, str_cap > used_str ? str_cap - used_str : 0);
+        if (!took) { rc = SEQALIGN_E_NOMEM; break; }
         seqalign_sw_hit_t &h = hits[found++];
         h = src;
         h.pair = c.first + k;
         h.str_off = used_str;
-        used_str += src.length + 1;
+        used_str += took;
       }
     }
     if (rc) break;
@@ -883,11 +930,9 @@ static int sw_batch_host_enumeration(seqalign_ctx *ctx, const seqalign_batch_t *
   return rc;
 }
 
-extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
-                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
-                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
-  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
-  CallScope scope(ctx);
+static int sw_batch_impl(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                         const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                         uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
   *n_hits = 0;
   int rc = check_batch(batch);
   if (rc) return rc;
@@ -928,3 +973,24 @@ extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *ba
                                    str_cap);
 }
 
+extern "C" int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                 const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits,
+                                 uint64_t hit_cap, uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap) {
+  if (!ctx || !scoring || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
+  return sw_batch_impl(ctx, batch, scoring, min_score, max_hits, hits, hit_cap, n_hits, out_a, out_b, str_cap);
+}
+
+// Local hits as CIGAR (include/seqalign_hip.h): the same call with one text per hit instead of two.  On the direction-byte paths
+// (the one-trip multi-hit call, the packed best-hit call) the walks come home as bit planes and the CIGAR is run-length encoded
+// from those, its exact length counted first so that the hits still lie back to back in `cigar`; the paths whose walkers write
+// strings (three matrices, the host enumeration) encode those strings (put_alignment).
+extern "C" int seqalign_sw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                                       const int32_t *min_score, uint32_t max_hits, int format, seqalign_sw_hit_t *hits,
+                                       uint64_t hit_cap, uint64_t *n_hits, char *cigar, uint64_t cigar_cap) {
+  if (!ctx || !scoring || !min_score || !hits || !n_hits || !cigar || (format != SEQALIGN_CIGAR_M && format != SEQALIGN_CIGAR_EQX))
+    return SEQALIGN_E_ARG;
+  CallScope scope(ctx);
+  CigarScope mode(ctx, format, !scoring->case_sensitive);
+  return sw_batch_impl(ctx, batch, scoring, min_score, max_hits, hits, hit_cap, n_hits, cigar, cigar, cigar_cap);
+}

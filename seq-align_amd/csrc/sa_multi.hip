@@ -91,11 +91,24 @@ extern "C" int seqalign_nw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   });
 }
 
-extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch,
-                                       const scoring_t *scoring, const int32_t *min_score, uint32_t max_hits,
-                                       seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, char *out_a,
-                                       char *out_b, uint64_t str_cap) {
-  if (bad_ctx_list(ctxs, n_ctx) || !batch || !min_score || !hits || !n_hits || !out_a || !out_b) return SEQALIGN_E_ARG;
+extern "C" int seqalign_nw_batch_cigar_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch,
+                                             const scoring_t *scoring, int format, const uint64_t *cigar_off, char *cigar,
+                                             uint32_t *cigar_len, int32_t *out_score) {
+  if (bad_ctx_list(ctxs, n_ctx) || !batch || !cigar_off || !cigar || !cigar_len || !out_score) return SEQALIGN_E_ARG;
+  int rc = check_batch(batch);
+  if (rc) return rc;
+  return for_each_shard(shard_edges(batch, n_ctx), [&](int g, uint64_t first, uint64_t count) {
+    const seqalign_batch_t s = sub_batch(batch, first, count);   // cigar_off[] are absolute: one shared buffer
+    return seqalign_nw_batch_cigar(ctxs[g], &s, scoring, format, cigar_off + first, cigar, cigar_len + first, out_score + first);
+  });
+}
+
+// format 0: the two strings (seqalign_sw_batch_multi); 1 / 2: CIGAR (seqalign_sw_batch_cigar_multi; out_b unused)
+static int sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch,
+                          const scoring_t *scoring, const int32_t *min_score, uint32_t max_hits, int format,
+                          seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, char *out_a,
+                          char *out_b, uint64_t str_cap) {
+  if (bad_ctx_list(ctxs, n_ctx) || !batch || !min_score || !hits || !n_hits || !out_a || (!format && !out_b)) return SEQALIGN_E_ARG;
   *n_hits = 0;
   int rc = check_batch(batch);
   if (rc) return rc;
@@ -112,12 +125,15 @@ extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   rc = for_each_shard(edges, [&](int g, uint64_t first, uint64_t count) {
     const seqalign_batch_t s = sub_batch(batch, first, count);
     uint64_t found = 0;
-    const int r = seqalign_sw_batch(ctxs[g], &s, scoring, min_score + first, max_hits, hits + h0[g], h0[g + 1] - h0[g],
-                                    &found, out_a + s0[g], out_b + s0[g], s0[g + 1] - s0[g]);
+    const int r = format ? seqalign_sw_batch_cigar(ctxs[g], &s, scoring, min_score + first, max_hits, format, hits + h0[g], h0[g + 1] - h0[g],
+                                                   &found, out_a + s0[g], s0[g + 1] - s0[g])
+                         : seqalign_sw_batch(ctxs[g], &s, scoring, min_score + first, max_hits, hits + h0[g], h0[g + 1] - h0[g],
+                                             &found, out_a + s0[g], out_b + s0[g], s0[g + 1] - s0[g]);
     got[g] = found;
     for (uint64_t i = 0; i < found; ++i) {
       const seqalign_sw_hit_t &h = hits[h0[g] + i];
-      used[g] = std::max(used[g], h.str_off + h.length + 1);
+      // (a hit's text: its columns, or in CIGAR mode the CIGAR -- the hits lie back to back, so only the last one's end matters)
+      used[g] = std::max(used[g], h.str_off + (format ? strlen(out_a + s0[g] + h.str_off) : (size_t)h.length) + 1);
     }
     return r;
   });
@@ -127,7 +143,7 @@ extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
     const uint64_t first = edges[g];
     if (s0[g] != ns) {
       memmove(out_a + ns, out_a + s0[g], used[g]);
-      memmove(out_b + ns, out_b + s0[g], used[g]);
+      if (!format) memmove(out_b + ns, out_b + s0[g], used[g]);
     }
     for (uint64_t i = 0; i < got[g]; ++i) {
       seqalign_sw_hit_t h = hits[h0[g] + i];
@@ -141,3 +157,17 @@ extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, c
   return SEQALIGN_OK;
 }
 
+extern "C" int seqalign_sw_batch_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch,
+                                       const scoring_t *scoring, const int32_t *min_score, uint32_t max_hits,
+                                       seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, char *out_a,
+                                       char *out_b, uint64_t str_cap) {
+  return sw_batch_multi(ctxs, n_ctx, batch, scoring, min_score, max_hits, 0, hits, hit_cap, n_hits, out_a, out_b, str_cap);
+}
+
+extern "C" int seqalign_sw_batch_cigar_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch,
+                                             const scoring_t *scoring, const int32_t *min_score, uint32_t max_hits, int format,
+                                             seqalign_sw_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, char *cigar,
+                                             uint64_t cigar_cap) {
+  if (format != SEQALIGN_CIGAR_M && format != SEQALIGN_CIGAR_EQX) return SEQALIGN_E_ARG;
+  return sw_batch_multi(ctxs, n_ctx, batch, scoring, min_score, max_hits, format, hits, hit_cap, n_hits, cigar, nullptr, cigar_cap);
+}

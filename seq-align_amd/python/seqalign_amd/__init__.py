@@ -359,6 +359,61 @@ class Context:
                                          b=out_b[h.str_off:h.str_off + h.length].tobytes().decode()))
         return per_pair
 
+    # ---- CIGAR as the batch calls' output (seqalign_*_batch_cigar) -------------------------------
+    def nw_batch_cigar(self, batch, scoring: Scoring, fmt: int = 1, slot: int | None = None, raw: bool = False):
+        """seqalign_nw_batch_cigar -> [(score, cigar bytes)] (raw: the C-side arrays).  slot: bytes per pair (default: the worst
+        case 2 (len_a + len_b) + 2)."""
+        n = batch.n_pairs
+        cache = getattr(self, "_cg_buffers", None)
+        if raw and cache is not None and cache[0] is batch and cache[1] == slot:
+            off, out, out_len, out_score = cache[2]
+        else:
+            caps = (np.full(n, slot, np.uint64) if slot is not None else
+                    2 * (batch.len_a.astype(np.uint64) + batch.len_b.astype(np.uint64)) + np.uint64(2))
+            off = np.zeros(n + 1, np.uint64)
+            off[1:] = np.cumsum(caps)
+            out = np.zeros(int(off[n]) + 1, np.uint8)
+            out_len, out_score = np.zeros(n, np.uint32), np.zeros(n, np.int32)
+            if raw:
+                self._cg_buffers = (batch, slot, (off, out, out_len, out_score))
+        d = batch_desc(batch)
+        _check(lib().seqalign_nw_batch_cigar(self._h, C.byref(d), C.byref(scoring), C.c_int(fmt), _ptr(off), _ptr(out), _ptr(out_len),
+                                             _ptr(out_score)), "seqalign_nw_batch_cigar")
+        if raw:
+            return off, out, out_len, out_score
+        return [(int(out_score[p]), out[int(off[p]):int(off[p]) + int(out_len[p])].tobytes()) for p in range(n)]
+
+    def sw_batch_cigar(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, fmt: int = 1, hit_cap: int | None = None,
+                       cigar_cap: int | None = None, raw: bool = False):
+        """seqalign_sw_batch_cigar -> per pair a list of dict(score, pos_a, pos_b, len_a, len_b, length, cigar)."""
+        n = batch.n_pairs
+        ms = np.full(n, min_score, np.int32) if np.isscalar(min_score) else np.asarray(min_score, np.int32)
+        hit_cap = hit_cap or max(1024, 64 * n)
+        cigar_cap = cigar_cap or min(int(hit_cap * 2 * (int(batch.len_a.max(initial=0)) + int(batch.len_b.max(initial=0)) + 2)), 1 << 30)
+        cache = getattr(self, "_swcg_buffers", None)
+        if raw and cache is not None and cache[0] is batch and cache[1] == (hit_cap, cigar_cap):
+            hits, out = cache[2]
+        else:
+            hits, out = (SwHit * hit_cap)(), np.zeros(cigar_cap, np.uint8)
+            if raw:
+                self._swcg_buffers = (batch, (hit_cap, cigar_cap), (hits, out))
+        n_hits = C.c_uint64(0)
+        d = batch_desc(batch)
+        rc = lib().seqalign_sw_batch_cigar(self._h, C.byref(d), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
+                                           C.c_int(fmt), hits, C.c_uint64(hit_cap), C.byref(n_hits), _ptr(out), C.c_uint64(cigar_cap))
+        if raw:
+            return rc, n_hits.value, hits, out
+        _check(rc, "seqalign_sw_batch_cigar")
+        per_pair = [[] for _ in range(n)]
+        for k in range(n_hits.value):
+            h = hits[k]
+            end = int(h.str_off)
+            while out[end]:
+                end += 1
+            per_pair[h.pair].append(dict(score=h.score, pos_a=h.pos_a, pos_b=h.pos_b, len_a=h.len_a, len_b=h.len_b, length=h.length,
+                                         cigar=out[h.str_off:end].tobytes().decode()))
+        return per_pair
+
     def dpp_probe(self, fill: int = -7):
         out = np.zeros(64, np.int32)
         _check(lib().sa_dpp_probe(self._h, C.c_int32(fill), _ptr(out)), "sa_dpp_probe")
@@ -546,6 +601,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_arenas_info", "seqalign_pool_trim", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
     "seqalign_kernel_kind_name", "seqalign_host_legs_nw", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
+    "seqalign_nw_batch_cigar", "seqalign_sw_batch_cigar", "seqalign_nw_batch_cigar_multi", "seqalign_sw_batch_cigar_multi",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
     "seqalign_reader_next",
