@@ -530,6 +530,41 @@ def measure(args, grp, env, workload, steps, warmup, pairs):
             e2e["up_to_4_hits"] = {"call": "seqalign_sw_batch(max_hits=4)", "ms": wall4 * 1e3,
                                    "value": total_cells / wall4 / 1e9, "unit": "GCUPS"}
 
+    # the same call as a STREAM of batches (seqalign_*_batch_submit / seqalign_job_wait, sa_async.hip): `in_flight` batches at
+    # a time, the caller waiting that many behind its submits -- what an API caller streaming batches of this size gets, steady
+    # state: batch k + 1's packing and upload run beside batch k's walk and expansion (never `value`)
+    if e2e is not None and not args.no_stream:
+        in_flight, n_stream = 3, args.stream_batches
+        if is_sw:
+            mk = lambda: ((S.SwHit * (batch.n_pairs + 8))(), *(np.zeros(min(int((batch.n_pairs + 8) * (int(batch.len_a.max()) + int(batch.len_b.max()) + 2)), 1 << 30), np.uint8) for _ in range(2)))
+            sub = lambda buf: ctx.sw_batch_submit(batch, sc, thr, max_hits=1, hit_cap=batch.n_pairs + 8, buffers=buf)
+            call_s = "seqalign_sw_batch_submit(max_hits=1)"
+        else:
+            mk = lambda: ctx.nw_buffers(batch)
+            sub = lambda buf: ctx.nw_batch_submit(batch, sc, buf)
+            call_s = "seqalign_nw_batch_submit"
+        bufs = [mk() for _ in range(in_flight + 1)]
+        for j in [sub(b) for b in bufs]:          # every lane sizes its scratch, every buffer is touched
+            j.wait(raw=True)
+
+        def stream_once(n_b):
+            pending = []
+            for k in range(n_b):
+                if len(pending) == in_flight:
+                    pending.pop(0).wait(raw=True)
+                pending.append(sub(bufs[k % (in_flight + 1)]))
+            for j in pending:
+                j.wait(raw=True)
+        stream_once(2 * in_flight)
+        grp.barrier()
+        t1 = time.perf_counter()
+        stream_once(n_stream)
+        dt = grp.max_float(time.perf_counter() - t1)
+        e2e["stream"] = {"call": f"{call_s} x {n_stream}, {in_flight} in flight (seqalign_job_wait {in_flight} behind the submits), own output buffers per job in flight",
+                         "batches": n_stream, "in_flight": in_flight, "ms_per_batch": dt / n_stream * 1e3,
+                         "value": total_cells * n_stream / dt / 1e9, "unit": "GCUPS",
+                         "vs_synchronous": (total_cells * n_stream / dt) / (total_cells / wall)}
+
     torch.cuda.synchronize()
     for _ in range(warmup):
         db.fill(ctx, h, kernel, order_after_current=False)
@@ -703,6 +738,8 @@ def main() -> int:
     ap.add_argument("--no-configs", action="store_true",
                     help="N = 1, default workload: skip the `configs` block (C3, C4, C5's share measured beside the C2 headline)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip e2e.stream (the host-level call as a stream of submitted batches)")
+    ap.add_argument("--stream-batches", type=int, default=32)
     ap.add_argument("--no-unplaced", action="store_true",
                     help="skip the few steps of the same kernel on unplaced arenas (roofline.frac_unplaced)")
     ap.add_argument("--e2e-after", type=float, default=2.0,

@@ -272,6 +272,31 @@ int seqalign_sw_batch(seqalign_ctx_t *ctx, const seqalign_batch_t *batch,
                       uint64_t hit_cap, uint64_t *n_hits, char *out_a,
                       char *out_b, uint64_t str_cap);
 
+/* ---- asynchronous host-level calls ----------------------------------------------- */
+/* A host-level call on one batch is a serial chain (pack, upload, fill, walk, results home, expansion into the caller's strings)
+ * of which the kernels are about half; ACROSS batches the chain overlaps: batch k + 1's packing and upload need nothing of batch
+ * k's walk and expansion.  The reference has one pair in flight (src/alignment_cmdline.c:611-622); a caller streaming batches
+ * submits them and waits for them in order:
+ *     seqalign_nw_batch_submit(ctx, &batch[k], sc, ..., &job[k]);   ...   rc = seqalign_job_wait(job[k - 2]);
+ * Up to `async_lanes` (option, 1..8, default 3) submitted calls of a context are in flight at once, each on a lane with streams,
+ * pinned staging and device scratch of its own (so `async_lanes` times a synchronous call's scratch memory); jobs START in
+ * submission order and may finish in any.  A job IS the synchronous call -- same arguments, same results bit for bit -- run with a
+ * snapshot of the context's options taken at submit.  Everything passed (the batch's arrays, the scoring, the output buffers) is
+ * borrowed until seqalign_job_wait returns.  Submitting is thread-safe; any thread may wait for any job, once.
+ *   seqalign_job_wait   blocks until the job has run; returns its SEQALIGN_* code (its text: seqalign_last_error in the waiting
+ *                       thread; what it launched: seqalign_ctx_last_call_info of the context) and frees the ticket;
+ *   seqalign_job_done   1 when the job has finished (wait will not block), else 0; does not free.
+ * seqalign_ctx_destroy runs every submitted job to its end first; tickets never waited for are leaked, not dangling. */
+typedef struct seqalign_job seqalign_job_t;
+int seqalign_nw_batch_submit(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                             const uint64_t *str_off, char *out_a, char *out_b, uint32_t *out_len, int32_t *out_score,
+                             seqalign_job_t **job);
+int seqalign_sw_batch_submit(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
+                             const int32_t *min_score, uint32_t max_hits, seqalign_sw_hit_t *hits, uint64_t hit_cap,
+                             uint64_t *n_hits, char *out_a, char *out_b, uint64_t str_cap, seqalign_job_t **job);
+int seqalign_job_wait(seqalign_job_t *job);
+int seqalign_job_done(seqalign_job_t *job);
+
 /* ---- several GPUs from one process -------------------------------------------- */
 /* The same three calls over n_ctx contexts (normally one per GPU of the node): the
  * pairs are split into n_ctx contiguous index ranges of (nearly) equal DP cells --
@@ -364,6 +389,7 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *   sweep_mode      auto | pair | strips    multi-hit SW: one wave per pair / per strip
  *   sweep_strip     0 | 64 | 128 | 256      columns per strip       sweep_cpl  0 | 1 | 2 | 4
  *   chunk_bytes     0 | >= 1 MiB            device memory one host-level chunk may use
+ *   async_lanes     0 (= 3) | 1 .. 8        submitted calls in flight per context (seqalign_*_batch_submit)
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
  *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where scores fit int16 --
@@ -467,6 +493,9 @@ int seqalign_nw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, 
 int seqalign_sw_batch_cigar(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                             const int32_t *min_score, uint32_t max_hits, int format, seqalign_sw_hit_t *hits,
                             uint64_t hit_cap, uint64_t *n_hits, char *cigar, uint64_t cigar_cap);
+int seqalign_nw_batch_cigar_submit(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, const scoring_t *scoring, int format,
+                                   const uint64_t *cigar_off, char *cigar, uint32_t *cigar_len, int32_t *out_score,
+                                   seqalign_job_t **job);   /* (asynchronous: seqalign_job_wait, above) */
 /* ... and over several contexts (GPUs), as seqalign_nw_batch_multi / seqalign_sw_batch_multi */
 int seqalign_nw_batch_cigar_multi(seqalign_ctx_t *const *ctxs, int n_ctx, const seqalign_batch_t *batch, const scoring_t *scoring,
                                   int format, const uint64_t *cigar_off, char *cigar, uint32_t *cigar_len, int32_t *out_score);

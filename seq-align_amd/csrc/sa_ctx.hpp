@@ -333,6 +333,7 @@ struct SaOptions {
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
   uint32_t arena_free_pct = 60;   // arena_free_pct    share of the memory free at the start that an explicit placement walk may hold (10 .. 90)
+  uint32_t async_lanes = 0;       // async_lanes       1..8 (0 = 3): batches seqalign_*_batch_submit keeps in flight per context (sa_async.hip)
   uint32_t arena_keep_gib = 16;   // arena_keep_gib    how much of a walk's unused chunks stays with the process (the chunk pool: large scratch
                                   //                   buffers are mapped from it instead of freshly released, not yet cleared VRAM); 0: none
 };
@@ -373,6 +374,7 @@ struct seqalign_ctx {
   uint64_t cached_fp[2] = {0, 0};
   // what the host-level call in progress delivers per alignment (seqalign_*_batch_cigar set it for their duration; a context
   // serves one host-level call at a time): 0 = the two gapped strings, 1 = CIGAR with M, 2 = CIGAR with = / X
+  void *async = nullptr;        // the lanes of seqalign_*_batch_submit (sa_async.hip), created by the first submit
   int cigar_format = 0;
   bool cigar_fold = false;      // format 2: letters compared case-folded (the scoring is case-insensitive)
 };
@@ -390,6 +392,8 @@ struct CallScope {
   CallScope(const CallScope &) = delete;
   CallScope &operator=(const CallScope &) = delete;
 };
+
+void async_shutdown(seqalign_ctx *ctx);   // sa_async.hip: drain the submitted jobs, join the lanes (seqalign_ctx_destroy)
 
 struct CigarScope {   // RAII: the call's output format, put back on every way out
   seqalign_ctx *ctx;

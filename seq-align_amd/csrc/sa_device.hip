@@ -233,6 +233,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("upload_slices")) { if (!number(0, 16, &num)) return false; o.upload_slices = (uint32_t)num; return true; }
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
   if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
+  if (is("async_lanes")) { if (!number(0, 8, &num)) return false; o.async_lanes = (uint32_t)num; return true; }
   if (is("arena_free_pct")) { if (!number(10, 90, &num)) return false; o.arena_free_pct = (uint32_t)num; return true; }
   if (is("arena_quality")) {
     char *end = nullptr;
@@ -274,6 +275,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("upload_slices")) return n(o.upload_slices);
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
   if (is("arena_keep_gib")) return n(o.arena_keep_gib);
+  if (is("async_lanes")) return n(o.async_lanes);
   if (is("arena_free_pct")) return n(o.arena_free_pct);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
   return false;
@@ -283,7 +285,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -349,6 +351,7 @@ extern "C" int seqalign_ctx_create(int device, seqalign_ctx_t **out) {
 
 extern "C" void seqalign_ctx_destroy(seqalign_ctx_t *ctx) {
   if (!ctx) return;
+  async_shutdown(ctx);   // submitted jobs are run to the end, their lanes' contexts destroyed
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < 2; ++k) if (ctx->cached[k]) seqalign_scoring_release(ctx, ctx->cached[k]);

@@ -152,7 +152,7 @@ def batch_desc(batch: "workloads.Batch") -> BatchDesc:
 
 OPTION_DEFAULTS = {"kernel": "auto", "cpl": 0, "wpb": 0, "lds_pad": 0, "traceback": "device", "trace_kernel": "auto",
                    "sweep_mode": "auto", "sweep_strip": 0, "sweep_cpl": 0, "sweep_trace": 0, "sweep_dirs": 1, "nw_dirs": 1, "pack16": 1, "quad": 0, "walk_overlap": 0, "timing": 0, "chunk_bytes": 0,
-                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "arena_keep_gib": 16, "upload_slices": 0, "arena_free_pct": 60, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0}
+                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "arena_keep_gib": 16, "upload_slices": 0, "arena_free_pct": 60, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0, "async_lanes": 0}
 
 
 K_MAX = 32
@@ -359,6 +359,40 @@ class Context:
                                          b=out_b[h.str_off:h.str_off + h.length].tobytes().decode()))
         return per_pair
 
+    # ---- asynchronous host-level calls (seqalign_*_batch_submit / seqalign_job_wait) ---------------
+    def nw_buffers(self, batch):
+        """Output buffers of one seqalign_nw_batch call on `batch`: (str_off, out_a, out_b, out_len, out_score)."""
+        n = batch.n_pairs
+        caps = batch.len_a.astype(np.uint64) + batch.len_b.astype(np.uint64) + np.uint64(1)
+        str_off = np.zeros(n, np.uint64)
+        if n:
+            str_off[1:] = np.cumsum(caps)[:-1]
+        total = int(caps.sum()) + 1
+        return str_off, np.zeros(total, np.uint8), np.zeros(total, np.uint8), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+
+    def nw_batch_submit(self, batch, scoring: Scoring, buffers=None) -> "Job":
+        buffers = buffers or self.nw_buffers(batch)
+        str_off, out_a, out_b, out_len, out_score = buffers
+        job = Job(self, "nw", batch, scoring, buffers)
+        job.desc = batch_desc(batch)
+        _check(lib().seqalign_nw_batch_submit(self._h, C.byref(job.desc), C.byref(scoring), _ptr(str_off), _ptr(out_a), _ptr(out_b),
+                                              _ptr(out_len), _ptr(out_score), C.byref(job.handle)), "seqalign_nw_batch_submit")
+        return job
+
+    def sw_batch_submit(self, batch, scoring: Scoring, min_score, max_hits: int = 1 << 20, hit_cap: int | None = None, buffers=None) -> "Job":
+        n = batch.n_pairs
+        ms = np.full(n, min_score, np.int32) if np.isscalar(min_score) else np.asarray(min_score, np.int32)
+        hit_cap = hit_cap or max(1024, 64 * n)
+        str_cap = min(int(hit_cap * (int(batch.len_a.max(initial=0)) + int(batch.len_b.max(initial=0)) + 2)), 1 << 30)
+        buffers = buffers or ((SwHit * hit_cap)(), np.zeros(str_cap, np.uint8), np.zeros(str_cap, np.uint8))
+        hits, out_a, out_b = buffers
+        job = Job(self, "sw", batch, scoring, buffers)
+        job.desc, job.ms, job.n_hits = batch_desc(batch), ms, C.c_uint64(0)
+        _check(lib().seqalign_sw_batch_submit(self._h, C.byref(job.desc), C.byref(scoring), _ptr(ms), C.c_uint32(min(max_hits, 0xFFFFFFFF)),
+                                              hits, C.c_uint64(hit_cap), C.byref(job.n_hits), _ptr(out_a), _ptr(out_b), C.c_uint64(len(out_a)),
+                                              C.byref(job.handle)), "seqalign_sw_batch_submit")
+        return job
+
     # ---- CIGAR as the batch calls' output (seqalign_*_batch_cigar) -------------------------------
     def nw_batch_cigar(self, batch, scoring: Scoring, fmt: int = 1, slot: int | None = None, raw: bool = False):
         """seqalign_nw_batch_cigar -> [(score, cigar bytes)] (raw: the C-side arrays).  slot: bytes per pair (default: the worst
@@ -418,6 +452,36 @@ class Context:
         out = np.zeros(64, np.int32)
         _check(lib().sa_dpp_probe(self._h, C.c_int32(fill), _ptr(out)), "sa_dpp_probe")
         return out
+
+
+class Job:
+    """A submitted host-level call (seqalign_job_t*).  Keeps everything the C side borrows alive until wait()."""
+
+    def __init__(self, ctx, kind, batch, scoring, buffers):
+        self.ctx, self.kind, self.batch, self.scoring, self.buffers = ctx, kind, batch, scoring, buffers
+        self.handle = C.c_void_p(0)
+
+    def done(self) -> bool:
+        return bool(lib().seqalign_job_done(self.handle)) if self.handle else True
+
+    def wait(self, raw: bool = False):
+        """seqalign_job_wait; returns what the synchronous wrapper would have (raw: the buffers as they are)."""
+        h, self.handle = self.handle, C.c_void_p(0)
+        _check(lib().seqalign_job_wait(h), f"seqalign_job_wait({self.kind})")
+        if raw:
+            return self.buffers if self.kind == "nw" else (self.n_hits.value, *self.buffers)
+        if self.kind == "nw":
+            str_off, out_a, out_b, out_len, out_score = self.buffers
+            return [(int(out_score[p]), out_a[int(str_off[p]):int(str_off[p]) + int(out_len[p])].tobytes(),
+                     out_b[int(str_off[p]):int(str_off[p]) + int(out_len[p])].tobytes()) for p in range(self.batch.n_pairs)]
+        hits, out_a, out_b = self.buffers
+        per_pair = [[] for _ in range(self.batch.n_pairs)]
+        for k in range(self.n_hits.value):
+            h = hits[k]
+            per_pair[h.pair].append(dict(score=h.score, pos_a=h.pos_a, pos_b=h.pos_b, len_a=h.len_a, len_b=h.len_b,
+                                         a=out_a[h.str_off:h.str_off + h.length].tobytes().decode(),
+                                         b=out_b[h.str_off:h.str_off + h.length].tobytes().decode()))
+        return per_pair
 
 
 _ARENA_CTX = {}
@@ -601,6 +665,7 @@ EXPORTED_SYMBOLS = [
     "seqalign_arenas_info", "seqalign_pool_trim", "seqalign_ctx_set_option", "seqalign_ctx_get_option", "seqalign_ctx_last_call_info",
     "seqalign_kernel_kind_name", "seqalign_host_legs_nw", "seqalign_ctx_stream",
     "seqalign_fill_batch_multi", "seqalign_nw_batch_multi", "seqalign_sw_batch_multi", "seqalign_cigar",
+    "seqalign_nw_batch_submit", "seqalign_sw_batch_submit", "seqalign_nw_batch_cigar_submit", "seqalign_job_wait", "seqalign_job_done",
     "seqalign_nw_batch_cigar", "seqalign_sw_batch_cigar", "seqalign_nw_batch_cigar_multi", "seqalign_sw_batch_cigar_multi",
     # include/seqalign_io.h
     "seqalign_scoring_load_matrix", "seqalign_scoring_load_pairs", "seqalign_reader_open", "seqalign_reader_close",
