@@ -630,7 +630,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         if (use_dirs) { t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0; }
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
-        t.tune_walker = ctx->opt.trace_kernel;
+        t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;
         // the last group's walk has no fill to run beside: it stays in the fills' stream, right behind the last fill (on
         // its own stream it waited for the previous group's download -- streams share hardware queues; rocprofv3
         // timeline of C5's share: 0.6 ms)
@@ -996,7 +996,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
-        t.tune_walker = ctx->opt.trace_kernel;
+        t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;
         // the last group's walk has no fill to run beside: it stays in the fills' stream, right behind the last fill
         hipStream_t sg = g + 1 < n_grp ? sw : sf;
         if (sg != sf) {

@@ -263,7 +263,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.walks_per_pair = max_hits; t.hit_count = r.hit_count; t.sweep_status = r.status;
     t.hit_keys = r.hit_keys; t.hit_off = r.hit_off; t.layout = layout; t.fill_status = dd.status;
     t.n_pairs = (uint32_t)((k1 - k0) * max_hits); t.K = r.K; t.open1 = r.open1; t.ext = r.ext; t.gen_eq = r.gen_eq; t.gen_ne = r.gen_ne;
-    t.flags = r.flags; t.tune_walker = ctx->opt.trace_kernel; t.dirs = r.dirs;
+    t.flags = r.flags; t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group; t.dirs = r.dirs;
     if ((he = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(he, "sw hit traceback");
     piped_any = true;
     return SEQALIGN_OK;
@@ -523,7 +523,7 @@ static int sw_chunk_device_enumerate(seqalign_ctx *ctx, const seqalign_batch_t *
     t.trace_status = dv_meta + 3 * nw; t.out_pos = dv_meta + 4 * nw;
     t.walker_pair = dv_walk_pair; t.walker_rank = dv_walk_rank; t.hit_keys = q.hit_keys; t.hit_off = q.hit_off; t.layout = layout;
     t.n_pairs = (uint32_t)nw; t.K = q.K; t.open1 = q.open1; t.ext = q.ext; t.gen_eq = q.gen_eq; t.gen_ne = q.gen_ne;
-    t.flags = q.flags; t.tune_walker = ctx->opt.trace_kernel; t.dirs = q.dirs;
+    t.flags = q.flags; t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group; t.dirs = q.dirs;
     if ((e = sa_launch_nw_traceback(t, st)) != hipSuccess) return fail_hip(e, "sw hit traceback");
     // ---- round trip 2: the hits (their lengths size the packing)
     HIP_TRY(hipMemcpyAsync(ctx->h_misc.p, dv_meta, nw * 32, hipMemcpyDeviceToHost, st));
@@ -685,7 +685,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
     tp.dirs = ctx->dirs.as<uint8_t>(); tp.fill_status = d.status;
     tp.n_pairs = (uint32_t)n; tp.K = sc->flat.n_classes; tp.open1 = sc->flat.open1; tp.ext = sc->flat.ext;
-    tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel;
+    tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel; tp.tune_group = ctx->opt.walk_group;
     hipError_t e2 = sa_launch_nw_traceback(tp, st);
     if (e2 != hipSuccess) return fail_hip(e2, "sw best-hit traceback");
     tm.lap("sw best hit: fill + walk enqueued");

@@ -234,6 +234,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
   if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
   if (is("async_lanes")) { if (!number(0, 8, &num)) return false; o.async_lanes = (uint32_t)num; return true; }
+  if (is("walk_group")) { if (!number(0, 8, &num) || !(num == 0 || num == 1 || num == 4 || num == 8)) return false; o.walk_group = (uint32_t)num; return true; }
   if (is("arena_free_pct")) { if (!number(10, 90, &num)) return false; o.arena_free_pct = (uint32_t)num; return true; }
   if (is("arena_quality")) {
     char *end = nullptr;
@@ -276,6 +277,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
   if (is("arena_keep_gib")) return n(o.arena_keep_gib);
   if (is("async_lanes")) return n(o.async_lanes);
+  if (is("walk_group")) return n(o.walk_group);
   if (is("arena_free_pct")) return n(o.arena_free_pct);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
   return false;
@@ -285,7 +287,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes", "walk_group"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -641,7 +643,7 @@ int sa_host::sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t
   p.start_index = t->start_index; p.out_pos = t->out_pos;
   p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
   p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
-  p.tune_walker = ctx->opt.trace_kernel;
+  p.tune_walker = ctx->opt.trace_kernel; p.tune_group = ctx->opt.walk_group;
   hipError_t e = sa_launch_nw_traceback(p, st);
   if (e != hipSuccess) return fail_hip(e, "traceback launch");
   return SEQALIGN_OK;
@@ -693,7 +695,7 @@ static int launch_traceback(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *s
   p.start_index = sw ? t->start_index : nullptr; p.out_pos = sw ? t->out_pos : nullptr;
   p.n_pairs = (uint32_t)b->n_pairs; p.K = sc->flat.n_classes; p.open1 = sc->flat.open1; p.ext = sc->flat.ext;
   p.gen_eq = sc->flat.gen_eq; p.gen_ne = sc->flat.gen_ne; p.flags = sc->flat.flags;
-  p.tune_walker = ctx->opt.trace_kernel;
+  p.tune_walker = ctx->opt.trace_kernel; p.tune_group = ctx->opt.walk_group;
   hipError_t e = sa_launch_nw_traceback(p, st);
   if (e != hipSuccess) return fail_hip(e, "traceback launch");
   return SEQALIGN_OK;

@@ -34,7 +34,23 @@
 #include "sa_rowsweep.hpp"
 #include "sa_fill_nw_dirs_x1.hpp"
 
+// Round 6: the rows' LDS traffic as a software pipeline (1 = on; `make exp EXPFLAGS=-DSA_X2_LDS_PIPE=0` builds the round-5 form for a
+// same-box A/B).  What the counters said about BASELINE configs[3] (4 000 pairs = 2 000 waves, two per SIMD;
+// profiles/r05/r05b_sweep_pmc_C4_after.json, fill_dirs_x2_kernel<5,1,1024>): a wave spends 26 % of its cycles parked at s_waitcnt
+// (SQ_WAIT_ANY / SQ_WAVE_CYCLES) -- three LDS round trips per row, each issued and then waited for on the spot: the row's
+// profile words (10 ds_read_b32), the next row's profile build (ds_read_u16 -> ds_write_b32), the rings' flush (ds_read ->
+// global_store) -- and with two waves on a SIMD nobody covers them (0.55 of VALU issue; 0.68 with eight waves at 16 000 pairs).
+// Now every LDS read is issued a row ahead of its use: the next row's profile words while this row is computed (the row after
+// that's table entries too), and a ring block is read at the end of one row and stored to HBM at the end of the next.
+#ifndef SA_X2_LDS_PIPE
+#define SA_X2_LDS_PIPE 1
+#endif
+#ifndef SA_X2_FLUSH_DEFER
+#define SA_X2_FLUSH_DEFER SA_X2_LDS_PIPE
+#endif
 namespace sa {
+constexpr bool kLdsPipe = SA_X2_LDS_PIPE != 0;        // the row profile (table scorings) a row ahead
+constexpr bool kFlushDefer = SA_X2_FLUSH_DEFER != 0;  // a ring block read at the end of one row, stored at the end of the next
 
 typedef short pk16 __attribute__((ext_vector_type(2)));
 
@@ -174,6 +190,10 @@ struct SubstX2 {
   uint32_t fb = 0, kb0 = 0, kb1 = 0, b0 = 0;          // this row (wave-uniform): characters, table columns * 2, class-0 mask
   uint32_t prof = 0, bld_src = 0, bld_dst = 0;        // PROFILE: the wave's two buffers; this lane's table row / profile word
   pk16 sc[PROFILE ? CPL : 1];                         // PROFILE: this row's scores of my columns
+  // PROFILE, pipelined (kLdsPipe): what is on its way out of LDS for the rows to come -- raw, not looked at until merge_next()
+  uint32_t scn0[PROFILE ? CPL : 1], scn1[PROFILE ? CPL : 1];   // the next row's profile words of my columns (pair 0's, pair 1's)
+  uint32_t tv0 = 0, tv1 = 0, tvw = 0;                 // the row after next: my table row's two entries on their way; packed
+  pk16 scq[PROFILE ? CPL : 1];                        // the next row's scores, merged
   __device__ __forceinline__ void init(const SaFillParams &p, uint32_t tbl_lds = 0, int lane = 0) {
     s_eq = pk_splat(p.gen_eq); s_ne = pk_splat(p.gen_ne); s_delta = pk_splat(p.gen_ne - p.gen_eq);
     if constexpr (PROFILE) {
@@ -227,6 +247,90 @@ struct SubstX2 {
           sc[c] = pk_from(bfi(a0[c] & b0 & differ, pk_bits(s_ne), pk_bits(sc[c])));
         }
       }
+    }
+  }
+  // ---- the pipelined form: issue now, look later
+  __device__ __forceinline__ void issue_table_reads(uint32_t codes) {   // tv <- table[my row][class of the characters `codes`]
+    if constexpr (PROFILE) {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      const char *l = reinterpret_cast<const char *>(lds_base);
+      tv0 = *reinterpret_cast<const unsigned short *>(l + bld_src + ((codes >> 8) & 0xffu) * 2u);
+      tv1 = *reinterpret_cast<const unsigned short *>(l + bld_src + (codes >> 24) * 2u);
+    }
+  }
+  __device__ __forceinline__ void pack_table_reads() { tvw = tv0 | tv1 << 16; }
+  __device__ __forceinline__ void write_profile(uint32_t buf) const {   // my word of buffer `buf` <- tvw
+    if constexpr (PROFILE) {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds_base) + prof + buf * (kProfBytes / 2) + bld_dst) = tvw;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+  }
+  __device__ __forceinline__ void issue_profile_loads(uint32_t buf) {   // scn <- buffer `buf`'s words of my columns' classes
+    if constexpr (PROFILE) {
+      extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
+      const char *l = reinterpret_cast<const char *>(lds_base) + prof + buf * (kProfBytes / 2);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        scn0[c] = *reinterpret_cast<const uint32_t *>(l + ar0[c]);
+        scn1[c] = *reinterpret_cast<const uint32_t *>(l + ar1[c]);
+      }
+    }
+  }
+  // scq <- the scores of the row whose characters are `codes` out of the words issue_profile_loads asked for (load_profile's
+  // second half: the halves' select, and the class-0 fix-up on rows whose seq_b character is outside the table)
+  __device__ __forceinline__ void merge_next(uint32_t codes) {
+    if constexpr (PROFILE) {
+      const uint32_t fbn = codes & 0x00ff00ffu;
+      const uint32_t b0n = (((codes >> 8) & 0xffu) ? 0u : 0xffffu) | ((codes >> 24) ? 0u : 0xffff0000u);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) scq[c] = pk_from(bfi(0x0000ffffu, scn0[c], scn1[c]));
+      if (b0n) {   // (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const uint32_t ne01 = pk_min_u16(fa[c] ^ fbn, 0x00010001u);
+          const uint32_t differ = pk_bits(pk_splat(0) - pk_from(ne01));
+          scq[c] = pk_from(bfi(a0[c] & b0n & differ, pk_bits(s_ne), pk_bits(scq[c])));
+        }
+      }
+    }
+  }
+  // The row's scores, pipelined: call row_begin() where set_row / build_profile / load_profile stood, row_end() before the row's
+  // direction bytes go to the rings.  chunk: the lanes' seq_b codes of this chunk of 64 rows (row j is lane q's), lb: rows.
+  //   row_begin(j): this row's scores = what row_end(j - 1) merged (a chunk's first row: built, loaded and merged here, waited
+  //                 for on the spot -- one row in 64); then row j + 1's profile word is written (from the table entries read during
+  //                 row j - 1), its words of my columns asked for, and row j + 2's table entries asked for;
+  //   row_end(j):   those words -- asked for a row's work ago -- become row j + 1's scores, the table entries one packed word.
+  // Everything outside the chunk's-first-row block is UNCONDITIONAL: a load under a branch is a value merged at the branch's
+  // end, i.e. a register copy there, i.e. a wait for the load right behind its issue (the first version of this had exactly
+  // that: s_waitcnt lgkmcnt(0) + v_mov at the join).  What is asked for beyond the last row, or beyond the chunk's 64 rows, is
+  // some valid row's words (the lanes' codes are classes of the table whatever row they belong to) and is never looked at: a
+  // chunk's first row rebuilds its own.
+  __device__ __forceinline__ void row_begin(uint32_t chunk, int q, uint32_t j, uint32_t lb) {
+    if constexpr (PROFILE) {
+      const uint32_t codes = (uint32_t)read_lane((int)chunk, q);
+      set_row(codes);
+      if (q == 0) {
+        build_profile(codes, j & 1u);
+        issue_profile_loads(j & 1u);
+        merge_next(codes);
+        issue_table_reads((uint32_t)read_lane((int)chunk, 1));
+        pack_table_reads();
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) sc[c] = scq[c];
+      write_profile((j + 1u) & 1u);
+      issue_profile_loads((j + 1u) & 1u);
+      issue_table_reads((uint32_t)read_lane((int)chunk, (q + 2) & 63));
+    }
+  }
+  __device__ __forceinline__ void row_end(uint32_t chunk, int q, uint32_t j, uint32_t lb) {
+    if constexpr (PROFILE) {
+      merge_next((uint32_t)read_lane((int)chunk, (q + 1) & 63));
+      pack_table_reads();
+      // (here, not wherever the scheduler likes: behind the ring appends and the next block's read the wait for these two
+      // entries also waits for those)
+      asm volatile("" : "+v"(tvw) : : "memory");
     }
   }
   __device__ __forceinline__ pk16 score(int c) const {
@@ -307,8 +411,35 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     rv += 256;
   };
+  // kLdsPipe: a block is READ out of the rings at the end of the row that completed it and STORED at the end of the next row --
+  // its words have had a row's work to arrive, where flush_block waits for them on the spot (every row completes at least one
+  // block from W = 257 columns on; a second one in the same row goes the old way).  In-order LDS: the ring bytes a read was
+  // issued for may be overwritten by later appends, the read still sees the old ones.
+  typedef uint32_t fl_word_t __attribute__((ext_vector_type(LANES == 64 ? 1 : 2)));
+  fl_word_t fd0 = 0, fd1 = 0;
+  uint32_t pend_rv = 0;
+  bool pend = false;
+  auto flush_issue = [&]() __attribute__((always_inline)) {
+    const uint32_t o = (rv & (R - 1)) + kBytes * sl;
+    fd0 = *reinterpret_cast<const fl_word_t *>(ring0 + o);
+    fd1 = *reinterpret_cast<const fl_word_t *>(ring1 + o);
+    pend_rv = rv; pend = true;
+    rv += 256;
+  };
+  auto flush_commit = [&]() __attribute__((always_inline)) {
+    if (pend) {
+      if (has_lo) __builtin_nontemporal_store(fd0, reinterpret_cast<fl_word_t *>(gd0 + pend_rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(fd1, reinterpret_cast<fl_word_t *>(gd1 + pend_rv + kBytes * sl));
+      pend = false;
+    }
+  };
+  auto flush_rest = [&]() __attribute__((always_inline)) {
+    flush_commit();
+    while (rv < wv) flush_block();
+  };
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (kFlushDefer) flush_commit();
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const uint32_t o = (wv + sl * CPL + c) & (R - 1);
@@ -317,7 +448,12 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     wv += W;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (wv - rv >= 256u) flush_block();
+    if constexpr (kFlushDefer) {
+      while (wv - rv >= 512u) flush_block();
+      if (wv - rv >= 256u) flush_issue();
+    } else {
+      while (wv - rv >= 256u) flush_block();
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
@@ -365,6 +501,10 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     // this row's characters of seq_b: uniform over the wave, or over each span
     if constexpr (LANES == 64) {
+      constexpr bool kProfiled = SUBST == SA_SUBST_LDS;
+      if constexpr (kProfiled && kLdsPipe) {
+        sub.row_begin(chunk_code, q, j, lb);   // (the pipelined form: SubstX2::row_begin / row_end)
+      } else {
       const uint32_t codes = (uint32_t)read_lane((int)chunk_code, q);
       sub.set_row(codes);
       // the row's profile (table scorings): built during the row before, or here at a chunk's first row; the next row's goes
@@ -372,6 +512,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       if (q == 0) sub.build_profile(codes, j & 1u);
       sub.load_profile(j & 1u);
       if (q != LANES - 1 && j < lb) sub.build_profile((uint32_t)read_lane((int)chunk_code, q + 1), (j + 1u) & 1u);
+      }
     } else {
       const uint32_t r0 = (uint32_t)read_lane((int)chunk_code, q), r1 = (uint32_t)read_lane((int)chunk_code, q + 32);
       sub.set_row(span ? r1 : r0);
@@ -434,9 +575,10 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     // the border cell (0, j): never stood on with a move to make, but byte for byte what fill_nw_dirs_kernel stores
     // there -- GAP_A continues down the column (its first step only if gap_open is 0), else max(M, B) = B
     dv[0] = first_lane ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
+    if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) sub.row_end(chunk_code, q, j, lb);
     append_row(dv);
   }
-  while (rv < wv) flush_block();
+  flush_rest();
 
   // the end cell (la, lb): score and matrix the walk starts in (needleman_wunsch.c:53-66)
   const int owner = (int)(la / CPL), oc = (int)(la % CPL);
@@ -607,8 +749,36 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     rv += 256;
   };
+  // (kLdsPipe: read a block at the end of the row that completed it, store it at the end of the next -- see nw_dirs_x2_wave)
+  uint2 fq0 = {0, 0}, fq1 = {0, 0};
+  uint32_t fb0 = 0, fb1 = 0, pend_rv = 0;
+  bool pend = false;
+  auto flush_issue = [&]() __attribute__((always_inline)) {
+    const uint32_t o = (rv & (R - 1)) + kCells * sl;
+    fq0 = *reinterpret_cast<const uint2 *>(rm0 + o); fq1 = *reinterpret_cast<const uint2 *>(rm1 + o);
+    fb0 = *reinterpret_cast<const uint32_t *>(rd0 + o); fb1 = *reinterpret_cast<const uint32_t *>(rd1 + o);
+    pend_rv = rv; pend = true;
+    rv += 256;
+  };
+  auto flush_commit = [&]() __attribute__((always_inline)) {
+    typedef int v4i_a __attribute__((ext_vector_type(4)));
+    if (pend) {
+      if (has_lo) {
+        const v4i_a m0 = {(int)(fq0.x & 0xffffu), (int)(fq0.x >> 16), (int)(fq0.y & 0xffffu), (int)(fq0.y >> 16)};
+        __builtin_nontemporal_store(m0, reinterpret_cast<v4i_a *>(gm0 + pend_rv + kCells * sl));
+        __builtin_nontemporal_store(fb0, reinterpret_cast<uint32_t *>(gd0 + pend_rv + kCells * sl));
+      }
+      if (has_hi) {
+        const v4i_a m1 = {(int)(fq1.x & 0xffffu), (int)(fq1.x >> 16), (int)(fq1.y & 0xffffu), (int)(fq1.y >> 16)};
+        __builtin_nontemporal_store(m1, reinterpret_cast<v4i_a *>(gm1 + pend_rv + kCells * sl));
+        __builtin_nontemporal_store(fb1, reinterpret_cast<uint32_t *>(gd1 + pend_rv + kCells * sl));
+      }
+      pend = false;
+    }
+  };
   auto append_row = [&](const pk16 (&mv)[CPL], const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (kFlushDefer) flush_commit();
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const uint32_t o = (wv + sl * CPL + c) & (R - 1);
@@ -618,7 +788,12 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
     wv += W;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (wv - rv >= 256u) flush_block();
+    if constexpr (kFlushDefer) {
+      while (wv - rv >= 512u) flush_block();
+      if (wv - rv >= 256u) flush_issue();
+    } else {
+      while (wv - rv >= 256u) flush_block();
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
@@ -663,7 +838,9 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    {
+    if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) {
+      sub.row_begin(chunk_code, q, j, lb);   // (the pipelined form: SubstX2::row_begin / row_end)
+    } else {
       const uint32_t codes = row_codes<LANES>(chunk_code, q, span);
       sub.set_row(codes);
       if constexpr (LANES == 64) {   // the row's profile (table scorings): see nw_dirs_x2_wave
@@ -726,6 +903,7 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
         TY4[c] = ty4;
       }
     }
+    if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) sub.row_end(chunk_code, q, j, lb);
     append_row(mv, dv);
 
     // candidates of this row in my columns, per pair
@@ -740,6 +918,7 @@ __device__ __forceinline__ void sw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       last_row[h] = has ? j : last_row[h];
     }
   }
+  flush_commit();
   while (rv < wv) flush_block();
 
 #pragma unroll
@@ -835,8 +1014,35 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
     }
     rv += 256;
   };
+  // kLdsPipe: a block is READ out of the rings at the end of the row that completed it and STORED at the end of the next row --
+  // its words have had a row's work to arrive, where flush_block waits for them on the spot (every row completes at least one
+  // block from W = 257 columns on; a second one in the same row goes the old way).  In-order LDS: the ring bytes a read was
+  // issued for may be overwritten by later appends, the read still sees the old ones.
+  typedef uint32_t fl_word_t __attribute__((ext_vector_type(LANES == 64 ? 1 : 2)));
+  fl_word_t fd0 = 0, fd1 = 0;
+  uint32_t pend_rv = 0;
+  bool pend = false;
+  auto flush_issue = [&]() __attribute__((always_inline)) {
+    const uint32_t o = (rv & (R - 1)) + kBytes * sl;
+    fd0 = *reinterpret_cast<const fl_word_t *>(ring0 + o);
+    fd1 = *reinterpret_cast<const fl_word_t *>(ring1 + o);
+    pend_rv = rv; pend = true;
+    rv += 256;
+  };
+  auto flush_commit = [&]() __attribute__((always_inline)) {
+    if (pend) {
+      if (has_lo) __builtin_nontemporal_store(fd0, reinterpret_cast<fl_word_t *>(gd0 + pend_rv + kBytes * sl));
+      if (has_hi) __builtin_nontemporal_store(fd1, reinterpret_cast<fl_word_t *>(gd1 + pend_rv + kBytes * sl));
+      pend = false;
+    }
+  };
+  auto flush_rest = [&]() __attribute__((always_inline)) {
+    flush_commit();
+    while (rv < wv) flush_block();
+  };
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (kFlushDefer) flush_commit();
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const uint32_t o = (wv + sl * CPL + c) & (R - 1);
@@ -845,7 +1051,12 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
     }
     wv += W;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (wv - rv >= 256u) flush_block();
+    if constexpr (kFlushDefer) {
+      while (wv - rv >= 512u) flush_block();
+      if (wv - rv >= 256u) flush_issue();
+    } else {
+      while (wv - rv >= 256u) flush_block();
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
 
@@ -883,7 +1094,9 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
       __builtin_amdgcn_s_waitcnt(kWaitVm0);
     }
-    {
+    if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) {
+      sub.row_begin(chunk_code, q, j, lb);   // (the pipelined form: SubstX2::row_begin / row_end)
+    } else {
       const uint32_t codes = row_codes<LANES>(chunk_code, q, span);
       sub.set_row(codes);
       if constexpr (LANES == 64) {   // the row's profile (table scorings): see nw_dirs_x2_wave
@@ -948,9 +1161,10 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
         TY4[c] = ty4;
       }
     }
+    if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) sub.row_end(chunk_code, q, j, lb);
     append_row(dv);
   }
-  while (rv < wv) flush_block();
+  flush_rest();
 
   // the pair's best cell: highest score, then lowest column, then lowest row (per column: the first row above)
 #pragma unroll

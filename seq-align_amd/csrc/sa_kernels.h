@@ -192,6 +192,7 @@ struct SaTraceParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
+  uint32_t tune_group;         /* host side only: the tile walker on moves: 0 / 4 = four walks per wave in lockstep, 8 = eight, 1 = one (option walk_group) */
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
   const int32_t *nw_score;     /* NW behind the directions-only fill (dirs != NULL): per pair the end cell's score ...            */
   const uint64_t *nw_state;    /* ... and the matrix the walk starts in (0 MATCH, 1 GAP_A, 2 GAP_B)                                */

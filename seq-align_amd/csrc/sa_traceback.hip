@@ -540,6 +540,117 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 }
 
 // ---------------------------------------------------------------------------
+// Round 6: G walks per wave, in lockstep.
+// The tile walker above keeps a walk's state wave-uniform, i.e. in SCALAR registers: a step is ~16 instructions, most of them
+// scalar, and a SIMD's eight waves queue for its one scalar issue slot -- C2's 10 000 walks took 63 us where the walks'
+// dependent accesses alone would take 6 (profiles/r05/r05g_e2e_roofline.json: 0.05-0.12 of its latency bound).  Here a wave
+// carries G walks (G = 4: 16 lanes each, a 64 x 64-byte tile per walk in LDS), every lane holds ITS group's state in vector
+// registers, and one step -- the same ~12 vector instructions -- moves G walks: 3-4 instructions per walk and step instead of
+// 16.  The walks step in LOCKSTEP: all live walks of the wave have taken the same number of steps k, so bursts (steps that
+// can neither leave any group's tile nor pass the end of a 32-column word) have one wave-uniform length, word boundaries
+// coincide, and the only scalar work is per burst: its length, and whether some group needs a new tile (a group that does
+// gets one -- its 16 lanes load four rows each -- the others keep theirs).  A walk that ends (NW: the matrix border; SW: a
+// state whose score is 0) goes quiet: its lanes' updates are predicated off, its step count stays.
+// Same moves, same words, same meta as traceback_moves_tile_kernel (every walker test runs both: option trace_kernel).
+template <bool NW, int G>
+__global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTraceParams p) {
+  constexpr int kT = 64, L = 64 / G;           // tile edge; lanes per walk
+  constexpr int kRows = kT / L;                // tile rows a lane loads
+  static_assert(G == 2 || G == 4 || G == 8, "walks per wave");
+  __shared__ __attribute__((aligned(16))) uint8_t tiles[G * kT * kT];
+  const int lane = threadIdx.x, g = lane / L, lg = lane % L;
+  uint8_t *const tile = tiles + g * (kT * kT);
+  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  const uint32_t w_raw = blockIdx.x * G + g;
+  const bool exists = w_raw < p.n_pairs;
+  const uint32_t w = exists ? w_raw : p.n_pairs - 1;     // (a group without a walk shadows the last one and delivers nothing)
+  const MoveWalk m = move_walk<NW>(p, w);
+  const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+  const MoveSlot s = m.slot;
+  uint32_t x = m.x, y = m.y, st = m.st, kk = 0, reg_a = 0, reg_b = 0, ox = 0, oy = 0, at = 0;
+  unsigned long long codes = 0;                // the states of the current word's steps, two bits each, the first step on top
+  bool live = exists && m.valid;
+  if constexpr (NW) live = live && x != 0 && y != 0;
+  bool fresh = true;                           // no tile yet
+  uint32_t k = 0;                              // steps every live walk has taken (wave-uniform)
+  // word j (the walk's steps 32 j .. 32 j + 31) of my group's walk: lane 15 - j % L keeps it; a block of L words leaves as one run
+  auto keep_word = [&](uint32_t j, uint32_t wa, uint32_t wb, bool mine) __attribute__((always_inline)) {
+    if (mine && lg == (L - 1) - (int)(j % L)) { reg_a = wa; reg_b = wb; }
+  };
+  auto flush = [&](uint32_t q, int first_slot, bool mine) __attribute__((always_inline)) {
+    const int dst = s.nw - L * (int)(q + 1) + lg;
+    if (mine && lg >= first_slot) { s.plane_a[dst] = reg_a; s.plane_b[dst] = reg_b; }
+  };
+  while (__any(live)) {
+    // ---- tiles: a live group that has none, or whose walk stands on its tile's first row or column, gets the tile whose
+    // bottom-right cell is (x, y)
+    const uint32_t tx0 = at & (kT - 1), ty0 = at >> 6;
+    const bool need = live && (fresh || tx0 == 0 || ty0 == 0);
+    if (__any(need)) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tiles
+      if (need) {
+        ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+#pragma unroll
+        for (int r4 = 0; r4 < kRows; ++r4) {
+          const uint32_t tr = (uint32_t)(lg * kRows + r4), r = oy + tr;
+          if (r <= lb) {
+            // 64 bytes of row r from column ox on (past the row's end: the next row, or the buffer's slack -- never looked at)
+            const uint8_t *src = Dg + (uint64_t)r * W + ox;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+          }
+        }
+        at = (y - oy) * kT + (x - ox);
+        fresh = false;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);                           // the tiles are in LDS before anyone reads them (one wave)
+    }
+    // ---- a burst: steps during which no live walk can leave its tile (at least one: a walk on its tile's edge has just been
+    // given a new tile -- or stands on the matrix border, SW only, where every state's score is 0 and the step ends it), and
+    // none passes the end of a word
+    uint32_t room = live ? max(min(at & (kT - 1), at >> 6), 1u) : 64u;
+#pragma unroll
+    for (int o = L; o < 64; o <<= 1) room = min(room, (uint32_t)__shfl_xor((int)room, o));
+    const uint32_t n = min((uint32_t)__builtin_amdgcn_readfirstlane((int)room), 32u - (k & 31u));
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t f = ((uint32_t)tile[at] >> (2u * st)) & 3u;
+      bool go = live;
+      if constexpr (!NW) go = go && f != 3u;   // this state's score is 0: the hit starts here (smith_waterman.c:192)
+      codes = go ? (codes << 2) | st : codes;
+      at -= go ? (0x00014041u >> (8u * st)) & 0xffu : 0u;   // MATCH: a row and a column back (65), GAP_A: a row (64), GAP_B: a column (1)
+      st = go ? f : st;
+      kk += go;
+      if constexpr (!NW) live = go;
+    }
+    k += n;
+    x = ox + (at & (kT - 1)); y = oy + (at >> 6);
+    // a word of 32 columns complete: for the walks that have come this far
+    if ((k & 31u) == 0) {
+      const bool mine = exists && m.valid && kk == k;
+      const uint32_t j = (k >> 5) - 1;
+      keep_word(j, even_bits(codes), even_bits(codes >> 1), mine);
+      codes = mine ? 0ull : codes;
+      if (j % L == L - 1) flush(j / L, 0, mine);
+    }
+    if constexpr (NW) live = live && x != 0 && y != 0;
+  }
+  const bool mine = exists && m.valid;
+  if (kk & 31u) {   // the unfinished word: its columns on top
+    const uint32_t j = kk >> 5;
+    const unsigned long long top = codes << (2u * (32u - (kk & 31u)));
+    keep_word(j, even_bits(top), even_bits(top >> 1), mine);
+  }
+  if (kk) {         // the last block of words: from the slot of the last word on
+    const uint32_t j = (kk - 1) >> 5;
+    flush(j / L, (L - 1) - (int)(j % L), mine);
+  }
+  if (mine && lg == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, kk);
+}
+
+// ---------------------------------------------------------------------------
 // One WAVE per pair, the walk's neighbourhood staged in LDS.
 //
 // A step needs the three matrices at ONE predecessor cell and the two sequence
@@ -702,7 +813,10 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
-        if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
+        // (round 6: four walks per wave in lockstep, vector state -- tune_group 1 = the one-walk-per-wave form, 8 = eight per wave)
+        if (tiles && p.tune_group == 1) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
+        else if (tiles && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+        else if (tiles) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
         else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
@@ -718,7 +832,10 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       sa_record_launch(wtiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;
-      if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
+      // (walks_per_pair -- the one-trip multi-hit call, most slots empty -- stays one wave per pair)
+      if (wtiles && !p.walks_per_pair && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+      else if (wtiles && !p.walks_per_pair && p.tune_group != 1) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+      else if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
       else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip

@@ -654,7 +654,7 @@ def test_context_options(ctx):
         ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave"])
+@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave", "directions-wave-1", "directions-wave-8"])
 def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     """The device walkers -- one lane per pair from the three matrices in HBM, one wave per pair from 16x16 LDS tiles
     of them, and the ones that follow the fill's direction bytes (sa_fill_dirs.hip; plain scorings, rows <= 512
@@ -662,7 +662,8 @@ def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     if walker == "directions":
         opts(nw_dirs=1, sweep_dirs=1)
     elif walker.startswith("directions-"):      # one lane per walk from HBM / one wave per walk from 64 x 64-byte LDS tiles
-        opts(nw_dirs=1, sweep_dirs=1, trace_kernel=walker.split("-")[1])
+        # (round 6: "wave" = four walks per wave in lockstep; -1: one wave per walk, round 5's form; -8: eight per wave)
+        opts(nw_dirs=1, sweep_dirs=1, trace_kernel=walker.split("-")[1], walk_group=int((walker.split("-") + ["0"])[2]))
     else:
         opts(trace_kernel=walker, nw_dirs=0, sweep_dirs=0)
     pairs = [(b"ACGT" * 40, b"ACGT" * 40), (b"A" * 100, b"A" * 17), (b"C" * 5, b"G" * 90), (b"ACGTTGCA" * 9, b"TTTT" + b"ACGTTGCA" * 7),
