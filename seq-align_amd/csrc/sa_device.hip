@@ -875,13 +875,16 @@ int run_one_group(OneRequest *lead, const std::vector<OneRequest *> &grp) {
   db.gap_a_scores = reinterpret_cast<int32_t *>(kOneMatrixBytes);
   db.gap_b_scores = reinterpret_cast<int32_t *>(2 * kOneMatrixBytes);
   hipStream_t stream = ctx->stream;
+  StageTimer tm(ctx->opt.timing);   // (option timing: where a single pair's microseconds go -- tools/legacy_latency.py)
   int rc = sa_host::fill_device(ctx, lead->dsc, &db, SEQALIGN_KERNEL_AUTO, stream, nullptr, nullptr, nullptr);
+  tm.lap("one pair: launch enqueued");
   // kernel end + wait: the GPU's writes to the (coherent) pinned blocks are visible
   // (polled: a blocking wait adds the wake-up of a sleeping thread to every pair; a launch of this size takes ~50 us)
   hipError_t e = hipErrorNotReady;
   for (unsigned spins = 0; rc == SEQALIGN_OK && spins < 20000 && (e = hipStreamQuery(stream)) == hipErrorNotReady; ++spins) __builtin_ia32_pause();
   if (e == hipErrorNotReady || rc != SEQALIGN_OK) e = hipStreamSynchronize(stream);
   if (rc == SEQALIGN_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+  tm.lap("one pair: polled until done");
   for (size_t k = 0; k < grp.size(); ++k) { grp[k]->status = st[k]; grp[k]->rc = rc; }
   return rc;
 }
@@ -938,9 +941,11 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
                                 const char *b, size_t len_b, int32_t *M, int32_t *A, int32_t *B, uint64_t *status) {
   if (len_a > 0xFFFFFFFEull || len_b > 0xFFFFFFFEull) return SEQALIGN_E_TOO_LARGE;
   CallScope scope(ctx);
+  StageTimer tm(ctx->opt.timing);
   HIP_TRY(hipSetDevice(ctx->device));
   seqalign_dev_scoring *dsc = nullptr;
   { int rc = cached_scoring(ctx, sc, is_sw, &dsc); if (rc) return rc; }
+  tm.lap("one pair: device + scoring fingerprint");
   const uint64_t cells = ((uint64_t)len_a + 1) * ((uint64_t)len_b + 1);
   if (cells >= (1ull << 31)) return SEQALIGN_E_TOO_LARGE;
   if (cells * 4 <= kOneMatrixBytes && len_a + len_b <= kOneSeqBytes) {
@@ -965,10 +970,13 @@ extern "C" int sa_fill_one_pair(seqalign_ctx_t *ctx, const scoring_t *sc, int is
     req.ctx = ctx; req.dsc = dsc; req.fp = ctx->cached_fp[is_sw ? 1 : 0]; req.is_sw = is_sw ? 1 : 0;
     req.len_a = (uint32_t)len_a; req.len_b = (uint32_t)len_b;
     req.block_dev = reinterpret_cast<uint64_t>(ctx->one_dev);
+    tm.lap("one pair: sequences into the block");
     if ((rc = combine_and_run(&req))) return rc;
+    tm.lap("one pair: combine + launch + wait");
     memcpy(M, h + kOneMatAt, cells * 4);
     memcpy(A, h + kOneMatAt + kOneMatrixBytes, cells * 4);
     memcpy(B, h + kOneMatAt + 2 * kOneMatrixBytes, cells * 4);
+    tm.lap("one pair: matrices out of the block");
     if (status) *status = req.status;
     return req.status == ~0ull ? SEQALIGN_OK : SEQALIGN_E_UNKNOWN_PAIR;
   }

@@ -106,6 +106,29 @@ struct StreamOut {
     rv += FB;
   }
 
+#ifdef SA_EXP_DEPHASE
+  // Experiment build (profiles/r06/r06_dephase.txt): the three streams DE-PHASED inside the kernel.  A wave
+  // flushes block k of match_scores, block k - 1 of gap_a_scores and block k - 2 of gap_b_scores at a time, so that the three arenas
+  // are never written at the same relative offset at the same moment -- in case what makes three plainly allocated arenas
+  // disturb each other (0.65 of the HBM peak against 0.84 placed) is a bank or channel all three hit at equal offsets.
+  uint32_t rvm[3] = {0, 0, 0};
+  __device__ __forceinline__ void flush_one(int m) {
+    const uint32_t r = rvm[m];
+    const bool inside = (r >= a0) && (r + FB <= vend);
+    const v4i_a q = *reinterpret_cast<const v4i_a *>(lds + rd_lane + ((r & (R - 1)) << 2) + m * kRingBytes);
+    if (inside) {
+      __builtin_nontemporal_store(q, reinterpret_cast<v4i_a *>(reinterpret_cast<char *>(g0[m] + r) + st_lane));
+    } else {
+      const uint32_t e = r + (st_lane >> 2);
+      int32_t *dst = g0[m] + e;
+      if (e + 0 >= a0 && e + 0 < vend) dst[0] = q.x;
+      if (e + 1 >= a0 && e + 1 < vend) dst[1] = q.y;
+      if (e + 2 >= a0 && e + 2 < vend) dst[2] = q.z;
+      if (e + 3 >= a0 && e + 3 < vend) dst[3] = q.w;
+    }
+    rvm[m] = r + FB;
+  }
+#endif
   __device__ __forceinline__ void start(int lane) {
     rd_lane = ring_b + 16u * lane;
     st_lane = 16u * lane;
@@ -122,7 +145,11 @@ struct StreamOut {
   // by W ints per row and wraps inside the 4R-byte aligned ring (v_add + v_and_or).
   __device__ __forceinline__ void append_row(uint32_t W, const int (&mv)[CPL], const int (&av)[CPL],
                                              const int (&bv)[CPL]) {
+#ifdef SA_EXP_DEPHASE
+    static_assert(FB == kKiBInts && 3 * FB - 1 + kWave * CPL <= R, "de-phased streams: the ring holds two more blocks");
+#else
     static_assert(FB - 1 + kWave * CPL <= R, "ring too small for unpredicated appends");
+#endif
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       char *cell = lds + wr[c];
@@ -138,12 +165,22 @@ struct StreamOut {
     // reads below see the writes above: one wave, LDS ops execute in order; the
     // fence only stops the compiler from reordering them
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#ifdef SA_EXP_DEPHASE
+    while (wv - rvm[0] >= (uint32_t)FB) flush_one(0);
+    while (wv - rvm[1] >= 2u * FB) flush_one(1);
+    while (wv - rvm[2] >= 3u * FB) flush_one(2);
+#else
     while (wv - rv >= (uint32_t)FB) flush_block();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 
   __device__ __forceinline__ void finish() {
+#ifdef SA_EXP_DEPHASE
+    for (int m = 0; m < 3; ++m) while (rvm[m] < wv) flush_one(m);
+#else
     while (rv < wv) flush_block();
+#endif
   }
 };
 
@@ -362,6 +399,16 @@ static hipError_t launch_cpl_mode(const SaFillParams &p, hipStream_t stream) {
 template <int MODE>
 static hipError_t launch_stream_mode(const SaFillParams &p, uint32_t max_len_a, hipStream_t stream) {
   const uint32_t need = columns_per_lane(max_len_a + 1, p.tune_cpl);
+#ifdef SA_EXP_DEPHASE   // (two more blocks in the rings: 1 024 ints up to 3 columns per lane, 2 048 beyond)
+  if (need <= 1) return launch_cpl_mode<1, 1024, 256, MODE>(p, stream);
+  if (need <= 2) return launch_cpl_mode<2, 1024, 256, MODE>(p, stream);
+  if (need <= 3) return launch_cpl_mode<3, 1024, 256, MODE>(p, stream);
+  if (need <= 4) return launch_cpl_mode<4, 2048, 256, MODE, 2>(p, stream);
+  if (need <= 5) return launch_cpl_mode<5, 2048, 256, MODE, 2>(p, stream);
+  if (need <= 6) return launch_cpl_mode<6, 2048, 256, MODE, 2>(p, stream);
+  if (need <= 8) return launch_cpl_mode<8, 2048, 256, MODE, 2>(p, stream);
+  return hipErrorInvalidValue;
+#else
   if (need <= 1) return launch_cpl_mode<1, 512, 256, MODE>(p, stream);
   if (need <= 2) return launch_cpl_mode<2, 512, 256, MODE>(p, stream);
   if (need <= 3) return launch_cpl_mode<3, 512, 256, MODE>(p, stream);
@@ -372,6 +419,7 @@ static hipError_t launch_stream_mode(const SaFillParams &p, uint32_t max_len_a, 
   // 513..1023 columns: 12 / 16 columns per lane, 24 KiB of rings per wave -> 2 pairs per workgroup
   if (need <= 12) return launch_cpl_mode<12, 2048, 256, MODE, 2>(p, stream);
   return launch_cpl_mode<16, 2048, 256, MODE, 2>(p, stream);
+#endif
 }
 
 }  // namespace sa

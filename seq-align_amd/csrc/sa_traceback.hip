@@ -551,7 +551,16 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 // coincide, and the only scalar work is per burst: its length, and whether some group needs a new tile (a group that does
 // gets one -- its 16 lanes load four rows each -- the others keep theirs).  A walk that ends (NW: the matrix border; SW: a
 // state whose score is 0) goes quiet: its lanes' updates are predicated off, its step count stays.
-// Same moves, same words, same meta as traceback_moves_tile_kernel (every walker test runs both: option trace_kernel).
+// Same moves, same words, same meta as traceback_moves_tile_kernel (every walker test runs both: option walk_group).
+// MEASURED (profiles/r06/r06_walkers.txt): correct, and NOT faster -- C2's 10 000 walks 70 us with four or eight walks per wave
+// against 62 us with one; the first version, which renewed a group's tile alone and waited row by row, 97 / 153 us.  The premise
+// was wrong: with 3-4 vector instructions per walk and step the walks take what they took with 16 scalar ones, so instructions
+// are not what bounds them.  A tile is 64 row pieces of 64 bytes at a row pitch of len_a + 1 bytes: every piece lies on its own
+// 128-byte line (1.5 on average), and a walk that climbs a row per step pulls in at least a line per step -- 10 000 walks x 3.7
+// tiles x 64 rows x ~190 B = 0.45 GB per launch, 62 us = ~7 TB/s of line traffic out of L2 / HBM.  The walkers are bound by the
+// lines their rows' pieces pull in, whatever carries the state; only a blocked layout of the direction bytes (8 x 16-cell blocks
+// per line: a diagonal walk crosses ~30 of them instead of 171 rows) would change that -- DESIGN.md 8.  Kept as option walk_group
+// = 4 | 8 (default 1: one wave per walk).
 template <bool NW, int G>
 __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTraceParams p) {
   constexpr int kT = 64, L = 64 / G;           // tile edge; lanes per walk
@@ -583,28 +592,34 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
     if (mine && lg >= first_slot) { s.plane_a[dst] = reg_a; s.plane_b[dst] = reg_b; }
   };
   while (__any(live)) {
-    // ---- tiles: a live group that has none, or whose walk stands on its tile's first row or column, gets the tile whose
-    // bottom-right cell is (x, y)
+    // ---- tiles: when some live walk has none, or stands on its tile's first row or column, EVERY live walk gets the tile whose
+    // bottom-right cell is where it stands.  (A first version gave a new tile only to the group that needed one: four walks'
+    // tiles then run out at four different times, ~15 reloads per wave instead of a walk's own 3-4, each a full memory latency
+    // for everybody -- 97 us for C2's walks where one wave per walk takes 63.  Walks leave a tile after 63 .. 126 steps whatever
+    // their shape, so tiles renewed together run out together: max steps / 63 reloads per wave.)  All of a lane's rows are asked
+    // for before the first is written to LDS: one latency per reload, not one per row.
     const uint32_t tx0 = at & (kT - 1), ty0 = at >> 6;
-    const bool need = live && (fresh || tx0 == 0 || ty0 == 0);
-    if (__any(need)) {
+    if (__any(live && (fresh || tx0 == 0 || ty0 == 0))) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tiles
-      if (need) {
-        ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      u4_u buf[kRows][4];
 #pragma unroll
-        for (int r4 = 0; r4 < kRows; ++r4) {
-          const uint32_t tr = (uint32_t)(lg * kRows + r4), r = oy + tr;
-          if (r <= lb) {
-            // 64 bytes of row r from column ox on (past the row's end: the next row, or the buffer's slack -- never looked at)
-            const uint8_t *src = Dg + (uint64_t)r * W + ox;
+      for (int r4 = 0; r4 < kRows; ++r4) {
+        // 64 bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
+        // pair's last: that last row again -- never looked at: the walk only moves up and left of (x, y))
+        const uint32_t tr = (uint32_t)(lg * kRows + r4), r = min(oy + tr, lb);
+        const uint8_t *src = Dg + (uint64_t)r * W + ox;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
-          }
-        }
-        at = (y - oy) * kT + (x - ox);
-        fresh = false;
+        for (int q = 0; q < 4; ++q) buf[r4][q] = *reinterpret_cast<const u4_u *>(src + 16 * q);
       }
+#pragma unroll
+      for (int r4 = 0; r4 < kRows; ++r4) {
+        const uint32_t tr = (uint32_t)(lg * kRows + r4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
+      }
+      at = (y - oy) * kT + (x - ox);
+      fresh = false;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_s_waitcnt(0);                           // the tiles are in LDS before anyone reads them (one wave)
     }
@@ -813,10 +828,11 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
-        // (round 6: four walks per wave in lockstep, vector state -- tune_group 1 = the one-walk-per-wave form, 8 = eight per wave)
-        if (tiles && p.tune_group == 1) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
-        else if (tiles && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
-        else if (tiles) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+        // (round 6: tune_group 4 / 8 = that many walks per wave in lockstep, vector state -- measured no faster, see the kernel's
+        // comment: the walks are bound by the lines their tiles' rows pull out of HBM, not by instructions; default: one wave per walk)
+        if (tiles && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+        else if (tiles && p.tune_group == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+        else if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
         else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
@@ -834,7 +850,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (wpb > 8) return hipErrorInvalidValue;
       // (walks_per_pair -- the one-trip multi-hit call, most slots empty -- stays one wave per pair)
       if (wtiles && !p.walks_per_pair && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
-      else if (wtiles && !p.walks_per_pair && p.tune_group != 1) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+      else if (wtiles && !p.walks_per_pair && p.tune_group == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
       else if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
       else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);

@@ -654,7 +654,7 @@ def test_context_options(ctx):
         ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave", "directions-wave-1", "directions-wave-8"])
+@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave", "directions-wave-4", "directions-wave-8"])
 def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     """The device walkers -- one lane per pair from the three matrices in HBM, one wave per pair from 16x16 LDS tiles
     of them, and the ones that follow the fill's direction bytes (sa_fill_dirs.hip; plain scorings, rows <= 512
@@ -662,7 +662,7 @@ def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     if walker == "directions":
         opts(nw_dirs=1, sweep_dirs=1)
     elif walker.startswith("directions-"):      # one lane per walk from HBM / one wave per walk from 64 x 64-byte LDS tiles
-        # (round 6: "wave" = four walks per wave in lockstep; -1: one wave per walk, round 5's form; -8: eight per wave)
+        # (round 6: -4 / -8: four / eight walks per wave in lockstep, option walk_group)
         opts(nw_dirs=1, sweep_dirs=1, trace_kernel=walker.split("-")[1], walk_group=int((walker.split("-") + ["0"])[2]))
     else:
         opts(trace_kernel=walker, nw_dirs=0, sweep_dirs=0)
@@ -950,6 +950,21 @@ def test_multi_context_calls_equal_single_context(ctx):
         assert ctx.sw_batch(lop, sw, 8, max_hits=3, peers=peers) == ctx.sw_batch(lop, sw, 8, max_hits=3)
         tiny = W.from_pairs([(b"ACGT", b"AGGT")])                        # fewer pairs than contexts
         assert ctx.nw_batch(tiny, sc, peers=peers) == ctx.nw_batch(tiny, sc)
+        # ... and the multi-context results against the ORACLE directly, not only against one context:
+        # matrices, global alignments, local hit lists of the ragged / lopsided batches above
+        osc, osw = oracle_scoring_of(sc), oracle_scoring_of(sw)
+        M, A, B, mat_off, status = many
+        res = ctx.nw_batch(lop, sc, peers=peers)
+        hits = ctx.sw_batch(lop, sw, 8, max_hits=3, peers=peers)
+        for p in range(0, batch.n_pairs, 7):
+            rc, oM, oA, oB = O.oracle_fill(osc, batch.seq_a(p), batch.seq_b(p), 0)
+            o = int(mat_off[p])
+            assert rc == 0 and np.array_equal(M[o:o + oM.size], oM) and np.array_equal(A[o:o + oA.size], oA) and np.array_equal(B[o:o + oB.size], oB), p
+        for p in range(lop.n_pairs):
+            rc, s_, ra, rb = O.oracle_nw(osc, lop.seq_a(p), lop.seq_b(p))
+            assert rc == 0 and res[p] == (s_, ra, rb), p
+            rc, want = O.oracle_sw(osw, lop.seq_a(p), lop.seq_b(p), 8, 3)
+            assert rc == 0 and hits[p] == want, p
     finally:
         for c in peers:
             c.close()

@@ -488,13 +488,13 @@ def test_scratch_comes_from_the_chunk_pool(opts):
         assert keeper.pool_trim(0) == 0
 
 
-@pytest.mark.parametrize("walker", ["wave", "lane", "wave-1", "wave-8"])
+@pytest.mark.parametrize("walker", ["wave", "lane", "wave-4", "wave-8"])
 def test_long_walks_cross_move_blocks(ctx, opts, walker):
     """Walks of several thousand columns: the wave-per-walk walker keeps 64 words (2 048 columns) of each plane in its lanes and
     stores whole blocks; here walks of up to ~5 000 columns cross two and more block boundaries, end exactly on one (2 048 and
     4 096 walked columns: identical sequences) and one column past it.  needleman_wunsch.c:82-145 via the oracle."""
-    # ("wave": four walks per wave in lockstep, 16 words of each plane per walk in its lanes -- blocks of 512 columns; "wave-1": one
-    #  wave per walk, 64 words; "wave-8": eight per wave, blocks of 256 columns)
+    # ("wave": one wave per walk, 64 words of each plane in its lanes; "wave-4": four walks per wave in lockstep, 16 words per walk --
+    #  blocks of 512 columns; "wave-8": eight per wave, blocks of 256 columns)
     walker, group = (walker.split("-") + ["0"])[:2]
     opts(trace_kernel=walker, pack16=0, walk_group=int(group))
     rng = W.Rng(808)
