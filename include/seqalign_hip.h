@@ -139,7 +139,14 @@ enum {
 
 /* THE HOT PATH.  Replaces alignment_fill_matrices (src/alignment.c:28-168) for a
  * whole batch: enqueues the fill on `stream` (a hipStream_t passed as void*,
- * NULL = the context's own stream) and returns without synchronising. */
+ * NULL = the context's own stream) and returns without synchronising.
+ * WHERE the three output arenas lie decides how fast it runs (it is bound by HBM writes): with arenas from
+ * seqalign_arenas_alloc (placed by a measured walk) BASELINE configs[1] runs at 0.82-0.86 of the 8 TB/s peak;
+ * with three buffers of the caller's own (hipMalloc, a torch tensor) at 0.65 -- or 0.83 when the allocator happens to hand out
+ * memory of different classes: both were seen for the same call on one box (bench.py: roofline.frac_unplaced; round 6:
+ * 0.824 / 0.650 / 0.835 in three consecutive processes).  De-phasing the three streams inside the kernel changes nothing
+ * (profiles/r06/r06_dephase.txt): it is which memory, not which offsets.  Callers who own the buffers should get them from
+ * seqalign_arenas_alloc. */
 int seqalign_fill_batch_device(seqalign_ctx_t *ctx,
                                const seqalign_dev_scoring_t *scoring,
                                const seqalign_dev_batch_t *batch, int kernel,

@@ -18,11 +18,13 @@ N_SIMD, CLOCK = 1024, 2.4e9
 LAT = {"lds": 50 / CLOCK, "l2": 200 / CLOCK, "hbm": 900 / CLOCK}
 def walker_bound(kernel, launches_items, steps):
     """(bound seconds, description) of one launch of a walker kernel over `launches_items` walks of `steps` steps each."""
-    if "tile" in kernel:
-        slots = N_SIMD * 8                              # waves resident at once
-        rounds = max(1.0, launches_items / slots)
-        per_walk = steps * LAT["lds"] + (steps / 64.0 + 1.0) * LAT["hbm"]
-        return rounds * per_walk, f"{rounds:.2f} rounds of resident walks x ({steps:.0f} steps x 50-cycle LDS read + {steps / 64 + 1:.1f} tiles x 900-cycle miss)"
+    if "tile" in kernel or "group" in kernel:
+        # Round 6: the tile walkers are bound by the LINES their tiles' row pieces pull in, not by a latency chain or by instructions
+        # (a form with 3-4 vector instructions per walk and step instead of 16 scalar ones took the same time; TCC_MISS / FETCH_SIZE of
+        # C2's launch: 278 MB, 1.27 lines of 128 B per step -- profiles/r06/r06_walkers.txt).  A tile is 64 row pieces of 64 bytes at a
+        # pitch of len_a + 1 bytes: each on ~1.5 lines, and a walk uses a tile for 63 .. 126 steps: lines per step ~ 64 x 1.5 / 75.
+        lines = launches_items * steps * 1.27
+        return lines * 128 / 8.0e12, f"hbm lines: {launches_items:.0f} walks x {steps:.0f} steps x 1.27 lines of 128 B per step (measured: TCC_MISS, profiles/r06/r06_walkers.txt) at 8 TB/s"
     per_walk = steps * LAT["hbm"] / 2.0
     return per_walk, f"{steps:.0f} steps x 900-cycle miss / 2 loads in flight per lane (every walk has a lane: one round)"
 res = {}
@@ -71,7 +73,7 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
         if "traceback" in k and steps:
             launches_per_call = max(1, round(len(dur[k]) / 6)) if key.startswith(("C2", "C5")) else max(1, round(len(dur[k]) / 3))
             b, how = walker_bound(k, walks / launches_per_call, steps)
-            e["bound"] = "dependent_latency"
+            e["bound"] = "hbm_lines" if ("tile" in k or "group" in k) else "dependent_latency"
             e["bound_ms"] = b * 1e3
             e["frac"] = b * 1e3 / e["kernel_ms"]
             e["bound_model"] = how

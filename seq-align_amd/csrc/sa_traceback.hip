@@ -556,11 +556,12 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 // against 62 us with one; the first version, which renewed a group's tile alone and waited row by row, 97 / 153 us.  The premise
 // was wrong: with 3-4 vector instructions per walk and step the walks take what they took with 16 scalar ones, so instructions
 // are not what bounds them.  A tile is 64 row pieces of 64 bytes at a row pitch of len_a + 1 bytes: every piece lies on its own
-// 128-byte line (1.5 on average), and a walk that climbs a row per step pulls in at least a line per step -- 10 000 walks x 3.7
-// tiles x 64 rows x ~190 B = 0.45 GB per launch, 62 us = ~7 TB/s of line traffic out of L2 / HBM.  The walkers are bound by the
-// lines their rows' pieces pull in, whatever carries the state; only a blocked layout of the direction bytes (8 x 16-cell blocks
-// per line: a diagonal walk crosses ~30 of them instead of 171 rows) would change that -- DESIGN.md 8.  Kept as option walk_group
-// = 4 | 8 (default 1: one wave per walk).
+// 128-byte line (1.5 of them on average), and a walk that climbs a row per step pulls in at least a line per step.  The counters
+// say so (profiles/r06/r06_walkers.txt; rocprofv3 --pmc, C2's 10 000 walks of ~171 steps): TCC_MISS 2.17 M lines = 278 MB per
+// launch (FETCH_SIZE 135.8 MiB x 2, the guide's gfx950 correction: the same), 1.27 lines per step -- in 62 us that is 4.5 TB/s
+// = 0.56 of the HBM peak on 64-byte pieces scattered over 228 MB.  The walkers are bound by the lines their rows' pieces pull in,
+// whatever carries the state; only a blocked layout of the direction bytes (8 x 16-cell blocks per line: a diagonal walk crosses
+// ~30 of them instead of 171 rows) would change that -- DESIGN.md 8.  Kept as option walk_group = 4 | 8 (default 1: one wave per walk).
 template <bool NW, int G>
 __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTraceParams p) {
   constexpr int kT = 64, L = 64 / G;           // tile edge; lanes per walk
