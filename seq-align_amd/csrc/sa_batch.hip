@@ -75,7 +75,9 @@ int sa_host::run_chunk(seqalign_ctx *ctx, const seqalign_batch_t *b, const Chunk
     h_off_b[k] = pos; pos += b->len_b[p];
     h_len_a[k] = b->len_a[p]; h_len_b[k] = b->len_b[p];
     h_mat[k] = uniform_stride ? k * uniform_stride : cell;
-    const uint64_t cells_k = (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
+    // (the best-hit fill's direction bytes -- nobody's but the walkers' -- in blocks of 8 x 16 cells: sa_kernels.h)
+    const uint64_t cells_k = (cand && cand->best_only && sa_dirs_blocked_shape(c.max_a)) ? sa_dirs_blocked_bytes(b->len_a[p], b->len_b[p])
+                                                                                       : (uint64_t)(b->len_a[p] + 1ull) * (b->len_b[p] + 1ull);
     cell += bucket ? ((cells_k + 255u) & ~(uint64_t)255u) : cells_k;
   }
   const uint64_t mat_total = uniform_stride ? n * uniform_stride : cell;
@@ -470,16 +472,27 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
   // Plain scorings, rows up to 1 024 columns: the fill writes ONE byte of directions per cell and nothing else
   // (sa_fill_dirs.hip) -- the three matrices are never needed, so they are not even allocated.
   const bool use_dirs = nw_dirs_applicable(ctx, sc, c.max_a, n);
+  // ... in blocks of 8 x 16 cells where every row of the chunk has at most 512 columns (sa_kernels.h, round 6): a pair takes
+  // ceil(rows / 8) x ceil(columns / 16) x 128 bytes and starts on a multiple of 256
+  const bool blocked = use_dirs && sa_dirs_blocked_shape(c.max_a);
+  auto dir_bytes = [&](uint32_t la, uint32_t lb) -> uint64_t {
+    return ((blocked ? sa_dirs_blocked_bytes(la, lb) : (uint64_t)(la + 1ull) * (lb + 1ull)) + 255u) & ~(uint64_t)255u;
+  };
+  if (blocked) {
+    uint64_t at = 0;
+    for (uint64_t k = 0; k < n; ++k) { h_mat[k] = at; at += dir_bytes(h_len_a[k], h_len_b[k]); }
+    cell = at;
+  }
   // Every pair the same shape (reads of one length), match / mismatch scoring: two pairs per wave in packed int16
   // (sa_fill_dirs_x2.hip); each pair's bytes then start on a 256-byte boundary
-  uint64_t stride = 0, mat_total = c.cells;
+  uint64_t stride = 0, mat_total = blocked ? cell : c.cells;
   // ... and a chunk whose pairs are MOSTLY of one shape (reads of one length, some trimmed): the pairs of that shape through
   // the packed kernel, the others through the one-pair kernel, each launch with the list of its pairs (SaFillParams::
   // pair_list); every pair's bytes start on a 256-byte boundary then
   uint32_t modal_a = 0, modal_b = 0;
   bool mixed = false;
   if (use_dirs && same_shape && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2) && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
-    stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+    stride = dir_bytes(c.max_a, c.max_b);
     for (uint64_t k = 0; k < n; ++k) h_mat[k] = k * stride;
     mat_total = n * stride;
   } else if (use_dirs && !same_shape && ctx->opt.pack16 && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2)) {
@@ -498,7 +511,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
       uint64_t at = 0;
       for (uint64_t k = 0; k < n; ++k) {
         h_mat[k] = at;
-        at += (((uint64_t)(h_len_a[k] + 1ull) * (h_len_b[k] + 1ull)) + 255u) & ~(uint64_t)255u;
+        at += dir_bytes(h_len_a[k], h_len_b[k]);
       }
       mat_total = at;
     }
@@ -627,7 +640,7 @@ static int nw_chunk_pipelined(seqalign_ctx *ctx, const seqalign_batch_t *batch, 
         t.out_a = d_chars + 2 * c0 - c0;                  // + slot offset: a-strings at [2 c0, 2 c0 + (c1 - c0))
         t.out_b = d_chars + 2 * c0 + (c1 - c0) - c0;      //                b-strings right behind them
         t.out_meta4 = d_meta + 4 * g0; t.fill_status = d.status;
-        if (use_dirs) { t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0; }
+        if (use_dirs) { t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0; }
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;
@@ -716,7 +729,7 @@ uint64_t host_block_pairs(const seqalign_ctx *ctx, uint64_t n) {
   return blk;
 }
 struct BlkSum {
-  uint64_t chars = 0, cells = 0, cells256 = 0;
+  uint64_t chars = 0, cells = 0, cells256 = 0, blk256 = 0;   // (blk256: the pairs' direction bytes in 8 x 16 blocks, each rounded up to 256)
   uint32_t max_a = 0, max_b = 0;
   bool same = true, too_large = false;
   bool packed = true;   // the block's sequences lie in the caller's arena as they will in ours: a, b, a, b, ... back to back
@@ -733,6 +746,7 @@ void scan_blocks(const seqalign_batch_t *b, uint64_t first, uint64_t n, uint64_t
       const uint32_t la = b->len_a[first + k], lb = b->len_b[first + k];
       const uint64_t cells = (uint64_t)(la + 1ull) * (lb + 1ull);
       s.chars += (uint64_t)la + lb; s.cells += cells; s.cells256 += (cells + 255u) & ~(uint64_t)255u;
+      s.blk256 += (sa_dirs_blocked_bytes(la, lb) + 255u) & ~(uint64_t)255u;
       s.max_a = std::max(s.max_a, la); s.max_b = std::max(s.max_b, lb);
       s.same = s.same && la == la0 && lb == lb0;
       s.too_large = s.too_large || cells >= (1ull << 31);
@@ -766,10 +780,16 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   // two-pairs-per-wave fill) / mostly one shape: every pair on a multiple of 256, the modal shape's pairs packed
   enum { kBackToBack, kUniform, kMixed } layout = kBackToBack;
   uint64_t stride = 0;
+  // (round 6) rows of up to 512 columns: the direction bytes in blocks of 8 x 16 cells (sa_kernels.h) -- a pair takes
+  // ceil(rows / 8) x ceil(columns / 16) x 128 bytes and starts on a multiple of 256 whatever the layout of the chunk
+  const bool blocked = sa_dirs_blocked_shape(c.max_a);
+  auto dir_bytes = [&](uint32_t la, uint32_t lb) -> uint64_t {
+    return ((blocked ? sa_dirs_blocked_bytes(la, lb) : (uint64_t)(la + 1ull) * (lb + 1ull)) + 255u) & ~(uint64_t)255u;
+  };
   const bool may_pack = ctx->opt.pack16 && (n >= kPackedFillMinPairs || ctx->opt.pack16 == 2);
   if (same_shape && may_pack && nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     layout = kUniform;
-    stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+    stride = dir_bytes(c.max_a, c.max_b);
   } else if (!same_shape && may_pack && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2) && (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull) <= kShapeTableMax &&
              nw_dirs_x2_applicable(ctx, sc, c.max_a, c.max_b)) {
     // ragged (reads trimmed to various lengths): pairs of EQUAL shape are found per sub-batch and go two per wave, the ones
@@ -781,7 +801,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   for (uint64_t bi = 0; bi < nb; ++bi) {
     chars_at[bi + 1] = chars_at[bi] + blk[bi].chars;
     const uint64_t in_blk = std::min(n, (bi + 1) * kHostBlk) - bi * kHostBlk;
-    cells_at[bi + 1] = cells_at[bi] + (layout == kUniform ? in_blk * stride : layout == kMixed ? blk[bi].cells256 : blk[bi].cells);
+    cells_at[bi + 1] = cells_at[bi] + (layout == kUniform ? in_blk * stride : blocked ? blk[bi].blk256 : layout == kMixed ? blk[bi].cells256 : blk[bi].cells);
   }
   const uint64_t total = chars_at[nb], mat_total = cells_at[nb];
 
@@ -812,7 +832,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
       h_len_a[k] = la; h_len_b[k] = lb;
       h_mat[k] = cell;
       const uint64_t cells = (uint64_t)(la + 1ull) * (lb + 1ull);
-      cell += layout == kUniform ? stride : layout == kMixed ? ((cells + 255u) & ~(uint64_t)255u) : cells;
+      cell += layout == kUniform ? stride : blocked ? dir_bytes(la, lb) : layout == kMixed ? ((cells + 255u) & ~(uint64_t)255u) : cells;
     }
   });
   h_slot[n] = total;
@@ -993,7 +1013,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         t.moves = dv_moves + 2 * g0;        // walk w of the launch is pair g0 + w: words 2 ((slot >> 5) + g0 + w)
         t.out_meta2 = dv_meta + 2 * g0;
         t.fill_status = d.status;
-        t.dirs = ctx->dirs.as<uint8_t>(); t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
+        t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;
@@ -1147,7 +1167,7 @@ static int nw_batch_impl(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, con
   uint64_t cells256 = 0;
   for (const BlkSum &s : blk) {
     if (s.too_large) return SEQALIGN_E_TOO_LARGE;
-    whole.cells += s.cells; whole.seq_bytes += s.chars; cells256 += s.cells256;
+    whole.cells += s.cells; whole.seq_bytes += s.chars; cells256 += std::max(s.cells256, s.blk256);   // (the larger of the two layouts' bytes: which one a chunk takes follows from its widest row)
     whole.max_a = std::max(whole.max_a, s.max_a); whole.max_b = std::max(whole.max_b, s.max_b);
   }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1160,6 +1180,11 @@ static int nw_batch_impl(seqalign_ctx_t *ctx, const seqalign_batch_t *batch, con
     if (cells256 + 64 * batch->n_pairs + whole.seq_bytes <= ctx->chunk_budget)
       return nw_chunk_moves(ctx, batch, whole, sc, blk, blk_pairs, str_off, out_a, out_b, out_len, out_score);
     std::vector<uint64_t> extra(batch->n_pairs, 256 + 64);
+    if (SA_DIRS_BLOCKED)   // (in blocks of 8 x 16 cells a pair's direction bytes are up to 8 columns' + 16 rows' worth more than its cells)
+      for (uint64_t p = 0; p < batch->n_pairs; ++p) {
+        const uint64_t cells = (uint64_t)(batch->len_a[p] + 1ull) * (batch->len_b[p] + 1ull), bb = sa_dirs_blocked_bytes(batch->len_a[p], batch->len_b[p]);
+        if (bb > cells) extra[p] += bb - cells;
+      }
     for (const Chunk &c : plan_chunks(batch, ctx->chunk_budget, 1, extra.data())) {
       const uint64_t bp = host_block_pairs(ctx, c.count);
       scan_blocks(batch, c.first, c.count, bp, blk);

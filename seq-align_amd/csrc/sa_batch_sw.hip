@@ -619,7 +619,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     // 2 047: 4.10 -> 2.11): a wave's row costs more with two pairs in it, which is what a launch too small to fill the chip pays.
     const uint64_t best_min_pairs = sc->flat.n_classes > 1 ? 128 : c.max_a + 1 > 512 ? 1024 : 1536;
     if (same_shape && (n >= best_min_pairs || ctx->opt.pack16 == 2) && sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
-      stride = (((uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
+      stride = ((sa_dirs_blocked_shape(c.max_a) ? sa_dirs_blocked_bytes(c.max_a, c.max_b) : (uint64_t)(c.max_a + 1ull) * (c.max_b + 1ull)) + 255u) & ~(uint64_t)255u;
     else if (!same_shape && (n >= kBucketedFillMinPairs || ctx->opt.pack16 == 2) && ((uint64_t)c.max_a + 1) * ((uint64_t)c.max_b + 1) <= kShapeTableMax &&
              sw_best_x2_applicable(ctx, sc, c.max_a, c.max_b))
       stride = kBucketShapes;   // ragged: run_chunk pairs up the pairs of equal shape
@@ -628,7 +628,10 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     uint64_t dir_bytes = n * stride;
     if (stride == kBucketShapes) {
       dir_bytes = 0;
-      for (uint64_t k = 0; k < n; ++k) dir_bytes += (((uint64_t)batch->len_a[c.first + k] + 1) * ((uint64_t)batch->len_b[c.first + k] + 1) + 255u) & ~(uint64_t)255u;
+      for (uint64_t k = 0; k < n; ++k) {
+        const uint32_t xa = batch->len_a[c.first + k], xb = batch->len_b[c.first + k];
+        dir_bytes += ((sa_dirs_blocked_shape(c.max_a) ? sa_dirs_blocked_bytes(xa, xb) : ((uint64_t)xa + 1) * ((uint64_t)xb + 1)) + 255u) & ~(uint64_t)255u;
+      }
     }
     if ((rc = ctx->dirs.reserve(dir_bytes + 4096))) return rc;
     SaCandBox bc;
@@ -683,7 +686,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tp.stage_words = (c.max_a + c.max_b + 31u) >> 5;
     tp.moves = ctx->h_ta.dev_as<uint32_t>(); tp.out_meta4 = ctx->h_B.dev_as<uint32_t>();
     tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
-    tp.dirs = ctx->dirs.as<uint8_t>(); tp.fill_status = d.status;
+    tp.dirs = ctx->dirs.as<uint8_t>(); tp.dirs_blocked = sa_dirs_blocked_shape(c.max_a); tp.fill_status = d.status;
     tp.n_pairs = (uint32_t)n; tp.K = sc->flat.n_classes; tp.open1 = sc->flat.open1; tp.ext = sc->flat.ext;
     tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel; tp.tune_group = ctx->opt.walk_group;
     hipError_t e2 = sa_launch_nw_traceback(tp, st);

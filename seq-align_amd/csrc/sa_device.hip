@@ -638,6 +638,7 @@ int sa_host::sw_traceback_dirs(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t
   memset(&p, 0, sizeof(p));
   p.arena = b->arena; p.off_a = b->off_a; p.len_a = b->len_a; p.off_b = b->off_b; p.len_b = b->len_b;
   p.mat_off = b->mat_off; p.dirs = dirs; p.start_score = start_score; p.fill_status = nullptr;
+  p.dirs_blocked = sa_dirs_blocked_shape(b->max_len_a);   // (the best-hit fill's layout for this chunk: sa_kernels.h)
   p.code = sc->d_code; p.table = sc->d_table; p.str_off = t->str_off; p.out_a = t->out_a; p.out_b = t->out_b;
   p.out_head = t->out_head; p.out_len = t->out_len; p.out_score = t->out_score; p.trace_status = t->status;
   p.start_index = t->start_index; p.out_pos = t->out_pos;

@@ -20,6 +20,8 @@
 // BASELINE SW config is), rows up to 1 024 columns (the sweep's rows-in-registers forms; 513 and up: round 5).  Everything else takes the
 // three-matrix path.  The decisions are the SAME expressions the sweep evaluated (sa_sw_sweep.hip, `plain`), on the
 // same int32 values; tests/test_gpu_parity.py runs every hit-list test through both paths.
+#include <algorithm>
+
 #include "sa_rowsweep.hpp"
 #include "sa_fill_nw_dirs_x1.hpp"
 
@@ -257,8 +259,10 @@ fill_nw_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   nw_dirs_x1_wave<CPL, SUBST, R>(p, dirs_arena, pair, lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
 }
 
-template <int CPL, int R>
+template <int CPL, int R0>
 static hipError_t launch_nw_dirs_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  // (blocked direction bytes, sa_kernels.h: one block row of 64 x CPL columns per pair in LDS instead of the ring)
+  constexpr int R = (SA_DIRS_BLOCKED != 0 && kWave * CPL <= 512 && kWave * CPL * 8 > R0) ? kWave * CPL * 8 : R0;
   const int wpb = 4;
   const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
   const size_t rings = (size_t)wpb * R;
@@ -319,7 +323,7 @@ bool sa_nw_dirs_fill_applicable(const SaFillParams &p, uint32_t max_len_a, const
 hipError_t sa_launch_fill_nw_dirs(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
   sa_record_launch(SEQALIGN_K_FILL_NW_DIRS, p.n_pairs);
-  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, sa_dirs_blocked_shape(max_len_a) ? std::min<uint32_t>(p.tune_cpl, 8u) : p.tune_cpl);
   if (need <= 1) return sa::launch_nw_dirs_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_nw_dirs_cpl<2, 512>(p, dirs, stream);
   if (need <= 3) return sa::launch_nw_dirs_cpl<3, 512>(p, dirs, stream);

@@ -49,8 +49,11 @@
 #define SA_X2_FLUSH_DEFER SA_X2_LDS_PIPE
 #endif
 namespace sa {
+// bytes of LDS per pair of the NW / best-hit fills: the ring of the row-major form, or one block row of LANES x CPL columns
+constexpr int x2_ring(int lanes, int cpl, int ring) { return (SA_DIRS_BLOCKED != 0 && lanes * cpl <= 512 && lanes * cpl * 8 > ring) ? lanes * cpl * 8 : ring; }
 constexpr bool kLdsPipe = SA_X2_LDS_PIPE != 0;        // the row profile (table scorings) a row ahead
 constexpr bool kFlushDefer = SA_X2_FLUSH_DEFER != 0;  // a ring block read at the end of one row, stored at the end of the next
+constexpr bool kDirsBlocked = SA_DIRS_BLOCKED != 0;    // the NW / best-hit fills write the direction bytes in 8 x 16 blocks (sa_kernels.h)
 
 typedef short pk16 __attribute__((ext_vector_type(2)));
 
@@ -393,6 +396,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   sub.init(p, tbl_lds, lane);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
+  constexpr bool BLK = kDirsBlocked && LANES * CPL <= 512;   // (rows of up to 512 columns: sa_dirs_blocked_shape)
   uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;   // my span's rings: low halves, high halves
   uint32_t wv = 0, rv = 0;   // stream positions = cell indices: written up to wv, flushed up to rv
   auto flush_block = [&]() __attribute__((always_inline)) {
@@ -434,11 +438,45 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     }
   };
   auto flush_rest = [&]() __attribute__((always_inline)) {
+    if constexpr (BLK) return;   // (the pair's last row flushed its block row)
     flush_commit();
     while (rv < wv) flush_block();
   };
+  // BLK (round 6, sa_kernels.h: the direction bytes in blocks of 8 rows x 16 columns): the LDS buffer is ONE BLOCK ROW of the
+  // pair -- nbx blocks of 128 bytes, laid out as they lie in memory -- my column g's byte of row j at
+  // (g / 16) * 128 + (j % 8) * 16 + g % 16; after the block row's eighth row (or the pair's last) its nbx x 128 bytes leave as
+  // 16 bytes per lane, contiguous.  No stream positions, no ring arithmetic per cell, one flush per eight rows.
+  uint32_t cur_row = 0;                    // (BLK) the row append_row is called for
+  uint32_t cb[BLK ? CPL : 1];              // (BLK) my columns' place in a block row
+  const uint32_t nbx = (W + 15u) >> 4;
+  if constexpr (BLK) {
+    static_assert(!BLK || LANES * CPL * 8 <= R, "the LDS buffer holds a block row of LANES x CPL columns");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const uint32_t g = (uint32_t)(sl * CPL + c); cb[c] = (g >> 4) * 128u + (g & 15u); }
+  }
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (BLK) {
+      typedef uint32_t blk_v4 __attribute__((ext_vector_type(4)));
+      const uint32_t ro = (cur_row & 7u) << 4;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        ring0[cb[c] + ro] = (uint8_t)dv[c];
+        ring1[cb[c] + ro] = (uint8_t)(dv[c] >> 16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if ((cur_row & 7u) == 7u || cur_row == lb) {   // (wave-uniform) the block row is complete, or it is the pair's last
+        const uint32_t bytes = nbx * 128u;
+        const uint64_t at = (uint64_t)(cur_row >> 3) * bytes;
+        for (uint32_t o = (uint32_t)sl * 16u; o < bytes; o += LANES * 16u) {
+          const blk_v4 q0 = *reinterpret_cast<const blk_v4 *>(ring0 + o), q1 = *reinterpret_cast<const blk_v4 *>(ring1 + o);
+          if (has_lo) __builtin_nontemporal_store(q0, reinterpret_cast<blk_v4 *>(gd0 + at + o));
+          if (has_hi) __builtin_nontemporal_store(q1, reinterpret_cast<blk_v4 *>(gd1 + at + o));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      return;
+    }
     if constexpr (kFlushDefer) flush_commit();
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -494,6 +532,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   uint32_t chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
     const int q = (j - 1) & (LANES - 1);
+    cur_row = j;
     if (q == 0) {
       const uint32_t r = j + sl;
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
@@ -996,6 +1035,7 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
   SubstX2<SUBST, CPL, (SUBST == SA_SUBST_LDS && LANES == 64)> sub;
   sub.init(p, tbl_lds, lane);
 
+  constexpr bool BLK = kDirsBlocked && LANES * CPL <= 512;   // (rows of up to 512 columns: sa_dirs_blocked_shape)
   uint8_t *ring0 = ring_wave + span * (2 * R), *ring1 = ring0 + R;
   uint32_t wv = 0, rv = 0;
   auto flush_block = [&]() __attribute__((always_inline)) {
@@ -1037,11 +1077,45 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
     }
   };
   auto flush_rest = [&]() __attribute__((always_inline)) {
+    if constexpr (BLK) return;   // (the pair's last row flushed its block row)
     flush_commit();
     while (rv < wv) flush_block();
   };
+  // BLK (round 6, sa_kernels.h: the direction bytes in blocks of 8 rows x 16 columns): the LDS buffer is ONE BLOCK ROW of the
+  // pair -- nbx blocks of 128 bytes, laid out as they lie in memory -- my column g's byte of row j at
+  // (g / 16) * 128 + (j % 8) * 16 + g % 16; after the block row's eighth row (or the pair's last) its nbx x 128 bytes leave as
+  // 16 bytes per lane, contiguous.  No stream positions, no ring arithmetic per cell, one flush per eight rows.
+  uint32_t cur_row = 0;                    // (BLK) the row append_row is called for
+  uint32_t cb[BLK ? CPL : 1];              // (BLK) my columns' place in a block row
+  const uint32_t nbx = (W + 15u) >> 4;
+  if constexpr (BLK) {
+    static_assert(!BLK || LANES * CPL * 8 <= R, "the LDS buffer holds a block row of LANES x CPL columns");
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const uint32_t g = (uint32_t)(sl * CPL + c); cb[c] = (g >> 4) * 128u + (g & 15u); }
+  }
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + LANES * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (BLK) {
+      typedef uint32_t blk_v4 __attribute__((ext_vector_type(4)));
+      const uint32_t ro = (cur_row & 7u) << 4;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        ring0[cb[c] + ro] = (uint8_t)dv[c];
+        ring1[cb[c] + ro] = (uint8_t)(dv[c] >> 16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if ((cur_row & 7u) == 7u || cur_row == lb) {   // (wave-uniform) the block row is complete, or it is the pair's last
+        const uint32_t bytes = nbx * 128u;
+        const uint64_t at = (uint64_t)(cur_row >> 3) * bytes;
+        for (uint32_t o = (uint32_t)sl * 16u; o < bytes; o += LANES * 16u) {
+          const blk_v4 q0 = *reinterpret_cast<const blk_v4 *>(ring0 + o), q1 = *reinterpret_cast<const blk_v4 *>(ring1 + o);
+          if (has_lo) __builtin_nontemporal_store(q0, reinterpret_cast<blk_v4 *>(gd0 + at + o));
+          if (has_hi) __builtin_nontemporal_store(q1, reinterpret_cast<blk_v4 *>(gd1 + at + o));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      return;
+    }
     if constexpr (kFlushDefer) flush_commit();
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -1089,6 +1163,7 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
   uint32_t chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
     const int q = (j - 1) & (LANES - 1);
+    cur_row = j;
     if (q == 0) {
       const uint32_t r = j + sl;
       if (r <= lb) chunk_code = (uint32_t)p.code[sb0[r - 1]] | (uint32_t)p.code[sb1[r - 1]] << 16;
@@ -1225,8 +1300,9 @@ fill_sw_best_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   sw_best_x2_wave<CPL, SUBST, R, 32>(p, dirs_arena, lo, hi, has_lo, has_hi, lane, reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
-template <int CPL, int R>
+template <int CPL, int R0>
 static hipError_t launch_sw_best_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  constexpr int R = x2_ring(64, CPL, R0);   // (blocked direction bytes: a block row per pair instead of the ring)
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
@@ -1245,8 +1321,9 @@ static hipError_t launch_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipSt
   return hipGetLastError();
 }
 
-template <int CPL, int R>
+template <int CPL, int R0>
 static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
+  constexpr int R = x2_ring(64, CPL, R0);   // (blocked direction bytes: a block row per pair instead of the ring)
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
@@ -1257,7 +1334,7 @@ static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
 
 template <int CPL>
 static hipError_t launch_sw_best_x4_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
-  constexpr int R = 512;
+  constexpr int R = x2_ring(32, CPL, 512);
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 3) / 4;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
@@ -1268,7 +1345,7 @@ static hipError_t launch_sw_best_x4_cpl(const SaFillParams &p, uint8_t *dirs, hi
 
 template <int CPL>
 static hipError_t launch_nw_dirs_x4_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
-  constexpr int R = 512;   // (255 + 32 * 8 columns fit)
+  constexpr int R = x2_ring(32, CPL, 512);   // (255 + 32 * 8 columns fit)
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 3) / 4;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
@@ -1279,7 +1356,8 @@ static hipError_t launch_nw_dirs_x4_cpl(const SaFillParams &p, uint8_t *dirs, hi
 
 template <int CPL4>
 static hipError_t launch_nw_dirs_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t pairs_q, hipStream_t stream) {
-  constexpr int R = 512;
+  // (the four-per-wave waves: four pairs of 32 x CPL4 columns; the two-per-wave waves: two pairs of 64 x CPL2 in the same region)
+  constexpr int R = x2_ring(64, (CPL4 + 1) / 2, x2_ring(32, CPL4, 512));
   const int wpb = 4;
   const uint32_t q_blocks = (pairs_q / 4 + wpb - 1) / wpb, x2_blocks = ((p.n_pairs - pairs_q + 1) / 2 + wpb - 1) / wpb;
   const dim3 grid(q_blocks + x2_blocks), block(kWave * wpb);
@@ -1288,8 +1366,9 @@ static hipError_t launch_nw_dirs_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, 
   return hipGetLastError();
 }
 
-template <int CPL, int R>
+template <int CPL, int R0>
 static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t n_modal, uint32_t n_rest, hipStream_t stream) {
+  constexpr int R = x2_ring(64, CPL, R0);
   const int wpb = 4;
   const uint32_t x2_blocks = ((n_modal + 1) / 2 + wpb - 1) / wpb, x1_blocks = (n_rest + wpb - 1) / wpb;
   const dim3 grid(x2_blocks + x1_blocks), block(kWave * wpb);
@@ -1357,7 +1436,8 @@ hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, 
     }
   }
   sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, p.n_pairs);
-  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  // (blocked direction bytes are decided by the row's width -- host -- and by LANES x CPL <= 512 -- kernel: a forced wider CPL must not split them)
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, sa_dirs_blocked_shape(max_len_a) ? std::min<uint32_t>(p.tune_cpl, 8u) : p.tune_cpl);
   if (need <= 1) return sa::launch_nw_dirs_x2_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_nw_dirs_x2_cpl<2, 512>(p, dirs, stream);
   if (need <= 3) return sa::launch_nw_dirs_x2_cpl<3, 512>(p, dirs, stream);
@@ -1413,7 +1493,8 @@ hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, 
     }
   }
   sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X2, p.n_pairs);
-  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);
+  // (blocked direction bytes are decided by the row's width -- host -- and by LANES x CPL <= 512 -- kernel: a forced wider CPL must not split them)
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, sa_dirs_blocked_shape(max_len_a) ? std::min<uint32_t>(p.tune_cpl, 8u) : p.tune_cpl);
   if (need <= 1) return sa::launch_sw_best_x2_cpl<1, 512>(p, dirs, stream);
   if (need <= 2) return sa::launch_sw_best_x2_cpl<2, 512>(p, dirs, stream);
   if (need <= 3) return sa::launch_sw_best_x2_cpl<3, 512>(p, dirs, stream);
@@ -1433,7 +1514,8 @@ hipError_t sa_launch_fill_nw_dirs_mixed(const SaFillParams &p, uint32_t max_len_
   // one grid, two kinds of waves: the modal shape's pairs two per wave, the rest one per wave
   if (n_modal) sa_record_launch(SEQALIGN_K_FILL_NW_DIRS_X2, n_modal);
   if (n_rest) sa_record_launch(SEQALIGN_K_FILL_NW_DIRS, n_rest);
-  const uint32_t need = sa::columns_per_lane(max_len_a + 1, p.tune_cpl);   // (of the widest pair: the packed waves take it too)
+  // (blocked direction bytes are decided by the row's width -- host -- and by LANES x CPL <= 512 -- kernel: a forced wider CPL must not split them)
+  const uint32_t need = sa::columns_per_lane(max_len_a + 1, sa_dirs_blocked_shape(max_len_a) ? std::min<uint32_t>(p.tune_cpl, 8u) : p.tune_cpl);   // (of the widest pair: the packed waves take it too)
   if (need <= 1) return sa::launch_nw_dirs_mixed_cpl<1, 512>(p, dirs, n_modal, n_rest, stream);
   if (need <= 2) return sa::launch_nw_dirs_mixed_cpl<2, 512>(p, dirs, n_modal, n_rest, stream);
   if (need <= 3) return sa::launch_nw_dirs_mixed_cpl<3, 512>(p, dirs, n_modal, n_rest, stream);

@@ -17,6 +17,18 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
   const int open1 = p.open1, ext = p.ext, K = (int)p.K, gen_eq = p.gen_eq, gen_ne = p.gen_ne, floor_ = p.floor;
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
+  // BLK (round 6, sa_kernels.h): the direction bytes in blocks of 8 rows x 16 columns; the LDS buffer is one block row of the pair,
+  // laid out as it lies in memory, and leaves 16 bytes per lane after its eighth row (sa_fill_dirs_x2.hip: nw_dirs_x2_wave).  The
+  // host starts every pair on a multiple of 256 bytes then.
+  constexpr bool BLK = SA_DIRS_BLOCKED != 0 && kWave * CPL <= 512;
+  static_assert(!BLK || kWave * CPL * 8 <= R, "the LDS buffer holds a block row of 64 x CPL columns");
+  const uint32_t nbx = (W + 15u) >> 4;
+  uint32_t cur_row = 0;
+  uint32_t cb[BLK ? CPL : 1];
+  if constexpr (BLK) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const uint32_t g = (uint32_t)(lane * CPL + c); cb[c] = (g >> 4) * 128u + (g & 15u); }
+  }
   const uint32_t a0 = (uint32_t)((uintptr_t)(dirs_arena + mo) & 255u);
   uint8_t *const gd = dirs_arena + mo - a0;
   const uint32_t vend = a0 + W * (lb + 1);
@@ -35,6 +47,21 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
   };
   auto append_row = [&](const uint32_t (&dv)[CPL]) __attribute__((always_inline)) {
     static_assert(255 + kWave * CPL <= R, "ring too small for unpredicated appends");
+    if constexpr (BLK) {
+      typedef uint32_t blk_v4 __attribute__((ext_vector_type(4)));
+      const uint32_t ro = (cur_row & 7u) << 4;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) ring_d[cb[c] + ro] = (uint8_t)dv[c];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if ((cur_row & 7u) == 7u || cur_row == lb) {
+        const uint32_t bytes = nbx * 128u;
+        uint8_t *dst = dirs_arena + mo + (uint64_t)(cur_row >> 3) * bytes;
+        for (uint32_t o = (uint32_t)lane * 16u; o < bytes; o += kWave * 16u)
+          __builtin_nontemporal_store(*reinterpret_cast<const blk_v4 *>(ring_d + o), reinterpret_cast<blk_v4 *>(dst + o));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) ring_d[(wv + lane * CPL + c) & (R - 1)] = (uint8_t)dv[c];
     wv += W;
@@ -72,6 +99,7 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
   int chunk_code = 0;
   for (uint32_t j = 1; j <= lb; ++j) {
     const int q = (j - 1) & (kWave - 1);
+    cur_row = j;
     if (q == 0) {
       const uint32_t r = j + lane;
       if (r <= lb) chunk_code = p.code[sb_[r - 1]];
@@ -127,7 +155,7 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
     }
     append_row(dv);
   }
-  while (rv < wv) flush_block();
+  if constexpr (!BLK) { while (rv < wv) flush_block(); }
 
   // the end cell (la, lb): score and matrix the walk starts in (needleman_wunsch.c:53-66)
   const int owner = (int)(la / CPL), oc = (int)(la % CPL);

@@ -11,6 +11,24 @@ extern "C" {
 }
 
 /* Everything one fill launch needs; passed by value as the kernarg. */
+/* ---- the direction bytes in BLOCKS (round 6) --------------------------------------------------------------------------
+ * Where nobody but the walkers reads them -- seqalign_nw_batch's directions-only fills and the packed SW best-hit fill; not the
+ * multi-hit path, whose sweep reads rows -- a pair's direction bytes are laid out in blocks of 8 rows x 16 columns = one 128-byte
+ * line, block rows first:
+ *     byte of cell (x, y)  at  ((y / 8) * nbx + x / 16) * 128 + (y % 8) * 16 + x % 16,      nbx = ceil((len_a + 1) / 16)
+ * Row-major at a pitch of len_a + 1 bytes, a walk that climbs a row per step pulls in a new 128-byte line per step (measured:
+ * 1.27 lines per step, 278 MB for C2's 10 000 walks, the walkers bound by exactly that: profiles/r06/r06_walkers.txt); in blocks a
+ * diagonal walk stays 8-16 steps in a line.  The fills write a block row (8 rows: nbx x 128 contiguous bytes) at a time out of an
+ * LDS buffer that is laid out the same way.  Rows of up to 512 columns (wider: row-major as before).  SA_DIRS_BLOCKED=0 (make exp)
+ * builds the row-major form for an A/B. */
+#ifndef SA_DIRS_BLOCKED
+#define SA_DIRS_BLOCKED 1
+#endif
+static inline bool sa_dirs_blocked_shape(uint32_t max_len_a) { return SA_DIRS_BLOCKED != 0 && max_len_a + 1u <= 512u; }
+static inline uint64_t sa_dirs_blocked_bytes(uint32_t len_a, uint32_t len_b) {   /* a multiple of 128 */
+  return (uint64_t)((len_b + 8u) >> 3) * (uint64_t)((len_a + 16u) >> 4) * 128u;
+}
+
 struct SaFillParams {
   const uint8_t *arena;
   const uint64_t *off_a;
@@ -192,6 +210,7 @@ struct SaTraceParams {
   int32_t open1, ext, gen_eq, gen_ne;
   uint32_t flags;
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
+  uint32_t dirs_blocked;       /* `dirs` is laid out in blocks of 8 x 16 cells (above) instead of row-major at pitch len_a + 1 */
   uint32_t tune_group;         /* host side only: the tile walker on moves: 0 / 4 = four walks per wave in lockstep, 8 = eight, 1 = one (option walk_group) */
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
   const int32_t *nw_score;     /* NW behind the directions-only fill (dirs != NULL): per pair the end cell's score ...            */

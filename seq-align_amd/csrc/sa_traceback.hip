@@ -16,6 +16,52 @@
 
 namespace sa {
 
+// Where the direction byte of cell (x, y) lies: row-major at pitch W, or -- SaTraceParams::dirs_blocked (sa_kernels.h: the NW and
+// best-hit fills of round 6) -- in blocks of 8 rows x 16 columns, nbx = ceil(W / 16) blocks per block row.
+__device__ __forceinline__ uint32_t dirs_at(bool blocked, uint32_t x, uint32_t y, uint32_t W, uint32_t nbx) {
+  const uint32_t blk = ((y >> 3) * nbx + (x >> 4)) * 128u + ((y & 7u) << 4) + (x & 15u);
+  return blocked ? blk : y * W + x;
+}
+// A walker's 64 x 64 tile of direction bytes into LDS, row-major there whatever the layout in memory.
+//   row-major: the 64 rows x 64 bytes that END at (x, y) -- lane r one row; ox / oy = its first column / row;
+//   blocked:   the 8 x 4 BLOCKS (8 block rows of 4 blocks = 512 contiguous bytes each: 32 whole lines, all of them used, where
+//              the row-major tile's 64 pieces of 64 bytes lie on ~96 lines) whose last block row / block column hold (x, y):
+//              ox / oy are multiples of 16 / 8, (x, y) sits at least 48 columns and 56 rows from the tile's first.
+// lane l loads 64 bytes: row-major its row; blocked piece p = 4 l + q of the tile's 256 16-byte pieces = block row p / 32, block
+// p / 8 % 4, row p % 8 of the block.  Rows / block rows past the pair's last are not loaded (never looked at).
+template <int kT>
+__device__ __forceinline__ void load_dirs_tile(uint8_t *tile, const uint8_t *__restrict__ Dg, bool blocked, uint32_t x, uint32_t y,
+                                               uint32_t W, uint32_t nbx, uint32_t lb, int lane, uint32_t &ox, uint32_t &oy) {
+  static_assert(kT == 64, "tiles are 64 x 64");
+  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  typedef uint32_t u4_a __attribute__((ext_vector_type(4)));
+  if (blocked) {
+    const uint32_t bx0 = (x >> 4) >= 3u ? (x >> 4) - 3u : 0u, by0 = (y >> 3) >= 7u ? (y >> 3) - 7u : 0u;
+    ox = bx0 << 4; oy = by0 << 3;
+    const uint32_t nby = (lb + 8u) >> 3;                 // block rows of the pair
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t pc = 4u * (uint32_t)lane + (uint32_t)q, br = pc >> 5, bc = (pc >> 3) & 3u, r = pc & 7u;
+      if (by0 + br < nby) {
+        // (a block column past the pair's last: the next block row's first blocks, or the buffer's slack -- never looked at)
+        const u4_a v = *reinterpret_cast<const u4_a *>(Dg + ((uint64_t)(by0 + br) * nbx + bx0 + bc) * 128u + r * 16u);
+        *reinterpret_cast<u4_a *>(tile + (br * 8u + r) * kT + bc * 16u) = v;
+      }
+    }
+  } else {
+    ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+    const uint32_t r = oy + lane;
+    if (r <= lb) {
+      // 64 bytes of row r from column ox on; past the row's end that is the next row (or, behind the last pair, the
+      // slack every directions buffer has) -- never used: the walk only reads columns <= x
+      const uint8_t *src = Dg + (uint64_t)r * W + ox;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
+    }
+  }
+}
+
 // Where SW walk `w` starts: the cell start_index[w], or -- walks of the multi-hit path (sa_sw_sweep.hip) -- the cell
 // packed in hit number walker_rank[w] of its pair's sorted hit keys.
 __device__ __forceinline__ void sw_walk_start(const SaTraceParams &p, uint32_t w, uint32_t pair, uint32_t W, uint32_t &x, uint32_t &y) {
@@ -129,8 +175,10 @@ __global__ void __launch_bounds__(64) traceback_dirs_kernel(const SaTraceParams 
   const int score = p.start_score ? p.start_score[w] : p.M[mo + (uint64_t)y * W + x];
   const uint32_t end_x = x, end_y = y;
   uint32_t st = MAT_MATCH;
+  const bool blk = p.dirs_blocked != 0;
+  const uint32_t nbx = (W + 15u) >> 4;
   for (;;) {
-    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    const uint32_t f = ((uint32_t)Dg[dirs_at(blk, x, y, W, nbx)] >> (2u * st)) & 3u;
     if (f == 3u) break;                               // this state's score is 0: the hit starts here
     --head;
     oa[head] = (st == MAT_GAP_A) ? '-' : (char)sa_[x - 1];
@@ -158,8 +206,10 @@ __global__ void __launch_bounds__(64) traceback_nw_dirs_kernel(const SaTracePara
   char *oa = p.out_a + p.str_off[w];
   char *ob = p.out_b + p.str_off[w];
   uint32_t x = la, y = lb, head = la + lb, st = (uint32_t)p.nw_state[w];
+  const bool blk = p.dirs_blocked != 0;
+  const uint32_t nbx = (W + 15u) >> 4;
   while (x > 0 && y > 0) {
-    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    const uint32_t f = ((uint32_t)Dg[dirs_at(blk, x, y, W, nbx)] >> (2u * st)) & 3u;
     --head;
     oa[head] = (st == MAT_GAP_A) ? '-' : (char)sa_[x - 1];
     ob[head] = (st == MAT_GAP_B) ? '-' : (char)sb_[y - 1];
@@ -206,22 +256,11 @@ __global__ void __launch_bounds__(64) traceback_dirs_tile_kernel(const SaTracePa
   const uint32_t end_x = x, end_y = y;
   uint32_t ox = 0, oy = 0;
   bool loaded = false;
-  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
   for (;;) {
     if constexpr (NW) { if (x == 0 || y == 0) break; }
-    if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell
-      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0;
-      oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+    if (!loaded || x < ox || y < oy) {   // (wave-uniform) make (x, y) the tile's bottom-right cell (blocked: its last blocks')
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tile
-      const uint32_t r = oy + lane;
-      if (r <= lb) {
-        // 64 bytes of row r from column ox on; past the row's end that is the next row (or, behind the last pair, the
-        // slack every directions buffer has) -- never used: the walk only reads columns <= x
-        const uint8_t *src = Dg + (uint64_t)r * W + ox;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
-      }
+      load_dirs_tile<kT>(tile, Dg, p.dirs_blocked != 0, x, y, W, (W + 15u) >> 4, lb, lane, ox, oy);
       { const uint32_t i = ox + lane; ca[lane] = (i >= 1 && i <= la) ? sa_[i - 1] : (uint8_t)0; }
       { const uint32_t j = oy + lane; cb[lane] = (j >= 1 && j <= lb) ? sb_[j - 1] : (uint8_t)0; }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -334,9 +373,11 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_kernel(const SaTraceP
   const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
   const MoveSlot s = m.slot;
   uint32_t x = m.x, y = m.y, st = m.st, k = 0, acc_a = 0, acc_b = 0;
+  const bool blk = p.dirs_blocked != 0;
+  const uint32_t nbx = (W + 15u) >> 4;
   for (;;) {
     if constexpr (NW) { if (x == 0 || y == 0) break; }
-    const uint32_t f = ((uint32_t)Dg[y * W + x] >> (2u * st)) & 3u;
+    const uint32_t f = ((uint32_t)Dg[dirs_at(blk, x, y, W, nbx)] >> (2u * st)) & 3u;
     if constexpr (!NW) { if (f == 3u) break; }   // this state's score is 0: the hit starts here (smith_waterman.c:192)
     const uint32_t bit = 0x80000000u >> (k & 31u);   // the walk runs backwards: a word's columns arrive last first
     acc_a |= st == MAT_GAP_A ? bit : 0u;
@@ -382,9 +423,11 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_ahead_kernel(const Sa
   bool alive = exists && m.valid;
   if constexpr (NW) alive = alive && x != 0 && y != 0;
   struct Ahead { uint32_t raw; bool inside; };
+  const bool blk = p.dirs_blocked != 0;
+  const uint32_t nbx = (W + 15u) >> 4;
   auto ask = [&](uint32_t cx, uint32_t cy) __attribute__((always_inline)) -> Ahead {
     const bool inside = cx <= la && cy <= lb;
-    return Ahead{(uint32_t)Dg[inside ? cy * W + cx : 0u], inside};
+    return Ahead{(uint32_t)Dg[inside ? dirs_at(blk, cx, cy, W, nbx) : 0u], inside};
   };
   Ahead b0 = ask(x, y);
   uint32_t nx = x - (st != MAT_GAP_A), ny = y - (st != MAT_GAP_B);   // (may wrap below 0: `inside` answers, nobody stands there)
@@ -446,7 +489,6 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
   __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
   const int lane = threadIdx.x;
   const uint32_t reps = (!NW && p.walks_per_pair) ? p.walks_per_pair : 1u;
-  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
   auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   for (uint32_t rep = 0; rep < reps; ++rep) {
     const uint32_t w = blockIdx.x * reps + rep;
@@ -465,18 +507,11 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
     bool over = false;
     while (!over) {
       if constexpr (NW) { if (x == 0 || y == 0) break; }
-      // ---- the tile whose bottom-right cell is (x, y)
-      const uint32_t ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0, oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+      // ---- the tile whose bottom-right cell is (x, y) (blocked direction bytes: whose last block row / column hold it)
+      uint32_t ox, oy;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      {
-        const uint32_t r = oy + lane;
-        if (r <= lb) {
-          const uint8_t *src = Dg + (uint64_t)r * W + ox;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<u4_u *>(tile + lane * kT + 16 * q) = *reinterpret_cast<const u4_u *>(src + 16 * q);
-        }
-      }
+      load_dirs_tile<kT>(tile, Dg, p.dirs_blocked != 0, x, y, W, (W + 15u) >> 4, lb, lane, ox, oy);
+      ox = uni(ox); oy = uni(oy);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_s_waitcnt(0);
       uint32_t at = (y - oy) * kT + (x - ox);   // the place of the cell the walk stands on: ty * 64 + tx
@@ -602,8 +637,23 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
     const uint32_t tx0 = at & (kT - 1), ty0 = at >> 6;
     if (__any(live && (fresh || tx0 == 0 || ty0 == 0))) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tiles
-      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
       u4_u buf[kRows][4];
+      if (p.dirs_blocked) {   // (wave-uniform) 8 x 4 blocks whose last block row / column hold (x, y): load_dirs_tile, 16 lanes a tile
+        const uint32_t nbx = (W + 15u) >> 4, nby = (lb + 8u) >> 3;
+        const uint32_t bx0 = (x >> 4) >= 3u ? (x >> 4) - 3u : 0u, by0 = (y >> 3) >= 7u ? (y >> 3) - 7u : 0u;
+        ox = bx0 << 4; oy = by0 << 3;
+#pragma unroll
+        for (int i = 0; i < kRows * 4; ++i) {
+          const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = min(by0 + (pc >> 5), nby - 1u), bc = (pc >> 3) & 3u, r = pc & 7u;
+          buf[i >> 2][i & 3] = *reinterpret_cast<const u4_u *>(Dg + ((uint64_t)br * nbx + bx0 + bc) * 128u + r * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < kRows * 4; ++i) {
+          const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = pc >> 5, bc = (pc >> 3) & 3u, r = pc & 7u;
+          *reinterpret_cast<u4_u *>(tile + (br * 8u + r) * kT + bc * 16u) = buf[i >> 2][i & 3];
+        }
+      } else {
+      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
 #pragma unroll
       for (int r4 = 0; r4 < kRows; ++r4) {
         // 64 bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
@@ -618,6 +668,7 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
         const uint32_t tr = (uint32_t)(lg * kRows + r4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
+      }
       }
       at = (y - oy) * kT + (x - ox);
       fresh = false;
