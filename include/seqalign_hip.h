@@ -397,8 +397,8 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *   sweep_strip     0 | 64 | 128 | 256      columns per strip       sweep_cpl  0 | 1 | 2 | 4
  *   chunk_bytes     0 | >= 1 MiB            device memory one host-level chunk may use
  *   async_lanes     0 (= 3) | 1 .. 8        submitted calls in flight per context (seqalign_*_batch_submit)
- *   walk_group      0 (= 1) | 1 | 4 | 8     walks per wave of the device walker on LDS tiles (4 / 8: in lockstep, vector state; measured no
- *                                           faster than one wave per walk -- the walks are bound by the lines their tiles pull in)
+ *   walk_group      0 | 1 | 4 | 8           walks per wave of the device walker on LDS tiles (4 / 8: in lockstep, vector state); 0: four on
+ *                                           direction bytes laid out in blocks (NW, best hit; rows <= 512 columns), else one wave per walk
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)
  *   pack16          1 | 0 | 2               direction-byte fills take two pairs per wave in packed int16 where scores fit int16 --

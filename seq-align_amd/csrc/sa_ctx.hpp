@@ -333,7 +333,7 @@ struct SaOptions {
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
   uint32_t arena_free_pct = 60;   // arena_free_pct    share of the memory free at the start that an explicit placement walk may hold (10 .. 90)
-  uint32_t walk_group = 0;        // walk_group        0|1|4|8: walks per wave of the tile walker on moves (0 = 1: one wave per walk; 4 / 8: in lockstep)
+  uint32_t walk_group = 0;        // walk_group        0|1|4|8: walks per wave of the tile walker on moves (0: four in lockstep on blocked direction bytes, else one; 1 / 4 / 8: forced)
   uint32_t async_lanes = 0;       // async_lanes       1..8 (0 = 3): batches seqalign_*_batch_submit keeps in flight per context (sa_async.hip)
   uint32_t arena_keep_gib = 16;   // arena_keep_gib    how much of a walk's unused chunks stays with the process (the chunk pool: large scratch
                                   //                   buffers are mapped from it instead of freshly released, not yet cleared VRAM); 0: none

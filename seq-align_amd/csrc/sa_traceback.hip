@@ -587,16 +587,19 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 // gets one -- its 16 lanes load four rows each -- the others keep theirs).  A walk that ends (NW: the matrix border; SW: a
 // state whose score is 0) goes quiet: its lanes' updates are predicated off, its step count stays.
 // Same moves, same words, same meta as traceback_moves_tile_kernel (every walker test runs both: option walk_group).
-// MEASURED (profiles/r06/r06_walkers.txt): correct, and NOT faster -- C2's 10 000 walks 70 us with four or eight walks per wave
-// against 62 us with one; the first version, which renewed a group's tile alone and waited row by row, 97 / 153 us.  The premise
-// was wrong: with 3-4 vector instructions per walk and step the walks take what they took with 16 scalar ones, so instructions
-// are not what bounds them.  A tile is 64 row pieces of 64 bytes at a row pitch of len_a + 1 bytes: every piece lies on its own
-// 128-byte line (1.5 of them on average), and a walk that climbs a row per step pulls in at least a line per step.  The counters
-// say so (profiles/r06/r06_walkers.txt; rocprofv3 --pmc, C2's 10 000 walks of ~171 steps): TCC_MISS 2.17 M lines = 278 MB per
-// launch (FETCH_SIZE 135.8 MiB x 2, the guide's gfx950 correction: the same), 1.27 lines per step -- in 62 us that is 4.5 TB/s
-// = 0.56 of the HBM peak on 64-byte pieces scattered over 228 MB.  The walkers are bound by the lines their rows' pieces pull in,
-// whatever carries the state; only a blocked layout of the direction bytes (8 x 16-cell blocks per line: a diagonal walk crosses
-// ~30 of them instead of 171 rows) would change that -- DESIGN.md 8.  Kept as option walk_group = 4 | 8 (default 1: one wave per walk).
+// MEASURED (profiles/r06/r06_walkers.txt), on ROW-MAJOR direction bytes: correct, and NOT faster -- C2's 10 000 walks 70 us with
+// four or eight walks per wave against 62 us with one; the first version, which renewed a group's tile alone and waited row by
+// row, 97 / 153 us.  With 3-4 vector instructions per walk and step the walks take what they took with 16 scalar ones, so
+// instructions are not what bounds them THERE.  A tile is 64 row pieces of 64 bytes at a row pitch of len_a + 1 bytes: every piece
+// lies on its own 128-byte line (1.5 of them on average), and a walk that climbs a row per step pulls in at least a line per step.
+// The counters say so (rocprofv3 --pmc, C2's 10 000 walks of ~171 steps): TCC_MISS 2.17 M lines = 278 MB per launch (FETCH_SIZE
+// 135.8 MiB x 2, the guide's gfx950 correction: the same), 1.27 lines per step -- in 62 us that is 4.5 TB/s = 0.56 of the HBM peak
+// on 64-byte pieces scattered over 228 MB.  So the direction bytes of the paths only walkers read went into BLOCKS of 8 rows x 16
+// columns per line (sa_kernels.h: SA_DIRS_BLOCKED; a tile is then 32 whole lines).  On those this kernel is the faster one: C2's
+// walks into a device buffer 42.9 us against 54.6 with one wave per walk, C4's best-hit walks 52 against 72 -- and when the moves
+// are written in place into pinned host memory (seqalign_nw_batch's small chunks: no copy behind the kernel) both forms take
+// 60-65 us: 20 000 scattered 24-byte pieces over PCIe, ~9 GB/s, are then what the kernel's end waits for.  Default (option
+// walk_group = 0): four walks per wave on blocked direction bytes, one wave per walk on row-major ones.
 template <bool NW, int G>
 __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTraceParams p) {
   constexpr int kT = 64, L = 64 / G;           // tile edge; lanes per walk
@@ -880,10 +883,12 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.moves) {    // ... sending home moves instead of strings
         if (!p.out_meta2) return hipErrorInvalidValue;
         sa_record_launch(tiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
-        // (round 6: tune_group 4 / 8 = that many walks per wave in lockstep, vector state -- measured no faster, see the kernel's
-        // comment: the walks are bound by the lines their tiles' rows pull out of HBM, not by instructions; default: one wave per walk)
-        if (tiles && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
-        else if (tiles && p.tune_group == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+        // (round 6: walks per wave of the tile walker -- option walk_group; by itself: four in lockstep on BLOCKED direction bytes
+        // (43 against 55 us for C2's walks into a device buffer, 52 against 72 for C4's), one wave per walk on row-major ones, where
+        // both are bound by the lines the rows' pieces pull in and the lockstep form is the slower: profiles/r06/r06_walkers.txt)
+        const uint32_t grp = p.tune_group ? p.tune_group : (p.dirs_blocked ? 4u : 1u);
+        if (tiles && grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+        else if (tiles && grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
         else if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
         else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
@@ -901,8 +906,9 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;
       // (walks_per_pair -- the one-trip multi-hit call, most slots empty -- stays one wave per pair)
-      if (wtiles && !p.walks_per_pair && p.tune_group == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
-      else if (wtiles && !p.walks_per_pair && p.tune_group == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+      const uint32_t grp = p.tune_group ? p.tune_group : (p.dirs_blocked ? 4u : 1u);
+      if (wtiles && !p.walks_per_pair && grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+      else if (wtiles && !p.walks_per_pair && grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
       else if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
       else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);

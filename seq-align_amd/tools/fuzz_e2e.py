@@ -68,7 +68,7 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
             pairs.append((a, b))
         batch = W.from_pairs(pairs)
         ctx.set_option("trace_kernel", ("lane", "wave")[int(v[0] >> 7) & 1])
-        ctx.set_option("walk_group", (0, 4, 4, 8)[int(v[0] >> 17) & 3])   # the tile walker: one walk per wave, or 4 / 8 in lockstep
+        ctx.set_option("walk_group", (0, 1, 4, 8)[int(v[0] >> 17) & 3])   # the tile walker: one walk per wave, or 4 / 8 in lockstep
         # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
         # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
         for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "pack16"):

@@ -654,7 +654,7 @@ def test_context_options(ctx):
         ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave", "directions-wave-4", "directions-wave-8"])
+@pytest.mark.parametrize("walker", ["lane", "wave", "directions", "directions-lane", "directions-wave", "directions-wave-1", "directions-wave-4", "directions-wave-8"])
 def test_device_traceback_walkers_agree_with_oracle(ctx, walker, opts):
     """The device walkers -- one lane per pair from the three matrices in HBM, one wave per pair from 16x16 LDS tiles
     of them, and the ones that follow the fill's direction bytes (sa_fill_dirs.hip; plain scorings, rows <= 512

@@ -488,7 +488,7 @@ def test_scratch_comes_from_the_chunk_pool(opts):
         assert keeper.pool_trim(0) == 0
 
 
-@pytest.mark.parametrize("walker", ["wave", "lane", "wave-4", "wave-8"])
+@pytest.mark.parametrize("walker", ["wave", "lane", "wave-1", "wave-4", "wave-8"])
 def test_long_walks_cross_move_blocks(ctx, opts, walker):
     """Walks of several thousand columns: the wave-per-walk walker keeps 64 words (2 048 columns) of each plane in its lanes and
     stores whole blocks; here walks of up to ~5 000 columns cross two and more block boundaries, end exactly on one (2 048 and
