@@ -530,6 +530,24 @@ def measure(args, grp, env, workload, steps, warmup, pairs):
             e2e["up_to_4_hits"] = {"call": "seqalign_sw_batch(max_hits=4)", "ms": wall4 * 1e3,
                                    "value": total_cells / wall4 / 1e9, "unit": "GCUPS"}
 
+    # ... and with CIGAR as its output (seqalign_nw_batch_cigar: run lengths straight from the walks' bit planes, no strings expanded;
+    # north_star: "identical CIGAR/alignment strings"), same batch, same steady state
+    if e2e is not None and not is_sw:
+        fnc = lambda: ctx.nw_batch_cigar(batch, sc, 1, slot=64, raw=True)
+        try:
+            settle(fnc)
+            walls = []
+            for _ in range(5):
+                grp.barrier()
+                t1 = time.perf_counter()
+                fnc()
+                walls.append(time.perf_counter() - t1)
+            wc = grp.max_float(float(np.median(walls)))
+            e2e["cigar"] = {"call": "seqalign_nw_batch_cigar(SEQALIGN_CIGAR_M, 64-byte slots)", "ms": wc * 1e3, "value": total_cells / wc / 1e9,
+                            "unit": "GCUPS", "launched": ctx.last_call()}
+        except S.SeqAlignError as ex:      # (a CIGAR longer than its 64-byte slot: say so, do not hide the line)
+            e2e["cigar"] = {"error": str(ex)}
+
     # the same call as a STREAM of batches (seqalign_*_batch_submit / seqalign_job_wait, sa_async.hip): `in_flight` batches at
     # a time, the caller waiting that many behind its submits -- what an API caller streaming batches of this size gets, steady
     # state: batch k + 1's packing and upload run beside batch k's walk and expansion (never `value`)

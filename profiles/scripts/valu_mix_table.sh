@@ -1,7 +1,8 @@
 #!/bin/bash
 # Static VALU mix of the hot loops of the VALU-bound kernels on the host-level paths (run anywhere hipcc is: no GPU needed):
 #   bash profiles/scripts/valu_mix_table.sh > profiles/r04/r04_valu_mix.json
-# One line of JSON per kernel instantiation; profiles/scripts/e2e_roofline.sh looks kernels up here by demangled name.
+# One line of JSON per kernel instantiation (matched by name and the first two template arguments -- the third, the LDS bytes per pair,
+# changed when the direction bytes went into blocks); profiles/scripts/e2e_roofline.sh looks kernels up here by demangled name.
 R=$(cd "$(dirname "$0")/../.." && pwd)
 T=$R/seq-align_amd/tools/valu_mix.py
 C=$R/seq-align_amd/csrc
@@ -14,15 +15,15 @@ emit() { # file function mangled-args demangled
   first=0
   echo "{\"demangled\": \"$4\", \"mix\": $out}"
 }
-emit sa_fill_dirs_x2.hip fill_nw_dirs_x2_kernel ILi3ELi0ELi512E "fill_nw_dirs_x2_kernel<3, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_nw_dirs_x4_kernel ILi5ELi0ELi512E "fill_nw_dirs_x4_kernel<5, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_nw_dirs_x4x2_kernel ILi5ELi0ELi512E "fill_nw_dirs_x4x2_kernel<5, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_sw_best_x4_kernel ILi5ELi0ELi512E "fill_sw_best_x4_kernel<5, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi3ELi0ELi512E "fill_sw_best_x2_kernel<3, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi5ELi1ELi1024E "fill_sw_best_x2_kernel<5, 1, 1024>"
-emit sa_fill_dirs_x2.hip fill_dirs_x2_kernel ILi3ELi0ELi512E "fill_dirs_x2_kernel<3, 0, 512>"
-emit sa_fill_dirs_x2.hip fill_dirs_x2_kernel ILi5ELi1ELi1024E "fill_dirs_x2_kernel<5, 1, 1024>"
-emit sa_fill_dirs.hip fill_nw_dirs_kernel ILi3ELi0ELi512E "fill_nw_dirs_kernel<3, 0, 512>"
+emit sa_fill_dirs_x2.hip fill_nw_dirs_x2_kernel ILi3ELi0ELi "fill_nw_dirs_x2_kernel<3, 0,"
+emit sa_fill_dirs_x2.hip fill_nw_dirs_x4_kernel ILi5ELi0ELi "fill_nw_dirs_x4_kernel<5, 0,"
+emit sa_fill_dirs_x2.hip fill_nw_dirs_x4x2_kernel ILi5ELi0ELi "fill_nw_dirs_x4x2_kernel<5, 0,"
+emit sa_fill_dirs_x2.hip fill_sw_best_x4_kernel ILi5ELi0ELi "fill_sw_best_x4_kernel<5, 0,"
+emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi3ELi0ELi "fill_sw_best_x2_kernel<3, 0,"
+emit sa_fill_dirs_x2.hip fill_sw_best_x2_kernel ILi5ELi1ELi "fill_sw_best_x2_kernel<5, 1,"
+emit sa_fill_dirs_x2.hip fill_dirs_x2_kernel ILi3ELi0ELi "fill_dirs_x2_kernel<3, 0,"
+emit sa_fill_dirs_x2.hip fill_dirs_x2_kernel ILi5ELi1ELi "fill_dirs_x2_kernel<5, 1,"
+emit sa_fill_dirs.hip fill_nw_dirs_kernel ILi3ELi0ELi "fill_nw_dirs_kernel<3, 0,"
 emit sa_sw_sweep.hip sw_sweep_dirs_kernel ILi3E "sw_sweep_dirs_kernel<3"
 emit sa_sw_sweep.hip sw_sweep_dirs_kernel ILi5E "sw_sweep_dirs_kernel<5"
 emit sa_sw_sweep.hip sw_sweep_dirs_ev_kernel ILi3Ej "sw_sweep_dirs_ev_kernel<3"
