@@ -675,3 +675,59 @@ def test_sweep_reads_the_right_rows_beyond_2_30_cells(ctx):
     assert len({h["score"] for h in want[:3]}) == 3
     assert got == want, (len(got), len(want), [h["score"] for h in got[:5]], [h["score"] for h in want[:5]])
     assert sum(h["pos_b"] > 2_143_237 for h in got) >= 2
+
+
+# ------------------------------------------------------------------ direction bytes in blocks of 8 x 16 cells (round 6) ---
+
+@pytest.mark.parametrize("form", ["x1", "x2", "x4", "mixed"])
+def test_blocked_direction_bytes_at_the_blocks_edges(ctx, opts, form):
+    """Round 6: where only walkers read them (seqalign_nw_batch, seqalign_sw_batch best hit; rows <= 512 columns) the direction bytes lie
+    in blocks of 8 rows x 16 columns (csrc/sa_kernels.h).  Shapes whose rows / columns end exactly on, one short of and one past a block
+    edge, the narrowest and the widest blocked rows (len_a + 1 = 512) and the first row-major one (513), through the one-pair fill, the
+    packed fills with two and four pairs per wave and the mixed grid, every tile-walker form and the lane walker -- global alignments and
+    best local hits against the oracle (needleman_wunsch.c:53-145, smith_waterman.c:165-277)."""
+    rng = W.Rng(4242)
+    rnd = lambda n: bytes(b"ACGT"[i] for i in rng.below(4, n)) if n else b""
+    las = (0, 1, 14, 15, 16, 17, 30, 31, 32, 47, 63, 64, 150, 191, 255, 300, 510, 511, 512)
+    lbs = (0, 1, 6, 7, 8, 9, 15, 16, 62, 63, 64, 65, 150, 301)
+    sc = S.make_scoring({"preset": "default"})
+    sw = S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    osc, osw = osc_of(sc), osc_of(sw)
+    if form == "x1":
+        opts(pack16=0)
+    elif form == "x2":
+        opts(pack16=2, quad=1)
+    elif form == "x4":
+        opts(pack16=2, quad=2)
+    else:
+        opts(pack16=2)
+    for la in las:
+        if form == "x4" and la + 1 > 192:
+            continue
+        shapes = [(la, lb) for lb in lbs]
+        pairs = []
+        for la_, lb_ in shapes:
+            a = rnd(la_)
+            b = (a[: lb_] if lb_ <= la_ else a + rnd(lb_ - la_))          # related: long diagonal runs, then a tail of gaps
+            for _ in range(6 if form != "x1" else 2):                      # several pairs of each shape: the packed fills pair them up
+                pairs.append((a, bytes(b)))
+                b = bytearray(b)
+                if b: b[int(rng.below(len(b), 1)[0])] = b"ACGT"[int(rng.below(4, 1)[0])]
+                b = bytes(b)
+        if form in ("x2", "x4"):            # uniform chunks: one shape per call
+            groups = {}
+            for a, b in pairs: groups.setdefault((len(a), len(b)), []).append((a, b))
+            batches = list(groups.values())
+        else:
+            batches = [pairs]
+        for walker, grp in (("wave", 0), ("wave", 1), ("wave", 8), ("lane", 0)):
+            opts(trace_kernel=walker, walk_group=grp)
+            for bp in batches[:: (3 if (walker, grp) != ("wave", 0) else 1)]:
+                batch = W.from_pairs(bp)
+                got = ctx.nw_batch(batch, sc)
+                best = ctx.sw_batch(batch, sw, 4, max_hits=1)
+                for p, (a, b) in enumerate(bp):
+                    rc, s_, ra, rb = O.oracle_nw(osc, a, b)
+                    assert rc == 0 and got[p] == (s_, ra, rb), (form, walker, grp, la, len(b), p)
+                    rc, want = O.oracle_sw(osw, a, b, 4, 1)
+                    assert rc == 0 and best[p] == want, (form, walker, grp, la, len(b), p)
