@@ -16,15 +16,24 @@ N_SIMD, CLOCK = 1024, 2.4e9
 #   lane walker (one lane per walk, the next byte asked for ahead): a step is a byte load that misses (the bytes left L2 long
 #   ago: C5's share writes 2.9 GB of them), two in flight per lane.
 LAT = {"lds": 50 / CLOCK, "l2": 200 / CLOCK, "hbm": 900 / CLOCK}
-def walker_bound(kernel, launches_items, steps):
+def walker_bound(kernel, launches_items, steps, blocked=False):
     """(bound seconds, description) of one launch of a walker kernel over `launches_items` walks of `steps` steps each."""
     if "tile" in kernel or "group" in kernel:
-        # Round 6: the tile walkers are bound by the LINES their tiles' row pieces pull in, not by a latency chain or by instructions
-        # (a form with 3-4 vector instructions per walk and step instead of 16 scalar ones took the same time; TCC_MISS / FETCH_SIZE of
-        # C2's launch: 278 MB, 1.27 lines of 128 B per step -- profiles/r06/r06_walkers.txt).  A tile is 64 row pieces of 64 bytes at a
-        # pitch of len_a + 1 bytes: each on ~1.5 lines, and a walk uses a tile for 63 .. 126 steps: lines per step ~ 64 x 1.5 / 75.
-        lines = launches_items * steps * 1.27
-        return lines * 128 / 8.0e12, f"hbm lines: {launches_items:.0f} walks x {steps:.0f} steps x 1.27 lines of 128 B per step (measured: TCC_MISS, profiles/r06/r06_walkers.txt) at 8 TB/s"
+        # Round 6: the tile walkers are bound by the LINES their tiles pull in, not by a latency chain or by instructions (a form with
+        # 3-4 vector instructions per walk and step instead of 16 scalar ones took the same time on row-major bytes; TCC_MISS / FETCH_SIZE
+        # of C2's launch: 278 MB -- profiles/r06/r06_walkers.txt).
+        #   row-major direction bytes (the multi-hit path): a tile is 64 row pieces of 64 bytes at a pitch of len_a + 1 bytes, each on
+        #     ~1.5 lines of 128 B, used for 63 .. 126 steps: measured 1.27 lines per step;
+        #   blocked (NW, best hit; round 6): a tile is 8 x 4 whole blocks = 32 lines, good for >= 48 steps: (steps / 48 + 1) x 32 lines
+        #     per walk -- and when the moves go in place to pinned host memory the kernel's end also waits for those PCIe writes
+        #     (~9 GB/s on 24-byte pieces: 60-65 us for C2's 10 000 walks whatever the walker; not in this bound).
+        if blocked:
+            lines = launches_items * (steps / 48.0 + 1.0) * 32.0
+            how = f"hbm lines: {launches_items:.0f} walks x ({steps:.0f} / 48 + 1) tiles x 32 lines of 128 B (blocked direction bytes) at 8 TB/s; the moves' PCIe writes (in place) come on top"
+        else:
+            lines = launches_items * steps * 1.27
+            how = f"hbm lines: {launches_items:.0f} walks x {steps:.0f} steps x 1.27 lines of 128 B per step (measured: TCC_MISS, profiles/r06/r06_walkers.txt) at 8 TB/s"
+        return lines * 128 / 8.0e12, how
     per_walk = steps * LAT["hbm"] / 2.0
     return per_walk, f"{steps:.0f} steps x 900-cycle miss / 2 loads in flight per lane (every walk has a lane: one round)"
 res = {}
@@ -72,7 +81,7 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
             e["frac"] = e["instructions"] * cpi / (N_SIMD * CLOCK * e["kernel_ms"] * 1e-3)
         if "traceback" in k and steps:
             launches_per_call = max(1, round(len(dur[k]) / 6)) if key.startswith(("C2", "C5")) else max(1, round(len(dur[k]) / 3))
-            b, how = walker_bound(k, walks / launches_per_call, steps)
+            b, how = walker_bound(k, walks / launches_per_call, steps, blocked="hits4" not in key)
             e["bound"] = "hbm_lines" if ("tile" in k or "group" in k) else "dependent_latency"
             e["bound_ms"] = b * 1e3
             e["frac"] = b * 1e3 / e["kernel_ms"]
