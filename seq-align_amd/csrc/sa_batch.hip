@@ -773,6 +773,8 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   const bool auto_zc = ctx->opt.zero_copy == 4u;
   const bool tile_walks = ctx->opt.trace_kernel ? ctx->opt.trace_kernel == 2 : n < SA_WALK_TILE_MAX;
   const bool zc_in = !auto_zc && (ctx->opt.zero_copy & 1u) != 0, zc_out = auto_zc ? tile_walks : (ctx->opt.zero_copy & 2u) != 0;
+  // (tile walks: the fills write the direction byte's LOCAL form -- a cell's own comparisons, resolved by the walker: sa_kernels.h)
+  const bool local = tile_walks && ctx->opt.dirs_local;
   bool same_shape = true;
   for (const BlkSum &s : blk) same_shape = same_shape && s.same;
 
@@ -990,12 +992,12 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         const seqalign_dev_batch_t dm = dev_range(0, n);
         const uint32_t m0 = list_at[2 * s], m1 = list_at[2 * s + 1], r1 = list_at[2 * s + 2];
         if ((rc = nw_dirs_fill_mixed(ctx, sc, &dm, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>(), ctx->best_index.as<uint64_t>(),
-                                     sf, dv_list + m0, m1 - m0, r1 - m1, c.max_a, c.max_b)))
+                                     sf, dv_list + m0, m1 - m0, r1 - m1, c.max_a, c.max_b, local)))
           return rc;
       } else {
         bool used = false;
         if ((rc = nw_dirs_fill(ctx, sc, &d, ctx->dirs.as<uint8_t>(), ctx->best_score.as<int32_t>() + k0,
-                               ctx->best_index.as<uint64_t>() + k0, sf, &used, layout == kUniform ? stride : 0)))
+                               ctx->best_index.as<uint64_t>() + k0, sf, &used, layout == kUniform ? stride : 0, nullptr, 0, local)))
           return rc;
         if (!used) { set_last_error("seqalign_nw_batch: internal error: directions-only fill refused a batch it had accepted"); return SEQALIGN_E_HIP; }
       }
@@ -1013,7 +1015,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         t.moves = dv_moves + 2 * g0;        // walk w of the launch is pair g0 + w: words 2 ((slot >> 5) + g0 + w)
         t.out_meta2 = dv_meta + 2 * g0;
         t.fill_status = d.status;
-        t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
+        t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.dirs_local = local; t.tune_stage = ctx->opt.walk_stage; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;

@@ -608,6 +608,8 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
   // the walk follows the bytes.  No match_scores, no gap matrices: they are not even allocated.
   bool dirs_used = false;
   uint64_t stride = 0;
+  // (the walks below as tile walks sending home moves: the fill writes the direction byte's LOCAL form, sa_kernels.h)
+  const bool local = ctx->opt.dirs_local && ctx->opt.nw_moves && (ctx->opt.trace_kernel ? ctx->opt.trace_kernel == 2 : n < SA_WALK_TILE_MAX);
   {
     bool same_shape = true;
     for (uint64_t k = 1; k < n && same_shape; ++k)
@@ -636,7 +638,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     if ((rc = ctx->dirs.reserve(dir_bytes + 4096))) return rc;
     SaCandBox bc;
     memset(&bc, 0, sizeof(bc));
-    bc.dirs = ctx->dirs.as<uint8_t>(); bc.dirs_used = &dirs_used; bc.best_only = true; bc.uniform_stride = stride == kBucketShapes ? 256 : stride;
+    bc.dirs = ctx->dirs.as<uint8_t>(); bc.dirs_used = &dirs_used; bc.best_only = true; bc.dirs_local = local; bc.uniform_stride = stride == kBucketShapes ? 256 : stride;
     if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best, &bc, nullptr, stride))) return rc;
     if (!dirs_used || !have_best) { set_last_error("seqalign_sw_batch: internal error: the best-hit direction fill did not run"); return SEQALIGN_E_HIP; }
   } else if ((rc = run_chunk(ctx, batch, c, sc, &d, &have_best))) {
@@ -686,7 +688,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tp.stage_words = (c.max_a + c.max_b + 31u) >> 5;
     tp.moves = ctx->h_ta.dev_as<uint32_t>(); tp.out_meta4 = ctx->h_B.dev_as<uint32_t>();
     tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
-    tp.dirs = ctx->dirs.as<uint8_t>(); tp.dirs_blocked = sa_dirs_blocked_shape(c.max_a); tp.fill_status = d.status;
+    tp.dirs = ctx->dirs.as<uint8_t>(); tp.dirs_blocked = sa_dirs_blocked_shape(c.max_a); tp.dirs_local = local; tp.tune_stage = ctx->opt.walk_stage; tp.fill_status = d.status;
     tp.n_pairs = (uint32_t)n; tp.K = sc->flat.n_classes; tp.open1 = sc->flat.open1; tp.ext = sc->flat.ext;
     tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel; tp.tune_group = ctx->opt.walk_group;
     hipError_t e2 = sa_launch_nw_traceback(tp, st);

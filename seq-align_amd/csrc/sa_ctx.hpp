@@ -333,6 +333,8 @@ struct SaOptions {
                                   //                   for memory that does not disturb the first two arenas (0: allocate plainly)
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
   uint32_t arena_free_pct = 60;   // arena_free_pct    share of the memory free at the start that an explicit placement walk may hold (10 .. 90)
+  uint32_t dirs_local = 1;        // dirs_local        1|0: chunks whose walks are tile walks (NW moves path, SW best hit) get the LOCAL form of the direction byte (sa_kernels.h): cheaper to write, resolved by the walker
+  uint32_t walk_stage = 1;        // walk_stage        1|0: the local tile walker writes a wave's moves as one contiguous run out of LDS (whole lines over PCIe) instead of two pieces per walk
   uint32_t walk_group = 0;        // walk_group        0|1|4|8: walks per wave of the tile walker on moves (0: four in lockstep on blocked direction bytes, else one; 1 / 4 / 8: forced)
   uint32_t async_lanes = 0;       // async_lanes       1..8 (0 = 3): batches seqalign_*_batch_submit keeps in flight per context (sa_async.hip)
   uint32_t arena_keep_gib = 16;   // arena_keep_gib    how much of a walk's unused chunks stays with the process (the chunk pool: large scratch
@@ -447,10 +449,10 @@ constexpr uint64_t kShapeTableMax = (uint64_t)1 << 20;   // (len_a + 1) x (len_b
 int fetch_status(seqalign_ctx *ctx, const Chunk &c, uint64_t *status_out);
 int nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                  int32_t *end_score, uint64_t *end_state, void *stream, bool *used, uint64_t uniform_stride = 0,
-                 const uint32_t *pair_list = nullptr, uint32_t list_count = 0);
+                 const uint32_t *pair_list = nullptr, uint32_t list_count = 0, bool local = false);
 int nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch, uint8_t *dirs,
                        int32_t *end_score, uint64_t *end_state, void *stream, const uint32_t *list, uint32_t n_modal, uint32_t n_rest,
-                       uint32_t modal_a, uint32_t modal_b);
+                       uint32_t modal_a, uint32_t modal_b, bool local = false);
 // (n_pairs: of the chunk -- FEW pairs with rows over 768 columns stay with three matrices, whose fills put several waves on a pair)
 bool nw_dirs_applicable(const seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, uint32_t max_len_a, uint64_t n_pairs = ~0ull);
 // whether a chunk whose pairs all are len_a x len_b may take the packed two-pairs-per-wave fill (its layout: every pair's

@@ -234,6 +234,8 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("arena_scan_gib")) { if (!number(0, 1024, &num)) return false; o.arena_scan_gib = (uint32_t)num; return true; }
   if (is("arena_keep_gib")) { if (!number(0, 1024, &num)) return false; o.arena_keep_gib = (uint32_t)num; return true; }
   if (is("async_lanes")) { if (!number(0, 8, &num)) return false; o.async_lanes = (uint32_t)num; return true; }
+  if (is("dirs_local")) { if (!number(0, 1, &num)) return false; o.dirs_local = (uint32_t)num; return true; }
+  if (is("walk_stage")) { if (!number(0, 1, &num)) return false; o.walk_stage = (uint32_t)num; return true; }
   if (is("walk_group")) { if (!number(0, 8, &num) || !(num == 0 || num == 1 || num == 4 || num == 8)) return false; o.walk_group = (uint32_t)num; return true; }
   if (is("arena_free_pct")) { if (!number(10, 90, &num)) return false; o.arena_free_pct = (uint32_t)num; return true; }
   if (is("arena_quality")) {
@@ -277,6 +279,8 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("arena_scan_gib")) return n(o.arena_scan_gib);
   if (is("arena_keep_gib")) return n(o.arena_keep_gib);
   if (is("async_lanes")) return n(o.async_lanes);
+  if (is("dirs_local")) return n(o.dirs_local);
+  if (is("walk_stage")) return n(o.walk_stage);
   if (is("walk_group")) return n(o.walk_group);
   if (is("arena_free_pct")) return n(o.arena_free_pct);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
@@ -287,7 +291,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes", "walk_group"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes", "walk_group", "dirs_local", "walk_stage"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);
@@ -500,6 +504,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
     // asked sw_best_x2_applicable first and has no matrices to fall back to
     p.best_score = best_score; p.best_index = best_index;
     p.uniform_stride = cand->uniform_stride;
+    p.dirs_local = cand->dirs_local ? 1u : 0u;
     if (cand->pair_list) { p.pair_list = cand->pair_list; p.n_pairs = cand->list_count; }
     if (!cand->dirs || !cand->dirs_used || !sa_sw_best_x2_applicable(p, batch->max_len_a, batch->max_len_b, cand->dirs)) {
       set_last_error("internal error: the best-hit direction fill was asked for a batch outside its domain");
@@ -563,7 +568,7 @@ int sa_host::fill_device(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scor
 // (and nothing launched) when the scoring or the batch is outside that kernel's domain, or the option nw_dirs is off.
 int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                           uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, bool *used,
-                          uint64_t uniform_stride, const uint32_t *pair_list, uint32_t list_count) {
+                          uint64_t uniform_stride, const uint32_t *pair_list, uint32_t list_count, bool local) {
   *used = false;
   if (!ctx->opt.nw_dirs || ctx->opt.kernel != SEQALIGN_KERNEL_AUTO || batch->n_pairs == 0 || batch->n_pairs > 0xFFFFFFFFull) return SEQALIGN_OK;
   SaFillParams p = make_params(ctx, scoring, batch);
@@ -575,6 +580,7 @@ int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sco
     p.pair_list = pair_list; p.n_pairs = list_count;
   }
   p.uniform_stride = ctx->opt.pack16 ? uniform_stride : 0;
+  p.dirs_local = local ? 1u : 0u;
   hipError_t e = sa_nw_dirs_x2_applicable(p, batch->max_len_a, batch->max_len_b, dirs)
                      ? sa_launch_fill_nw_dirs_x2(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream)
                      : sa_launch_fill_nw_dirs(p, batch->max_len_a, dirs, stream ? (hipStream_t)stream : ctx->stream);
@@ -587,11 +593,11 @@ int sa_host::nw_dirs_fill(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *sco
 // chunk's arrays (the list holds indices into them); every pair's bytes start on a multiple of 256.
 int sa_host::nw_dirs_fill_mixed(seqalign_ctx_t *ctx, const seqalign_dev_scoring_t *scoring, const seqalign_dev_batch_t *batch,
                                 uint8_t *dirs, int32_t *end_score, uint64_t *end_state, void *stream, const uint32_t *list,
-                                uint32_t n_modal, uint32_t n_rest, uint32_t modal_a, uint32_t modal_b) {
+                                uint32_t n_modal, uint32_t n_rest, uint32_t modal_a, uint32_t modal_b, bool local) {
   if (n_modal + n_rest == 0) return SEQALIGN_OK;
   SaFillParams p = make_params(ctx, scoring, batch);
   p.best_score = end_score; p.best_index = end_state;
-  p.pair_list = list; p.uniform_stride = 256;
+  p.pair_list = list; p.uniform_stride = 256; p.dirs_local = local ? 1u : 0u;
   if (!list || !sa_nw_dirs_fill_applicable(p, batch->max_len_a, dirs) || !sa_nw_dirs_x2_applicable(p, modal_a, modal_b, dirs)) {
     set_last_error("seqalign_nw_batch: internal error: the mixed directions-only fill was asked for a chunk outside its domain");
     return SEQALIGN_E_ARG;

@@ -238,7 +238,7 @@ fill_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 // A = gap_open + j*ext.  No state ever "ends" (code 3 is not used): the walk stops at x == 0 or y == 0.
 // Cells whose score is the floor by clamping carry a meaningless direction, like the reference's traceback (which
 // exits on them, alignment.c:328-349) they are never stood on inside the parity domain.
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -256,7 +256,7 @@ fill_nw_dirs_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   if (slot >= p.n_pairs) return;
   const uint32_t pair = p.pair_list ? p.pair_list[slot] : slot;
 
-  nw_dirs_x1_wave<CPL, SUBST, R>(p, dirs_arena, pair, lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
+  nw_dirs_x1_wave<CPL, SUBST, R, LOCAL>(p, dirs_arena, pair, lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
 }
 
 template <int CPL, int R0>
@@ -266,12 +266,12 @@ static hipError_t launch_nw_dirs_cpl(const SaFillParams &p, uint8_t *dirs, hipSt
   const int wpb = 4;
   const dim3 grid((p.n_pairs + wpb - 1) / wpb), block(kWave * wpb);
   const size_t rings = (size_t)wpb * R;
-  if (p.K <= 1) {
-    hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, rings, stream, p, dirs);
-  } else {
-    const size_t lds = rings + (((size_t)p.K * p.K + 3u) & ~(size_t)3u) * sizeof(int32_t);
-    hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_LDS, R>), grid, block, lds, stream, p, dirs);
-  }
+  const size_t lds = rings + (((size_t)p.K * p.K + 3u) & ~(size_t)3u) * sizeof(int32_t);
+  // (dirs_local: the byte's local form for the tile walkers, sa_kernels.h)
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, rings, stream, p, dirs);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, rings, stream, p, dirs);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, lds, stream, p, dirs);
+  else hipLaunchKernelGGL((fill_nw_dirs_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, lds, stream, p, dirs);
   return hipGetLastError();
 }
 

@@ -165,6 +165,16 @@ __device__ __forceinline__ uint32_t row_codes(uint32_t chunk_code, int q, uint32
 
 constexpr uint32_t kBoth = 0x00010001u;   // a 1 in each half
 
+// The LOCAL form of the direction byte (sa_kernels.h: SA_LD_*): a decision is the sign of a saturating difference d = x -sat y
+// (set where x < y), and its bit of the byte -- set where x >= y, which among the recurrence's own operands means x == y -- is that
+// sign shifted into place: one v_lshrrev_b32 + one v_bitop3_b32 (acc | (~shifted & bit)), both halves at once, where the older form
+// smears the sign over its half (v_pk_ashrrev_i16), selects a two-bit code with it (v_bfi) and merges the codes.
+template <int K>
+__device__ __forceinline__ uint32_t put_ge(uint32_t acc, pk16 d) {
+  static_assert(K >= 0 && K <= 7, "a bit of the direction byte");
+  return __builtin_amdgcn_bitop3_b32(acc, pk_bits(d) >> (15 - K), (1u << K) * kBoth, 0xF2);   // a | (~b & c)
+}
+
 // The substitution score of my columns against this row's character, both pairs at once.
 //   SA_SUBST_SIMPLE (K <= 1): equal characters -> gen_eq, else gen_ne = gen_eq + min(fa ^ fb, 1) * (gen_ne - gen_eq).
 //   SA_SUBST_LDS: the K x K table (int16 in LDS, behind the rings), row = class of the seq_a character; the two pairs'
@@ -378,7 +388,7 @@ __device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tb
 // does not depend on the row's width (scan, lane shifts, this row's character, the loop) serves four rows instead of two.
 // All pairs of a wave have the same shape: one set of stream positions, one row counter; the spans never exchange anything
 // (the lane shifts' hand-over at lane 32 is cut: first_lane).
-template <int CPL, int SUBST, int R, int LANES>
+template <int CPL, int SUBST, int R, int LANES, bool LOCAL = false>
 __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair_lo,
                                                 const uint32_t pair_hi, const bool has_lo, const bool has_hi, const int lane,
                                                 uint8_t *ring_wave, const uint32_t tbl_lds) {
@@ -570,10 +580,14 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       const pk16 ae = pk_adds(Ap[c], ext);
       pk16 a = pk_max(pk_adds(Yp[c], open1), ae);                                          // alignment.c:128-135
       if (c == 0) m = first_lane ? floor_ : m;                                             // the border column's match score
+      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
+      if constexpr (LOCAL) {
+        dv[c] = put_ge<2>(0u, pk_subs(ae, a));                                             // CA: gap_a + ext IS the max
+      } else {
       const uint32_t opened = pk_lt(ae, a);                                                // gap_a + ext is NOT the max
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);                                 // GAP_A (1) first, else B >= M ? 2 : 0
-      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
       dv[c] = td; dvA[c] = dA;
+      }
     }
     pk16 Pm[CPL];                         // de-trended gap_b: prefix max up to and including my column
     pk16 e;                               //                   prefix max of the lanes to my left
@@ -598,22 +612,32 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
         const pk16 b = bv[c];
         // alignment.c:311-327 for GAP_B: the left cell's gap_a + open1 first, then its gap_b + ext, else match.
         // gap_b(left) + ext == b  <=>  the prefix max did not grow at my column (de-trended: Pm(left) == Pm(mine))
+        const pk16 yn = pk_max(mv[c], b);
+        if constexpr (LOCAL) {
+          // this cell's own comparisons, a bit each (sa_kernels.h): FA, FB, BM (B >= M), GA (A >= max(M, B)); no tags carried
+          uint32_t d = put_ge<3>(dv[c], pk_subs(pk_adds(aL, open1), b));
+          d = put_ge<4>(d, pk_subs(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]));
+          d = put_ge<1>(d, pk_subs(b, mv[c]));
+          dv[c] = put_ge<0>(d, pk_subs(av[c], yn));
+          X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
+        } else {
         const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
         const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
         const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
         dv[c] = or3(dv[c], dvA[c], dB);
-        const pk16 yn = pk_max(mv[c], b);
         const uint32_t m_wins = pk_lt(b, mv[c]);      // B < M
         const uint32_t a_loses = pk_lt(av[c], yn);    // A < max(M, B)
         const uint32_t ty4 = bfi(m_wins, 0u, 8u * kBoth);
         X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
         T[c] = bfi(a_loses, ty4 >> 2, kBoth);         // GAP_A first, then GAP_B, then MATCH
         TY4[c] = ty4;
+        }
       }
     }
     // the border cell (0, j): never stood on with a move to make, but byte for byte what fill_nw_dirs_kernel stores
-    // there -- GAP_A continues down the column (its first step only if gap_open is 0), else max(M, B) = B
-    dv[0] = first_lane ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
+    // there -- GAP_A continues down the column (its first step only if gap_open is 0), else max(M, B) = B (local form: 0)
+    if constexpr (LOCAL) dv[0] = first_lane ? 0u : dv[0];
+    else dv[0] = first_lane ? ((j == 1 && p.gap_open != 0) ? 8u : 4u) * kBoth : dv[0];
     if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) sub.row_end(chunk_code, q, j, lb);
     append_row(dv);
   }
@@ -641,7 +665,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   }
 }
 
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -655,12 +679,12 @@ fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   const uint32_t pair0 = p.pair_list ? p.pair_list[2 * unit] : 2 * unit;
   const uint32_t pair1 = two ? (p.pair_list ? p.pair_list[2 * unit + 1] : 2 * unit + 1) : pair0;
 
-  nw_dirs_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+  nw_dirs_x2_wave<CPL, SUBST, R, 64, LOCAL>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
 }
 
 // four pairs per wave: pairs 4 unit .. 4 unit + 3 of the launch (all of one shape, no pair list); the pairs a short last wave
 // does not have shadow its first one
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -672,7 +696,7 @@ fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   if (4 * unit >= p.n_pairs) return;
   const uint32_t lo = 4 * unit + 2 * ((uint32_t)lane >> 5), hi = lo + 1;
   const bool has_lo = lo < p.n_pairs, has_hi = hi < p.n_pairs;
-  nw_dirs_x2_wave<CPL, SUBST, R, 32>(p, dirs_arena, has_lo ? lo : 4 * unit, has_hi ? hi : 4 * unit, has_lo, has_hi, lane,
+  nw_dirs_x2_wave<CPL, SUBST, R, 32, LOCAL>(p, dirs_arena, has_lo ? lo : 4 * unit, has_hi ? hi : 4 * unit, has_lo, has_hi, lane,
                                      reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
@@ -681,7 +705,7 @@ fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 // others the remaining pairs two per wave.  C2's 10 000 pairs are 2 500 four-per-wave waves: 452 SIMDs get three of them and
 // the rest wait with two (0.56 of the issue peak); as 2 048 four-per-wave + 904 two-per-wave waves every SIMD has two of the
 // former and at most one of the latter, ~12 % less work on the busiest SIMD (sa_launch_fill_nw_dirs_x2 decides).
-template <int CPL4, int SUBST, int R>
+template <int CPL4, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t q_blocks, const uint32_t pairs_q) {
   constexpr int CPL2 = (CPL4 + 1) / 2;
@@ -696,12 +720,12 @@ fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena,
     const uint32_t unit = blockIdx.x * waves + wave;
     if (4 * unit >= pairs_q) return;
     const uint32_t lo = 4 * unit + 2 * ((uint32_t)lane >> 5);
-    nw_dirs_x2_wave<CPL4, SUBST, R, 32>(p, dirs_arena, lo, lo + 1, true, true, lane, ring, tbl_lds);
+    nw_dirs_x2_wave<CPL4, SUBST, R, 32, LOCAL>(p, dirs_arena, lo, lo + 1, true, true, lane, ring, tbl_lds);
   } else {
     const uint32_t pair0 = pairs_q + 2 * ((blockIdx.x - q_blocks) * waves + wave);
     if (pair0 >= p.n_pairs) return;
     const bool two = pair0 + 1 < p.n_pairs;
-    nw_dirs_x2_wave<CPL2, SUBST, R, 64>(p, dirs_arena, pair0, two ? pair0 + 1 : pair0, true, two, lane, ring, tbl_lds);
+    nw_dirs_x2_wave<CPL2, SUBST, R, 64, LOCAL>(p, dirs_arena, pair0, two ? pair0 + 1 : pair0, true, two, lane, ring, tbl_lds);
   }
 }
 
@@ -709,7 +733,7 @@ fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena,
 // pairs of the modal shape two per wave (p.pair_list[0 .. n_modal)), the others the n_rest remaining pairs one per wave
 // (p.pair_list[n_modal ..), fill_nw_dirs_kernel's body).  Two launches would run one after the other, and a launch of a
 // few hundred one-pair waves takes as long as its longest pair's rows however few they are (profiles/r03/r03_mixed_check.txt; today: tools/x2_check.py check_mixed).
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t x2_blocks, const uint32_t n_modal,
                           const uint32_t n_rest) {
@@ -724,7 +748,7 @@ fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena
     if (2 * unit >= n_modal) return;
     const bool two = 2 * unit + 1 < n_modal;
     const uint32_t pair0 = p.pair_list[2 * unit], pair1 = two ? p.pair_list[2 * unit + 1] : pair0;
-    nw_dirs_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+    nw_dirs_x2_wave<CPL, SUBST, R, 64, LOCAL>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
   } else {
     const int32_t *table = p.table;
     if constexpr (SUBST == SA_SUBST_LDS) {
@@ -735,7 +759,7 @@ fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena
     }
     const uint32_t slot = (blockIdx.x - x2_blocks) * waves + wave;
     if (slot >= n_rest) return;
-    nw_dirs_x1_wave<CPL, SUBST, R>(p, dirs_arena, p.pair_list[n_modal + slot], lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
+    nw_dirs_x1_wave<CPL, SUBST, R, LOCAL>(p, dirs_arena, p.pair_list[n_modal + slot], lane, reinterpret_cast<uint8_t *>(lds) + wave * R, table);
   }
 }
 
@@ -1019,7 +1043,7 @@ fill_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
 // smith_waterman.c:71-86).  So this fill writes the direction byte only (1 B per cell, as fill_nw_dirs_x2_kernel) and
 // tracks, per column, the highest score and the first row that reached it; the pair's best cell and score go to
 // best_index / best_score (index 0, score 0: no cell above 0).
-template <int CPL, int SUBST, int R, int LANES>
+template <int CPL, int SUBST, int R, int LANES, bool LOCAL = false>
 __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair_lo,
                                                 const uint32_t pair_hi, const bool has_lo, const bool has_hi, const int lane,
                                                 uint8_t *ring_wave, const uint32_t tbl_lds) {
@@ -1156,7 +1180,7 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
   {
     uint32_t dv[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) dv[c] = 0x3fu * kBoth;   // row 0: scores 0, every state ends
+    for (int c = 0; c < CPL; ++c) dv[c] = (LOCAL ? 7u * SA_LD_END0 : 0x3fu) * kBoth;   // row 0: scores 0, every state ends
     append_row(dv);
   }
 
@@ -1193,10 +1217,15 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
       const pk16 m = pk_max(pk_adds(xd, s), zero);
       const pk16 ae = pk_adds(Ap[c], ext);
       const pk16 a = pk_max(pk_max(pk_adds(Yp[c], open1), ae), zero);
+      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
+      if constexpr (LOCAL) {
+        // CA (gap_a + ext IS the max), and the states whose score is 0 (0 >= m, 0 >= a: a walk standing there ends)
+        dv[c] = put_ge<6>(put_ge<5>(put_ge<2>(0u, pk_subs(ae, a)), pk_subs(zero, m)), pk_subs(zero, a));
+      } else {
       const uint32_t opened = pk_lt(ae, a);
       const uint32_t dA = bfi(opened, TY4[c], 4u * kBoth);
-      mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
       dv[c] = bfi(pos_mask(m), td, 3u * kBoth); dvA[c] = bfi(pos_mask(a), dA, 12u * kBoth);
+      }
       // the best cell of my column: a strictly higher score moves it (the first row keeps a tie)
       const pk16 mine = pk_from(pk_bits(m) & valid[c]);
       const uint32_t up = pk_lt(best_s[c], mine);
@@ -1223,17 +1252,26 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
       for (int c = 0; c < CPL; ++c) {
         const pk16 aL = c ? av[c - (c ? 1 : 0)] : al;
         const pk16 b = bv[c];
+        const pk16 yn = pk_max(mv[c], b);
+        if constexpr (LOCAL) {
+          uint32_t d = put_ge<3>(dv[c], pk_subs(pk_adds(aL, open1), b));     // FA
+          d = put_ge<4>(d, pk_subs(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]));      // FB
+          d = put_ge<7>(d, pk_subs(zero, b));                                 // gap_b's score is 0
+          d = put_ge<1>(d, pk_subs(b, mv[c]));                                // BM
+          dv[c] = put_ge<0>(d, pk_subs(av[c], yn));                           // GA
+          X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
+        } else {
         const uint32_t not_a = pk_lt(pk_adds(aL, open1), b);
         const uint32_t not_b = pk_lt(c ? Pm[c - (c ? 1 : 0)] : e, Pm[c]);
         const uint32_t dB = bfi(not_a, bfi(not_b, 0u, 32u * kBoth), 16u * kBoth);
         dv[c] = or3(dv[c], dvA[c], bfi(pos_mask(b), dB, 48u * kBoth));
-        const pk16 yn = pk_max(mv[c], b);
         const uint32_t m_wins = pk_lt(b, mv[c]);
         const uint32_t a_loses = pk_lt(av[c], yn);
         const uint32_t ty4 = bfi(m_wins, 0u, 8u * kBoth);
         X[c] = pk_max(z[c], b); Yp[c] = yn; Ap[c] = av[c];
         T[c] = bfi(a_loses, ty4 >> 2, kBoth);
         TY4[c] = ty4;
+        }
       }
     }
     if constexpr (LANES == 64 && SUBST == SA_SUBST_LDS && kLdsPipe) sub.row_end(chunk_code, q, j, lb);
@@ -1269,7 +1307,7 @@ __device__ __forceinline__ void sw_best_x2_wave(const SaFillParams &p, uint8_t *
   }
 }
 
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -1281,10 +1319,10 @@ fill_sw_best_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   if (2 * unit >= p.n_pairs) return;
   uint32_t pair0, pair1;
   const bool two = x2_pairs_of(p, unit, &pair0, &pair1);
-  sw_best_x2_wave<CPL, SUBST, R, 64>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
+  sw_best_x2_wave<CPL, SUBST, R, 64, LOCAL>(p, dirs_arena, pair0, pair1, true, two, lane, reinterpret_cast<uint8_t *>(lds) + wave * (2 * R), tbl_lds);
 }
 
-template <int CPL, int SUBST, int R>
+template <int CPL, int SUBST, int R, bool LOCAL>
 __global__ void __launch_bounds__(kWave * 4)
 fill_sw_best_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -1297,7 +1335,7 @@ fill_sw_best_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   uint32_t lo, hi;
   bool has_lo, has_hi;
   x4_pairs_of(p, unit, lane, &lo, &hi, &has_lo, &has_hi);
-  sw_best_x2_wave<CPL, SUBST, R, 32>(p, dirs_arena, lo, hi, has_lo, has_hi, lane, reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
+  sw_best_x2_wave<CPL, SUBST, R, 32, LOCAL>(p, dirs_arena, lo, hi, has_lo, has_hi, lane, reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
 template <int CPL, int R0>
@@ -1306,8 +1344,10 @@ static hipError_t launch_sw_best_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
-  else hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
+  else hipLaunchKernelGGL((fill_sw_best_x2_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -1327,8 +1367,10 @@ static hipError_t launch_nw_dirs_x2_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 1) / 2;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
-  else hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
+  else hipLaunchKernelGGL((fill_nw_dirs_x2_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 2 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -1338,8 +1380,10 @@ static hipError_t launch_sw_best_x4_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 3) / 4;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
-  else hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  else hipLaunchKernelGGL((fill_sw_best_x4_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -1349,8 +1393,10 @@ static hipError_t launch_nw_dirs_x4_cpl(const SaFillParams &p, uint8_t *dirs, hi
   const int wpb = 4;
   const uint32_t units = (p.n_pairs + 3) / 4;
   const dim3 grid((units + wpb - 1) / wpb), block(kWave * wpb);
-  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
-  else hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
+  else hipLaunchKernelGGL((fill_nw_dirs_x4_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs);
   return hipGetLastError();
 }
 
@@ -1361,8 +1407,10 @@ static hipError_t launch_nw_dirs_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, 
   const int wpb = 4;
   const uint32_t q_blocks = (pairs_q / 4 + wpb - 1) / wpb, x2_blocks = ((p.n_pairs - pairs_q + 1) / 2 + wpb - 1) / wpb;
   const dim3 grid(q_blocks + x2_blocks), block(kWave * wpb);
-  if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
-  else hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
+  else hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
   return hipGetLastError();
 }
 
@@ -1373,10 +1421,12 @@ static hipError_t launch_nw_dirs_mixed_cpl(const SaFillParams &p, uint8_t *dirs,
   const uint32_t x2_blocks = ((n_modal + 1) / 2 + wpb - 1) / wpb, x1_blocks = (n_rest + wpb - 1) / wpb;
   const dim3 grid(x2_blocks + x1_blocks), block(kWave * wpb);
   if (p.K <= 1) {
-    hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_SIMPLE, R>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs, x2_blocks, n_modal, n_rest);
+    if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs, x2_blocks, n_modal, n_rest);
+    else hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 2 * R, stream, p, dirs, x2_blocks, n_modal, n_rest);
   } else {
     const size_t lds = std::max((size_t)wpb * 2 * R + table_lds_bytes(p), (size_t)wpb * R + (((size_t)p.K * p.K + 3u) & ~(size_t)3u) * sizeof(int32_t));
-    hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_LDS, R>), grid, block, lds, stream, p, dirs, x2_blocks, n_modal, n_rest);
+    if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_LDS, R, true>), grid, block, lds, stream, p, dirs, x2_blocks, n_modal, n_rest);
+    else hipLaunchKernelGGL((fill_nw_dirs_mixed_kernel<CPL, SA_SUBST_LDS, R, false>), grid, block, lds, stream, p, dirs, x2_blocks, n_modal, n_rest);
   }
   return hipGetLastError();
 }

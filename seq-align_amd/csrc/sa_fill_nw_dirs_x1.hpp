@@ -7,7 +7,8 @@
 
 namespace sa {
 
-template <int CPL, int SUBST, int R>
+// LOCAL: the byte in its local form (sa_kernels.h: SA_LD_*) -- this cell's own five comparisons, for the tile walkers.
+template <int CPL, int SUBST, int R, bool LOCAL = false>
 __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *__restrict__ dirs_arena, const uint32_t pair,
                                                 const int lane, uint8_t *ring_d, const int32_t *table) {
   const uint32_t la = p.len_a[pair], lb = p.len_b[pair], W = la + 1;
@@ -122,7 +123,8 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
       if (c == 0) { m = lane == 0 ? floor_ : m; a = lane == 0 ? edge_a : a; }             // the border column
       const uint32_t dA = (ae == a) ? 1u : TY[c];
       mv[c] = m; av[c] = a; z[c] = max(m, a);
-      dv[c] = td | (dA << 2);
+      if constexpr (LOCAL) dv[c] = (ae == a) ? SA_LD_CA : 0u;
+      else dv[c] = td | (dA << 2);
     }
     {
       const int zin = wave_shr1(z[CPL - 1], z[CPL - 1]);
@@ -146,13 +148,19 @@ __device__ __forceinline__ void nw_dirs_x1_wave(const SaFillParams &p, uint8_t *
         const int aL = c ? av[c - (c ? 1 : 0)] : al, bL = c ? bv[c - (c ? 1 : 0)] : bl;
         const int b = bv[c];
         const uint32_t dB = (addw(aL, open1) == b) ? 1u : (addw(bL, ext) == b) ? 2u : 0u;
-        dv[c] |= dB << 4;
         const int xn = max(z[c], b);
+        if constexpr (LOCAL) {
+          dv[c] |= ((addw(aL, open1) == b) ? SA_LD_FA : 0u) | ((addw(bL, ext) == b) ? SA_LD_FB : 0u) |
+                   ((av[c] == xn) ? SA_LD_GA : 0u) | ((b >= mv[c]) ? SA_LD_BM : 0u);
+        } else {
+          dv[c] |= dB << 4;
+        }
         X[c] = xn; Yp[c] = max(mv[c], b); Ap[c] = av[c];
         T[c] = (av[c] == xn) ? 1u : (b == xn) ? 2u : 0u;
         TY[c] = (b >= mv[c]) ? 2u : 0u;
       }
     }
+    if constexpr (LOCAL) dv[0] = lane == 0 ? 0u : dv[0];   // the border column: never stood on with a move to make, never arrived at with one either
     append_row(dv);
   }
   if constexpr (!BLK) { while (rv < wv) flush_block(); }

@@ -10,6 +10,33 @@ extern "C" {
 #include "sa_internal.h"   /* SA_F_* */
 }
 
+/* ---- the direction byte in its LOCAL form (round 6, second half) -----------------------------------------------------
+ * The direction byte of sa_fill_dirs.hip answers, per state, "in which state does a walk that leaves this cell ARRIVE" -- for MATCH
+ * and GAP_A that is a fact about the NEIGHBOUR (which of M / A / B is the maximum of the cell up-left; whether B >= M in the cell
+ * above), which the fills carry over from the previous row and then convert, cell by cell, from comparison masks into two-bit
+ * codes: select upon select -- 15-25 of a packed cell's ~115-165 issue cycles (profiles/r06/r06_local_dirs.txt).  A walk visits
+ * ~170 of a pair's 22 801 cells.  So where ONLY tile walkers read the bytes (seqalign_nw_batch's and the best-hit path's chunks
+ * below SA_WALK_TILE_MAX walks: every BASELINE config but configs[4]'s 125 000-pair share) the fill stores each cell's OWN five
+ * comparisons as five raw bits -- the sign bit of each saturating difference shifted into place, one v_lshrrev + one v_bitop3
+ * per decision, no mask, no select, no carried tags -- and the walker reads the state it arrives in from the byte of the cell it
+ * arrives at (it reads that byte anyway: it is the next step's):
+ *     bit 0  GA  gap_a >= max(match, gap_b)        a walk that ARRIVES here by a MATCH move is in GAP_A if GA, else GAP_B if BM,
+ *     bit 1  BM  gap_b >= match                     else MATCH (alignment.c:311-327's order); a GAP_A walk that opened its gap in
+ *                                                   the cell below arrives in GAP_B if BM, else MATCH
+ *     bit 2  CA  gap_a(above) + extend == gap_a     a GAP_A walk LEAVING this cell stays in GAP_A
+ *     bit 3  FA  gap_a(left) + open + extend == gap_b   a GAP_B walk leaving this cell arrives in GAP_A,
+ *     bit 4  FB  gap_b(left) + extend == gap_b          else GAP_B if FB, else MATCH
+ *     bits 5 6 7 (Smith-Waterman)  this cell's match / gap_a / gap_b score is 0: a walk standing here in that state ends
+ * The lane walkers (large launches) look a cell AHEAD -- where a walk goes next must not wait for the byte of the cell it arrives
+ * at -- and keep the older form; so do the multi-hit path's bytes, whose sweep routes arrivals by them.  SaFillParams::dirs_local /
+ * SaTraceParams::dirs_local say which form a launch writes / reads (option dirs_local = 0: the older form everywhere). */
+#define SA_LD_GA 1u
+#define SA_LD_BM 2u
+#define SA_LD_CA 4u
+#define SA_LD_FA 8u
+#define SA_LD_FB 16u
+#define SA_LD_END0 32u   /* << state */
+
 /* Everything one fill launch needs; passed by value as the kernarg. */
 /* ---- the direction bytes in BLOCKS (round 6) --------------------------------------------------------------------------
  * Where nobody but the walkers reads them -- seqalign_nw_batch's directions-only fills and the packed SW best-hit fill; not the
@@ -70,6 +97,7 @@ struct SaFillParams {
                                    shape goes through the packed kernel with the list of those, the others through the one-pair
                                    kernel with the list of the rest */
   int32_t table_abs_max;        /* host side only: the largest |entry| of the K x K table (0 for K <= 1): the packed fills' int16 bound */
+  uint32_t dirs_local = 0;      /* host side only: the NW / best-hit direction fills write the LOCAL form of the byte (above) */
 };
 
 /* How the multi-hit path packs a match_scores cell into a 64-bit key whose ascending order IS the reference's hit
@@ -119,6 +147,7 @@ struct SaCandBox {
                                  list_count / 2 waves, wave u the pairs pair_list[2u], pair_list[2u + 1] of the descriptor arrays -- equal in
                                  shape, or the same pair twice (it has the wave to itself)                                               */
   uint32_t list_count;
+  bool dirs_local;            /* best_only: the fill writes the LOCAL form of the direction byte (tile walkers behind it) */
 };
 
 /* SW multi-hit enumeration: the reverse sweep (sa_sw_sweep.hip) */
@@ -212,6 +241,8 @@ struct SaTraceParams {
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
   uint32_t dirs_blocked;       /* `dirs` is laid out in blocks of 8 x 16 cells (above) instead of row-major at pitch len_a + 1 */
   uint32_t tune_group;         /* host side only: the tile walker on moves: 0 / 4 = four walks per wave in lockstep, 8 = eight, 1 = one (option walk_group) */
+  uint32_t tune_stage;         /* host side only: the local tile walker writes a wave's moves as one run out of LDS (option walk_stage) */
+  uint32_t dirs_local;         /* `dirs` holds the LOCAL form of the direction byte (above): tile walkers on moves only */
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */
   const int32_t *nw_score;     /* NW behind the directions-only fill (dirs != NULL): per pair the end cell's score ...            */
   const uint64_t *nw_state;    /* ... and the matrix the walk starts in (0 MATCH, 1 GAP_A, 2 GAP_B)                                */

@@ -475,6 +475,25 @@ __global__ void __launch_bounds__(64) traceback_moves_lane_ahead_kernel(const Sa
 // (walks_per_pair: one WAVE per pair walks the pair's hits one after the other -- nearly every pair has one; launched as one
 // workgroup per walk slot, the 30 000 of C3's 40 000 slots that return at once cost 0.2 ms of workgroup dispatch, and as one
 // workgroup per pair with a wave per slot, four times the LDS per workgroup held for waves that had nothing to do)
+// The LOCAL form of the direction byte (sa_kernels.h: SA_LD_*; the fills of chunks whose walks are tile walks write it): the byte
+// of a cell holds that cell's OWN comparisons, and the state a walk arrives in follows from the state it left, the byte of the
+// cell it left and the byte of the cell it arrives at -- which the walk reads anyway, as the next step's.  alignment.c:311-327:
+// GAP_A is tested first, then GAP_B, else MATCH.  Split in two so that only two instructions sit between a step's byte and the
+// next step's address (the walks are a chain of dependent LDS reads): when a walk LEAVES a cell it works out which bits of the
+// arrival cell's byte will decide (`am`) and what is decided already (`fx`) --
+//     leaving in MATCH:  GA and BM of the arrival cell;   in GAP_A: CA ? GAP_A : BM of the arrival cell;
+//     in GAP_B: FA ? GAP_A : FB ? GAP_B : MATCH, both of the cell it leaves
+// -- beside the read of the next byte, and on arrival the state is one and-or and one look-up in a four-entry constant.
+// (A walk that has not moved yet: am = 0, fx = the state it starts in.)
+__device__ __forceinline__ void local_depart(uint32_t st, uint32_t cur, uint32_t &am, uint32_t &fx) {
+  const uint32_t from_b = (0x64u >> (2u * ((cur >> 3) & 3u))) & 3u;   // FA | FB << 1  ->  GAP_A, GAP_B or MATCH (0x64: 0, 1, 2, 1)
+  const bool ca = (cur & SA_LD_CA) != 0;
+  am = st == MAT_MATCH ? 3u : (st == MAT_GAP_A && !ca) ? 2u : 0u;
+  fx = st == MAT_GAP_B ? from_b : (st == MAT_GAP_A && ca) ? (uint32_t)MAT_GAP_A : 0u;
+}
+__device__ __forceinline__ uint32_t local_arrive(uint32_t cur, uint32_t am, uint32_t fx) {
+  return (0x64u >> (2u * ((cur & am) | fx))) & 3u;   // 0: MATCH, 1: GAP_A, 2: GAP_B, 3 (GA and BM): GAP_A
+}
 __device__ __forceinline__ uint32_t even_bits(unsigned long long v) {   // bits 0, 2, 4, ... of v as a 32-bit word
   v &= 0x5555555555555555ull;
   v = (v | (v >> 1)) & 0x3333333333333333ull;
@@ -483,7 +502,7 @@ __device__ __forceinline__ uint32_t even_bits(unsigned long long v) {   // bits 
   v = (v | (v >> 8)) & 0x0000ffff0000ffffull;
   return (uint32_t)(v | (v >> 16));
 }
-template <bool NW>
+template <bool NW, bool LOCAL = false>
 __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceParams p) {
   constexpr int kT = 64;
   __shared__ __attribute__((aligned(16))) uint8_t tile[kT * kT];
@@ -499,6 +518,7 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
     const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
     const MoveSlot s = m.slot;
     uint32_t x = uni(m.x), y = uni(m.y), st = uni(m.st), k = 0, reg_a = 0, reg_b = 0;
+    uint32_t am = 0, fx = st;       // LOCAL: what decides the state at the next cell (local_depart; no step yet: the given state)
     unsigned long long codes = 0;   // the states of the current word's steps, two bits each, the first step on top
     auto flush = [&](int q, int first_slot) {
       const int at = s.nw - 64 * (q + 1) + lane;
@@ -529,17 +549,36 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
         uint32_t n = min(min(tx, ty), 32u - (k & 31u));
         if (n == 0) {
           // on the tile's first row or column: one step with the coordinates spelled out, then the next tile
-          const uint32_t f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
-          if constexpr (!NW) { if (f == 3u) { over = true; break; } }
+          uint32_t f = 0;
+          if constexpr (LOCAL) {
+            const uint32_t cur = uni((uint32_t)tile[at]);
+            st = local_arrive(cur, am, fx);
+            if constexpr (!NW) { if ((cur >> (5u + st)) & 1u) { over = true; break; } }
+            local_depart(st, cur, am, fx);
+          } else {
+            f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
+            if constexpr (!NW) { if (f == 3u) { over = true; break; } }
+          }
           codes = (codes << 2) | st;
           x = ox + tx - (st != MAT_GAP_A); y = oy + ty - (st != MAT_GAP_B);
-          st = f;
+          if constexpr (!LOCAL) st = f;
           ++k;
           word_done();
           break;
         }
         // (two steps per turn of the loop: its counter and branch are 3 of a step's 16 instructions)
         auto one = [&]() __attribute__((always_inline)) -> bool {
+          if constexpr (LOCAL) {
+            // the state the walk stands in HERE: from the step that brought it (the state and the cell it left) and this cell's byte
+            const uint32_t cur = uni((uint32_t)tile[at]);
+            st = local_arrive(cur, am, fx);
+            if constexpr (!NW) { if ((cur >> (5u + st)) & 1u) return true; }   // this state's score is 0: the hit starts here
+            codes = (codes << 2) | st;
+            at -= (0x00014041u >> (8u * st)) & 0xffu;
+            local_depart(st, cur, am, fx);
+            ++k;
+            return false;
+          } else {
           const uint32_t f = uni(((uint32_t)tile[at] >> (2u * st)) & 3u);
           if constexpr (!NW) { if (f == 3u) return true; }
           codes = (codes << 2) | st;
@@ -547,6 +586,7 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
           st = f;
           ++k;
           return false;
+          }
         };
         bool ended = false;
         for (; n >= 2u; n -= 2u) {
@@ -600,15 +640,56 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 // are written in place into pinned host memory (seqalign_nw_batch's small chunks: no copy behind the kernel) both forms take
 // 60-65 us: 20 000 scattered 24-byte pieces over PCIe, ~9 GB/s, are then what the kernel's end waits for.  Default (option
 // walk_group = 0): four walks per wave on blocked direction bytes, one wave per walk on row-major ones.
+// The tile of one group's walk: 64 x 64 bytes whose bottom-right cell is where the walk stands (blocked direction bytes: whose
+// last block row / column hold it), L = 64 / G lanes loading kT / L rows each; all of a lane's rows are asked for before the
+// first is written to LDS: one latency per reload, not one per row.  ox / oy: the matrix cell of the tile's first byte.
+template <int G>
+__device__ __forceinline__ void group_load_tile(const SaTraceParams &p, uint8_t *tile, const uint8_t *__restrict__ Dg, uint32_t x, uint32_t y,
+                                                uint32_t W, uint32_t lb, int lg, uint32_t &ox, uint32_t &oy) {
+  constexpr int kT = 64, L = 64 / G, kRows = kT / L;
+  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
+  u4_u buf[kRows][4];
+  if (p.dirs_blocked) {   // (wave-uniform) 8 x 4 blocks whose last block row / column hold (x, y): load_dirs_tile, 16 lanes a tile
+    const uint32_t nbx = (W + 15u) >> 4, nby = (lb + 8u) >> 3;
+    const uint32_t bx0 = (x >> 4) >= 3u ? (x >> 4) - 3u : 0u, by0 = (y >> 3) >= 7u ? (y >> 3) - 7u : 0u;
+    ox = bx0 << 4; oy = by0 << 3;
+#pragma unroll
+    for (int i = 0; i < kRows * 4; ++i) {
+      const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = min(by0 + (pc >> 5), nby - 1u), bc = (pc >> 3) & 3u, r = pc & 7u;
+      buf[i >> 2][i & 3] = *reinterpret_cast<const u4_u *>(Dg + ((uint64_t)br * nbx + bx0 + bc) * 128u + r * 16u);
+    }
+#pragma unroll
+    for (int i = 0; i < kRows * 4; ++i) {
+      const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = pc >> 5, bc = (pc >> 3) & 3u, r = pc & 7u;
+      *reinterpret_cast<u4_u *>(tile + (br * 8u + r) * kT + bc * 16u) = buf[i >> 2][i & 3];
+    }
+  } else {
+    ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
+#pragma unroll
+    for (int r4 = 0; r4 < kRows; ++r4) {
+      // 64 bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
+      // pair's last: that last row again -- never looked at: the walk only moves up and left of (x, y))
+      const uint32_t tr = (uint32_t)(lg * kRows + r4), r = min(oy + tr, lb);
+      const uint8_t *src = Dg + (uint64_t)r * W + ox;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) buf[r4][q] = *reinterpret_cast<const u4_u *>(src + 16 * q);
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < kRows; ++r4) {
+      const uint32_t tr = (uint32_t)(lg * kRows + r4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
+    }
+  }
+}
+
 template <bool NW, int G>
 __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTraceParams p) {
   constexpr int kT = 64, L = 64 / G;           // tile edge; lanes per walk
-  constexpr int kRows = kT / L;                // tile rows a lane loads
   static_assert(G == 2 || G == 4 || G == 8, "walks per wave");
   __shared__ __attribute__((aligned(16))) uint8_t tiles[G * kT * kT];
   const int lane = threadIdx.x, g = lane / L, lg = lane % L;
   uint8_t *const tile = tiles + g * (kT * kT);
-  typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
   const uint32_t w_raw = blockIdx.x * G + g;
   const bool exists = w_raw < p.n_pairs;
   const uint32_t w = exists ? w_raw : p.n_pairs - 1;     // (a group without a walk shadows the last one and delivers nothing)
@@ -635,44 +716,11 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
     // bottom-right cell is where it stands.  (A first version gave a new tile only to the group that needed one: four walks'
     // tiles then run out at four different times, ~15 reloads per wave instead of a walk's own 3-4, each a full memory latency
     // for everybody -- 97 us for C2's walks where one wave per walk takes 63.  Walks leave a tile after 63 .. 126 steps whatever
-    // their shape, so tiles renewed together run out together: max steps / 63 reloads per wave.)  All of a lane's rows are asked
-    // for before the first is written to LDS: one latency per reload, not one per row.
+    // their shape, so tiles renewed together run out together: max steps / 63 reloads per wave.)
     const uint32_t tx0 = at & (kT - 1), ty0 = at >> 6;
     if (__any(live && (fresh || tx0 == 0 || ty0 == 0))) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // earlier LDS reads are done with the old tiles
-      u4_u buf[kRows][4];
-      if (p.dirs_blocked) {   // (wave-uniform) 8 x 4 blocks whose last block row / column hold (x, y): load_dirs_tile, 16 lanes a tile
-        const uint32_t nbx = (W + 15u) >> 4, nby = (lb + 8u) >> 3;
-        const uint32_t bx0 = (x >> 4) >= 3u ? (x >> 4) - 3u : 0u, by0 = (y >> 3) >= 7u ? (y >> 3) - 7u : 0u;
-        ox = bx0 << 4; oy = by0 << 3;
-#pragma unroll
-        for (int i = 0; i < kRows * 4; ++i) {
-          const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = min(by0 + (pc >> 5), nby - 1u), bc = (pc >> 3) & 3u, r = pc & 7u;
-          buf[i >> 2][i & 3] = *reinterpret_cast<const u4_u *>(Dg + ((uint64_t)br * nbx + bx0 + bc) * 128u + r * 16u);
-        }
-#pragma unroll
-        for (int i = 0; i < kRows * 4; ++i) {
-          const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = pc >> 5, bc = (pc >> 3) & 3u, r = pc & 7u;
-          *reinterpret_cast<u4_u *>(tile + (br * 8u + r) * kT + bc * 16u) = buf[i >> 2][i & 3];
-        }
-      } else {
-      ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
-#pragma unroll
-      for (int r4 = 0; r4 < kRows; ++r4) {
-        // 64 bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
-        // pair's last: that last row again -- never looked at: the walk only moves up and left of (x, y))
-        const uint32_t tr = (uint32_t)(lg * kRows + r4), r = min(oy + tr, lb);
-        const uint8_t *src = Dg + (uint64_t)r * W + ox;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) buf[r4][q] = *reinterpret_cast<const u4_u *>(src + 16 * q);
-      }
-#pragma unroll
-      for (int r4 = 0; r4 < kRows; ++r4) {
-        const uint32_t tr = (uint32_t)(lg * kRows + r4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
-      }
-      }
+      group_load_tile<G>(p, tile, Dg, x, y, W, lb, lg, ox, oy);
       at = (y - oy) * kT + (x - ox);
       fresh = false;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -714,6 +762,165 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
     keep_word(j, even_bits(top), even_bits(top >> 1), mine);
   }
   if (kk) {         // the last block of words: from the slot of the last word on
+    const uint32_t j = (kk - 1) >> 5;
+    flush(j / L, (L - 1) - (int)(j % L), mine);
+  }
+  if (mine && lg == 0) write_moves_meta<NW>(p, w, m, m.x, m.y, kk);
+}
+
+// The same walker on the LOCAL form of the direction byte (sa_kernels.h: SA_LD_*; local_depart / local_arrive above), its step
+// written for the instruction count: with two or three such waves on a SIMD all in the same phase (tiles arrive together, bursts
+// run together) every instruction of the step costs the launch 0.7 us (profiles/r06/r06_local_dirs.txt: the first form of this
+// decode, 29 vector instructions per step where the older byte takes 14, ran 71 us where that takes 60).  So:
+//   * every small function of two or three bits is ONE v_perm_b32 -- a byte look-up in a constant (selector bytes 1-3 = 0x0c
+//     give zero bytes, entry 7 of the eight-entry tables provides that 0x0c for the next selector): the state a walk arrives in
+//     and the distance to the next cell from t = (cur & am) | fx; which bits of the byte the departure looks at, from the state;
+//     am and fx from those bits;
+//   * the field of the byte a departure looks at (GAP_A: CA; GAP_B: FA, FB; MATCH: none) is one v_bfe_u32 whose WIDTH is the
+//     state itself (0, 1, 2 bits) and whose offset comes from the table;
+//   * the states of 16 steps collect in 32 bits (v_lshl_or_b32; 64-bit shifts are four instructions with their selects);
+//   * Needleman-Wunsch: nothing is predicated per step -- within a burst no walk can reach the border, a walk that is over
+//     gets 0 as its table of distances (it stays where it is) and its words are put back after the burst.
+// Same moves, words and meta as the kernels above; tests run every form (options dirs_local, walk_group).
+template <bool NW, int G>
+__global__ void __launch_bounds__(64) traceback_moves_group_local_kernel(const SaTraceParams p) {
+  constexpr int kT = 64, L = 64 / G;
+  static_assert(G == 2 || G == 4 || G == 8, "walks per wave");
+  __shared__ __attribute__((aligned(16))) uint8_t tiles[G * kT * kT];
+  const int lane = threadIdx.x, g = lane / L, lg = lane % L;
+  const uint32_t tbase = (uint32_t)g * (kT * kT);
+  const uint32_t w_raw = blockIdx.x * G + g;
+  const bool exists = w_raw < p.n_pairs;
+  const uint32_t w = exists ? w_raw : p.n_pairs - 1;
+  const MoveWalk m = move_walk<NW>(p, w);
+  const uint32_t lb = p.len_b[m.pair], W = p.len_a[m.pair] + 1;
+  const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
+  const MoveSlot s = m.slot;
+  constexpr uint32_t kState = 0x01020100u;                   // t -> MATCH, GAP_A, GAP_B, GAP_A (GA and BM)
+  constexpr uint32_t kDist = 0x40014041u;                    // t -> 65 (a row and a column back), 64 (a row), 1 (a column), 64
+  constexpr uint32_t kField = 0x00632202u;                   // state -> offset of the departure's field | first table entry << 5
+  constexpr uint32_t kAmLo = 0x00000203u, kAmHi = 0u;        // entry -> am: MATCH 3; GAP_A: !CA 2, CA 0; GAP_B 0
+  constexpr uint32_t kFxLo = 0x00010000u, kFxHi = 0x0c010201u;   // entry -> fx: GAP_A & CA: GAP_A; GAP_B: FA | FB << 1 -> 0 1 2 1; [7] = 0x0c
+  constexpr uint32_t kEnd = 0x00804020u;                     // state -> its "score is 0" bit of the byte (SW)
+  uint32_t x = m.x, y = m.y, kk = 0, reg_a = 0, reg_b = 0, ox = 0, oy = 0, at = tbase;
+  // what the LAST step left behind: the state it left in and the byte of the cell it left -- the departure's half of the decode
+  // (local_depart) is worked out from them at the START of the next step, beside that step's LDS read, so that only the arrival's
+  // three instructions sit between a byte and the next address.  No step yet: "left in GAP_B with FA / FB saying the given state".
+  uint32_t ps = MAT_GAP_B, pc = m.st << 3;
+  uint32_t codes = 0, codes_hi = 0;            // the states of the current word's steps, two bits each: steps 16-31 / steps 0-15, the first on top
+  bool live = exists && m.valid;
+  if constexpr (NW) live = live && x != 0 && y != 0;
+  bool fresh = true;
+  uint32_t k = 0;                              // steps every live walk has taken (wave-uniform)
+  auto keep_word = [&](uint32_t j, uint32_t wa, uint32_t wb, bool mine) __attribute__((always_inline)) {
+    if (mine && lg == (L - 1) - (int)(j % L)) { reg_a = wa; reg_b = wb; }
+  };
+  auto flush = [&](uint32_t q, int first_slot, bool mine) __attribute__((always_inline)) {
+    const int dst = s.nw - L * (int)(q + 1) + lg;
+    if (mine && lg >= first_slot) { s.plane_a[dst] = reg_a; s.plane_b[dst] = reg_b; }
+  };
+  // one step: the byte is asked for, the last step's departure decoded while it is on its way (am: which bits of this byte decide,
+  // fx: what is decided already), then the arrival: t, the state the walk stands in here
+  auto step_state = [&](uint32_t &cur, uint32_t &t) __attribute__((always_inline)) -> uint32_t {
+    cur = (uint32_t)tiles[at];
+    const uint32_t fld = __builtin_amdgcn_perm(0u, kField, ps);
+    const uint32_t q = __builtin_amdgcn_ubfe(pc, fld, ps) + __builtin_amdgcn_ubfe(fld, 5u, 3u) + 0x07070700u;
+    const uint32_t am = __builtin_amdgcn_perm(kAmHi, kAmLo, q), fx = __builtin_amdgcn_perm(kFxHi, kFxLo, q);
+    t = (cur & am) | fx;
+    return __builtin_amdgcn_perm(0u, kState, t);
+  };
+  while (__any(live)) {
+    const uint32_t tx0 = at & (kT - 1), ty0 = (at >> 6) & (kT - 1);
+    if (__any(live && (fresh || tx0 == 0 || ty0 == 0))) {   // (tiles renewed together: traceback_moves_group_kernel)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      group_load_tile<G>(p, tiles + tbase, Dg, x, y, W, lb, lg, ox, oy);
+      at = tbase + (y - oy) * kT + (x - ox);
+      fresh = false;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+    // ---- a burst: no live walk can leave its tile, none passes the end of a half word
+    uint32_t room = live ? max(min(at & (kT - 1), (at >> 6) & (kT - 1)), 1u) : 64u;
+#pragma unroll
+    for (int o = L; o < 64; o <<= 1) room = min(room, (uint32_t)__shfl_xor((int)room, o));
+    const uint32_t n = min((uint32_t)__builtin_amdgcn_readfirstlane((int)room), 16u - (k & 15u));
+    if constexpr (NW) {
+      const uint32_t dist = live ? kDist : 0u, codes0 = codes;
+      for (uint32_t i = 0; i < n; ++i) {
+        uint32_t cur, t;
+        const uint32_t st = step_state(cur, t);
+        at -= __builtin_amdgcn_perm(0u, dist, t);
+        codes = (codes << 2) | st;
+        ps = st; pc = cur;
+      }
+      codes = live ? codes : codes0;
+      kk += live ? n : 0u;
+    } else {
+      uint32_t dist = live ? kDist : 0u;
+      for (uint32_t i = 0; i < n; ++i) {
+        uint32_t cur, t;
+        const uint32_t st = step_state(cur, t);
+        const bool go = live && (cur & __builtin_amdgcn_perm(0u, kEnd, st)) == 0;   // else: this state's score is 0, the hit starts here
+        dist = go ? dist : 0u;
+        at -= __builtin_amdgcn_perm(0u, dist, t);
+        codes = go ? (codes << 2) | st : codes;
+        kk += go;
+        ps = go ? st : ps; pc = go ? cur : pc;
+        live = go;
+      }
+    }
+    k += n;
+    x = ox + (at & (kT - 1)); y = oy + ((at >> 6) & (kT - 1));
+    // half a word / a word of 32 columns complete: for the walks that have come this far
+    if ((k & 15u) == 0) {
+      const bool mine = exists && m.valid && kk == k;
+      if (k & 16u) {
+        codes_hi = mine ? codes : codes_hi;
+        codes = mine ? 0u : codes;
+      } else {
+        const unsigned long long full = (unsigned long long)codes_hi << 32 | codes;
+        const uint32_t j = (k >> 5) - 1;
+        keep_word(j, even_bits(full), even_bits(full >> 1), mine);
+        codes = mine ? 0u : codes; codes_hi = mine ? 0u : codes_hi;
+        if (j % L == L - 1) flush(j / L, 0, mine);
+      }
+    }
+    if constexpr (NW) live = live && x != 0 && y != 0;
+  }
+  const bool mine = exists && m.valid;
+  if (kk & 31u) {   // the unfinished word: its columns on top
+    const uint32_t j = kk >> 5, r = kk & 31u;
+    const unsigned long long part = r >= 16u ? ((unsigned long long)codes_hi << (2u * (r - 16u))) | codes : (unsigned long long)codes;
+    const unsigned long long top = part << (2u * (32u - r));
+    keep_word(j, even_bits(top), even_bits(top >> 1), mine);
+  }
+  // The words' way home.  In place over PCIe (seqalign_nw_batch's small chunks: no copy behind the kernel) a wave's G walks leave
+  // as 2 G pieces of ~24 bytes, each its own partial line -- ~20 000 of them for BASELINE configs[1], and the kernel's end waits
+  // for them (60 us where the walk needs 43: profiles/r06/r06_walkers.txt).  The walks' slots lie one behind the other
+  // (move_walk), so when every walk of the wave fits ONE block of L words per plane the wave puts its words where they belong
+  // in a copy of its whole region in LDS -- the tiles are done with -- zeros elsewhere, and writes the region as one run of
+  // consecutive lanes: whole lines but for its two ends.  (Words of a slot that the walk did not fill are never looked at:
+  // host/sa_moves.c takes the last ceil(columns / 32) of each plane.)
+  const uint32_t nwu = (uint32_t)s.nw;
+  if (p.tune_stage && !__any(exists && nwu > (uint32_t)L)) {
+    uint32_t *stg = reinterpret_cast<uint32_t *>(tiles);
+    const unsigned long long base_me = (unsigned long long)(s.plane_a - p.moves);      // my slot, in words from p.moves
+    const uint32_t n_here = min((uint32_t)G, p.n_pairs - blockIdx.x * G);               // walks of this wave (>= 1)
+    const unsigned long long base0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base_me, 0) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base_me >> 32), 0) << 32;
+    const uint32_t off = (uint32_t)(base_me - base0);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + 2u * nwu), (int)((n_here - 1u) * L));   // (slots ascend)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (uint32_t i = (uint32_t)lane; i < total; i += 64u) stg[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (mine && kk) {
+      const uint32_t j = (kk - 1) >> 5;                      // (< L: one block)
+      const int dst = (int)nwu - L + lg;
+      if (lg >= (L - 1) - (int)j) { stg[off + (uint32_t)dst] = reg_a; stg[off + nwu + (uint32_t)dst] = reg_b; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (uint32_t i = (uint32_t)lane; i < total; i += 64u) p.moves[base0 + i] = stg[i];
+  } else if (kk) {
     const uint32_t j = (kk - 1) >> 5;
     flush(j / L, (L - 1) - (int)(j % L), mine);
   }
@@ -887,12 +1094,19 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
         // (43 against 55 us for C2's walks into a device buffer, 52 against 72 for C4's), one wave per walk on row-major ones, where
         // both are bound by the lines the rows' pieces pull in and the lockstep form is the slower: profiles/r06/r06_walkers.txt)
         const uint32_t grp = p.tune_group ? p.tune_group : (p.dirs_blocked ? 4u : 1u);
+        if (p.dirs_local) {   // the byte's local form (sa_kernels.h): read by the tile walkers only -- the host asked for it knowing that
+          if (!tiles) return hipErrorInvalidValue;
+          if (grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+          else if (grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+          else hipLaunchKernelGGL((sa::traceback_moves_tile_kernel<true, true>), dim3(p.n_pairs), dim3(64), 0, stream, p);
+        } else
         if (tiles && grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
         else if (tiles && grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
         else if (tiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
         else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
         else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<true>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
       } else {
+      if (p.dirs_local) return hipErrorInvalidValue;   // (the walkers that write strings read the older form)
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<true>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_nw_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
@@ -907,13 +1121,19 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (wpb > 8) return hipErrorInvalidValue;
       // (walks_per_pair -- the one-trip multi-hit call, most slots empty -- stays one wave per pair)
       const uint32_t grp = p.tune_group ? p.tune_group : (p.dirs_blocked ? 4u : 1u);
+      if (p.dirs_local) {   // the best-hit path's bytes in their local form: tile walkers, one walk per pair
+        if (!wtiles || p.walks_per_pair) return hipErrorInvalidValue;
+        if (grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+        else if (grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((sa::traceback_moves_tile_kernel<false, true>), dim3(p.n_pairs), dim3(64), 0, stream, p);
+      } else
       if (wtiles && !p.walks_per_pair && grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
       else if (wtiles && !p.walks_per_pair && grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
       else if (wtiles) hipLaunchKernelGGL(sa::traceback_moves_tile_kernel<false>, dim3((p.n_pairs + wpb - 1) / wpb), dim3(64), 0, stream, p);
       else if (p.stage_words && p.stage_words <= 95u) hipLaunchKernelGGL(sa::traceback_moves_lane_ahead_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), (size_t)(p.stage_words + 1) * 512, stream, p);
       else hipLaunchKernelGGL(sa::traceback_moves_lane_kernel<false>, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);
     } else {            // SW hits behind sa_fill_dirs.hip
-      if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos) return hipErrorInvalidValue;
+      if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_pos || p.dirs_local) return hipErrorInvalidValue;
       sa_record_launch(tiles ? SEQALIGN_K_WALK_DIRS_TILE : SEQALIGN_K_WALK_DIRS_LANE, p.n_pairs);
       if (tiles) hipLaunchKernelGGL(sa::traceback_dirs_tile_kernel<false>, dim3(p.n_pairs), dim3(64), 0, stream, p);
       else hipLaunchKernelGGL(sa::traceback_dirs_kernel, dim3((p.n_pairs + 63) / 64), dim3(64), 0, stream, p);

@@ -720,14 +720,16 @@ def test_blocked_direction_bytes_at_the_blocks_edges(ctx, opts, form):
             batches = list(groups.values())
         else:
             batches = [pairs]
-        for walker, grp in (("wave", 0), ("wave", 1), ("wave", 8), ("lane", 0)):
-            opts(trace_kernel=walker, walk_group=grp)
-            for bp in batches[:: (3 if (walker, grp) != ("wave", 0) else 1)]:
+        # (dirs_local: the byte's LOCAL form -- a cell's own comparisons, the tile walkers resolve the state they arrive in,
+        #  csrc/sa_kernels.h -- is what tile walks get by default; 0: the older form through the same fills and walkers)
+        for walker, grp, local in (("wave", 0, 1), ("wave", 1, 1), ("wave", 8, 1), ("lane", 0, 1), ("wave", 0, 0), ("wave", 1, 0)):
+            opts(trace_kernel=walker, walk_group=grp, dirs_local=local)
+            for bp in batches[:: (3 if (walker, grp, local) != ("wave", 0, 1) else 1)]:
                 batch = W.from_pairs(bp)
                 got = ctx.nw_batch(batch, sc)
                 best = ctx.sw_batch(batch, sw, 4, max_hits=1)
                 for p, (a, b) in enumerate(bp):
                     rc, s_, ra, rb = O.oracle_nw(osc, a, b)
-                    assert rc == 0 and got[p] == (s_, ra, rb), (form, walker, grp, la, len(b), p)
+                    assert rc == 0 and got[p] == (s_, ra, rb), (form, walker, grp, local, la, len(b), p)
                     rc, want = O.oracle_sw(osw, a, b, 4, 1)
-                    assert rc == 0 and best[p] == want, (form, walker, grp, la, len(b), p)
+                    assert rc == 0 and best[p] == want, (form, walker, grp, local, la, len(b), p)
