@@ -74,7 +74,7 @@ for key in ("C2_10000", "C5_125000", "C3_10000", "C4_4000", "C3_10000_hits4", "C
         iv = insts.get(k)
         if iv:
             e["instructions"] = sum(iv) / len(iv)
-        m = next((x for x in mix if x["demangled"] in k.replace("sa::", "")), None)
+        m = next((x for x in mix if x["demangled"] in k.replace("sa::", "") and k.rstrip().endswith(x.get("ends", ""))), None)
         if m and iv:
             cpi = m["mix"]["cycles_per_valu_instruction"]
             e["cycles_per_instruction"] = cpi

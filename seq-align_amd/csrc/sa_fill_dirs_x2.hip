@@ -1338,6 +1338,33 @@ fill_sw_best_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   sw_best_x2_wave<CPL, SUBST, R, 32, LOCAL>(p, dirs_arena, lo, hi, has_lo, has_hi, lane, reinterpret_cast<uint8_t *>(lds) + wave * (4 * R), tbl_lds);
 }
 
+// Four AND two pairs per wave in one grid (fill_nw_dirs_x4x2_kernel's idea for the best-hit fill): BASELINE configs[2]'s 10 000
+// pairs of 151-column rows are 5 000 two-per-wave waves -- some SIMDs five, some four -- or 2 500 four-per-wave ones -- three or
+// two; as 2 048 four-per-wave waves (two on every SIMD) + 904 two-per-wave ones the busiest SIMD has the least to do.
+template <int CPL4, int SUBST, int R, bool LOCAL>
+__global__ void __launch_bounds__(kWave * 4)
+fill_sw_best_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena, const uint32_t q_blocks, const uint32_t pairs_q) {
+  constexpr int CPL2 = (CPL4 + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const uint32_t waves = blockDim.x >> 6;
+  const uint32_t tbl_lds = waves * (4 * R);
+  load_table_x2<SUBST>(p, tbl_lds);
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (4 * R);
+  if (blockIdx.x < q_blocks) {   // (uniform per workgroup)
+    const uint32_t unit = blockIdx.x * waves + wave;
+    if (4 * unit >= pairs_q) return;
+    const uint32_t lo = 4 * unit + 2 * ((uint32_t)lane >> 5);
+    sw_best_x2_wave<CPL4, SUBST, R, 32, LOCAL>(p, dirs_arena, lo, lo + 1, true, true, lane, ring, tbl_lds);
+  } else {
+    const uint32_t pair0 = pairs_q + 2 * ((blockIdx.x - q_blocks) * waves + wave);
+    if (pair0 >= p.n_pairs) return;
+    const bool two = pair0 + 1 < p.n_pairs;
+    sw_best_x2_wave<CPL2, SUBST, R, 64, LOCAL>(p, dirs_arena, pair0, two ? pair0 + 1 : pair0, true, two, lane, ring, tbl_lds);
+  }
+}
+
 template <int CPL, int R0>
 static hipError_t launch_sw_best_x2_cpl(const SaFillParams &p, uint8_t *dirs, hipStream_t stream) {
   constexpr int R = x2_ring(64, CPL, R0);   // (blocked direction bytes: a block row per pair instead of the ring)
@@ -1411,6 +1438,19 @@ static hipError_t launch_nw_dirs_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, 
   else if (p.K <= 1) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
   else if (p.dirs_local) hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
   else hipLaunchKernelGGL((fill_nw_dirs_x4x2_kernel<CPL4, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
+  return hipGetLastError();
+}
+
+template <int CPL4>
+static hipError_t launch_sw_best_x4x2_cpl(const SaFillParams &p, uint8_t *dirs, uint32_t pairs_q, hipStream_t stream) {
+  constexpr int R = x2_ring(64, (CPL4 + 1) / 2, x2_ring(32, CPL4, 512));
+  const int wpb = 4;
+  const uint32_t q_blocks = (pairs_q / 4 + wpb - 1) / wpb, x2_blocks = ((p.n_pairs - pairs_q + 1) / 2 + wpb - 1) / wpb;
+  const dim3 grid(q_blocks + x2_blocks), block(kWave * wpb);
+  if (p.K <= 1 && p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R, true>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
+  else if (p.K <= 1) hipLaunchKernelGGL((fill_sw_best_x4x2_kernel<CPL4, SA_SUBST_SIMPLE, R, false>), grid, block, (size_t)wpb * 4 * R, stream, p, dirs, q_blocks, pairs_q);
+  else if (p.dirs_local) hipLaunchKernelGGL((fill_sw_best_x4x2_kernel<CPL4, SA_SUBST_LDS, R, true>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
+  else hipLaunchKernelGGL((fill_sw_best_x4x2_kernel<CPL4, SA_SUBST_LDS, R, false>), grid, block, (size_t)wpb * 4 * R + table_lds_bytes(p), stream, p, dirs, q_blocks, pairs_q);
   return hipGetLastError();
 }
 
@@ -1531,6 +1571,23 @@ bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
+  // whole rounds of four-per-wave waves + a rest that is less than half a round: both kinds of waves in one grid (round 6: from
+  // 8 192 pairs, and only when the choice is left to the library)
+  if (const int c4 = p.tune_quad == 0 ? sa_x4_columns(p, max_len_a, 8192u) : 0) {
+    const uint32_t pairs_q = p.n_pairs / 4096u * 4096u, rest = p.n_pairs - pairs_q;
+    if (pairs_q && rest && rest <= 2048u) {
+      sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X4, pairs_q);
+      sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X2, rest);
+      switch (c4) {
+        case 1: return sa::launch_sw_best_x4x2_cpl<1>(p, dirs, pairs_q, stream);
+        case 2: return sa::launch_sw_best_x4x2_cpl<2>(p, dirs, pairs_q, stream);
+        case 3: return sa::launch_sw_best_x4x2_cpl<3>(p, dirs, pairs_q, stream);
+        case 4: return sa::launch_sw_best_x4x2_cpl<4>(p, dirs, pairs_q, stream);
+        case 5: return sa::launch_sw_best_x4x2_cpl<5>(p, dirs, pairs_q, stream);
+        default: return sa::launch_sw_best_x4x2_cpl<6>(p, dirs, pairs_q, stream);
+      }
+    }
+  }
   if (const int c4 = sa_x4_columns(p, max_len_a, 16384u)) {
     sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X4, p.n_pairs);
     switch (c4) {

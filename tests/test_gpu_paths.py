@@ -311,7 +311,7 @@ def test_four_pairs_per_wave(ctx, opts, la, lb):
 
 
 def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
-    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 16 384, rows up to 192 columns; ragged
+    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 16 384 (from 8 192 as whole rounds + a short rest), rows up to 192 columns; ragged
     chunks (a pair list) and the multi-hit fill stay two per wave; a substitution table (BLOSUM62) goes four per wave too."""
     sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     opts(pack16=1, quad=0)
@@ -355,6 +355,25 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
     assert ctx.last_call()["fill_sw_best_x4"] == (1, 16384)
     opts(quad=1)
     assert got == ctx.sw_batch(sw, sc_sw, 10, max_hits=1)
+    # the best-hit fill's mixed grid (round 6): whole rounds of four-per-wave waves + a rest of less than half a round two per wave,
+    # from 8 192 pairs on -- BASELINE configs[2]'s 10 000 pairs are 8 192 + 1 808 -- with match / mismatch and with a table
+    opts(quad=0, pack16=1)
+    for spec, alpha, thr in (({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, b"ACGT", 10), ({"preset": "BLOSUM62"}, b"ARNDCQEGHILKMFPSTWYV", 20)):
+        scx = S.make_scoring(spec)
+        mixed, pairs = gap_rich(8192 + 213, 38, 61, 79, alpha=alpha)
+        got = ctx.sw_batch(mixed, scx, thr, max_hits=1)
+        info = ctx.last_call()
+        assert info["fill_sw_best_x4"] == (1, 8192) and info["fill_sw_best_x2"] == (1, 213), info
+        opts(quad=1)
+        assert got == ctx.sw_batch(mixed, scx, thr, max_hits=1)
+        assert "fill_sw_best_x4" not in ctx.last_call()
+        opts(quad=0)
+        ox = osc_of(scx)
+        for p in list(range(0, 8192, 397)) + list(range(8186, 8405)):
+            rc, want = O.oracle_sw(ox, *pairs[p], thr, 1)
+            assert rc == 0 and got[p] == want, (spec, p)
+    ctx.sw_batch(uniform(8192 + 2049, 40, 30, 9), sc_sw, 10, max_hits=1)   # more than half a round left: two per wave (below 16 384 pairs)
+    assert "fill_sw_best_x2" in ctx.last_call() and "fill_sw_best_x4" not in ctx.last_call()
     opts(quad=2, pack16=2)
     ctx.sw_batch(uniform(64, 40, 30, 5), sc_sw, 10, max_hits=4)      # the multi-hit fill has no such form
     assert "fill_sw_dirs_x2" in ctx.last_call()
