@@ -16,6 +16,7 @@ name, local = sys.argv[1], sys.argv[2]
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 extra = dict(a.split("=", 1) for a in sys.argv[4:])   # further options of the context: key=value
 gen, kwargs, n, is_sw, spec, _ = WORKLOADS[name]
+n = int(extra.pop("pairs", n))   # (pairs=N: the config's shape, another batch size)
 batch = W.dna_nw_indexed(0, n, **kwargs) if name == "C5" else getattr(W, gen)(n, **kwargs)
 sc = S.make_scoring(spec)
 thr = W.default_minscore(sc.match, int(batch.len_a[0]), int(batch.len_b[0])) if is_sw else 0

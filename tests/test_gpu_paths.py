@@ -311,7 +311,7 @@ def test_four_pairs_per_wave(ctx, opts, la, lb):
 
 
 def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
-    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 16 384 (from 8 192 as whole rounds + a short rest), rows up to 192 columns; ragged
+    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 8 192 (whole rounds + a short rest two per wave in the same grid), rows up to 192 columns; ragged
     chunks (a pair list) and the multi-hit fill stay two per wave; a substitution table (BLOSUM62) goes four per wave too."""
     sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     opts(pack16=1, quad=0)
@@ -372,7 +372,9 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
         for p in list(range(0, 8192, 397)) + list(range(8186, 8405)):
             rc, want = O.oracle_sw(ox, *pairs[p], thr, 1)
             assert rc == 0 and got[p] == want, (spec, p)
-    ctx.sw_batch(uniform(8192 + 2049, 40, 30, 9), sc_sw, 10, max_hits=1)   # more than half a round left: two per wave (below 16 384 pairs)
+    ctx.sw_batch(uniform(8192 + 2049, 40, 30, 9), sc_sw, 10, max_hits=1)   # more than half a round left: four per wave throughout
+    assert ctx.last_call()["fill_sw_best_x4"] == (1, 8192 + 2049) and "fill_sw_best_x2" not in ctx.last_call()
+    ctx.sw_batch(uniform(8191, 40, 30, 10), sc_sw, 10, max_hits=1)         # below two whole rounds: two per wave
     assert "fill_sw_best_x2" in ctx.last_call() and "fill_sw_best_x4" not in ctx.last_call()
     opts(quad=2, pack16=2)
     ctx.sw_batch(uniform(64, 40, 30, 5), sc_sw, 10, max_hits=4)      # the multi-hit fill has no such form
