@@ -574,14 +574,20 @@ def measure(args, grp, env, workload, steps, warmup, pairs):
             for j in pending:
                 j.wait(raw=True)
         stream_once(2 * in_flight)
-        grp.barrier()
-        t1 = time.perf_counter()
-        stream_once(n_stream)
-        dt = grp.max_float(time.perf_counter() - t1)
+        # (the lanes' host threads share the box's CPUs with whatever else runs there: one stream of 32 batches took 1.8 - 3.1 ms per C3
+        #  batch within one minute on one box -- three streams, the median one is the figure, all three are in the line)
+        dts = []
+        for _ in range(3):
+            grp.barrier()
+            t1 = time.perf_counter()
+            stream_once(n_stream)
+            dts.append(grp.max_float(time.perf_counter() - t1))
+        dt = sorted(dts)[1]
         e2e["stream"] = {"call": f"{call_s} x {n_stream}, {in_flight} in flight (seqalign_job_wait {in_flight} behind the submits), own output buffers per job in flight",
                          "batches": n_stream, "in_flight": in_flight, "ms_per_batch": dt / n_stream * 1e3,
                          "value": total_cells * n_stream / dt / 1e9, "unit": "GCUPS",
-                         "vs_synchronous": (total_cells * n_stream / dt) / (total_cells / wall)}
+                         "vs_synchronous": (total_cells * n_stream / dt) / (total_cells / wall),
+                         "streams_ms_per_batch": [round(x / n_stream * 1e3, 4) for x in dts], "of_three_streams": "the median"}
 
     torch.cuda.synchronize()
     for _ in range(warmup):

@@ -1487,8 +1487,8 @@ bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 // Four pairs per wave (32 lanes a couple) instead of two: every pair of the launch one shape (no pair list), rows up to 192
 // columns (six columns per lane of a span: beyond that the registers cost more than the lanes save), and pairs enough that
 // half as many waves still fill the chip (min_pairs: NW 4 096 -- measured 3-7 % faster from there to 40 000 pairs of 150 x 150;
-// SW best hit 8 192 -- round 4 measured 150 x 1000 level at 10 000 pairs, where 2 500 waves leave some SIMDs with three and some
-// with two, and 8-9 % ahead from 16 000 on (profiles/r04/r04_quad_fills.txt); round 6 by whole rounds: ahead from 8 192 on, and
+// SW best hit 4 097 -- round 4 measured 150 x 1000 level at 10 000 pairs, where 2 500 waves leave some SIMDs with three and some
+// with two, and 8-9 % ahead from 16 000 on (profiles/r04/r04_quad_fills.txt); round 6 by whole rounds: ahead from more than one round (4 096 pairs) on, and
 // the short rest two per wave in the same grid, sa_launch_fill_sw_best_x2) -- or whenever the shape allows (option quad = 2: tests), or never
 // (quad = 1).  Returns the columns per lane of a span, 0 = two pairs per wave.
 static int sa_x4_columns(const SaFillParams &p, uint32_t max_len_a, uint32_t min_pairs) {
@@ -1572,11 +1572,15 @@ bool sa_sw_best_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  // Four pairs per wave from 8 192 pairs on (round 6; 16 384 before): by batch size, 150 x 1 000 (profiles/r06/r06_local_dirs.txt) -- 8 192
-  // pairs: 1 346 us two per wave / 1 206 four per wave, 11 000: 1 942 / 1 685, 12 288: 1 978 / 1 695, 16 384: 2 613 / 2 190; 6 144: 1 050 /
-  // 1 183.  A rest of less than half a round of four-per-wave waves goes two per wave in the same grid (fill_sw_best_x4x2_kernel:
-  // 10 000 pairs 1 643 / 1 680 -> 1 393, 14 000: 2 282 / 2 168 -> 1 886) when the choice is left to the library.
-  if (const int c4 = sa_x4_columns(p, max_len_a, 8192u)) {
+  // Four pairs per wave from MORE than one whole round of four-per-wave waves on (4 097 pairs; round 6 -- 16 384 before): the cost is a
+  // step function of whole rounds of resident waves.  By batch size, 150 x 1 000, two / four per wave, us (profiles/r06/r06_local_dirs.txt):
+  // 4 096 pairs 746 / 797; 7 000: 1 343 / 1 185; 8 192: 1 346 / 1 206; 11 000: 1 942 / 1 685; 12 288: 1 978 / 1 695; 16 384: 2 613 / 2 190.  A rest of
+  // less than half a round of four-per-wave waves goes two per wave in the same grid (fill_sw_best_x4x2_kernel: 5 000 pairs 1 032 -> 893,
+  // 6 144: 1 048 -> 914, 10 000: 1 643 / 1 680 -> 1 393, 14 000: 2 282 / 2 168 -> 1 886) when the choice is left to the library.
+#ifndef SA_BEST_X4_MIN
+#define SA_BEST_X4_MIN 4097u
+#endif
+  if (const int c4 = sa_x4_columns(p, max_len_a, SA_BEST_X4_MIN)) {
     const uint32_t pairs_q = p.n_pairs / 4096u * 4096u, rest = p.n_pairs - pairs_q;
     if (p.tune_quad == 0 && pairs_q && rest && rest <= 2048u) {
       sa_record_launch(SEQALIGN_K_FILL_SW_BEST_X4, pairs_q);

@@ -311,7 +311,7 @@ def test_four_pairs_per_wave(ctx, opts, la, lb):
 
 
 def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
-    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 8 192 (whole rounds + a short rest two per wave in the same grid), rows up to 192 columns; ragged
+    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 4 097 (whole rounds + a short rest two per wave in the same grid), rows up to 192 columns; ragged
     chunks (a pair list) and the multi-hit fill stay two per wave; a substitution table (BLOSUM62) goes four per wave too."""
     sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     opts(pack16=1, quad=0)
@@ -356,7 +356,7 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
     opts(quad=1)
     assert got == ctx.sw_batch(sw, sc_sw, 10, max_hits=1)
     # the best-hit fill's mixed grid (round 6): whole rounds of four-per-wave waves + a rest of less than half a round two per wave,
-    # from 8 192 pairs on -- BASELINE configs[2]'s 10 000 pairs are 8 192 + 1 808 -- with match / mismatch and with a table
+    # from 4 097 pairs on -- BASELINE configs[2]'s 10 000 pairs are 8 192 + 1 808 -- with match / mismatch and with a table
     opts(quad=0, pack16=1)
     for spec, alpha, thr in (({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]}, b"ACGT", 10), ({"preset": "BLOSUM62"}, b"ARNDCQEGHILKMFPSTWYV", 20)):
         scx = S.make_scoring(spec)
@@ -374,8 +374,14 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
             assert rc == 0 and got[p] == want, (spec, p)
     ctx.sw_batch(uniform(8192 + 2049, 40, 30, 9), sc_sw, 10, max_hits=1)   # more than half a round left: four per wave throughout
     assert ctx.last_call()["fill_sw_best_x4"] == (1, 8192 + 2049) and "fill_sw_best_x2" not in ctx.last_call()
-    ctx.sw_batch(uniform(8191, 40, 30, 10), sc_sw, 10, max_hits=1)         # below two whole rounds: two per wave
+    ctx.sw_batch(uniform(4096, 40, 30, 10), sc_sw, 10, max_hits=1)         # one whole round and nothing more: two per wave
     assert "fill_sw_best_x2" in ctx.last_call() and "fill_sw_best_x4" not in ctx.last_call()
+    small, pairs = gap_rich(4096 + 300, 38, 61, 80)
+    got = ctx.sw_batch(small, sc_sw, 10, max_hits=1)
+    assert ctx.last_call()["fill_sw_best_x4"] == (1, 4096) and ctx.last_call()["fill_sw_best_x2"] == (1, 300)
+    for p in list(range(0, 4096, 509)) + list(range(4090, 4396, 7)):
+        rc, want = O.oracle_sw(osc_of(sc_sw), *pairs[p], 10, 1)
+        assert rc == 0 and got[p] == want, p
     opts(quad=2, pack16=2)
     ctx.sw_batch(uniform(64, 40, 30, 5), sc_sw, 10, max_hits=4)      # the multi-hit fill has no such form
     assert "fill_sw_dirs_x2" in ctx.last_call()
