@@ -401,6 +401,7 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *                                           direction bytes laid out in blocks (NW, best hit; rows <= 512 columns), else one wave per walk
  *   dirs_local      1 | 0                   chunks whose walks are tile walks: the direction byte holds the cell's own comparisons and the
  *                                           walker resolves the state it arrives in (cheaper to write; 0: the older form everywhere)
+ *   walk_tile       0 | 32 | 64             that walker's tile edge in bytes (0: 32 for global walks -- fewer lines per reload --, 64 for best-hit walks)
  *   walk_stage      1 | 0                   that walker sends a wave's moves home as one run of whole lines out of LDS (0: two pieces per walk)
  *   subbatches      0 (by size) .. 256      sub-batches a chunk of seqalign_nw_batch is pipelined in (1 = off)
  *   nw_dirs, sweep_dirs  1 | 0              direction bytes instead of the three matrices where they apply (above)

@@ -1015,7 +1015,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
         t.moves = dv_moves + 2 * g0;        // walk w of the launch is pair g0 + w: words 2 ((slot >> 5) + g0 + w)
         t.out_meta2 = dv_meta + 2 * g0;
         t.fill_status = d.status;
-        t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.dirs_local = local; t.tune_stage = ctx->opt.walk_stage; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
+        t.dirs = ctx->dirs.as<uint8_t>(); t.dirs_blocked = blocked; t.dirs_local = local; t.tune_stage = ctx->opt.walk_stage; t.tune_tile = ctx->opt.walk_tile; t.nw_score = ctx->best_score.as<int32_t>() + g0; t.nw_state = ctx->best_index.as<uint64_t>() + g0;
         t.n_pairs = (uint32_t)(g1 - g0); t.K = sc->flat.n_classes; t.open1 = sc->flat.open1; t.ext = sc->flat.ext;
         t.gen_eq = sc->flat.gen_eq; t.gen_ne = sc->flat.gen_ne; t.flags = sc->flat.flags;
         t.tune_walker = ctx->opt.trace_kernel; t.tune_group = ctx->opt.walk_group;

@@ -688,7 +688,7 @@ static int sw_chunk_best_hit(seqalign_ctx *ctx, const seqalign_batch_t *batch, c
     tp.stage_words = (c.max_a + c.max_b + 31u) >> 5;
     tp.moves = ctx->h_ta.dev_as<uint32_t>(); tp.out_meta4 = ctx->h_B.dev_as<uint32_t>();
     tp.start_index = ctx->best_index.as<uint64_t>(); tp.start_score = ctx->best_score.as<int32_t>();
-    tp.dirs = ctx->dirs.as<uint8_t>(); tp.dirs_blocked = sa_dirs_blocked_shape(c.max_a); tp.dirs_local = local; tp.tune_stage = ctx->opt.walk_stage; tp.fill_status = d.status;
+    tp.dirs = ctx->dirs.as<uint8_t>(); tp.dirs_blocked = sa_dirs_blocked_shape(c.max_a); tp.dirs_local = local; tp.tune_stage = ctx->opt.walk_stage; tp.tune_tile = ctx->opt.walk_tile; tp.fill_status = d.status;
     tp.n_pairs = (uint32_t)n; tp.K = sc->flat.n_classes; tp.open1 = sc->flat.open1; tp.ext = sc->flat.ext;
     tp.gen_eq = sc->flat.gen_eq; tp.gen_ne = sc->flat.gen_ne; tp.flags = sc->flat.flags; tp.tune_walker = ctx->opt.trace_kernel; tp.tune_group = ctx->opt.walk_group;
     hipError_t e2 = sa_launch_nw_traceback(tp, st);

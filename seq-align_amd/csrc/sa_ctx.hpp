@@ -334,6 +334,7 @@ struct SaOptions {
   float arena_quality = 1.045f;    // arena_quality     placement probe ratio that ends the walk early (else: the best candidate of the whole walk)
   uint32_t arena_free_pct = 60;   // arena_free_pct    share of the memory free at the start that an explicit placement walk may hold (10 .. 90)
   uint32_t dirs_local = 1;        // dirs_local        1|0: chunks whose walks are tile walks (NW moves path, SW best hit) get the LOCAL form of the direction byte (sa_kernels.h): cheaper to write, resolved by the walker
+  uint32_t walk_tile = 0;         // walk_tile         0|32|64: the local tile walker's tile edge in bytes (0: 32 for global walks, 64 for best-hit walks)
   uint32_t walk_stage = 1;        // walk_stage        1|0: the local tile walker writes a wave's moves as one contiguous run out of LDS (whole lines over PCIe) instead of two pieces per walk
   uint32_t walk_group = 0;        // walk_group        0|1|4|8: walks per wave of the tile walker on moves (0: four in lockstep on blocked direction bytes, else one; 1 / 4 / 8: forced)
   uint32_t async_lanes = 0;       // async_lanes       1..8 (0 = 3): batches seqalign_*_batch_submit keeps in flight per context (sa_async.hip)

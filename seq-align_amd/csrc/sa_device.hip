@@ -236,6 +236,7 @@ static bool set_option(seqalign_ctx *ctx, const char *key, const char *val) {
   if (is("async_lanes")) { if (!number(0, 8, &num)) return false; o.async_lanes = (uint32_t)num; return true; }
   if (is("dirs_local")) { if (!number(0, 1, &num)) return false; o.dirs_local = (uint32_t)num; return true; }
   if (is("walk_stage")) { if (!number(0, 1, &num)) return false; o.walk_stage = (uint32_t)num; return true; }
+  if (is("walk_tile")) { if (!number(0, 64, &num) || !(num == 0 || num == 32 || num == 64)) return false; o.walk_tile = (uint32_t)num; return true; }
   if (is("walk_group")) { if (!number(0, 8, &num) || !(num == 0 || num == 1 || num == 4 || num == 8)) return false; o.walk_group = (uint32_t)num; return true; }
   if (is("arena_free_pct")) { if (!number(10, 90, &num)) return false; o.arena_free_pct = (uint32_t)num; return true; }
   if (is("arena_quality")) {
@@ -281,6 +282,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
   if (is("async_lanes")) return n(o.async_lanes);
   if (is("dirs_local")) return n(o.dirs_local);
   if (is("walk_stage")) return n(o.walk_stage);
+  if (is("walk_tile")) return n(o.walk_tile);
   if (is("walk_group")) return n(o.walk_group);
   if (is("arena_free_pct")) return n(o.arena_free_pct);
   if (is("arena_quality")) { char buf[32]; snprintf(buf, sizeof(buf), "%.6g", (double)o.arena_quality); *out = buf; return true; }
@@ -291,7 +293,7 @@ static bool get_option(const seqalign_ctx *ctx, const char *key, std::string *ou
 // SEQALIGN_HOST_THREADS: the process-wide worker pool, sa_ctx.hpp)
 static void options_from_env(seqalign_ctx *ctx) {
   static const char *keys[] = {"kernel", "cpl", "wpb", "lds_pad", "traceback", "trace_kernel", "sweep_mode", "sweep_strip",
-                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes", "walk_group", "dirs_local", "walk_stage"};
+                               "sweep_cpl", "sweep_ev", "sweep_trace", "sweep_dirs", "nw_dirs", "pack16", "quad", "walk_overlap", "nw_moves", "zero_copy", "reduce_depth", "timing", "chunk_bytes", "subbatches", "arena_scan_gib", "arena_quality", "arena_keep_gib", "upload_slices", "arena_free_pct", "async_lanes", "walk_group", "dirs_local", "walk_stage", "walk_tile"};
   for (const char *k : keys) {
     std::string name = "SEQALIGN_";
     for (const char *c = k; *c; ++c) name += (char)toupper((unsigned char)*c);

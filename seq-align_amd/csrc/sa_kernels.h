@@ -241,6 +241,7 @@ struct SaTraceParams {
   uint32_t tune_walker;        /* host side only: 0 = by batch shape, 1 = one lane per walk, 2 = one wave per walk (option trace_kernel) */
   uint32_t dirs_blocked;       /* `dirs` is laid out in blocks of 8 x 16 cells (above) instead of row-major at pitch len_a + 1 */
   uint32_t tune_group;         /* host side only: the tile walker on moves: 0 / 4 = four walks per wave in lockstep, 8 = eight, 1 = one (option walk_group) */
+  uint32_t tune_tile;          /* host side only: the local tile walker's tile edge: 32 or 64 bytes; 0 = 32 for NW walks, 64 for SW ones (option walk_tile) */
   uint32_t tune_stage;         /* host side only: the local tile walker writes a wave's moves as one run out of LDS (option walk_stage) */
   uint32_t dirs_local;         /* `dirs` holds the LOCAL form of the direction byte (above): tile walkers on moves only */
   const uint8_t *dirs;         /* SW multi-hit path behind sa_fill_dirs.hip: walks follow the direction bytes (hit_keys != NULL) */

@@ -640,45 +640,46 @@ __global__ void __launch_bounds__(64) traceback_moves_tile_kernel(const SaTraceP
 // are written in place into pinned host memory (seqalign_nw_batch's small chunks: no copy behind the kernel) both forms take
 // 60-65 us: 20 000 scattered 24-byte pieces over PCIe, ~9 GB/s, are then what the kernel's end waits for.  Default (option
 // walk_group = 0): four walks per wave on blocked direction bytes, one wave per walk on row-major ones.
-// The tile of one group's walk: 64 x 64 bytes whose bottom-right cell is where the walk stands (blocked direction bytes: whose
-// last block row / column hold it), L = 64 / G lanes loading kT / L rows each; all of a lane's rows are asked for before the
+// The tile of one group's walk: KT x KT bytes whose bottom-right cell is where the walk stands (blocked direction bytes: whose
+// last block row / column hold it), L = 64 / G lanes loading KT / L rows each; all of a lane's pieces are asked for before the
 // first is written to LDS: one latency per reload, not one per row.  ox / oy: the matrix cell of the tile's first byte.
-template <int G>
+template <int G, int KT = 64>
 __device__ __forceinline__ void group_load_tile(const SaTraceParams &p, uint8_t *tile, const uint8_t *__restrict__ Dg, uint32_t x, uint32_t y,
                                                 uint32_t W, uint32_t lb, int lg, uint32_t &ox, uint32_t &oy) {
-  constexpr int kT = 64, L = 64 / G, kRows = kT / L;
+  constexpr int kT = KT, L = 64 / G, kRows = kT / L, kQ = kT / 16;   // rows per lane; 16-byte pieces per row = block columns of a tile
+  static_assert(kT % L == 0 && kT % 16 == 0, "whole rows per lane, whole blocks per row");
   typedef uint32_t u4_u __attribute__((ext_vector_type(4), aligned(1)));
-  u4_u buf[kRows][4];
-  if (p.dirs_blocked) {   // (wave-uniform) 8 x 4 blocks whose last block row / column hold (x, y): load_dirs_tile, 16 lanes a tile
+  u4_u buf[kRows][kQ];
+  if (p.dirs_blocked) {   // (wave-uniform) kT / 8 x kQ blocks whose last block row / column hold (x, y): load_dirs_tile, L lanes a tile
     const uint32_t nbx = (W + 15u) >> 4, nby = (lb + 8u) >> 3;
-    const uint32_t bx0 = (x >> 4) >= 3u ? (x >> 4) - 3u : 0u, by0 = (y >> 3) >= 7u ? (y >> 3) - 7u : 0u;
+    const uint32_t bx0 = (x >> 4) >= (uint32_t)(kQ - 1) ? (x >> 4) - (kQ - 1) : 0u, by0 = (y >> 3) >= (uint32_t)(kT / 8 - 1) ? (y >> 3) - (kT / 8 - 1) : 0u;
     ox = bx0 << 4; oy = by0 << 3;
 #pragma unroll
-    for (int i = 0; i < kRows * 4; ++i) {
-      const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = min(by0 + (pc >> 5), nby - 1u), bc = (pc >> 3) & 3u, r = pc & 7u;
-      buf[i >> 2][i & 3] = *reinterpret_cast<const u4_u *>(Dg + ((uint64_t)br * nbx + bx0 + bc) * 128u + r * 16u);
+    for (int i = 0; i < kRows * kQ; ++i) {
+      const uint32_t pc = (uint32_t)(lg * kRows * kQ + i), br = min(by0 + pc / (8u * kQ), nby - 1u), bc = (pc >> 3) % kQ, r = pc & 7u;
+      buf[i / kQ][i % kQ] = *reinterpret_cast<const u4_u *>(Dg + ((uint64_t)br * nbx + bx0 + bc) * 128u + r * 16u);
     }
 #pragma unroll
-    for (int i = 0; i < kRows * 4; ++i) {
-      const uint32_t pc = (uint32_t)(lg * kRows * 4 + i), br = pc >> 5, bc = (pc >> 3) & 3u, r = pc & 7u;
-      *reinterpret_cast<u4_u *>(tile + (br * 8u + r) * kT + bc * 16u) = buf[i >> 2][i & 3];
+    for (int i = 0; i < kRows * kQ; ++i) {
+      const uint32_t pc = (uint32_t)(lg * kRows * kQ + i), br = pc / (8u * kQ), bc = (pc >> 3) % kQ, r = pc & 7u;
+      *reinterpret_cast<u4_u *>(tile + (br * 8u + r) * kT + bc * 16u) = buf[i / kQ][i % kQ];
     }
   } else {
     ox = x >= (uint32_t)(kT - 1) ? x - (kT - 1) : 0; oy = y >= (uint32_t)(kT - 1) ? y - (kT - 1) : 0;
 #pragma unroll
     for (int r4 = 0; r4 < kRows; ++r4) {
-      // 64 bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
+      // kT bytes of row oy + tr from column ox on (past the row's end: the next row, or the buffer's slack; a row past the
       // pair's last: that last row again -- never looked at: the walk only moves up and left of (x, y))
       const uint32_t tr = (uint32_t)(lg * kRows + r4), r = min(oy + tr, lb);
       const uint8_t *src = Dg + (uint64_t)r * W + ox;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) buf[r4][q] = *reinterpret_cast<const u4_u *>(src + 16 * q);
+      for (int q = 0; q < kQ; ++q) buf[r4][q] = *reinterpret_cast<const u4_u *>(src + 16 * q);
     }
 #pragma unroll
     for (int r4 = 0; r4 < kRows; ++r4) {
       const uint32_t tr = (uint32_t)(lg * kRows + r4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
+      for (int q = 0; q < kQ; ++q) *reinterpret_cast<u4_u *>(tile + tr * kT + 16 * q) = buf[r4][q];
     }
   }
 }
@@ -782,9 +783,10 @@ __global__ void __launch_bounds__(64) traceback_moves_group_kernel(const SaTrace
 //   * Needleman-Wunsch: nothing is predicated per step -- within a burst no walk can reach the border, a walk that is over
 //     gets 0 as its table of distances (it stays where it is) and its words are put back after the burst.
 // Same moves, words and meta as the kernels above; tests run every form (options dirs_local, walk_group).
-template <bool NW, int G>
+template <bool NW, int G, int KT = 64>
 __global__ void __launch_bounds__(64) traceback_moves_group_local_kernel(const SaTraceParams p) {
-  constexpr int kT = 64, L = 64 / G;
+  constexpr int kT = KT, L = 64 / G, kSh = KT == 64 ? 6 : 5;
+  static_assert(KT == 64 || KT == 32, "tile edge");
   static_assert(G == 2 || G == 4 || G == 8, "walks per wave");
   __shared__ __attribute__((aligned(16))) uint8_t tiles[G * kT * kT];
   const int lane = threadIdx.x, g = lane / L, lg = lane % L;
@@ -797,7 +799,7 @@ __global__ void __launch_bounds__(64) traceback_moves_group_local_kernel(const S
   const uint8_t *__restrict__ Dg = p.dirs + p.mat_off[m.pair];
   const MoveSlot s = m.slot;
   constexpr uint32_t kState = 0x01020100u;                   // t -> MATCH, GAP_A, GAP_B, GAP_A (GA and BM)
-  constexpr uint32_t kDist = 0x40014041u;                    // t -> 65 (a row and a column back), 64 (a row), 1 (a column), 64
+  constexpr uint32_t kDist = (uint32_t)kT << 24 | 1u << 16 | (uint32_t)kT << 8 | (uint32_t)(kT + 1);   // t -> a row and a column back (kT + 1), a row (kT), a column (1), a row
   constexpr uint32_t kField = 0x00632202u;                   // state -> offset of the departure's field | first table entry << 5
   constexpr uint32_t kAmLo = 0x00000203u, kAmHi = 0u;        // entry -> am: MATCH 3; GAP_A: !CA 2, CA 0; GAP_B 0
   constexpr uint32_t kFxLo = 0x00010000u, kFxHi = 0x0c010201u;   // entry -> fx: GAP_A & CA: GAP_A; GAP_B: FA | FB << 1 -> 0 1 2 1; [7] = 0x0c
@@ -830,17 +832,17 @@ __global__ void __launch_bounds__(64) traceback_moves_group_local_kernel(const S
     return __builtin_amdgcn_perm(0u, kState, t);
   };
   while (__any(live)) {
-    const uint32_t tx0 = at & (kT - 1), ty0 = (at >> 6) & (kT - 1);
+    const uint32_t tx0 = at & (kT - 1), ty0 = (at >> kSh) & (kT - 1);
     if (__any(live && (fresh || tx0 == 0 || ty0 == 0))) {   // (tiles renewed together: traceback_moves_group_kernel)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      group_load_tile<G>(p, tiles + tbase, Dg, x, y, W, lb, lg, ox, oy);
+      group_load_tile<G, KT>(p, tiles + tbase, Dg, x, y, W, lb, lg, ox, oy);
       at = tbase + (y - oy) * kT + (x - ox);
       fresh = false;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_s_waitcnt(0);
     }
     // ---- a burst: no live walk can leave its tile, none passes the end of a half word
-    uint32_t room = live ? max(min(at & (kT - 1), (at >> 6) & (kT - 1)), 1u) : 64u;
+    uint32_t room = live ? max(min(at & (kT - 1), (at >> kSh) & (kT - 1)), 1u) : 64u;
 #pragma unroll
     for (int o = L; o < 64; o <<= 1) room = min(room, (uint32_t)__shfl_xor((int)room, o));
     const uint32_t n = min((uint32_t)__builtin_amdgcn_readfirstlane((int)room), 16u - (k & 15u));
@@ -870,7 +872,7 @@ __global__ void __launch_bounds__(64) traceback_moves_group_local_kernel(const S
       }
     }
     k += n;
-    x = ox + (at & (kT - 1)); y = oy + ((at >> 6) & (kT - 1));
+    x = ox + (at & (kT - 1)); y = oy + ((at >> kSh) & (kT - 1));
     // half a word / a word of 32 columns complete: for the walks that have come this far
     if ((k & 15u) == 0) {
       const bool mine = exists && m.valid && kk == k;
@@ -1097,6 +1099,10 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
         if (p.dirs_local) {   // the byte's local form (sa_kernels.h): read by the tile walkers only -- the host asked for it knowing that
           if (!tiles) return hipErrorInvalidValue;
           if (grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<true, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+          // (tile edge, option walk_tile: 32 x 32 bytes by default for these walks -- 8 lines per reload instead of 32, good for >= 16 steps
+          //  instead of >= 48: C2's walks 58.7 -> 53.4 us; the best-hit walks are level, 64.5-65.1 against 65.7-66.6, and keep 64:
+          //  profiles/r06/r06_local_dirs.txt)
+          else if (grp == 4 && p.tune_tile != 64) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<true, 4, 32>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
           else if (grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<true, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
           else hipLaunchKernelGGL((sa::traceback_moves_tile_kernel<true, true>), dim3(p.n_pairs), dim3(64), 0, stream, p);
         } else
@@ -1124,6 +1130,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (p.dirs_local) {   // the best-hit path's bytes in their local form: tile walkers, one walk per pair
         if (!wtiles || p.walks_per_pair) return hipErrorInvalidValue;
         if (grp == 8) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<false, 8>), dim3((p.n_pairs + 7) / 8), dim3(64), 0, stream, p);
+        else if (grp == 4 && p.tune_tile == 32) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<false, 4, 32>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
         else if (grp == 4) hipLaunchKernelGGL((sa::traceback_moves_group_local_kernel<false, 4>), dim3((p.n_pairs + 3) / 4), dim3(64), 0, stream, p);
         else hipLaunchKernelGGL((sa::traceback_moves_tile_kernel<false, true>), dim3(p.n_pairs), dim3(64), 0, stream, p);
       } else

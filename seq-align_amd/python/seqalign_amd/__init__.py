@@ -152,7 +152,7 @@ def batch_desc(batch: "workloads.Batch") -> BatchDesc:
 
 OPTION_DEFAULTS = {"kernel": "auto", "cpl": 0, "wpb": 0, "lds_pad": 0, "traceback": "device", "trace_kernel": "auto",
                    "sweep_mode": "auto", "sweep_strip": 0, "sweep_cpl": 0, "sweep_trace": 0, "sweep_dirs": 1, "nw_dirs": 1, "pack16": 1, "quad": 0, "walk_overlap": 0, "timing": 0, "chunk_bytes": 0,
-                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "arena_keep_gib": 16, "upload_slices": 0, "arena_free_pct": 60, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0, "async_lanes": 0, "walk_group": 0, "dirs_local": 1, "walk_stage": 1}
+                   "subbatches": 0, "arena_scan_gib": 160, "arena_quality": 1.045, "arena_keep_gib": 16, "upload_slices": 0, "arena_free_pct": 60, "nw_moves": 1, "zero_copy": "auto", "sweep_ev": 1, "reduce_depth": 0, "async_lanes": 0, "walk_group": 0, "dirs_local": 1, "walk_stage": 1, "walk_tile": 0}
 
 
 K_MAX = 32

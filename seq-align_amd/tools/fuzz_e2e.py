@@ -69,6 +69,7 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
         batch = W.from_pairs(pairs)
         ctx.set_option("trace_kernel", ("lane", "wave")[int(v[0] >> 7) & 1])
         ctx.set_option("walk_group", (0, 1, 4, 8)[int(v[0] >> 17) & 3])   # the tile walker: one walk per wave, or 4 / 8 in lockstep
+        ctx.set_option("walk_tile", (0, 32, 64, 0)[int(v[0] >> 21) & 3])      # the local tile walker's tile edge
         ctx.set_option("dirs_local", 0 if (int(v[0] >> 19) & 3) == 0 else 1)   # the direction byte's local form (tile walks) / a quarter of the draws: the older form
         # multi-hit enumeration (the reverse sweep): segments of 64 / 128 / 256 columns with the winners of two rows in
         # LDS, one wave per 256-column strip, or behind a fill that cannot report the candidates' box and rows
@@ -112,7 +113,7 @@ def run(seconds=120.0, seed=1, max_trials=1 << 60, ctx=None):
     msg = (f"fuzz_e2e ok: {trials} random scorings x batches; {nw_checked} NW alignments, {sw_checked} SW hit lists identical "
            f"to the oracle (seed {seed})")
     print(msg, flush=True)
-    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "trace_kernel", "pack16", "walk_group", "dirs_local"):
+    for key in ("sweep_cpl", "sweep_mode", "kernel", "subbatches", "nw_dirs", "sweep_dirs", "trace_kernel", "pack16", "walk_group", "dirs_local", "walk_tile"):
         ctx.set_option(key, S.OPTION_DEFAULTS[key])
     return {"trials": trials, "nw_checked": nw_checked, "sw_checked": sw_checked}
 
