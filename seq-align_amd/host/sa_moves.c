@@ -177,11 +177,22 @@ typedef struct {
 
 static inline void cigar_flush(cigar_sink *s) {
   if (!s->op) return;
+  uint64_t v = s->run;
+  if (v < 100) {   /* nearly every run of a read-sized alignment: one or two digits, no division loop */
+    const int n = v < 10 ? 1 : 2;
+    if (s->out && s->used + (uint64_t)n + 1 < s->cap) {   /* (+ 1 op, and the NUL must still fit behind it: <) */
+      char *o = s->out + s->used;
+      if (n == 2) { *o++ = (char)('0' + v / 10); v %= 10; }
+      o[0] = (char)('0' + v); o[1] = s->op;
+    }
+    s->used += (uint64_t)n + 1;
+    s->op = 0; s->run = 0;
+    return;
+  }
   char tmp[24];
   int n = 0;
-  uint64_t v = s->run;
   do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-  if (s->out && s->used + (uint64_t)n + 1 < s->cap) {   /* (+ 1 op, and the NUL must still fit behind it: <) */
+  if (s->out && s->used + (uint64_t)n + 1 < s->cap) {
     for (int k = 0; k < n; ++k) s->out[s->used + k] = tmp[n - 1 - k];
     s->out[s->used + n] = s->op;
   }
