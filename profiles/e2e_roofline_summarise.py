@@ -27,7 +27,11 @@ def walker_bound(kernel, launches_items, steps, blocked=False):
         #   blocked (NW, best hit; round 6): a tile is 8 x 4 whole blocks = 32 lines, good for >= 48 steps: (steps / 48 + 1) x 32 lines
         #     per walk -- and when the moves go in place to pinned host memory the kernel's end also waits for those PCIe writes
         #     (~9 GB/s on 24-byte pieces: 60-65 us for C2's 10 000 walks whatever the walker; not in this bound).
-        if blocked:
+        if blocked and ", 32>" in kernel:
+            # (round 6, second half: tiles of 32 x 32 bytes = 4 x 2 blocks = 8 lines, good for >= 16 steps -- the anchor rounds down to blocks of 8 x 16 cells)
+            lines = launches_items * (steps / 16.0 + 1.0) * 8.0
+            how = f"hbm lines: {launches_items:.0f} walks x ({steps:.0f} / 16 + 1) tiles x 8 lines of 128 B (blocked direction bytes, 32 x 32-byte tiles) at 8 TB/s; the moves' PCIe writes (in place) come on top"
+        elif blocked:
             lines = launches_items * (steps / 48.0 + 1.0) * 32.0
             how = f"hbm lines: {launches_items:.0f} walks x ({steps:.0f} / 48 + 1) tiles x 32 lines of 128 B (blocked direction bytes) at 8 TB/s; the moves' PCIe writes (in place) come on top"
         else:
