@@ -751,7 +751,8 @@ def test_blocked_direction_bytes_at_the_blocks_edges(ctx, opts, form):
         #  csrc/sa_kernels.h -- is what tile walks get by default; 0: the older form through the same fills and walkers)
         for walker, grp, local in (("wave", 0, 1), ("wave", 1, 1), ("wave", 8, 1), ("lane", 0, 1), ("wave", 0, 0), ("wave", 1, 0), ("wave", 0, 64), ("wave", 0, 32)):
             # (local = 32 / 64: the local form with the walker's tile edge forced, option walk_tile)
-            opts(trace_kernel=walker, walk_group=grp, dirs_local=min(local, 1), walk_tile=local if local > 1 else 0)
+            # (the 64-byte-tile form also with the moves leaving as two pieces per walk instead of one run per wave: option walk_stage)
+            opts(trace_kernel=walker, walk_group=grp, dirs_local=min(local, 1), walk_tile=local if local > 1 else 0, walk_stage=0 if local == 64 else 1)
             for bp in batches[:: (3 if (walker, grp, local) != ("wave", 0, 1) else 1)]:
                 batch = W.from_pairs(bp)
                 got = ctx.nw_batch(batch, sc)
