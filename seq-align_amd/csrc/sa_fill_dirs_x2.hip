@@ -29,6 +29,9 @@
 // that does not depend on the width serves four rows; NW and the SW best-hit fill: nw_dirs_x2_wave / sw_best_x2_wave) -- and a
 // launch whose last round of four-per-wave waves would be less than half full runs that round two per wave in the same grid
 // (fill_nw_dirs_x4x2_kernel).  DESIGN.md 3.5f; profiles/r04/r04_quad_fills.txt.
+// Round 6: the NW and best-hit wave functions take LOCAL -- the direction byte as the cell's own comparisons, one raw bit each
+// (sa_kernels.h: SA_LD_*; put_ge below), for chunks whose walks are tile walks -- and the best-hit fill has the NW fills' mixed
+// grid too (fill_sw_best_x4x2_kernel).  DESIGN.md 3.5g; profiles/r06/r06_local_dirs.txt.
 #include <algorithm>
 
 #include "sa_rowsweep.hpp"

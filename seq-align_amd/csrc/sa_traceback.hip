@@ -12,6 +12,11 @@
 // (~len_a+len_b steps), so the only parallelism is across pairs.  Each lane
 // writes its alignment right-to-left into its slot and reports where it starts;
 // the host left-aligns while copying out of the staging buffer.
+//
+// Further down, the walkers of the direction-byte paths (one byte per cell instead of the three matrices): on strings or on
+// MOVES (two bits per column, expanded by the host), one lane per walk with the next byte asked for ahead, one wave per walk
+// from LDS tiles, four / eight walks per wave in lockstep -- and (round 6) traceback_moves_group_local_kernel for the byte's
+// LOCAL form (sa_kernels.h: SA_LD_*): a cell's own comparisons, the state a walk arrives in resolved by byte look-ups.
 #include "sa_trace_common.hpp"
 
 namespace sa {
