@@ -51,6 +51,10 @@
 #ifndef SA_X2_FLUSH_DEFER
 #define SA_X2_FLUSH_DEFER SA_X2_LDS_PIPE
 #endif
+// from how many pairs the best-hit fill goes four per wave (sa_launch_fill_sw_best_x2; `make exp EXPFLAGS=-DSA_BEST_X4_MIN=8192u` for an A/B)
+#ifndef SA_BEST_X4_MIN
+#define SA_BEST_X4_MIN 4097u
+#endif
 namespace sa {
 // bytes of LDS per pair of the NW / best-hit fills: the ring of the row-major form, or one block row of LANES x CPL columns
 constexpr int x2_ring(int lanes, int cpl, int ring) { return (SA_DIRS_BLOCKED != 0 && lanes * cpl <= 512 && lanes * cpl * 8 > ring) ? lanes * cpl * 8 : ring; }
@@ -1580,9 +1584,6 @@ hipError_t sa_launch_fill_sw_best_x2(const SaFillParams &p, uint32_t max_len_a, 
   // 4 096 pairs 746 / 797; 7 000: 1 343 / 1 185; 8 192: 1 346 / 1 206; 11 000: 1 942 / 1 685; 12 288: 1 978 / 1 695; 16 384: 2 613 / 2 190.  A rest of
   // less than half a round of four-per-wave waves goes two per wave in the same grid (fill_sw_best_x4x2_kernel: 5 000 pairs 1 032 -> 893,
   // 6 144: 1 048 -> 914, 10 000: 1 643 / 1 680 -> 1 393, 14 000: 2 282 / 2 168 -> 1 886) when the choice is left to the library.
-#ifndef SA_BEST_X4_MIN
-#define SA_BEST_X4_MIN 4097u
-#endif
   if (const int c4 = sa_x4_columns(p, max_len_a, SA_BEST_X4_MIN)) {
     const uint32_t pairs_q = p.n_pairs / 4096u * 4096u, rest = p.n_pairs - pairs_q;
     if (p.tune_quad == 0 && pairs_q && rest && rest <= 2048u) {
