@@ -168,3 +168,49 @@ def test_sw_best_hit_walks_on_local_bytes_equal_the_oracle(seed):
         wa, wb, ex, ey = walk(D, a, b, x, y, MATCH, True)
         assert h["score"] == best and (wa.decode(), wb.decode()) == (h["a"], h["b"]), (seed, trial, kind, a, b, h)
         assert (ex, ey) == (h["pos_a"], h["pos_b"])
+
+
+AMINO = b"ARNDCQEGHILKMFPSTWYV"
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_walks_on_local_bytes_equal_the_oracle_with_a_substitution_table(seed):
+    """BLOSUM62 (BASELINE configs[3]'s scoring; alignment_scoring.c:349-360): the decisions never look at the substitution score itself,
+    only at the matrices it produced -- global alignments and best local hits of protein pairs, related and random."""
+    rng = np.random.default_rng(300 + seed)
+    import seqalign_amd as S    # (the preset comes from the product's builder -- byte-equal to the compiled reference's: tests/test_host_api.py)
+    sc = O.Scoring.from_buffer_copy(bytes(S.make_scoring({"preset": "BLOSUM62"})))
+    gap_open, gap_extend = int(sc.gap_open), int(sc.gap_extend)
+    for trial in range(12):
+        kind = ("random", "related")[trial % 2]
+        a, b = random_pair(rng, kind, int(rng.integers(1, 45)), int(rng.integers(1, 45)), alphabet=AMINO)
+        la, lb = len(a), len(b)
+        W = la + 1
+        rc, M, A, B = O.oracle_fill(sc, a, b, 0)
+        assert rc == 0
+        rc, score, ra, rb = O.oracle_nw(sc, a, b)
+        assert rc == 0
+        D = local_bytes(M, A, B, la, lb, gap_open + gap_extend, gap_extend, False)
+        m, ga, gb = int(M[lb * W + la]), int(A[lb * W + la]), int(B[lb * W + la])
+        st, s = MATCH, m
+        if gb >= s:
+            st, s = GAP_B, gb
+        if ga >= s:
+            st, s = GAP_A, ga
+        wa, wb, _, _ = walk(D, a, b, la, lb, st, False)
+        assert s == score and (wa, wb) == (ra, rb), (seed, trial, kind, a, b)
+        rc, M, A, B = O.oracle_fill(sc, a, b, 1)
+        assert rc == 0
+        rc, hits = O.oracle_sw_hits(sc, a, b, M, A, B, 1, 1)
+        assert rc == 0
+        if not hits:
+            continue
+        D = local_bytes(M, A, B, la, lb, gap_open + gap_extend, gap_extend, True)
+        Mm = M.reshape(lb + 1, W)
+        best = int(Mm.max())
+        ys, xs = np.nonzero(Mm == best)
+        x = int(xs.min()); y = int(ys[xs == x].min())
+        wa, wb, ex, ey = walk(D, a, b, x, y, MATCH, True)
+        h = hits[0]
+        assert h["score"] == best and (wa.decode(), wb.decode()) == (h["a"], h["b"]) and (ex, ey) == (h["pos_a"], h["pos_b"]), (seed, trial, kind, a, b, h)
+
