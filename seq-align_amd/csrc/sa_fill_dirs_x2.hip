@@ -1493,7 +1493,8 @@ bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_
 
 // Four pairs per wave (32 lanes a couple) instead of two: every pair of the launch one shape (no pair list), rows up to 192
 // columns (six columns per lane of a span: beyond that the registers cost more than the lanes save), and pairs enough that
-// half as many waves still fill the chip (min_pairs: NW 4 096 -- measured 3-7 % faster from there to 40 000 pairs of 150 x 150;
+// half as many waves still fill the chip (min_pairs: NW 4 097 -- round 4 measured 3-7 % faster from 4 096 to 40 000 pairs of 150 x 150; round 6:
+// exactly one round is 9 % slower than two rounds of two-per-wave waves, more than one is ahead;
 // SW best hit 4 097 -- round 4 measured 150 x 1000 level at 10 000 pairs, where 2 500 waves leave some SIMDs with three and some
 // with two, and 8-9 % ahead from 16 000 on (profiles/r04/r04_quad_fills.txt); round 6 by whole rounds: ahead from more than one round (4 096 pairs) on, and
 // the short rest two per wave in the same grid, sa_launch_fill_sw_best_x2) -- or whenever the shape allows (option quad = 2: tests), or never
@@ -1508,7 +1509,10 @@ static int sa_x4_columns(const SaFillParams &p, uint32_t max_len_a, uint32_t min
 
 hipError_t sa_launch_fill_nw_dirs_x2(const SaFillParams &p, uint32_t max_len_a, uint8_t *dirs, hipStream_t stream) {
   if (p.n_pairs == 0) return hipSuccess;
-  if (const int c4 = sa_x4_columns(p, max_len_a, 4096u)) {
+  // (from MORE than one whole round of four-per-wave waves: exactly 4 096 pairs are one wave per SIMD four per wave, two per SIMD two per
+  //  wave -- 96.7 against 87.8 us, 150 x 150; 5 000: 108.6 mixed / 119.1 two per wave, 8 192: 141.6 / 155.0, 16 384: 248.7 / 287.7:
+  //  profiles/r06/r06_local_dirs.txt)
+  if (const int c4 = sa_x4_columns(p, max_len_a, 4097u)) {
     // the last round of four-per-wave waves less than half full (and the choice left to the library): those pairs two per wave
     const uint32_t pairs_q = p.n_pairs / 4096u * 4096u, rest = p.n_pairs - pairs_q;
     if (p.tune_quad == 0 && pairs_q && rest && rest <= 2048u) {

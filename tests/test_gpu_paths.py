@@ -311,15 +311,15 @@ def test_four_pairs_per_wave(ctx, opts, la, lb):
 
 
 def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
-    """quad = 0 (the default): NW from 4 096 pairs of one shape, the SW best hit from 4 097 (whole rounds + a short rest two per wave in the same grid), rows up to 192 columns; ragged
+    """quad = 0 (the default): NW and the SW best hit from 4 097 pairs of one shape (whole rounds + a short rest two per wave in the same grid), rows up to 192 columns; ragged
     chunks (a pair list) and the multi-hit fill stay two per wave; a substitution table (BLOSUM62) goes four per wave too."""
     sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
     opts(pack16=1, quad=0)
-    ctx.nw_batch(uniform(4095, 60, 50, 1), sc_nw)
+    ctx.nw_batch(uniform(4096, 60, 50, 1), sc_nw)            # exactly one round of four-per-wave waves: two per wave
     assert "fill_nw_dirs_x2" in ctx.last_call() and "fill_nw_dirs_x4" not in ctx.last_call()
-    big = uniform(4096, 60, 50, 2)
+    big = uniform(8192, 60, 50, 2)
     got = ctx.nw_batch(big, sc_nw)
-    assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 4096)
+    assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 8192)
     opts(quad=1)
     assert got == ctx.nw_batch(big, sc_nw)
     opts(quad=0)
@@ -348,7 +348,7 @@ def test_four_pairs_per_wave_is_chosen_by_size_and_shape(ctx, opts):
             assert rc == 0 and got[p] == (s_, ra, rb), (spec, p)
     ctx.nw_batch(uniform(4096 + 2049, 60, 50, 8), sc_nw)     # more than half a round left: four per wave throughout
     assert ctx.last_call()["fill_nw_dirs_x4"] == (1, 4096 + 2049) and "fill_nw_dirs_x2" not in ctx.last_call()
-    ctx.nw_batch(uniform(4096, 192, 20, 3), sc_nw)           # 193 columns: seven per lane of a span -- two pairs per wave
+    ctx.nw_batch(uniform(8192, 192, 20, 3), sc_nw)           # 193 columns: seven per lane of a span -- two pairs per wave
     assert "fill_nw_dirs_x2" in ctx.last_call() and "fill_nw_dirs_x4" not in ctx.last_call()
     sw = uniform(16384, 40, 30, 4)
     got = ctx.sw_batch(sw, sc_sw, 10, max_hits=1)
