@@ -399,7 +399,7 @@ int seqalign_pool_trim(seqalign_ctx_t *ctx, uint64_t keep_bytes, uint64_t *held_
  *   async_lanes     0 (= 3) | 1 .. 8        submitted calls in flight per context (seqalign_*_batch_submit)
  *   walk_group      0 | 1 | 4 | 8           walks per wave of the device walker on LDS tiles (4 / 8: in lockstep, vector state); 0: four on
  *                                           direction bytes laid out in blocks (NW, best hit; rows <= 512 columns), else one wave per walk
- *   dirs_local      1 | 0                   chunks whose walks are tile walks: the direction byte holds the cell's own comparisons and the
+ *   dirs_local      1 | 0                   seqalign_nw_batch / seqalign_sw_batch(max_hits = 1) on direction bytes: the byte holds the cell's own comparisons and the
  *                                           walker resolves the state it arrives in (cheaper to write; 0: the older form everywhere)
  *   walk_tile       0 | 32 | 64             that walker's tile edge in bytes (0: 32 for global walks -- fewer lines per reload --, 64 for best-hit walks)
  *   walk_stage      1 | 0                   that walker sends a wave's moves home as one run of whole lines out of LDS (0: two pieces per walk)

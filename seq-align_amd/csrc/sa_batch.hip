@@ -771,7 +771,9 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
   // loses when every lane stores its own 4 bytes (one lane per walk, the large groups: C5's share 3.6 -> 4.4).  So auto =
   // sequences through the copy engine, moves in place exactly when the walks run one wave each.
   const bool auto_zc = ctx->opt.zero_copy == 4u;
-  const bool tile_walks = ctx->opt.trace_kernel ? ctx->opt.trace_kernel == 2 : n < SA_WALK_TILE_MAX;
+  // (round 6: with the direction byte's local form the tile walks are level with or ahead of the lane walkers at every batch size --
+  //  30 000 pairs 0.99 / 1.04 ms, 65 536: 1.63 / 1.78, 125 000: 2.93 / 2.93-2.95 -- so they walk every chunk; dirs_local = 0: round 4's rule)
+  const bool tile_walks = ctx->opt.trace_kernel ? ctx->opt.trace_kernel == 2 : (ctx->opt.dirs_local != 0 || n < SA_WALK_TILE_MAX);
   const bool zc_in = !auto_zc && (ctx->opt.zero_copy & 1u) != 0, zc_out = auto_zc ? tile_walks : (ctx->opt.zero_copy & 2u) != 0;
   // (tile walks: the fills write the direction byte's LOCAL form -- a cell's own comparisons, resolved by the walker: sa_kernels.h)
   const bool local = tile_walks && ctx->opt.dirs_local;
@@ -859,7 +861,7 @@ static int nw_chunk_moves(seqalign_ctx *ctx, const seqalign_batch_t *batch, cons
     }
   }
   auto pair_at = [&](uint64_t bi) { return std::min(n, bi * kHostBlk); };
-  constexpr uint64_t kGroupPairs = 32768;   // (measured, C5 share, walks in stream order: 2 groups 3.49 ms, 3 groups 3.31, 4 groups 3.44;
+  constexpr uint64_t kGroupPairs = 32768;   // (measured, C5 share, walks in stream order: 2 groups 3.49 ms, 3 groups 3.31, 4 groups 3.44; round 6, tile walks: groups of 16 384 are level (C5's share 2.93-3.11 / 2.91-3.05, 65 536 pairs 1.85 / 1.70);
                                             //  with the lane walker's look-ahead 3 / 4 / 8 groups and a short last group: 3.12-3.27, no order)
   std::vector<uint32_t> gcut{0};
   for (uint32_t s = 1; s < n_sub; ++s)

@@ -15,8 +15,8 @@ extern "C" {
  * and GAP_A that is a fact about the NEIGHBOUR (which of M / A / B is the maximum of the cell up-left; whether B >= M in the cell
  * above), which the fills carry over from the previous row and then convert, cell by cell, from comparison masks into two-bit
  * codes: select upon select -- 15-25 of a packed cell's ~115-165 issue cycles (profiles/r06/r06_local_dirs.txt).  A walk visits
- * ~170 of a pair's 22 801 cells.  So where ONLY tile walkers read the bytes (seqalign_nw_batch's and the best-hit path's chunks
- * below SA_WALK_TILE_MAX walks: every BASELINE config but configs[4]'s 125 000-pair share) the fill stores each cell's OWN five
+ * ~170 of a pair's 22 801 cells.  So where ONLY tile walkers read the bytes (seqalign_nw_batch's moves path and the best-hit path:
+ * every BASELINE config's host-level call but the multi-hit one) the fill stores each cell's OWN five
  * comparisons as five raw bits -- the sign bit of each saturating difference shifted into place, one v_lshrrev + one v_bitop3
  * per decision, no mask, no select, no carried tags -- and the walker reads the state it arrives in from the byte of the cell it
  * arrives at (it reads that byte anyway: it is the next step's):
@@ -27,8 +27,10 @@ extern "C" {
  *     bit 3  FA  gap_a(left) + open + extend == gap_b   a GAP_B walk leaving this cell arrives in GAP_A,
  *     bit 4  FB  gap_b(left) + extend == gap_b          else GAP_B if FB, else MATCH
  *     bits 5 6 7 (Smith-Waterman)  this cell's match / gap_a / gap_b score is 0: a walk standing here in that state ends
- * The lane walkers (large launches) look a cell AHEAD -- where a walk goes next must not wait for the byte of the cell it arrives
- * at -- and keep the older form; so do the multi-hit path's bytes, whose sweep routes arrivals by them.  SaFillParams::dirs_local /
+ * The lane walkers look a cell AHEAD -- where a walk goes next must not wait for the byte of the cell it arrives at -- and keep the
+ * older form (they walked launches of >= SA_WALK_TILE_MAX walks until the tile walks on the local form drew level with them at every
+ * size: option trace_kernel = lane, or dirs_local = 0, brings them back); so do the multi-hit path's bytes, whose sweep routes
+ * arrivals by them.  SaFillParams::dirs_local /
  * SaTraceParams::dirs_local say which form a launch writes / reads (option dirs_local = 0: the older form everywhere). */
 #define SA_LD_GA 1u
 #define SA_LD_BM 2u

@@ -1091,7 +1091,8 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
     // bytes pull in: ~3.3 ns per walk -- 31 250 walks 0.104 ms, 46 875 walks 0.158 ms -- behind a device buffer and a copy).
     // seqalign_nw_batch end to end, 150 x 150: the tile form 8 % ahead at 10 000 pairs, 4 % at 24 576, equal at 32 768
     // (profiles/r04/r04_walkers.txt): SA_WALK_TILE_MAX.  The option trace_kernel = lane | wave forces one.
-    const bool tiles = p.tune_walker ? p.tune_walker == 2 : p.n_pairs < SA_WALK_TILE_MAX;
+    // (round 6: a launch on the byte's LOCAL form is a tile walk whatever its size -- the host chose the form knowing that)
+    const bool tiles = p.tune_walker ? p.tune_walker == 2 : (p.dirs_local != 0 || p.n_pairs < SA_WALK_TILE_MAX);
     if (p.nw_state) {   // NW behind the directions-only fill
       if (!p.nw_score) return hipErrorInvalidValue;
       if (p.moves) {    // ... sending home moves instead of strings
@@ -1126,7 +1127,7 @@ hipError_t sa_launch_nw_traceback(const SaTraceParams &p, hipStream_t stream) {
       if (!(p.hit_keys || (p.start_index && p.start_score)) || !p.out_meta4) return hipErrorInvalidValue;
       if (p.walks_per_pair && !(p.hit_keys && p.hit_count && p.sweep_status)) return hipErrorInvalidValue;
       // (walks_per_pair: most of the launch's walks return at once -- the choice follows the pairs, not the slots)
-      const bool wtiles = p.tune_walker ? p.tune_walker == 2 : (p.walks_per_pair ? p.n_pairs / p.walks_per_pair < SA_WALK_TILE_MAX : p.n_pairs < SA_WALK_TILE_MAX);
+      const bool wtiles = p.tune_walker ? p.tune_walker == 2 : (p.dirs_local != 0 || (p.walks_per_pair ? p.n_pairs / p.walks_per_pair < SA_WALK_TILE_MAX : p.n_pairs < SA_WALK_TILE_MAX));
       sa_record_launch(wtiles ? SEQALIGN_K_WALK_MOVES_TILE : SEQALIGN_K_WALK_MOVES_LANE, p.n_pairs);
       const uint32_t wpb = p.walks_per_pair ? p.walks_per_pair : 1u;   // (<= 8: seqalign_sw_batch's one-trip path)
       if (wpb > 8) return hipErrorInvalidValue;
