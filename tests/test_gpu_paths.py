@@ -704,6 +704,31 @@ def test_sweep_reads_the_right_rows_beyond_2_30_cells(ctx):
     assert sum(h["pos_b"] > 2_143_237 for h in got) >= 2
 
 
+def test_large_chunks_take_tile_walks_on_the_local_byte(ctx, opts):
+    """Round 6: with the direction byte's local form the tile walks are level with or ahead of the lane walkers at every batch size, so
+    chunks of 24 576 pairs and more (round 4's crossover) take them too; dirs_local = 0 brings back the older byte and, from that size on,
+    the lane walkers -- same alignments, same best hits, and a sample of both against the oracle."""
+    sc_nw, sc_sw = S.make_scoring({"preset": "default"}), S.make_scoring({"init": [2, -2, -2, -1, 0, 0, 0, 0, 0, 0]})
+    batch, pairs = gap_rich(24576 + 900, 38, 45, 81)
+    opts(dirs_local=1)
+    nw1 = ctx.nw_batch(batch, sc_nw)
+    assert "walk_moves_tile" in ctx.last_call() and "walk_moves_lane" not in ctx.last_call(), ctx.last_call()
+    sw1 = ctx.sw_batch(batch, sc_sw, 10, max_hits=1)
+    assert "walk_moves_tile" in ctx.last_call() and "walk_moves_lane" not in ctx.last_call(), ctx.last_call()
+    opts(dirs_local=0)
+    nw0 = ctx.nw_batch(batch, sc_nw)
+    assert "walk_moves_lane" in ctx.last_call() and "walk_moves_tile" not in ctx.last_call(), ctx.last_call()
+    sw0 = ctx.sw_batch(batch, sc_sw, 10, max_hits=1)
+    assert "walk_moves_lane" in ctx.last_call(), ctx.last_call()
+    assert nw1 == nw0 and sw1 == sw0
+    o_nw, o_sw = osc_of(sc_nw), osc_of(sc_sw)
+    for p in list(range(0, len(pairs), 997)) + list(range(24570, 24590)):
+        rc, s_, ra, rb = O.oracle_nw(o_nw, *pairs[p])
+        assert rc == 0 and nw1[p] == (s_, ra, rb), p
+        rc, want = O.oracle_sw(o_sw, *pairs[p], 10, 1)
+        assert rc == 0 and sw1[p] == want, p
+
+
 # ------------------------------------------------------------------ direction bytes in blocks of 8 x 16 cells (round 6) ---
 
 @pytest.mark.parametrize("form", ["x1", "x2", "x4", "mixed"])
