@@ -15,7 +15,8 @@
 //     floor)` is the identity and floor + penalty saturates back to the floor, which is what the reference's clamp
 //     does.  Every comparison that decides a direction is then between the same numbers as in 32 bits as long as
 //     no real score leaves the type: the launcher admits a batch only if
-//     (len_a + len_b + 2) * max|penalty| + (len_a + 1) * |gap_extend| <= 30000  (sa_x2_scores_fit).
+//     (len_a + len_b + 2) * max|penalty| + (len_a + 1) * |gap_extend| <= 30000  (sa_x2_scores_fit; the NW fills, whose values are
+//     de-trended by (column + row) x gap_extend: (len_a + len_b + 2) * (max|penalty| + |gap_extend|) <= 30000).
 //   * comparisons are sign bits: x < y  <=>  (x -sat y) >> 15 = 0xFFFF per half; selections are v_bfi_b32.
 //   * both pairs' rows have the same length, so ONE set of stream positions serves both rings; the caller lays the
 //     direction bytes out with every pair starting on a 256-byte boundary (SaFillParams::uniform_stride), so every
@@ -51,6 +52,15 @@
 #ifndef SA_X2_FLUSH_DEFER
 #define SA_X2_FLUSH_DEFER SA_X2_LDS_PIPE
 #endif
+// Round 6: the NW fills keep every value V of cell (g, j) as V' = V - (g + j) gap_extend.  gap_a's recurrence max(Y + open1, A + ext) becomes
+// max(Y' + gap_open, A'), gap_b's scan -- already de-trended along the row -- needs no re-trend, the diagonal step's "- 2 ext" goes into the
+// substitution scores (table and constants, once per launch), every comparison is between values of ONE cell or of cells whose g + j
+// differ by a constant that goes into the constant: two packed adds per cell less (C2's fill 163 -> 153 us; `make exp
+// EXPFLAGS=-DSA_NW_DETREND=0` builds the older arithmetic).  The end cell's score gets its (len_a + len_b) ext back; the admission
+// bound grows by the de-trend's range (sa_domain_nw_x2_scores_fit).
+#ifndef SA_NW_DETREND
+#define SA_NW_DETREND 1
+#endif
 // from how many pairs the best-hit fill goes four per wave (sa_launch_fill_sw_best_x2; `make exp EXPFLAGS=-DSA_BEST_X4_MIN=8192u` for an A/B)
 #ifndef SA_BEST_X4_MIN
 #define SA_BEST_X4_MIN 4097u
@@ -60,6 +70,7 @@ namespace sa {
 constexpr int x2_ring(int lanes, int cpl, int ring) { return (SA_DIRS_BLOCKED != 0 && lanes * cpl <= 512 && lanes * cpl * 8 > ring) ? lanes * cpl * 8 : ring; }
 constexpr bool kLdsPipe = SA_X2_LDS_PIPE != 0;        // the row profile (table scorings) a row ahead
 constexpr bool kFlushDefer = SA_X2_FLUSH_DEFER != 0;  // a ring block read at the end of one row, stored at the end of the next
+constexpr bool kNwDetrend = SA_NW_DETREND != 0;
 constexpr bool kDirsBlocked = SA_DIRS_BLOCKED != 0;    // the NW / best-hit fills write the direction bytes in 8 x 16 blocks (sa_kernels.h)
 
 typedef short pk16 __attribute__((ext_vector_type(2)));
@@ -214,8 +225,8 @@ struct SubstX2 {
   uint32_t scn0[PROFILE ? CPL : 1], scn1[PROFILE ? CPL : 1];   // the next row's profile words of my columns (pair 0's, pair 1's)
   uint32_t tv0 = 0, tv1 = 0, tvw = 0;                 // the row after next: my table row's two entries on their way; packed
   pk16 scq[PROFILE ? CPL : 1];                        // the next row's scores, merged
-  __device__ __forceinline__ void init(const SaFillParams &p, uint32_t tbl_lds = 0, int lane = 0) {
-    s_eq = pk_splat(p.gen_eq); s_ne = pk_splat(p.gen_ne); s_delta = pk_splat(p.gen_ne - p.gen_eq);
+  __device__ __forceinline__ void init(const SaFillParams &p, uint32_t tbl_lds = 0, int lane = 0, int shift = 0) {
+    s_eq = pk_splat(p.gen_eq + shift); s_ne = pk_splat(p.gen_ne + shift); s_delta = pk_splat(p.gen_ne - p.gen_eq);
     if constexpr (PROFILE) {
       const uint32_t k = min((uint32_t)lane, p.K - 1u);   // (lanes beyond the table repeat its last row: same word, same value)
       prof = tbl_lds + ((p.K * p.K * 2u + 15u) & ~15u) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kProfBytes;
@@ -377,11 +388,11 @@ static inline size_t table_lds_bytes(const SaFillParams &p) { return ((((size_t)
 
 // the table into LDS as int16 (every thread of the workgroup, before anyone leaves)
 template <int SUBST>
-__device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tbl_lds) {
+__device__ __forceinline__ void load_table_x2(const SaFillParams &p, uint32_t tbl_lds, int shift = 0) {
   if constexpr (SUBST == SA_SUBST_LDS) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_base[];
     short *t = reinterpret_cast<short *>(reinterpret_cast<char *>(lds_base) + tbl_lds);
-    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) t[k] = (short)p.table[k];
+    for (uint32_t k = threadIdx.x; k < p.K * p.K; k += blockDim.x) t[k] = (short)(p.table[k] + shift);
     __syncthreads();
   }
 }
@@ -408,9 +419,10 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
   const uint8_t *__restrict__ sa0 = p.arena + p.off_a[pair_lo], *__restrict__ sa1 = p.arena + p.off_a[pair_hi];
   const uint8_t *__restrict__ sb0 = p.arena + p.off_b[pair_lo], *__restrict__ sb1 = p.arena + p.off_b[pair_hi];
   uint8_t *const gd0 = dirs_arena + p.mat_off[pair_lo], *const gd1 = dirs_arena + p.mat_off[pair_hi];   // 256-byte aligned
-  const pk16 open1 = pk_splat(p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
+  // (kNwDetrend: every value V of cell (g, j) is kept as V - (g + j) ext: `open1` becomes gap_open, `+ ext` and the scan's re-trend vanish)
+  const pk16 open1 = pk_splat(kNwDetrend ? p.gap_open : p.open1), ext = pk_splat(p.ext), floor_ = pk_splat(-32768);
   SubstX2<SUBST, CPL, (SUBST == SA_SUBST_LDS && LANES == 64)> sub;
-  sub.init(p, tbl_lds, lane);
+  sub.init(p, tbl_lds, lane, kNwDetrend ? -2 * p.ext : 0);
   const Border bd{p.floor, p.gap_open, p.ext, false, false};
 
   constexpr bool BLK = kDirsBlocked && LANES * CPL <= 512;   // (rows of up to 512 columns: sa_dirs_blocked_shape)
@@ -523,14 +535,14 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
     const uint32_t code1 = (g >= 1 && g <= la) ? p.code[sa1[g - 1]] : 0u;
     sub.set_column(c, code0, code1, p.K, tbl_lds);
     // row 0 (alignment.c:46-69): the same in both halves
-    const int m0 = g ? -32768 : 0, a0 = m0, b0 = g ? bd.edge_gap(g) : 0;
+    const int m0 = g ? -32768 : 0, a0 = m0, b0 = g ? bd.edge_gap(g) - (kNwDetrend ? (int)g * p.ext : 0) : 0;
     const int x0 = max3i(m0, a0, b0);
     mv[c] = pk_splat(m0); av[c] = pk_splat(a0); bv[c] = pk_splat(b0);
     X[c] = pk_splat(x0); Yp[c] = pk_splat(max(m0, b0)); Ap[c] = pk_splat(a0);
     T[c] = ((a0 == x0) ? 1u : (b0 == x0) ? 2u : 0u) * kBoth;
     TY4[c] = ((b0 >= m0) ? 8u : 0u) * kBoth;
     const int g_ext = (int)g * p.ext;
-    c1[c] = pk_splat(p.open1 - g_ext); c3[c] = pk_splat(g_ext);
+    c1[c] = pk_splat(kNwDetrend ? p.gap_open : p.open1 - g_ext); c3[c] = pk_splat(kNwDetrend ? 0 : g_ext);
   }
   // The border column (the span's first lane, my column 0; alignment.c:72-80) comes out of the recurrence by itself, no selects
   // in the loop:
@@ -584,7 +596,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       const pk16 xd = c ? X[c - (c ? 1 : 0)] : x_ul;
       const uint32_t td = c ? T[c - (c ? 1 : 0)] : t_ul;
       pk16 m = pk_adds(xd, s);                                                             // alignment.c:101-116
-      const pk16 ae = pk_adds(Ap[c], ext);
+      const pk16 ae = kNwDetrend ? Ap[c] : pk_adds(Ap[c], ext);
       pk16 a = pk_max(pk_adds(Yp[c], open1), ae);                                          // alignment.c:128-135
       if (c == 0) m = first_lane ? floor_ : m;                                             // the border column's match score
       mv[c] = m; av[c] = a; z[c] = pk_max(m, a);
@@ -609,7 +621,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       }
       e = pk_scan_max_excl<LANES>(P[CPL - 1], first_lane);
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = pk_adds(Pm[c], c3[c]); }
+      for (int c = 0; c < CPL; ++c) { Pm[c] = pk_max(P[c], e); bv[c] = kNwDetrend ? Pm[c] : pk_adds(Pm[c], c3[c]); }
     }
     {
       const pk16 al = pk_shr1_zero(av[CPL - 1]);     // (a span's first lane: only the border cell's byte reads it, overridden below)
@@ -665,6 +677,7 @@ __device__ __forceinline__ void nw_dirs_x2_wave(const SaFillParams &p, uint8_t *
       if (b >= score) { st = 2; score = b; }          // GAP_B
       if (a >= score) { st = 1; score = a; }          // GAP_A
       const uint32_t pr = h ? pair_hi : pair_lo;
+      if constexpr (kNwDetrend) score += (int)(la + lb) * p.ext;
       p.best_score[pr] = score;
       p.best_index[pr] = st;
       p.status[pr] = ~0ull;
@@ -677,7 +690,7 @@ __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const uint32_t tbl_lds = (blockDim.x >> 6) * (2 * R);   // the table sits behind the rings
-  load_table_x2<SUBST>(p, tbl_lds);
+  load_table_x2<SUBST>(p, tbl_lds, kNwDetrend ? -2 * p.ext : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -696,7 +709,7 @@ __global__ void __launch_bounds__(kWave * 4)
 fill_nw_dirs_x4_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const uint32_t tbl_lds = (blockDim.x >> 6) * (4 * R);   // the table sits behind the rings
-  load_table_x2<SUBST>(p, tbl_lds);
+  load_table_x2<SUBST>(p, tbl_lds, kNwDetrend ? -2 * p.ext : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -719,7 +732,7 @@ fill_nw_dirs_x4x2_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena,
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const uint32_t waves = blockDim.x >> 6;
   const uint32_t tbl_lds = waves * (4 * R);   // the table sits behind the rings (the two-per-wave waves use half of theirs)
-  load_table_x2<SUBST>(p, tbl_lds);
+  load_table_x2<SUBST>(p, tbl_lds, kNwDetrend ? -2 * p.ext : 0);
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint8_t *ring = reinterpret_cast<uint8_t *>(lds) + wave * (4 * R);
@@ -750,7 +763,7 @@ fill_nw_dirs_mixed_kernel(const SaFillParams p, uint8_t *__restrict__ dirs_arena
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (blockIdx.x < x2_blocks) {   // (uniform per workgroup)
     const uint32_t tbl_lds = waves * (2 * R);
-    load_table_x2<SUBST>(p, tbl_lds);
+    load_table_x2<SUBST>(p, tbl_lds, kNwDetrend ? -2 * p.ext : 0);
     const uint32_t unit = blockIdx.x * waves + wave;
     if (2 * unit >= n_modal) return;
     const bool two = 2 * unit + 1 < n_modal;
@@ -1488,7 +1501,7 @@ bool sa_x2_scores_fit(const SaFillParams &p, uint32_t max_len_a, uint32_t max_le
 bool sa_nw_dirs_x2_applicable(const SaFillParams &p, uint32_t max_len_a, uint32_t max_len_b, const uint8_t *dirs) {
   if (!sa_nw_dirs_fill_applicable(p, max_len_a, dirs)) return false;
   if (p.K > SA_LDS_TABLE_MAX_K || p.uniform_stride == 0 || (p.uniform_stride & 255u)) return false;
-  return sa_x2_scores_fit(p, max_len_a, max_len_b);
+  return sa_domain_nw_x2_scores_fit(sa_traits_of(p), max_len_a, max_len_b);   // (the NW fills' values are de-trended: their own bound)
 }
 
 // Four pairs per wave (32 lanes a couple) instead of two: every pair of the launch one shape (no pair list), rows up to 192

@@ -320,8 +320,19 @@ inline bool sa_domain_x2_scores_fit(const SaScoringTraits &t, uint32_t max_len_a
   if (t.K > 1 && (int64_t)t.table_abs_max > pen) pen = t.table_abs_max;
   return ((int64_t)max_len_a + max_len_b + 2) * pen + ((int64_t)max_len_a + 1) * mag(t.ext) <= 30000;
 }
+/* ... and for the packed NW fills (round 6), which keep every value V of cell (g, j) as V - (g + j) gap_extend (the recurrence of gap_a
+ * loses its "+ extend", gap_b's scan its re-trend: two packed adds per cell): |V'| <= (la + lb + 2) (pen + |extend|) */
+inline bool sa_domain_nw_x2_scores_fit(const SaScoringTraits &t, uint32_t max_len_a, uint32_t max_len_b) {
+  auto mag = [](int64_t v) { return v < 0 ? -v : v; };
+  int64_t pen = mag(t.gen_eq) > mag(t.gen_ne) ? mag(t.gen_eq) : mag(t.gen_ne);
+  if (mag(t.open1) > pen) pen = mag(t.open1);
+  if (mag(t.ext) > pen) pen = mag(t.ext);
+  if (mag(t.gap_open) + mag(t.ext) > pen) pen = mag(t.gap_open) + mag(t.ext);
+  if (t.K > 1 && (int64_t)t.table_abs_max > pen) pen = t.table_abs_max;
+  return ((int64_t)max_len_a + max_len_b + 2) * (pen + mag(t.ext)) <= 30000;
+}
 inline bool sa_domain_nw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
-  return sa_domain_nw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);
+  return sa_domain_nw_dirs(t, la) && sa_domain_nw_x2_scores_fit(t, la, lb);
 }
 inline bool sa_domain_sw_dirs_x2(const SaScoringTraits &t, uint32_t la, uint32_t lb) {
   return sa_domain_sw_dirs(t, la) && sa_domain_x2_scores_fit(t, la, lb);

@@ -62,13 +62,19 @@ def same(r0, r1):
     return all(np.array_equal(x, y) for x, y in zip(r0, r1))
 
 
-def near_bound_spec(la, lb, v):
-    """A match / mismatch scoring whose int16 admission bound (sa_x2_scores_fit: (la + lb + 2) pen + (la + 1) |ext| <= 30 000)
-    evaluates to within 2 % of 30 000 for this shape -- where the packed halves come closest to leaving int16 -- or None."""
+def near_bound_spec(la, lb, v, nw=False):
+    """A match / mismatch scoring whose int16 admission bound (sa_x2_scores_fit: (la + lb + 2) pen + (la + 1) |ext| <= 30 000; nw: the
+    packed NW fills' own, sa_domain_nw_x2_scores_fit: (la + lb + 2) (pen + |ext|) <= 30 000) evaluates to within 2 % of 30 000 for this
+    shape -- where the packed halves come closest to leaving int16 -- or None."""
     ge = -int(v[6] % 4)
-    pen = (30000 - (la + 1) * abs(ge)) // (la + lb + 2)
-    if pen < 2 or (la + lb + 2) * pen + (la + 1) * abs(ge) < 29400:
-        return None
+    if nw:
+        pen = 30000 // (la + lb + 2) - abs(ge)
+        if pen < 2 or (la + lb + 2) * (pen + abs(ge)) < 29400:
+            return None
+    else:
+        pen = (30000 - (la + 1) * abs(ge)) // (la + lb + 2)
+        if pen < 2 or (la + lb + 2) * pen + (la + 1) * abs(ge) < 29400:
+            return None
     kind = int(v[5] % 3)          # which penalty sits at the bound: match, mismatch, or the first gap character
     match = pen if kind == 0 else max(1, pen // (2 + int(v[3] % 3)))
     mismatch = -pen if kind == 1 else -max(0, pen // (1 + int(v[4] % 4)))
@@ -89,8 +95,8 @@ def check_uniform(seconds, max_trials=1 << 60):
         go, ge = -int(v[5] % 12), -int(v[6] % 4)
         spec = {"init": [match, mismatch, go, ge, 0, 0, 0, 0, 0, int(v[7] & 1)], "wildcards": []}
         alpha = DNA
-        if trials % 5 == 4 and near_bound_spec(la, lb, v):      # a fifth of the scorings at the edge of int16
-            spec = near_bound_spec(la, lb, v)
+        if trials % 5 == 4 and near_bound_spec(la, lb, v, nw=True):      # a fifth of the scorings at the edge of int16
+            spec = near_bound_spec(la, lb, v, nw=True)
             match = spec["init"][0]
         elif v[11] % 5 == 0:      # a substitution table: BLOSUM62 on protein, or a wildcard
             spec, alpha = ({"preset": "BLOSUM62"}, PROT) if v[11] % 2 else ({**spec, "wildcards": [["N", int(v[10] % 3) - 1]]}, DNAN)

@@ -598,22 +598,30 @@ def x2_bound(la, lb, match, mismatch, gap_open, gap_extend):
     return (la + lb + 2) * pen + (la + 1) * abs(gap_extend)
 
 
+def x2_bound_nw(la, lb, match, mismatch, gap_open, gap_extend):
+    """sa_domain_nw_x2_scores_fit (csrc/sa_kernels.h): the packed NW fills keep their values de-trended by (column + row) x gap_extend."""
+    pen = max(abs(match), abs(mismatch), abs(gap_open + gap_extend), abs(gap_extend), abs(gap_open) + abs(gap_extend))
+    return (la + lb + 2) * (pen + abs(gap_extend))
+
+
 def edge_cases():
     """(la, lb, scoring numbers, bound) just inside and just outside the bound, at the widest admitted row and at read size."""
     out = []
     for la, lb in ((511, 300), (150, 150), (300, 300), (64, 511)):
         for ext in (-1, -7):
             inside = outside = None
-            for pen in range(8, 200):
-                b = x2_bound(la, lb, pen, -pen, -(pen + ext) if pen + ext > 0 else 0, ext)
-                if b <= 30000 and b >= 29400:
-                    inside = (pen, b)
-                if b > 30000 and outside is None:
-                    outside = (pen, b)
-            if inside:
-                out.append((la, lb, inside[0], ext, inside[1], True))
-            if outside:
-                out.append((la, lb, outside[0], ext, outside[1], False))
+            for bound_of in (x2_bound, x2_bound_nw):     # the edge of the SW fills' bound, and of the NW fills'
+                inside = outside = None
+                for pen in range(8, 200):
+                    b = bound_of(la, lb, pen, -pen, -(pen + ext) if pen + ext > 0 else 0, ext)
+                    if b <= 30000 and b >= 29400:
+                        inside = (pen, b)
+                    if b > 30000 and outside is None:
+                        outside = (pen, b)
+                if inside and (la, lb, inside[0], ext) not in [(x[0], x[1], x[2], x[3]) for x in out]:
+                    out.append((la, lb, inside[0], ext, inside[1], True))
+                if outside and (la, lb, outside[0], ext) not in [(x[0], x[1], x[2], x[3]) for x in out]:
+                    out.append((la, lb, outside[0], ext, outside[1], False))
     return out
 
 
@@ -634,21 +642,22 @@ def test_packed_fills_at_the_edge_of_int16(ctx, opts, la, lb, pen, ext, bound, p
     """Scorings whose admission bound evaluates to just under / just over 30 000 on worst-case inputs at that shape: packed
     (and equal to the oracle) / NOT packed (the 32-bit kernels take the chunk, same results).  Three score profiles per
     bound: match-heavy, mismatch-heavy, gap-heavy."""
-    assert (bound <= 30000) == packs
     go = -(pen + ext) if pen + ext > 0 else 0            # gap_open + gap_extend = -pen: the first gap character costs `pen`
+    assert (bound <= 30000) == packs and bound in (x2_bound(la, lb, pen, -pen, go, ext), x2_bound_nw(la, lb, pen, -pen, go, ext))
     profiles = [(pen, -pen, go, ext), (max(1, pen // 3), -pen, go, ext), (pen, -max(1, pen // 2), min(0, go // 4), ext)]
     opts(pack16=2)
     for match, mismatch, gap_open, gap_extend in profiles:
         spec = {"init": [match, mismatch, gap_open, gap_extend, 0, 0, 0, 0, 0, 0], "wildcards": []}
         fits = x2_bound(la, lb, match, mismatch, gap_open, gap_extend) <= 30000
+        fits_nw = x2_bound_nw(la, lb, match, mismatch, gap_open, gap_extend) <= 30000
         sc = S.make_scoring(spec)
         osc = osc_of(sc)
         pairs = worst_case_pairs(la, lb, 31 * la + lb + pen)
         batch = W.from_pairs(pairs)
         got = ctx.nw_batch(batch, sc)
         info = ctx.last_call()
-        assert ("fill_nw_dirs_x2" in info) == fits, (spec, info)
-        if not fits:
+        assert ("fill_nw_dirs_x2" in info) == fits_nw, (spec, info)
+        if not fits_nw:
             assert info.get("fill_nw_dirs", (0, 0))[1] == len(pairs), (spec, info)
         for p, (a, b) in enumerate(pairs):
             rc, s_, ra, rb = O.oracle_nw(osc, a, b)
